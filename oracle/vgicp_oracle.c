@@ -1,0 +1,846 @@
+/*
+ * vgicp_oracle.c -- see vgicp_oracle.h.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (header explains).
+ *
+ * Build: gcc -O2 -std=c11 -fopenmp -ffp-contract=off -march=x86-64-v3 -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off + explicit fma() keeps the FP64 point transform bit-identical to the HIP kernels.
+ */
+#include "vgicp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* helpers                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static int clamp_threads(int t) {
+  if (t <= 0) t = orc_max_threads();
+  return t < 1 ? 1 : t;
+}
+
+int32_t orc_fast_floor(double x) {
+  const int32_t i = (int32_t)x;
+  return i - (x < (double)i);
+}
+
+void orc_voxel_coord(const double* p, double inv_res, int32_t* c) {
+  c[0] = orc_fast_floor(p[0] * inv_res);
+  c[1] = orc_fast_floor(p[1] * inv_res);
+  c[2] = orc_fast_floor(p[2] * inv_res);
+}
+
+void orc_transform_point(const double* T, const double* p, double* q) {
+  for (int r = 0; r < 3; r++) {
+    q[r] = fma(T[4 * r + 0], p[0], fma(T[4 * r + 1], p[1], fma(T[4 * r + 2], p[2], T[4 * r + 3])));
+  }
+}
+
+static void hat3(const double* a, double* H /* row-major 3x3 */) {
+  H[0] = 0.0;   H[1] = -a[2]; H[2] = a[1];
+  H[3] = a[2];  H[4] = 0.0;   H[5] = -a[0];
+  H[6] = -a[1]; H[7] = a[0];  H[8] = 0.0;
+}
+
+static void mat3_mul(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+      C[3 * i + j] = s;
+    }
+}
+
+/* SE(3) exponential, [omega; v] order (gtsam::Pose3::Expmap). */
+void orc_se3_exp(const double* xi, double* T) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  const double th = sqrt(th2);
+  double W[9], W2[9];
+  hat3(xi, W);
+  mat3_mul(W, W, W2);
+  double a, b, c; /* R = I + a W + b W^2 ; V = I + b W + c W^2 */
+  if (th < 1e-8) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+    c = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    a = sin(th) / th;
+    b = (1.0 - cos(th)) / th2;
+    c = (th - sin(th)) / (th2 * th);
+  }
+  double R[9], V[9];
+  for (int i = 0; i < 9; i++) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    R[i] = I + a * W[i] + b * W2[i];
+    V[i] = I + b * W[i] + c * W2[i];
+  }
+  for (int r = 0; r < 3; r++) {
+    T[4 * r + 0] = R[3 * r + 0];
+    T[4 * r + 1] = R[3 * r + 1];
+    T[4 * r + 2] = R[3 * r + 2];
+    T[4 * r + 3] = V[3 * r + 0] * xi[3] + V[3 * r + 1] * xi[4] + V[3 * r + 2] * xi[5];
+  }
+}
+
+void orc_pose_compose(const double* A, const double* B, double* C) {
+  double out[12];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) out[4 * r + c] = A[4 * r + 0] * B[c] + A[4 * r + 1] * B[4 + c] + A[4 * r + 2] * B[8 + c];
+    out[4 * r + 3] = A[4 * r + 0] * B[3] + A[4 * r + 1] * B[7] + A[4 * r + 2] * B[11] + A[4 * r + 3];
+  }
+  memcpy(C, out, sizeof(out));
+}
+
+void orc_pose_inverse(const double* A, double* Ai) {
+  double out[12];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) out[4 * r + c] = A[4 * c + r];
+  for (int r = 0; r < 3; r++) out[4 * r + 3] = -(out[4 * r + 0] * A[3] + out[4 * r + 1] * A[7] + out[4 * r + 2] * A[11]);
+  memcpy(Ai, out, sizeof(out));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* kNN  -- src/glim/preprocess/cloud_preprocessor.cpp:190-221                                        */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* squared distance, fixed evaluation order (dx*dx + dy*dy) + dz*dz, no fma (part of the parity contract
+ * with the device kNN kernel: FP32-representable inputs make dx,dy,dz exact in FP64). */
+static inline double sqdist3(const double* a, const double* b) {
+  const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* keep the k best (d, idx) pairs sorted ascending by (d, idx) */
+static inline void knn_push(double* bd, int32_t* bi, int* cnt, int k, double d, int32_t idx) {
+  int n = *cnt;
+  if (n == k) {
+    if (d > bd[k - 1] || (d == bd[k - 1] && idx > bi[k - 1])) return;
+    n = k - 1;
+  }
+  int j = n;
+  while (j > 0 && (bd[j - 1] > d || (bd[j - 1] == d && bi[j - 1] > idx))) {
+    bd[j] = bd[j - 1];
+    bi[j] = bi[j - 1];
+    j--;
+  }
+  bd[j] = d;
+  bi[j] = idx;
+  *cnt = n + 1;
+}
+
+void orc_knn_bruteforce(const double* pts, int n, int k, int32_t* out, int num_threads) {
+  num_threads = clamp_threads(num_threads);
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    double bd[64];
+    int32_t bi[64];
+    int cnt = 0;
+    const int kk = k > 64 ? 64 : k;
+    for (int j = 0; j < n; j++) knn_push(bd, bi, &cnt, kk, sqdist3(pts + 4 * i, pts + 4 * j), j);
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : i; /* :197 pre-fill with i */
+  }
+}
+
+void orc_knn_grid(const double* pts, int n, int k, double cell, int32_t* out, int num_threads) {
+  num_threads = clamp_threads(num_threads);
+  if (n <= 0) return;
+  if (k > 64) k = 64;
+  double lo[3] = {pts[0], pts[1], pts[2]}, hi[3] = {pts[0], pts[1], pts[2]};
+  for (int i = 1; i < n; i++)
+    for (int a = 0; a < 3; a++) {
+      if (pts[4 * i + a] < lo[a]) lo[a] = pts[4 * i + a];
+      if (pts[4 * i + a] > hi[a]) hi[a] = pts[4 * i + a];
+    }
+  if (cell <= 0.0) {
+    /* surface-like clouds: aim for ~2 points per cell assuming a 2-D manifold in the bounding box */
+    double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+    cell = sqrt(2.0 * (2.0 * area + 1e-12) / (double)n);
+    if (!(cell > 1e-6)) cell = 1e-6;
+  }
+  int dim[3];
+  for (;;) {
+    double cells = 1.0;
+    for (int a = 0; a < 3; a++) {
+      dim[a] = (int)floor((hi[a] - lo[a]) / cell) + 1;
+      cells *= (double)dim[a];
+    }
+    if (cells <= 64.0e6) break;
+    cell *= 1.5;
+  }
+  const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
+  int32_t* start = (int32_t*)calloc(ncell + 1, sizeof(int32_t));
+  int32_t* cid = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  const double inv = 1.0 / cell;
+  for (int i = 0; i < n; i++) {
+    int c[3];
+    for (int a = 0; a < 3; a++) {
+      c[a] = (int)floor((pts[4 * i + a] - lo[a]) * inv);
+      if (c[a] < 0) c[a] = 0;
+      if (c[a] >= dim[a]) c[a] = dim[a] - 1;
+    }
+    cid[i] = (int32_t)(((size_t)c[2] * dim[1] + c[1]) * dim[0] + c[0]);
+    start[cid[i] + 1]++;
+  }
+  for (size_t c = 0; c < ncell; c++) start[c + 1] += start[c];
+  {
+    int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * ncell);
+    memcpy(cur, start, sizeof(int32_t) * ncell);
+    for (int i = 0; i < n; i++) order[cur[cid[i]]++] = i;
+    free(cur);
+  }
+  const int maxring = dim[0] > dim[1] ? (dim[0] > dim[2] ? dim[0] : dim[2]) : (dim[1] > dim[2] ? dim[1] : dim[2]);
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    double bd[64];
+    int32_t bi[64];
+    int cnt = 0;
+    const double* p = pts + 4 * i;
+    int c[3];
+    {
+      int32_t id = cid[i];
+      c[0] = id % dim[0];
+      c[1] = (id / dim[0]) % dim[1];
+      c[2] = id / (dim[0] * dim[1]);
+    }
+    for (int ring = 0; ring <= maxring; ring++) {
+      /* every point outside the (2 ring - 1)^3 cube already scanned is at distance >= (ring-1)*cell + margin;
+       * stop once the k-th best is provably inside the scanned region. */
+      if (cnt == k && ring >= 1) {
+        double margin = 1e300;
+        for (int a = 0; a < 3; a++) {
+          const double f = (p[a] - lo[a]) - (double)c[a] * cell; /* offset inside own cell */
+          const double m0 = f, m1 = cell - f;
+          if (m0 < margin) margin = m0;
+          if (m1 < margin) margin = m1;
+        }
+        if (margin < 0.0) margin = 0.0;
+        const double reach = (double)(ring - 1) * cell + margin;
+        if (bd[k - 1] < reach * reach) break;
+      }
+      for (int dz = -ring; dz <= ring; dz++) {
+        const int z = c[2] + dz;
+        if (z < 0 || z >= dim[2]) continue;
+        for (int dy = -ring; dy <= ring; dy++) {
+          const int y = c[1] + dy;
+          if (y < 0 || y >= dim[1]) continue;
+          const int on_shell_yz = (abs(dz) == ring) || (abs(dy) == ring);
+          for (int dx = -ring; dx <= ring; dx++) {
+            if (!on_shell_yz && abs(dx) != ring) continue;
+            const int x = c[0] + dx;
+            if (x < 0 || x >= dim[0]) continue;
+            const size_t cc = ((size_t)z * dim[1] + y) * dim[0] + x;
+            for (int32_t s = start[cc]; s < start[cc + 1]; s++) {
+              const int32_t j = order[s];
+              knn_push(bd, bi, &cnt, k, sqdist3(p, pts + 4 * j), j);
+            }
+          }
+        }
+      }
+    }
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : i;
+  }
+  free(start);
+  free(cid);
+  free(order);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* symmetric 3x3 eigen-solver: restatement of Eigen 3.4 SelfAdjointEigenSolver<Matrix3d>::computeDirect */
+/* (third-party dependency of the reference, not in /root/reference; used at                         */
+/* src/glim/common/cloud_covariance_estimation.cpp:182-183).  m(r,c) below is symmetric.            */
+/* ------------------------------------------------------------------------------------------------ */
+
+static void eig3_roots(const double m[3][3], double roots[3]) {
+  const double s_inv3 = 1.0 / 3.0;
+  const double s_sqrt3 = sqrt(3.0);
+  const double c0 = m[0][0] * m[1][1] * m[2][2] + 2.0 * m[1][0] * m[2][0] * m[2][1] - m[0][0] * m[2][1] * m[2][1] -
+                    m[1][1] * m[2][0] * m[2][0] - m[2][2] * m[1][0] * m[1][0];
+  const double c1 = m[0][0] * m[1][1] - m[1][0] * m[1][0] + m[0][0] * m[2][2] - m[2][0] * m[2][0] + m[1][1] * m[2][2] -
+                    m[2][1] * m[2][1];
+  const double c2 = m[0][0] + m[1][1] + m[2][2];
+  const double c2_over_3 = c2 * s_inv3;
+  double a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  if (a_over_3 < 0.0) a_over_3 = 0.0;
+  const double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+  double q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  if (q < 0.0) q = 0.0;
+  const double rho = sqrt(a_over_3);
+  const double theta = atan2(sqrt(q), half_b) * s_inv3;
+  const double cos_theta = cos(theta);
+  const double sin_theta = sin(theta);
+  roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 + 2.0 * rho * cos_theta;
+}
+
+static void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* kernel (null vector) of a rank-2 symmetric matrix; `rep` receives the representative column. */
+static void eig3_extract_kernel(const double mat[3][3], double* res, double* rep) {
+  int i0 = 0;
+  double best = fabs(mat[0][0]);
+  for (int i = 1; i < 3; i++)
+    if (fabs(mat[i][i]) > best) {
+      best = fabs(mat[i][i]);
+      i0 = i;
+    }
+  double col0[3], col1[3], col2[3];
+  for (int r = 0; r < 3; r++) {
+    col0[r] = mat[r][i0];
+    col1[r] = mat[r][(i0 + 1) % 3];
+    col2[r] = mat[r][(i0 + 2) % 3];
+  }
+  rep[0] = col0[0];
+  rep[1] = col0[1];
+  rep[2] = col0[2];
+  double c0[3], c1[3];
+  cross3(col0, col1, c0);
+  cross3(col0, col2, c1);
+  const double n0 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+  const double n1 = c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2];
+  if (n0 > n1) {
+    const double s = sqrt(n0);
+    res[0] = c0[0] / s;
+    res[1] = c0[1] / s;
+    res[2] = c0[2] / s;
+  } else {
+    const double s = sqrt(n1);
+    res[0] = c1[0] / s;
+    res[1] = c1[1] / s;
+    res[2] = c1[2] / s;
+  }
+}
+
+void orc_eigen3_direct(const double* m9, double* evals, double* evecs /* column-major */) {
+  const double eps = 2.220446049250313e-16;
+  double sm[3][3];
+  /* lower-triangular view mirrored (selfadjointView<Lower>) */
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) sm[r][c] = (r >= c) ? m9[3 * r + c] : m9[3 * c + r];
+  const double shift = (sm[0][0] + sm[1][1] + sm[2][2]) / 3.0;
+  for (int i = 0; i < 3; i++) sm[i][i] -= shift;
+  double scale = 0.0;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      if (fabs(sm[r][c]) > scale) scale = fabs(sm[r][c]);
+  if (scale > 0.0)
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) sm[r][c] /= scale;
+
+  double ev[3];
+  eig3_roots(sm, ev);
+
+  double V[3][3]; /* V[c] = eigenvector c */
+  if ((ev[2] - ev[0]) <= eps) {
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) V[c][r] = (r == c) ? 1.0 : 0.0;
+  } else {
+    double tmp[3][3];
+    memcpy(tmp, sm, sizeof(tmp));
+    double d0 = ev[2] - ev[1];
+    const double d1 = ev[1] - ev[0];
+    int k = 0, l = 2;
+    if (d0 > d1) {
+      k = 2;
+      l = 0;
+      d0 = d1;
+    }
+    for (int i = 0; i < 3; i++) tmp[i][i] -= ev[k];
+    eig3_extract_kernel(tmp, V[k], V[l]);
+    if (d0 <= 2.0 * eps * d1) {
+      const double dot = V[k][0] * V[l][0] + V[k][1] * V[l][1] + V[k][2] * V[l][2];
+      for (int r = 0; r < 3; r++) V[l][r] -= dot * V[l][r];
+      const double nn = sqrt(V[l][0] * V[l][0] + V[l][1] * V[l][1] + V[l][2] * V[l][2]);
+      for (int r = 0; r < 3; r++) V[l][r] /= nn;
+    } else {
+      memcpy(tmp, sm, sizeof(tmp));
+      for (int i = 0; i < 3; i++) tmp[i][i] -= ev[l];
+      double dummy[3];
+      eig3_extract_kernel(tmp, V[l], dummy);
+    }
+    double c1[3];
+    cross3(V[2], V[0], c1);
+    const double nn = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+    for (int r = 0; r < 3; r++) V[1][r] = c1[r] / nn;
+  }
+  for (int i = 0; i < 3; i++) evals[i] = ev[i] * scale + shift;
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) evecs[3 * c + r] = V[c][r];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* covariance + normal -- src/glim/common/cloud_covariance_estimation.cpp:43-122 and :175-196 (PLANE) */
+/* ------------------------------------------------------------------------------------------------ */
+
+int orc_covariance_estimate(const double* pts, int n, const int32_t* nbrs, int k_corr, int k_nbr, double* normals,
+                            double* covs, int num_threads) {
+  if (n <= 0) return 0;
+  if (k_nbr > k_corr || k_nbr <= 0) return -1;
+  num_threads = clamp_threads(num_threads);
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    /* :81-89  sum of neighbour points and of p p^T (the reference precomputes pt_cross[i] = p p^T, :57-75;
+     * the products are the same FP64 values either way) */
+    double s[4] = {0, 0, 0, 0};
+    double S[4][4];
+    memset(S, 0, sizeof(S));
+    const int32_t* row = nbrs + (size_t)k_corr * i;
+    for (int j = 0; j < k_nbr; j++) {
+      const double* p = pts + 4 * (size_t)row[j];
+      for (int a = 0; a < 4; a++) {
+        s[a] += p[a];
+        for (int b = 0; b < 4; b++) S[a][b] += p[a] * p[b];
+      }
+    }
+    /* :91-92  mean and population covariance (divide by k, not k-1) */
+    double mean[4], cov[3][3];
+    for (int a = 0; a < 4; a++) mean[a] = s[a] / (double)k_nbr;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) cov[a][b] = (S[a][b] - mean[a] * s[b]) / (double)k_nbr;
+    /* :181-196  PLANE regularisation: eigenvalues -> (1e-3, 1, 1), recompose V diag V^T */
+    double evals[3], V[9];
+    orc_eigen3_direct(&cov[0][0], evals, V);
+    const double vals[3] = {1e-3, 1.0, 1.0};
+    double* C = covs + 16 * (size_t)i;
+    memset(C, 0, sizeof(double) * 16);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double acc = 0.0;
+        for (int e = 0; e < 3; e++) acc += (V[3 * e + r] * vals[e]) * V[3 * e + c];
+        C[4 * c + r] = acc; /* column-major 4x4; (3,3) stays 0  (:96) */
+      }
+    /* :98-101  normal = eigenvector of the smallest eigenvalue, flipped to face the sensor origin */
+    double* nrm = normals + 4 * (size_t)i;
+    nrm[0] = V[0];
+    nrm[1] = V[1];
+    nrm[2] = V[2];
+    nrm[3] = 0.0;
+    const double* p = pts + 4 * (size_t)i;
+    if (p[0] * nrm[0] + p[1] * nrm[1] + p[2] * nrm[2] + p[3] * nrm[3] > 0.0) {
+      nrm[0] = -nrm[0];
+      nrm[1] = -nrm[1];
+      nrm[2] = -nrm[2];
+      nrm[3] = -nrm[3];
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Gaussian voxel map (CPU semantics)                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct {
+  int32_t coord[3];
+  int32_t num_points;
+  int finalized;
+  double mean[4];
+  double cov[16];
+} orc_voxel;
+
+struct orc_voxelmap {
+  double resolution;
+  double inv_resolution;
+  int num_voxels, cap_voxels;
+  orc_voxel* voxels;
+  size_t table_size; /* power of two */
+  int32_t* table;    /* voxel index or -1 */
+};
+
+/* XOR-prime spatial hash (gtsam_points util/vector3i_hash.hpp, upstream-recall; informative only). */
+static inline size_t coord_hash(const int32_t* c) {
+  return (size_t)(((int64_t)c[0] * 73856093) ^ ((int64_t)c[1] * 19349669) ^ ((int64_t)c[2] * 83492791));
+}
+
+orc_voxelmap* orc_voxelmap_create(double resolution) {
+  orc_voxelmap* m = (orc_voxelmap*)calloc(1, sizeof(orc_voxelmap));
+  m->resolution = resolution;
+  m->inv_resolution = 1.0 / resolution;
+  m->cap_voxels = 1024;
+  m->voxels = (orc_voxel*)malloc(sizeof(orc_voxel) * (size_t)m->cap_voxels);
+  m->table_size = 4096;
+  m->table = (int32_t*)malloc(sizeof(int32_t) * m->table_size);
+  memset(m->table, 0xff, sizeof(int32_t) * m->table_size);
+  return m;
+}
+
+void orc_voxelmap_destroy(orc_voxelmap* m) {
+  if (!m) return;
+  free(m->voxels);
+  free(m->table);
+  free(m);
+}
+
+int orc_voxelmap_num_voxels(const orc_voxelmap* m) { return m->num_voxels; }
+double orc_voxelmap_resolution(const orc_voxelmap* m) { return m->resolution; }
+
+int orc_voxelmap_lookup(const orc_voxelmap* m, const int32_t* c) {
+  size_t h = coord_hash(c) & (m->table_size - 1);
+  for (;;) {
+    const int32_t v = m->table[h];
+    if (v < 0) return -1;
+    const int32_t* vc = m->voxels[v].coord;
+    if (vc[0] == c[0] && vc[1] == c[1] && vc[2] == c[2]) return v;
+    h = (h + 1) & (m->table_size - 1);
+  }
+}
+
+static void voxelmap_rehash(orc_voxelmap* m, size_t new_size) {
+  free(m->table);
+  m->table_size = new_size;
+  m->table = (int32_t*)malloc(sizeof(int32_t) * new_size);
+  memset(m->table, 0xff, sizeof(int32_t) * new_size);
+  for (int v = 0; v < m->num_voxels; v++) {
+    size_t h = coord_hash(m->voxels[v].coord) & (new_size - 1);
+    while (m->table[h] >= 0) h = (h + 1) & (new_size - 1);
+    m->table[h] = v;
+  }
+}
+
+static int voxelmap_get_or_create(orc_voxelmap* m, const int32_t* c) {
+  size_t h = coord_hash(c) & (m->table_size - 1);
+  for (;;) {
+    const int32_t v = m->table[h];
+    if (v < 0) break;
+    const int32_t* vc = m->voxels[v].coord;
+    if (vc[0] == c[0] && vc[1] == c[1] && vc[2] == c[2]) return v;
+    h = (h + 1) & (m->table_size - 1);
+  }
+  if (m->num_voxels == m->cap_voxels) {
+    m->cap_voxels *= 2;
+    m->voxels = (orc_voxel*)realloc(m->voxels, sizeof(orc_voxel) * (size_t)m->cap_voxels);
+  }
+  const int v = m->num_voxels++;
+  orc_voxel* vx = &m->voxels[v];
+  memset(vx, 0, sizeof(*vx));
+  vx->coord[0] = c[0];
+  vx->coord[1] = c[1];
+  vx->coord[2] = c[2];
+  m->table[h] = v;
+  if ((size_t)m->num_voxels * 2 > m->table_size) voxelmap_rehash(m, m->table_size * 2);
+  return v;
+}
+
+void orc_voxelmap_insert(orc_voxelmap* m, const double* pts, const double* covs, int n) {
+  /* GaussianVoxel::add (upstream-recall): a finalized voxel is re-opened (mean *= n, cov *= n) before
+   * accumulating; num_points++, mean += p, cov += C. */
+  for (int i = 0; i < n; i++) {
+    int32_t c[3];
+    orc_voxel_coord(pts + 4 * (size_t)i, m->inv_resolution, c);
+    orc_voxel* vx = &m->voxels[voxelmap_get_or_create(m, c)];
+    if (vx->finalized) {
+      vx->finalized = 0;
+      for (int a = 0; a < 4; a++) vx->mean[a] *= (double)vx->num_points;
+      for (int a = 0; a < 16; a++) vx->cov[a] *= (double)vx->num_points;
+    }
+    vx->num_points++;
+    for (int a = 0; a < 4; a++) vx->mean[a] += pts[4 * (size_t)i + a];
+    for (int a = 0; a < 16; a++) vx->cov[a] += covs[16 * (size_t)i + a];
+  }
+  /* GaussianVoxel::finalize: mean /= n, cov /= n */
+  for (int v = 0; v < m->num_voxels; v++) {
+    orc_voxel* vx = &m->voxels[v];
+    if (vx->finalized) continue;
+    for (int a = 0; a < 4; a++) vx->mean[a] /= (double)vx->num_points;
+    for (int a = 0; a < 16; a++) vx->cov[a] /= (double)vx->num_points;
+    vx->finalized = 1;
+  }
+}
+
+void orc_voxelmap_get(const orc_voxelmap* m, int i, int32_t* coord, int32_t* num_points, double* mean, double* cov) {
+  const orc_voxel* vx = &m->voxels[i];
+  if (coord) memcpy(coord, vx->coord, sizeof(vx->coord));
+  if (num_points) *num_points = vx->num_points;
+  if (mean) memcpy(mean, vx->mean, sizeof(vx->mean));
+  if (cov) memcpy(cov, vx->cov, sizeof(vx->cov));
+}
+
+void orc_voxelmap_round_to_f32(orc_voxelmap* m) {
+  for (int v = 0; v < m->num_voxels; v++) {
+    orc_voxel* vx = &m->voxels[v];
+    for (int a = 0; a < 4; a++) vx->mean[a] = (double)(float)vx->mean[a];
+    for (int a = 0; a < 16; a++) vx->cov[a] = (double)(float)vx->cov[a];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* VGICP factor                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* inverse of a symmetric positive-definite 3x3 via cofactors (Eigen's fixed-size 3x3 inverse is the same
+ * cofactor/determinant form).  The reference inverts the 4x4 [S 0; 0 1]; its 3x3 block is S^-1. */
+static void inv3(const double* S, double* M) {
+  const double a = S[0], b = S[1], c = S[2], d = S[3], e = S[4], f = S[5], g = S[6], h = S[7], i = S[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double id = 1.0 / det;
+  M[0] = A * id;
+  M[1] = -(b * i - c * h) * id;
+  M[2] = (b * f - c * e) * id;
+  M[3] = B * id;
+  M[4] = (a * i - c * g) * id;
+  M[5] = -(a * f - c * d) * id;
+  M[6] = C * id;
+  M[7] = -(a * h - b * g) * id;
+  M[8] = (a * e - b * d) * id;
+}
+
+/* Mahalanobis matrix of one correspondence: (C_B + R C_A R^T)^-1 on the 3x3 block. */
+static void fused_mahalanobis(const double* covB16, const double* covA16, const double* T, double* M) {
+  double R[9], CA[9], RC[9], S[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      R[3 * r + c] = T[4 * r + c];
+      CA[3 * r + c] = covA16[4 * c + r];
+    }
+  mat3_mul(R, CA, RC);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += RC[3 * r + k] * R[3 * c + k];
+      S[3 * r + c] = covB16[4 * c + r] + s;
+    }
+  inv3(S, M);
+}
+
+typedef struct {
+  double H_tt[36], H_ss[36], H_ts[36], b_t[6], b_s[6], err;
+  int64_t inliers;
+} acc_t;
+
+/* accumulate one matched point (evaluate(), upstream-recall) */
+static void accumulate_point(acc_t* A, const double* T, const double* p, const double* q, const double* muB, const double* M,
+                             int need_H) {
+  double r[3] = {muB[0] - q[0], muB[1] - q[1], muB[2] - q[2]};
+  double Mr[3];
+  for (int a = 0; a < 3; a++) Mr[a] = M[3 * a + 0] * r[0] + M[3 * a + 1] * r[1] + M[3 * a + 2] * r[2];
+  A->err += r[0] * Mr[0] + r[1] * Mr[1] + r[2] * Mr[2];
+  A->inliers++;
+  if (!need_H) return;
+  /* J_t = [ -hat(q) | I ],  J_s = [ R hat(p) | -R ]   (3 x 6) */
+  double Jt[18], Js[18], Hq[9], Hp[9], R[9], RHp[9];
+  hat3(q, Hq);
+  hat3(p, Hp);
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) R[3 * a + b] = T[4 * a + b];
+  mat3_mul(R, Hp, RHp);
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      Jt[6 * a + b] = -Hq[3 * a + b];
+      Jt[6 * a + 3 + b] = (a == b) ? 1.0 : 0.0;
+      Js[6 * a + b] = RHp[3 * a + b];
+      Js[6 * a + 3 + b] = -R[3 * a + b];
+    }
+  /* JtM = J_t^T M (6x3), JsM = J_s^T M */
+  double JtM[18], JsM[18];
+  for (int a = 0; a < 6; a++)
+    for (int b = 0; b < 3; b++) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < 3; k++) {
+        s0 += Jt[6 * k + a] * M[3 * k + b];
+        s1 += Js[6 * k + a] * M[3 * k + b];
+      }
+      JtM[3 * a + b] = s0;
+      JsM[3 * a + b] = s1;
+    }
+  for (int a = 0; a < 6; a++) {
+    for (int b = 0; b < 6; b++) {
+      double tt = 0.0, ss = 0.0, ts = 0.0;
+      for (int k = 0; k < 3; k++) {
+        tt += JtM[3 * a + k] * Jt[6 * k + b];
+        ss += JsM[3 * a + k] * Js[6 * k + b];
+        ts += JtM[3 * a + k] * Js[6 * k + b];
+      }
+      A->H_tt[6 * a + b] += tt;
+      A->H_ss[6 * a + b] += ss;
+      A->H_ts[6 * a + b] += ts;
+    }
+    A->b_t[a] += JtM[3 * a + 0] * r[0] + JtM[3 * a + 1] * r[1] + JtM[3 * a + 2] * r[2];
+    A->b_s[a] += JsM[3 * a + 0] * r[0] + JsM[3 * a + 1] * r[1] + JsM[3 * a + 2] * r[2];
+  }
+}
+
+static void acc_add(acc_t* dst, const acc_t* src) {
+  for (int i = 0; i < 36; i++) {
+    dst->H_tt[i] += src->H_tt[i];
+    dst->H_ss[i] += src->H_ss[i];
+    dst->H_ts[i] += src->H_ts[i];
+  }
+  for (int i = 0; i < 6; i++) {
+    dst->b_t[i] += src->b_t[i];
+    dst->b_s[i] += src->b_s[i];
+  }
+  dst->err += src->err;
+  dst->inliers += src->inliers;
+}
+
+/* shared driver: correspondences at T_lin, residuals at T_eval */
+static void vgicp_run(const orc_voxelmap* map, const double* pts, const double* covs, int n, const double* T_lin,
+                      const double* T_eval, int num_threads, int need_H, acc_t* total, int32_t* corr) {
+  num_threads = clamp_threads(num_threads);
+  acc_t* parts = (acc_t*)calloc((size_t)num_threads, sizeof(acc_t));
+#pragma omp parallel num_threads(num_threads)
+  {
+#ifdef _OPENMP
+    acc_t* A = &parts[omp_get_thread_num()];
+#else
+    acc_t* A = &parts[0];
+#endif
+#pragma omp for schedule(guided, 8)
+    for (int i = 0; i < n; i++) {
+      const double* p = pts + 4 * (size_t)i;
+      double q_lin[3];
+      orc_transform_point(T_lin, p, q_lin);
+      int32_t c[3];
+      orc_voxel_coord(q_lin, map->inv_resolution, c);
+      const int v = orc_voxelmap_lookup(map, c);
+      if (corr) {
+        corr[4 * (size_t)i + 0] = c[0];
+        corr[4 * (size_t)i + 1] = c[1];
+        corr[4 * (size_t)i + 2] = c[2];
+        corr[4 * (size_t)i + 3] = v;
+      }
+      if (v < 0) continue;
+      const orc_voxel* vx = &map->voxels[v];
+      double M[9];
+      fused_mahalanobis(vx->cov, covs + 16 * (size_t)i, T_lin, M);
+      double q[3];
+      if (T_eval == T_lin) {
+        q[0] = q_lin[0];
+        q[1] = q_lin[1];
+        q[2] = q_lin[2];
+      } else {
+        orc_transform_point(T_eval, p, q);
+      }
+      accumulate_point(A, T_eval, p, q, vx->mean, M, need_H);
+    }
+  }
+  memset(total, 0, sizeof(*total));
+  for (int t = 0; t < num_threads; t++) acc_add(total, &parts[t]);
+  free(parts);
+}
+
+int orc_vgicp_linearize(const orc_voxelmap* target, const double* pts, const double* covs, int n, const double* delta,
+                        int num_threads, orc_linearized6* out, int32_t* corr) {
+  if (!target || !out) return -1;
+  acc_t total;
+  vgicp_run(target, pts, covs, n, delta, delta, num_threads, 1, &total, corr);
+  out->num_inliers = total.inliers;
+  out->error = ORC_ERROR_SCALE * total.err;
+  memcpy(out->H_tt, total.H_tt, sizeof(total.H_tt));
+  memcpy(out->H_ss, total.H_ss, sizeof(total.H_ss));
+  memcpy(out->H_ts, total.H_ts, sizeof(total.H_ts));
+  memcpy(out->b_t, total.b_t, sizeof(total.b_t));
+  memcpy(out->b_s, total.b_s, sizeof(total.b_s));
+  return 0;
+}
+
+double orc_vgicp_error(const orc_voxelmap* target, const double* pts, const double* covs, int n, const double* delta,
+                       int num_threads, int64_t* num_inliers) {
+  acc_t total;
+  vgicp_run(target, pts, covs, n, delta, delta, num_threads, 0, &total, NULL);
+  if (num_inliers) *num_inliers = total.inliers;
+  return ORC_ERROR_SCALE * total.err;
+}
+
+double orc_vgicp_error_frozen(const orc_voxelmap* target, const double* pts, const double* covs, int n, const double* delta_lin,
+                              const double* delta_eval, int num_threads, int64_t* num_inliers) {
+  acc_t total;
+  vgicp_run(target, pts, covs, n, delta_lin, delta_eval, num_threads, 0, &total, NULL);
+  if (num_inliers) *num_inliers = total.inliers;
+  return ORC_ERROR_SCALE * total.err;
+}
+
+double orc_overlap(const orc_voxelmap* const* targets, const double* deltas, int num_targets, const double* pts, int n,
+                   int num_threads) {
+  if (n <= 0) return 0.0;
+  num_threads = clamp_threads(num_threads);
+  long hits = 0;
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8) reduction(+ : hits)
+  for (int i = 0; i < n; i++) {
+    for (int t = 0; t < num_targets; t++) {
+      double q[3];
+      orc_transform_point(deltas + 12 * (size_t)t, pts + 4 * (size_t)i, q);
+      int32_t c[3];
+      orc_voxel_coord(q, targets[t]->inv_resolution, c);
+      if (orc_voxelmap_lookup(targets[t], c) >= 0) {
+        hits++;
+        break;
+      }
+    }
+  }
+  return (double)hits / (double)n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* one optimisation step                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+
+int orc_solve6(const double* H, const double* b, double lambda, double* x) {
+  double L[36];
+  memset(L, 0, sizeof(L));
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j <= i; j++) {
+      double s = 0.5 * (H[6 * i + j] + H[6 * j + i]) + ((i == j) ? lambda : 0.0);
+      for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k];
+      if (i == j) {
+        if (!(s > 0.0)) return -1;
+        L[6 * i + i] = sqrt(s);
+      } else {
+        L[6 * i + j] = s / L[6 * j + j];
+      }
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double s = -b[i];
+    for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k];
+    y[i] = s / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k];
+    x[i] = s / L[6 * i + i];
+  }
+  return 0;
+}
+
+int orc_gn_align(const orc_voxelmap* target, const double* pts, const double* covs, int n, double* T, int max_iters,
+                 double lambda, int num_threads, double* deltas_out) {
+  int it = 0;
+  for (; it < max_iters; it++) {
+    orc_linearized6 L;
+    orc_vgicp_linearize(target, pts, covs, n, T, num_threads, &L, NULL);
+    double d[6];
+    if (orc_solve6(L.H_ss, L.b_s, lambda, d) != 0) break;
+    if (deltas_out) memcpy(deltas_out + 6 * it, d, sizeof(d));
+    double E[12];
+    orc_se3_exp(d, E);
+    orc_pose_compose(T, E, T);
+    const double dt = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    const double dr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (dt < 1e-3 && dr < 1e-3 * 3.14159265358979323846 / 180.0) {
+      it++;
+      break;
+    }
+  }
+  return it;
+}

@@ -1,0 +1,136 @@
+/*
+ * vgicp_oracle.h -- CPU restatement (FP64, C99 + OpenMP) of GLIM's VGICP scan-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under glim_amd/ (the product) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it -- as the checker /
+ * the timed CPU baseline, never as the thing shipped.
+ *
+ * PARITY UNPINNED: the reference (koide3/glim v1.2.2) ships no tests, golden vectors or fixtures for
+ * this path, and the arithmetic of rows a4/a6 lives in the un-vendored dependency koide3/gtsam_points
+ * (required >= 1.2.2 by /root/reference/CMakeLists.txt:28), which is absent from this container.  The
+ * in-tree pieces (kNN contract, covariance estimation) are restated line-by-line from the files cited
+ * at each function; the gtsam_points pieces are restated from its published algorithm (VGICP, Koide et
+ * al. ICRA 2021) and from GLIM's call sites, and are pinned only by analytic known-answer tests
+ * (tests/test_oracle_*.py).  See DESIGN.md "Oracle".
+ *
+ * Layout conventions follow the reference: points are homogeneous Vector4d (x,y,z,1), covariances are
+ * Matrix4d (column-major 4x4, zero last row/col)  -- include/glim/preprocess/preprocessed_frame.hpp:31,
+ * src/glim/common/cloud_covariance_estimation.cpp:96.  Poses are passed as 12 doubles, row-major 3x4
+ * [R | t].  Tangent vectors are [omega(3); v(3)] (gtsam::Pose3 order), right perturbation.
+ */
+#ifndef VGICP_ORACLE_H
+#define VGICP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- small helpers ---------------------------------------------------------------------------- */
+
+/* fast_floor(x) = (int)x - (x < (int)x)   [gtsam_points util/fast_floor.hpp, upstream-recall; the same
+ * expression appears in-tree at src/glim/viewer/editor/points_selector.cpp:177]. */
+int32_t orc_fast_floor(double x);
+
+/* voxel coordinate of a point: fast_floor(p * inv_resolution) per axis. */
+void orc_voxel_coord(const double* p3, double inv_resolution, int32_t* c3);
+
+/* q = R p + t with the fixed fma order  q_r = fma(R_r0,px, fma(R_r1,py, fma(R_r2,pz, t_r))).
+ * This order is part of the parity contract: the HIP kernels evaluate the identical expression in FP64
+ * so that voxel coordinates (and therefore correspondences) are bit-exact. */
+void orc_transform_point(const double* T12, const double* p3, double* q3);
+
+/* SE(3) helpers (gtsam::Pose3 conventions: xi = [omega; v], T (+) xi = T * Exp(xi)). */
+void orc_se3_exp(const double* xi6, double* T12);
+void orc_pose_compose(const double* A12, const double* B12, double* AB12);
+void orc_pose_inverse(const double* A12, double* Ainv12);
+
+/* ---- kNN (row a1)  src/glim/preprocess/cloud_preprocessor.cpp:190-221 --------------------------- */
+/* For every i the k nearest points among all N points INCLUDING i itself, ascending squared distance,
+ * ties broken by ascending index (oracle rule; the reference's nanoflann order on exact ties is
+ * implementation defined).  If fewer than k points exist the tail stays i (cloud_preprocessor.cpp:197).
+ * points: N x 4 doubles.  out: N x k int32.  Brute force O(N^2). */
+void orc_knn_bruteforce(const double* points4, int n, int k, int32_t* out, int num_threads);
+/* Same result through a uniform grid (exact; cell size `cell`, <=0 picks one from the density). */
+void orc_knn_grid(const double* points4, int n, int k, double cell, int32_t* out, int num_threads);
+
+/* ---- covariance + normal (row a2)  src/glim/common/cloud_covariance_estimation.cpp:43-122,175-196 */
+/* neighbors: N x k_correspondences; the first k_neighbors of each row are used.
+ * normals: N x 4 (w = 0), covs: N x 16 (column-major 4x4).  Returns 0 on success. */
+int orc_covariance_estimate(const double* points4, int n, const int32_t* neighbors, int k_correspondences,
+                            int k_neighbors, double* normals4, double* covs16, int num_threads);
+
+/* Symmetric 3x3 eigen-decomposition restating Eigen::SelfAdjointEigenSolver<Matrix3d>::computeDirect
+ * (closed-form trigonometric; ascending eigenvalues; column j of evecs = eigenvector j).
+ * m: 9 doubles (symmetric, either major).  evals: 3.  evecs: 9 doubles COLUMN-major. */
+void orc_eigen3_direct(const double* m9, double* evals3, double* evecs9);
+
+/* ---- Gaussian voxel map (row a4)  [gtsam_points types/gaussian_voxelmap_cpu, upstream-recall] ---- */
+typedef struct orc_voxelmap orc_voxelmap;
+
+orc_voxelmap* orc_voxelmap_create(double resolution);
+void orc_voxelmap_destroy(orc_voxelmap* m);
+/* insert a cloud (points N x 4, covs N x 16).  Voxel = first-touch order; voxel statistic = mean of the
+ * member means and mean of the member covariances.  May be called repeatedly (incremental insert
+ * re-opens finalized voxels exactly like the reference: mean*=n, cov*=n, accumulate, divide again). */
+void orc_voxelmap_insert(orc_voxelmap* m, const double* points4, const double* covs16, int n);
+int orc_voxelmap_num_voxels(const orc_voxelmap* m);
+double orc_voxelmap_resolution(const orc_voxelmap* m);
+/* copy out voxel i: coord[3], num_points, mean[4], cov[16]. */
+void orc_voxelmap_get(const orc_voxelmap* m, int i, int32_t* coord3, int32_t* num_points, double* mean4, double* cov16);
+/* index of the voxel with this coordinate or -1. */
+int orc_voxelmap_lookup(const orc_voxelmap* m, const int32_t* coord3);
+/* Round every voxel mean/cov to FP32 (test aid: mimics the FP32 device storage so that factor parity
+ * can be checked to a tolerance that isolates the kernel arithmetic from the storage rounding). */
+void orc_voxelmap_round_to_f32(orc_voxelmap* m);
+
+/* ---- VGICP factor (row a6)  [gtsam_points factors/integrated_vgicp_factor, upstream-recall;
+ *      call sites src/glim/odometry/odometry_estimation_cpu.cpp:105-110, src/glim/mapping/sub_mapping.cpp:291,
+ *      src/glim/mapping/global_mapping.cpp:457] ----------------------------------------------------- */
+typedef struct {
+  int64_t num_inliers;
+  double error;       /* sum_i r_i^T M_i r_i  (scale flag: see ORC_ERROR_SCALE) */
+  double H_tt[36];    /* row-major 6x6 */
+  double H_ss[36];
+  double H_ts[36];
+  double b_t[6];
+  double b_s[6];
+} orc_linearized6;
+
+/* error scale: upstream-unverified whether error() carries a 1/2; H and b are unaffected. */
+#define ORC_ERROR_SCALE 1.0
+
+/* delta12 = T_target_source (row-major 3x4).  corr (optional, N x 4 int32): {cx, cy, cz, voxel index or -1}.
+ * Returns 0 on success. */
+int orc_vgicp_linearize(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
+                        const double* delta12, int num_threads, orc_linearized6* out, int32_t* corr);
+/* error only, correspondences recomputed at delta12 (CPU-factor semantics). */
+double orc_vgicp_error(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
+                       const double* delta12, int num_threads, int64_t* num_inliers);
+/* error at delta_eval with correspondences frozen at delta_lin (GPU-factor semantics, upstream-recall). */
+double orc_vgicp_error_frozen(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
+                              const double* delta_lin12, const double* delta_eval12, int num_threads, int64_t* num_inliers);
+
+/* overlap (row a8): fraction of source points whose transformed position hits an occupied voxel; the
+ * multi-target form counts a point once if any (map_j, delta_j) matches
+ * (src/glim/odometry/odometry_estimation_gpu.cpp:224-231). */
+double orc_overlap(const orc_voxelmap* const* targets, const double* deltas12, int num_targets,
+                   const double* src_points4, int n, int num_threads);
+
+/* ---- one optimisation step ---------------------------------------------------------- */
+/* solve (H + lambda I) x = -b for a symmetric 6x6 H (row-major).  Returns 0 ok, -1 if not PD. */
+int orc_solve6(const double* H36, const double* b6, double lambda, double* x6);
+/* damped Gauss-Newton on a unary factor (target fixed at identity): T_source <- T_source * Exp(delta).
+ * Runs up to max_iters iterations, stops when |dt| < 1e-3 m and |dr| < 1e-3 deg
+ * (src/glim/odometry/odometry_estimation_cpu.cpp:121-136).  deltas_out (optional): max_iters x 6.
+ * Returns the number of iterations performed. */
+int orc_gn_align(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
+                 double* T12_inout, int max_iters, double lambda, int num_threads, double* deltas_out);
+
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

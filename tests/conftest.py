@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle
+
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def small_pair(orc):
+    """Two small LiDAR scans (32 rings x 128 azimuths) 0.5 m / 2 deg apart with kNN covariances."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(32, 128)
+    poses = synth.arc_trajectory(2)
+    out = {"poses": poses, "delta": synth.relative_pose(poses[0], poses[1])}
+    for name, i in (("target", 0), ("source", 1)):
+        pts = synth.scan(scene, poses[i], dirs, frame_id=i)
+        nbrs = orc.knn(pts, 10)
+        normals, covs = orc.covariances(pts, nbrs)
+        # inputs are rounded to f32 before BOTH the oracle and the HIP path consume them
+        out[name] = {
+            "points": pts,
+            "covs": covs.astype(np.float32).astype(np.float64),
+            "normals": normals.astype(np.float32).astype(np.float64),
+            "neighbors": nbrs,
+        }
+    return out
