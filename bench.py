@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- VGICP linearize() throughput on MI355X (BASELINE.json metric M1; configs[1]).
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched through torch.distributed.run, one
+rank per GPU over RCCL.  Prints ONE JSON line on rank 0.
+
+Workload ("odometry128k"): F distinct VGICP factors per GPU, each a 131 072-point spinning-LiDAR scan (128 rings x 1024
+azimuths, synthetic analytic scene) matched against the 0.5 m Gaussian voxel map of the previous scan on a 0.5 m / 2 deg
+arc.  One STEP = one NonlinearFactorSetGPU::linearize over all F factors with inputs resident in HBM: pose upload (96 B per
+factor), the fused lookup + Mahalanobis residual + 6-DoF Jacobian + reduction kernel, the FP64 finalise, results left on the
+device.  F = 64 by default so that the working set (~0.5 GB) exceeds the 256 MiB Infinity Cache and the kernel really
+streams from HBM.  value = factors linearised per second over the whole job.
+
+N > 1 (weak scaling): every rank owns its own F factors (the factor list of a multi-scan cost is sharded, point data never
+crosses GPUs); each step ends with one RCCL all-reduce (sum) of the dense [N*F x 29] per-factor H/b/error block array, the
+exchange step BASELINE.json's north_star names.
+
+Also reported: `roofline` for the dominant kernel (HIP-event timed inside this process), `cpu_baseline` (the FP64 OpenMP
+oracle on the host cores, bounded sample), the synchronous single-factor loop rate, and the parity of one factor's
+Gauss-Newton step against the oracle.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable copy rate)
+HBM_ACHIEVABLE_GBS = 6290.0
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def build_workload(api, ctx, n_factors, rank, rings, azimuths, resolution, k=10):
+    """F (target voxel map, source cloud, pose) triples; everything (kNN, covariances, voxel maps) built on the device."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(rings, azimuths)
+    # each rank walks its own stretch of the trajectory
+    poses = synth.arc_trajectory(n_factors + 1, start=(-12.0 + 0.7 * rank, -7.0 + 0.9 * rank, 1.8), yaw0_deg=10.0 + 7.0 * rank)
+    clouds, vmaps, host_scans = [], [], []
+    t0 = time.time()
+    for i, T in enumerate(poses):
+        pts = synth.scan(scene, T, dirs, frame_id=1000 * rank + i)
+        host_scans.append(pts)
+        g = api.PointCloudGPU.clone(pts, ctx=ctx)
+        g.find_neighbors(k, download=False)
+        g.estimate_covariances(k)
+        clouds.append(g)
+        if i < n_factors:
+            vmaps.append(api.GaussianVoxelMapGPU(resolution, ctx=ctx).insert(g))
+    log(f"generated {len(poses)} scans of {len(host_scans[0])} pts in {time.time() - t0:.1f}s")
+    fset = api.NonlinearFactorSetGPU(ctx)
+    deltas = []
+    for i in range(n_factors):
+        fset.add(api.IntegratedVGICPFactorGPU(i, i + 1, vmaps[i], clouds[i + 1]))  # binary factor: target i, source i+1
+        deltas.append(api.pose12(synth.relative_pose(poses[i], poses[i + 1])))
+    return {"fset": fset, "clouds": clouds, "vmaps": vmaps, "deltas": np.stack(deltas), "scans": host_scans, "poses": poses}
+
+
+def cpu_baseline_and_parity(api, wl, resolution, budget_s=12.0):
+    """Time the FP64 OpenMP oracle (restatement of gtsam_points::IntegratedVGICPFactor::linearize) on one factor of the same
+    workload and check the GPU Gauss-Newton step against it."""
+    import ctypes as C
+
+    from oracle import oracle as orc
+
+    clouds = wl["clouds"]
+    tgt_xyz, tgt_cov, _ = clouds[0].download(normals=False)
+    src_xyz, src_cov, _ = clouds[1].download(normals=False)
+    vm = orc.VoxelMap(resolution).insert(tgt_xyz, tgt_cov.astype(np.float64))
+    p4 = orc.points4(src_xyz)
+    c16 = orc.covs16(src_cov.astype(np.float64))
+    T = np.ascontiguousarray(wl["deltas"][0])
+    L = orc.Linearized6()
+    lib = orc.lib()
+    cores = orc.max_threads()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+
+    def run(threads, budget):
+        lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(L), None)  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(L), None)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or n >= 2000:
+                return n / dt, n
+
+    rate_all, n_all = run(cores, budget_s)
+    rate_ref, _ = run(min(2, cores), budget_s / 4)  # the reference's shipped num_threads (config_odometry_cpu.json:36)
+    ref = orc._lin_to_dict(L)
+    got = wl["fset"].linearize_poses(wl["deltas"])[0]
+    d_got = np.linalg.solve(got["H_ss"], -got["b_s"])
+    d_ref = np.linalg.solve(ref["H_ss"], -ref["b_s"])
+    parity = {
+        "inliers_equal": bool(got["num_inliers"] == ref["num_inliers"]),
+        "max_pose_delta_err": float(np.abs(d_got - d_ref).max()),
+        "tolerance": 1e-4,
+    }
+    base = {
+        "value": rate_all, "unit": "calls/s", "cores": cores, "kind": "port",
+        "sample": f"{n_all} linearize() calls of one {len(p4)}-pt factor (oracle/vgicp_oracle.c, OpenMP guided,8, all host cores)",
+        "value_2_threads": rate_ref,
+    }
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--factors", type=int, default=64, help="factors per GPU per step")
+    ap.add_argument("--rings", type=int, default=128)
+    ap.add_argument("--azimuths", type=int, default=1024)
+    ap.add_argument("--resolution", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU; the product path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from glim_amd import api
+
+    # run on torch's current stream so that torch.cuda.synchronize(), RCCL and our kernels are ordered together
+    stream = torch.cuda.current_stream()
+    ctx = api.Context(local_rank, 1, external_stream=stream.cuda_stream)
+    info = ctx.device_info()
+    wl = build_workload(api, ctx, args.factors, rank, args.rings, args.azimuths, args.resolution)
+    fset, F = wl["fset"], args.factors
+    n_pts = [c.size() for c in wl["clouds"][1:]]
+    n_vox = [v.voxelmap_info()["num_voxels"] for v in wl["vmaps"]]
+
+    # a few linearisation points per factor (the optimiser moves the poses between calls)
+    rng = np.random.default_rng(1234 + rank)
+    from glim_amd.se3 import se3_exp
+
+    pose_sets = []
+    for s in range(4):
+        P = np.empty((F, 12))
+        for f in range(F):
+            D = np.eye(4)
+            D[:3, :4] = wl["deltas"][f].reshape(3, 4)
+            P[f] = api.pose12(D @ se3_exp(rng.normal(size=6) * [2e-3, 2e-3, 2e-3, 1e-2, 1e-2, 1e-2] * (s > 0)))
+        pose_sets.append(P)
+
+    out = torch.zeros(world * F, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+
+    def step(i):
+        fset.linearize_device_async(pose_sets[i % len(pose_sets)], out.data_ptr(), rank * F)
+        if world > 1:
+            dist.all_reduce(out)  # RCCL sum over xGMI of the [world*F x 29] block array (non-owned rows are zero)
+            # (each rank's own rows were just overwritten; the others are re-zeroed below for the next step)
+
+    def rezero():
+        if world > 1:
+            out.zero_()
+
+    for i in range(args.warmup):
+        rezero()
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rezero()
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * F * args.steps / elapsed
+
+    # roofline of the dominant kernel, HIP events on the stream the kernel runs on (inside the library)
+    ms_kernel, ms_lin = fset.profile(pose_sets[0], iters=max(10, args.steps))
+    algo_bytes = float(sum(48 * n + 68 * v + 488 for n, v in zip(n_pts, n_vox)))  # B_lin = 48 N + 68 V + 488 per factor
+    achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "vgicp_kernel<LINEARIZE>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,
+        "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": ms_kernel, "linearize_ms": ms_lin,
+    }
+
+    result = None
+    if rank == 0:
+        # synchronous single-factor loop (upload pose, launch, 232-B readback, host sync per call)
+        single = api.NonlinearFactorSetGPU(ctx)
+        single.add(api.IntegratedVGICPFactorGPU(0, 1, wl["vmaps"][0], wl["clouds"][1]))
+        T1 = wl["deltas"][:1]
+        for _ in range(20):
+            single.linearize_poses(T1)
+        t1 = time.perf_counter()
+        n_sync = 300
+        for _ in range(n_sync):
+            single.linearize_poses(T1)
+        sync_rate = n_sync / (time.perf_counter() - t1)
+
+        result = {
+            "metric": "vgicp_linearize_calls_per_s", "value": value, "unit": "calls/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1] odometry128k: 131072-pt spinning-LiDAR scans vs 0.5 m voxel maps, batched VGICP linearize",
+                "factors_per_gpu": F, "points_per_factor": int(np.mean(n_pts)), "voxels_per_factor": int(np.mean(n_vox)),
+                "voxel_resolution_m": args.resolution, "factor_type": "binary", "collective": "rccl_all_reduce[world*F x 29] f64" if world > 1 else "none",
+                "device": info["name"],
+            },
+            "roofline": roofline,
+            "sync_single_factor_calls_per_s": sync_rate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline_and_parity(api, wl, args.resolution)
+            result["cpu_baseline"] = base
+            result["parity"] = parity
+            result["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""ctypes loader for libglim_amd.so (the C-ABI shared library declared in include/glim_amd.h).
+
+The product path fails loudly when the HIP extension is missing: there is NO CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglim_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+COMPACT_DOUBLES = 29
+FACTOR_BINARY = 0x1
+FACTOR_SURFACE_VALIDATION = 0x2
+
+ERR = {
+    0: "ok", -1: "invalid argument", -2: "HIP runtime error", -3: "no HIP device", -4: "voxel coordinate out of key range",
+    -5: "invalid state for this call", -6: "unsupported", -7: "out of memory",
+}
+
+
+class Linearized6(C.Structure):
+    _fields_ = [
+        ("num_inliers", C.c_int64),
+        ("error", C.c_double),
+        ("H_tt", C.c_double * 36),
+        ("H_ss", C.c_double * 36),
+        ("H_ts", C.c_double * 36),
+        ("b_t", C.c_double * 6),
+        ("b_s", C.c_double * 6),
+    ]
+
+
+class GlimAmdError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {ERR.get(code, 'unknown error')} ({code}){(' -- ' + detail) if detail else ''}")
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 with hipcc (glim_amd/csrc/Makefile) into glim_amd/libglim_amd.so."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("hipcc build did not produce " + LIB_PATH)
+    return LIB_PATH
+
+
+# every symbol include/glim_amd.h declares: name -> (restype, argtypes)
+_vp, _i, _i32, _i64, _u32, _d, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint32, C.c_double, C.c_size_t
+_dp, _fp, _ip, _lp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "glim_amd_version": (_i, []),
+    "glim_amd_error_string": (C.c_char_p, [_i]),
+    "glim_amd_last_hip_error": (C.c_char_p, []),
+    "glim_amd_device_count": (_i, []),
+    "glim_amd_ctx_create": (_i, [_i, _i, _vp, _pp]),
+    "glim_amd_ctx_destroy": (_i, [_vp]),
+    "glim_amd_ctx_synchronize": (_i, [_vp]),
+    "glim_amd_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
+    "glim_amd_cloud_create": (_i, [_vp, _i64, _dp, _dp, _dp, _pp]),
+    "glim_amd_cloud_create_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _pp]),
+    "glim_amd_cloud_destroy": (_i, [_vp]),
+    "glim_amd_cloud_size": (_i, [_vp, _lp]),
+    "glim_amd_cloud_memory_usage": (_i, [_vp, C.POINTER(_sz)]),
+    "glim_amd_cloud_download": (_i, [_vp, _fp, _fp, _fp, _ip]),
+    "glim_amd_cloud_find_neighbors": (_i, [_vp, _i, _ip]),
+    "glim_amd_cloud_set_neighbors": (_i, [_vp, _i, _ip]),
+    "glim_amd_cloud_estimate_covariances": (_i, [_vp, _i]),
+    "glim_amd_voxelmap_create": (_i, [_vp, _d, _i, _i, _d, _pp]),
+    "glim_amd_voxelmap_insert": (_i, [_vp, _vp]),
+    "glim_amd_voxelmap_destroy": (_i, [_vp]),
+    "glim_amd_voxelmap_info": (_i, [_vp, _ip, _ip, _dp, C.POINTER(_sz)]),
+    "glim_amd_voxelmap_download": (_i, [_vp, _ip, _ip, _fp, _fp]),
+    "glim_amd_factor_set_create": (_i, [_vp, _pp]),
+    "glim_amd_factor_set_destroy": (_i, [_vp]),
+    "glim_amd_factor_set_add": (_i, [_vp, _vp, _vp, _u32, _ip]),
+    "glim_amd_factor_set_clear": (_i, [_vp]),
+    "glim_amd_factor_set_size": (_i, [_vp, _ip]),
+    "glim_amd_factor_set_linearize": (_i, [_vp, _dp, C.POINTER(Linearized6)]),
+    "glim_amd_factor_set_error": (_i, [_vp, _dp, _dp, _dp, _lp]),
+    "glim_amd_factor_set_correspondences": (_i, [_vp, _i32, _dp, _ip]),
+    "glim_amd_factor_set_linearize_device_async": (_i, [_vp, _dp, _vp, _i64]),
+    "glim_amd_expand_compact": (_i, [_dp, _dp, _u32, C.POINTER(Linearized6)]),
+    "glim_amd_factor_set_profile": (_i, [_vp, _dp, _i, _fp, _fp]),
+    "glim_amd_overlap": (_i, [_vp, _i32, _pp, _dp, _vp, _dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libglim_amd.so; raises (never falls back) when it is missing or lacks a declared symbol."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C glim_amd/csrc).  glim_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared entry point
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code != 0:
+        detail = lib().glim_amd_last_hip_error().decode() if code == -2 else ""
+        raise GlimAmdError(code, where, detail)

@@ -1,0 +1,427 @@
+"""Host-side mirror of the gtsam_points GPU interface GLIM uses for the VGICP hot path.
+
+Same names and argument meaning as the reference-side classes so that tests read like the reference's call sites:
+
+    frame     = PointCloudGPU.clone(points, covs)                    # odometry_estimation_gpu.cpp:96
+    voxelmap  = GaussianVoxelMapGPU(resolution); voxelmap.insert(frame)   # :103-104
+    factor    = IntegratedVGICPFactorGPU(target_key, source_key, voxelmap, frame)   # :144  (binary)
+    factor    = IntegratedVGICPFactorGPU(fixed_target_pose, source_key, voxelmap, frame)   # :161  (unary)
+    factor.set_enable_surface_validation(True)                       # :145
+    fset      = NonlinearFactorSetGPU(); fset.add(factor); fset.linearize(values)   # :383-386
+    overlap   = overlap_gpu(voxelmap, frame, delta)                  # :248
+
+Everything below is a thin ctypes shim over the C ABI (include/glim_amd.h); all arithmetic happens in the HIP kernels.
+`Values` is a plain dict {key: 4x4 pose}; a linearised factor is returned as the HessianFactor ingredients.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FACTOR_BINARY, FACTOR_SURFACE_VALIDATION, GlimAmdError, Linearized6, check, lib  # noqa: F401
+
+_default_ctx = None
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def pose12(T):
+    T = np.asarray(T, dtype=np.float64)
+    if T.size == 12:
+        return np.ascontiguousarray(T).reshape(12)
+    return np.ascontiguousarray(T[:3, :4]).reshape(12)
+
+
+def device_count():
+    return lib().glim_amd_device_count()
+
+
+class Context:
+    """Device + stream pool (gtsam_points::CUDAStream / StreamTempBufferRoundRobin)."""
+
+    def __init__(self, device=0, num_streams=1, external_stream=None):
+        h = C.c_void_p()
+        check(lib().glim_amd_ctx_create(int(device), int(num_streams), C.c_void_p(external_stream) if external_stream else None,
+                                        C.byref(h)), "glim_amd_ctx_create")
+        self._h = h
+        self.device = device
+
+    def synchronize(self):
+        check(lib().glim_amd_ctx_synchronize(self._h), "glim_amd_ctx_synchronize")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        free, total, cus = C.c_size_t(), C.c_size_t(), C.c_int()
+        check(lib().glim_amd_device_info(self._h, name, 256, C.byref(free), C.byref(total), C.byref(cus)), "glim_amd_device_info")
+        return {"name": name.value.decode(), "free_bytes": free.value, "total_bytes": total.value, "num_cus": cus.value}
+
+    def close(self):
+        if self._h:
+            lib().glim_amd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0, 1)
+    return _default_ctx
+
+
+class PointCloudGPU:
+    """gtsam_points::PointCloudGPU -- device-resident FP32 SoA copy of a frame."""
+
+    def __init__(self, handle, ctx):
+        self._h = handle
+        self.ctx = ctx
+
+    @staticmethod
+    def clone(points, covs=None, normals=None, ctx=None):
+        """points: N x 3 or N x 4 (homogeneous); covs: N x 3 x 3 or N x 4 x 4 (Matrix4d); normals: N x 3 / N x 4.
+        float64 inputs travel in the reference's Vector4d / Matrix4d layout and are packed on the device; float32 inputs use
+        the compact entry point."""
+        ctx = ctx or default_context()
+        points = np.asarray(points)
+        n = points.shape[0]
+        h = C.c_void_p()
+        if points.dtype == np.float32 and (covs is None or np.asarray(covs).dtype == np.float32):
+            xyz = np.ascontiguousarray(points[:, :3], dtype=np.float32)
+            c = None if covs is None else np.ascontiguousarray(np.asarray(covs, dtype=np.float32)[:, :3, :3]).reshape(n, 9)
+            nr = None if normals is None else np.ascontiguousarray(np.asarray(normals, dtype=np.float32)[:, :3])
+            check(lib().glim_amd_cloud_create_f32(ctx._h, n, _fp(xyz), _fp(c), _fp(nr), C.byref(h)), "glim_amd_cloud_create_f32")
+        else:
+            p4 = np.ones((n, 4), dtype=np.float64)
+            p4[:, : min(4, points.shape[1])] = points[:, :4]
+            p4[:, 3] = 1.0
+            c16 = None
+            if covs is not None:
+                covs = np.asarray(covs, dtype=np.float64)
+                m = np.zeros((n, 4, 4))
+                m[:, :3, :3] = covs[:, :3, :3]
+                c16 = np.ascontiguousarray(np.transpose(m, (0, 2, 1))).reshape(n, 16)  # column-major Matrix4d
+            n4 = None
+            if normals is not None:
+                normals = np.asarray(normals, dtype=np.float64)
+                n4 = np.zeros((n, 4))
+                n4[:, :3] = normals[:, :3]
+            check(lib().glim_amd_cloud_create(ctx._h, n, _dp(p4), _dp(c16), _dp(n4), C.byref(h)), "glim_amd_cloud_create")
+        return PointCloudGPU(h, ctx)
+
+    def size(self):
+        n = C.c_int64()
+        check(lib().glim_amd_cloud_size(self._h, C.byref(n)), "glim_amd_cloud_size")
+        return n.value
+
+    def memory_usage_gpu(self):
+        b = C.c_size_t()
+        check(lib().glim_amd_cloud_memory_usage(self._h, C.byref(b)), "glim_amd_cloud_memory_usage")
+        return b.value
+
+    def find_neighbors(self, k, download=True):
+        """CloudPreprocessor::find_neighbors on the device; returns N x k int32 when download."""
+        out = np.zeros((self.size(), k), dtype=np.int32) if download else None
+        check(lib().glim_amd_cloud_find_neighbors(self._h, int(k), _ip(out)), "glim_amd_cloud_find_neighbors")
+        return out
+
+    def set_neighbors(self, neighbors):
+        nb = np.ascontiguousarray(neighbors, dtype=np.int32)
+        check(lib().glim_amd_cloud_set_neighbors(self._h, nb.shape[1], _ip(nb)), "glim_amd_cloud_set_neighbors")
+
+    def estimate_covariances(self, k_neighbors):
+        """CloudCovarianceEstimation::estimate on the device (fills covs + normals)."""
+        check(lib().glim_amd_cloud_estimate_covariances(self._h, int(k_neighbors)), "glim_amd_cloud_estimate_covariances")
+
+    def download(self, covs=True, normals=True):
+        n = self.size()
+        xyz = np.zeros((n, 3), dtype=np.float32)
+        c = np.zeros((n, 9), dtype=np.float32) if covs else None
+        nr = np.zeros((n, 3), dtype=np.float32) if normals else None
+        check(lib().glim_amd_cloud_download(self._h, _fp(xyz), _fp(c), _fp(nr), None), "glim_amd_cloud_download")
+        return xyz, (c.reshape(n, 3, 3) if covs else None), nr
+
+    def close(self):
+        if self._h:
+            lib().glim_amd_cloud_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GaussianVoxelMapGPU:
+    """gtsam_points::GaussianVoxelMapGPU(resolution, init_num_buckets, max_bucket_scan_count, target_points_drop_rate)."""
+
+    def __init__(self, resolution, init_num_buckets=8192 * 2, max_bucket_scan_count=10, target_points_drop_rate=1e-3, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib().glim_amd_voxelmap_create(self.ctx._h, float(resolution), int(init_num_buckets), int(max_bucket_scan_count),
+                                             float(target_points_drop_rate), C.byref(h)), "glim_amd_voxelmap_create")
+        self._h = h
+        self._frame = None
+
+    def voxel_resolution(self):
+        return self.voxelmap_info()["voxel_resolution"]
+
+    def insert(self, frame):
+        check(lib().glim_amd_voxelmap_insert(self._h, frame._h), "glim_amd_voxelmap_insert")
+        return self
+
+    def voxelmap_info(self):
+        nv, nb, res, by = C.c_int32(), C.c_int32(), C.c_double(), C.c_size_t()
+        check(lib().glim_amd_voxelmap_info(self._h, C.byref(nv), C.byref(nb), C.byref(res), C.byref(by)), "glim_amd_voxelmap_info")
+        return {"num_voxels": nv.value, "num_buckets": nb.value, "voxel_resolution": res.value, "bytes": by.value}
+
+    def voxels(self):
+        """(coords V x 3, counts V, means V x 3, covs V x 3 x 3), unspecified order."""
+        v = self.voxelmap_info()["num_voxels"]
+        coords = np.zeros((v, 3), dtype=np.int32)
+        counts = np.zeros(v, dtype=np.int32)
+        means = np.zeros((v, 3), dtype=np.float32)
+        covs = np.zeros((v, 9), dtype=np.float32)
+        check(lib().glim_amd_voxelmap_download(self._h, _ip(coords), _ip(counts), _fp(means), _fp(covs)), "glim_amd_voxelmap_download")
+        return coords, counts, means, covs.reshape(v, 3, 3)
+
+    def close(self):
+        if self._h:
+            lib().glim_amd_voxelmap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _lin_to_dict(L):
+    return {
+        "num_inliers": int(L.num_inliers),
+        "error": float(L.error),
+        "H_tt": np.array(L.H_tt).reshape(6, 6),
+        "H_ss": np.array(L.H_ss).reshape(6, 6),
+        "H_ts": np.array(L.H_ts).reshape(6, 6),
+        "b_t": np.array(L.b_t),
+        "b_s": np.array(L.b_s),
+    }
+
+
+class IntegratedVGICPFactorGPU:
+    """gtsam_points::IntegratedVGICPFactorGPU.
+
+    IntegratedVGICPFactorGPU(target_key, source_key, target_voxelmap, source)            binary
+    IntegratedVGICPFactorGPU(fixed_target_pose(4x4), source_key, target_voxelmap, source)  unary
+    """
+
+    def __init__(self, target, source_key, target_voxelmap, source, stream=None, temp_buffer=None):
+        self.is_binary = not (isinstance(target, np.ndarray) or isinstance(target, (list, tuple)))
+        if self.is_binary:
+            self.target_key = target
+            self.fixed_target_pose = None
+        else:
+            self.target_key = None
+            self.fixed_target_pose = np.array(target, dtype=np.float64).reshape(4, 4)
+        self.source_key = source_key
+        self.target_voxelmap = target_voxelmap
+        self.source = source
+        self.enable_surface_validation = False
+        self._linearized = None  # filled by NonlinearFactorSetGPU (store_linearized in the reference's batch protocol)
+        self._own_set = None
+
+    # -- reference API ------------------------------------------------------------------------------------------
+    def set_enable_surface_validation(self, enable):
+        self.enable_surface_validation = bool(enable)
+        self._own_set = None
+
+    def keys(self):
+        return [self.target_key, self.source_key] if self.is_binary else [self.source_key]
+
+    def dim(self):
+        return 6
+
+    def get_fixed_target_pose(self):
+        return self.fixed_target_pose
+
+    def memory_usage(self):
+        return 976  # one glim_amd_linearized6 on the host
+
+    def memory_usage_gpu(self):
+        return self.source.memory_usage_gpu() + self.target_voxelmap.voxelmap_info()["bytes"]
+
+    def clone(self):
+        f = IntegratedVGICPFactorGPU(self.target_key if self.is_binary else self.fixed_target_pose, self.source_key,
+                                     self.target_voxelmap, self.source)
+        f.enable_surface_validation = self.enable_surface_validation
+        return f
+
+    def flags(self):
+        return (FACTOR_BINARY if self.is_binary else 0) | (FACTOR_SURFACE_VALIDATION if self.enable_surface_validation else 0)
+
+    def calc_delta(self, values):
+        """T_target_source at `values` (dict key -> 4x4)."""
+        Ts = np.asarray(values[self.source_key], dtype=np.float64)
+        Tt = np.asarray(values[self.target_key], dtype=np.float64) if self.is_binary else self.fixed_target_pose
+        return np.linalg.inv(Tt) @ Ts
+
+    def _single_set(self):
+        if self._own_set is None:
+            self._own_set = NonlinearFactorSetGPU(self.source.ctx)
+            self._own_set.add(self)
+        return self._own_set
+
+    def linearize(self, values):
+        """HessianFactor ingredients.  Uses the batch result when a NonlinearFactorSetGPU linearised this factor at the
+        same values; otherwise performs its own upload/launch/download (the reference's slow path)."""
+        delta = self.calc_delta(values)
+        if self._linearized is not None and np.array_equal(self._linearized[0], delta):
+            return self._linearized[1]
+        self._single_set().linearize(values)
+        return self._linearized[1]
+
+    def error(self, values):
+        return self._single_set().error(values)[0]
+
+    def inlier_fraction(self):
+        if self._linearized is None:
+            return 0.0
+        return self._linearized[1]["num_inliers"] / max(1, self.source.size())
+
+
+class NonlinearFactorSetGPU:
+    """gtsam_points::NonlinearFactorSetGPU: linearises every added GPU factor in one fused launch."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib().glim_amd_factor_set_create(self.ctx._h, C.byref(h)), "glim_amd_factor_set_create")
+        self._h = h
+        self.factors = []
+
+    def add(self, factor):
+        if not isinstance(factor, IntegratedVGICPFactorGPU):
+            return False  # non-GPU factors are ignored, like the reference
+        idx = C.c_int32()
+        check(lib().glim_amd_factor_set_add(self._h, factor.target_voxelmap._h, factor.source._h, factor.flags(), C.byref(idx)),
+              "glim_amd_factor_set_add")
+        self.factors.append(factor)
+        return True
+
+    def clear(self):
+        check(lib().glim_amd_factor_set_clear(self._h), "glim_amd_factor_set_clear")
+        self.factors = []
+
+    def size(self):
+        n = C.c_int32()
+        check(lib().glim_amd_factor_set_size(self._h, C.byref(n)), "glim_amd_factor_set_size")
+        return n.value
+
+    def _poses(self, values):
+        return np.ascontiguousarray(np.stack([pose12(f.calc_delta(values)) for f in self.factors])) if self.factors else np.zeros((0, 12))
+
+    def linearize(self, values):
+        n = len(self.factors)
+        if n == 0:
+            return []
+        T = self._poses(values)
+        out = (Linearized6 * n)()
+        check(lib().glim_amd_factor_set_linearize(self._h, _dp(T), out), "glim_amd_factor_set_linearize")
+        res = []
+        for f, L, t in zip(self.factors, out, T):
+            d = _lin_to_dict(L)
+            delta = np.eye(4)
+            delta[:3, :4] = t.reshape(3, 4)
+            f._linearized = (delta, d)
+            res.append(d)
+        return res
+
+    def linearize_poses(self, T_target_source):
+        """Same with explicit n x 12 poses (no Values indirection)."""
+        n = len(self.factors)
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(n, 12))
+        out = (Linearized6 * n)()
+        check(lib().glim_amd_factor_set_linearize(self._h, _dp(T), out), "glim_amd_factor_set_linearize")
+        return [_lin_to_dict(L) for L in out]
+
+    def error(self, values, values_lin=None):
+        n = len(self.factors)
+        if n == 0:
+            return []
+        Te = self._poses(values)
+        Tl = self._poses(values_lin) if values_lin is not None else None
+        err = np.zeros(n)
+        inl = np.zeros(n, dtype=np.int64)
+        check(lib().glim_amd_factor_set_error(self._h, _dp(Tl), _dp(Te), _dp(err), inl.ctypes.data_as(C.POINTER(C.c_int64))),
+              "glim_amd_factor_set_error")
+        self.last_error_inliers = inl
+        return list(err)
+
+    def correspondences(self, index, delta):
+        n = self.factors[index].source.size()
+        corr = np.zeros((n, 4), dtype=np.int32)
+        T = pose12(delta)
+        check(lib().glim_amd_factor_set_correspondences(self._h, int(index), _dp(T), _ip(corr)), "glim_amd_factor_set_correspondences")
+        return corr
+
+    def linearize_device_async(self, T_target_source, out_device_ptr, row_offset=0):
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
+        check(lib().glim_amd_factor_set_linearize_device_async(self._h, _dp(T), C.c_void_p(out_device_ptr), int(row_offset)),
+              "glim_amd_factor_set_linearize_device_async")
+
+    def profile(self, T_target_source, iters=20):
+        """(ms per fused VGICP kernel launch, ms per device-resident linearise) measured with HIP events on the set's stream."""
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
+        a, b = C.c_float(), C.c_float()
+        check(lib().glim_amd_factor_set_profile(self._h, _dp(T), int(iters), C.byref(a), C.byref(b)), "glim_amd_factor_set_profile")
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().glim_amd_factor_set_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def expand_compact(compact, T_target_source, flags):
+    c = np.ascontiguousarray(compact, dtype=np.float64).reshape(_lib.COMPACT_DOUBLES)
+    T = pose12(T_target_source)
+    L = Linearized6()
+    check(lib().glim_amd_expand_compact(_dp(c), _dp(T), int(flags), C.byref(L)), "glim_amd_expand_compact")
+    return _lin_to_dict(L)
+
+
+def overlap_gpu(target_voxelmaps, source, deltas, ctx=None):
+    """gtsam_points::overlap_gpu: single (voxelmap, source, delta) or multi-target (voxelmaps[], source, deltas[])."""
+    if isinstance(target_voxelmaps, GaussianVoxelMapGPU):
+        target_voxelmaps, deltas = [target_voxelmaps], [deltas]
+    ctx = ctx or source.ctx
+    hs = (C.c_void_p * len(target_voxelmaps))(*[m._h.value for m in target_voxelmaps])
+    T = np.ascontiguousarray(np.stack([pose12(d) for d in deltas]))
+    out = C.c_double()
+    check(lib().glim_amd_overlap(ctx._h, len(target_voxelmaps), hs, _dp(T), source._h, C.byref(out)), "glim_amd_overlap")
+    return out.value
+
+
+overlap_auto = overlap_gpu

@@ -1,0 +1,240 @@
+// cloud.hip -- PointCloudGPU equivalent: upload + FP64-AoS -> FP32-SoA pack on the device (kernel K7).
+// Replaces gtsam_points::PointCloudGPU::clone as called at src/glim/odometry/odometry_estimation_gpu.cpp:96,
+// src/glim/mapping/sub_mapping.cpp:168,393 and src/glim/mapping/global_mapping.cpp:253,260,743.
+#include "internal.hpp"
+
+using namespace glim_amd;
+
+namespace {
+
+// One thread per point: reads the reference's host layouts (Vector4d / column-major Matrix4d) from a raw device
+// staging copy and writes the SoA the hot kernels stream: float4 xyz1, float4 (c00 c01 c02 c11), float2 (c12 c22), float4 n.
+__global__ __launch_bounds__(256) void pack_f64_kernel(int64_t n, const double* __restrict__ points4, const double* __restrict__ covs16,
+                                                       const double* __restrict__ normals4, float4* __restrict__ pts,
+                                                       float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = reinterpret_cast<const double4*>(points4)[i];
+  pts[i] = make_float4((float)p.x, (float)p.y, (float)p.z, 1.0f);
+  if (covs16) {
+    const double* c = covs16 + 16 * i;  // column-major 4x4: (r,c) at c*4 + r
+    covA[i] = make_float4((float)c[0], (float)c[4], (float)c[8], (float)c[5]);
+    covB[i] = make_float2((float)c[9], (float)c[10]);
+  }
+  if (normals4) {
+    const double4 v = reinterpret_cast<const double4*>(normals4)[i];
+    nrm[i] = make_float4((float)v.x, (float)v.y, (float)v.z, 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_f32_kernel(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov33,
+                                                       const float* __restrict__ normals3, float4* __restrict__ pts,
+                                                       float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pts[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 1.0f);
+  if (cov33) {
+    const float* c = cov33 + 9 * i;
+    covA[i] = make_float4(c[0], c[1], c[2], c[4]);
+    covB[i] = make_float2(c[5], c[8]);
+  }
+  if (normals3) nrm[i] = make_float4(normals3[3 * i], normals3[3 * i + 1], normals3[3 * i + 2], 0.0f);
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __restrict__ pts, const float4* __restrict__ covA,
+                                                     const float2* __restrict__ covB, const float4* __restrict__ nrm, float* __restrict__ xyz,
+                                                     float* __restrict__ cov33, float* __restrict__ normals3) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (xyz) {
+    const float4 p = pts[i];
+    xyz[3 * i] = p.x;
+    xyz[3 * i + 1] = p.y;
+    xyz[3 * i + 2] = p.z;
+  }
+  if (cov33 && covA) {
+    const float4 a = covA[i];
+    const float2 b = covB[i];
+    float* c = cov33 + 9 * i;
+    c[0] = a.x; c[1] = a.y; c[2] = a.z;
+    c[3] = a.y; c[4] = a.w; c[5] = b.x;
+    c[6] = a.z; c[7] = b.x; c[8] = b.y;
+  }
+  if (normals3 && nrm) {
+    const float4 v = nrm[i];
+    normals3[3 * i] = v.x;
+    normals3[3 * i + 1] = v.y;
+    normals3[3 * i + 2] = v.z;
+  }
+}
+
+int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_cloud** out) {
+  glim_amd_cloud* c = new glim_amd_cloud();
+  c->ctx = ctx;
+  c->n = n;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  hipError_t e = hipMalloc(&c->pts, nn * sizeof(float4));
+  if (e == hipSuccess && covs) e = hipMalloc(&c->covA, nn * sizeof(float4));
+  if (e == hipSuccess && covs) e = hipMalloc(&c->covB, nn * sizeof(float2));
+  if (e == hipSuccess && normals) e = hipMalloc(&c->normals, nn * sizeof(float4));
+  if (e != hipSuccess) {
+    set_hip_error(e, "hipMalloc(cloud)");
+    glim_amd_cloud_destroy(c);
+    return e == hipErrorOutOfMemory ? GLIM_AMD_ERR_NOMEM : GLIM_AMD_ERR_HIP;
+  }
+  c->has_covs = covs;
+  c->has_normals = normals;
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+struct DeviceTemp {
+  void* p = nullptr;
+  ~DeviceTemp() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* covs16, const double* normals4,
+                          glim_amd_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !points4)) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  glim_amd_cloud* c = nullptr;
+  GA_TRY(alloc_cloud(ctx, n, covs16 != nullptr, normals4 != nullptr, &c));
+  if (n > 0) {
+    hipStream_t s = ctx->stream();
+    DeviceTemp dp, dc, dn;
+    hipError_t e = hipMalloc(&dp.p, (size_t)n * 4 * sizeof(double));
+    if (e == hipSuccess && covs16) e = hipMalloc(&dc.p, (size_t)n * 16 * sizeof(double));
+    if (e == hipSuccess && normals4) e = hipMalloc(&dn.p, (size_t)n * 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(dp.p, points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && covs16) e = hipMemcpyAsync(dc.p, covs16, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && normals4) e = hipMemcpyAsync(dn.p, normals4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      const int blocks = (int)((n + 255) / 256);
+      pack_f64_kernel<<<blocks, 256, 0, s>>>(n, (const double*)dp.p, (const double*)dc.p, (const double*)dn.p, c->pts, c->covA, c->covB,
+                                             c->normals);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      set_hip_error(e, "cloud_create upload/pack");
+      glim_amd_cloud_destroy(c);
+      return GLIM_AMD_ERR_HIP;
+    }
+  }
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, const float* cov33, const float* normals3,
+                              glim_amd_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  glim_amd_cloud* c = nullptr;
+  GA_TRY(alloc_cloud(ctx, n, cov33 != nullptr, normals3 != nullptr, &c));
+  if (n > 0) {
+    hipStream_t s = ctx->stream();
+    DeviceTemp dp, dc, dn;
+    hipError_t e = hipMalloc(&dp.p, (size_t)n * 3 * sizeof(float));
+    if (e == hipSuccess && cov33) e = hipMalloc(&dc.p, (size_t)n * 9 * sizeof(float));
+    if (e == hipSuccess && normals3) e = hipMalloc(&dn.p, (size_t)n * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dp.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && cov33) e = hipMemcpyAsync(dc.p, cov33, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && normals3) e = hipMemcpyAsync(dn.p, normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      const int blocks = (int)((n + 255) / 256);
+      pack_f32_kernel<<<blocks, 256, 0, s>>>(n, (const float*)dp.p, (const float*)dc.p, (const float*)dn.p, c->pts, c->covA, c->covB,
+                                             c->normals);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      set_hip_error(e, "cloud_create_f32 upload/pack");
+      glim_amd_cloud_destroy(c);
+      return GLIM_AMD_ERR_HIP;
+    }
+  }
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_destroy(glim_amd_cloud* c) {
+  if (!c) return GLIM_AMD_OK;
+  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->pts) (void)hipFree(c->pts);
+  if (c->covA) (void)hipFree(c->covA);
+  if (c->covB) (void)hipFree(c->covB);
+  if (c->normals) (void)hipFree(c->normals);
+  if (c->neighbors) (void)hipFree(c->neighbors);
+  delete c;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_size(const glim_amd_cloud* c, int64_t* n) {
+  if (!c || !n) return GLIM_AMD_ERR_INVALID;
+  *n = c->n;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_memory_usage(const glim_amd_cloud* c, size_t* bytes) {
+  if (!c || !bytes) return GLIM_AMD_ERR_INVALID;
+  *bytes = c->bytes();
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_download(const glim_amd_cloud* c, float* xyz, float* cov33, float* normals3, int32_t* neighbors) {
+  if (!c) return GLIM_AMD_ERR_INVALID;
+  if (cov33 && !c->has_covs) return GLIM_AMD_ERR_STATE;
+  if (normals3 && !c->has_normals) return GLIM_AMD_ERR_STATE;
+  if (neighbors && !c->neighbors) return GLIM_AMD_ERR_STATE;
+  if (c->n == 0) return GLIM_AMD_OK;
+  glim_amd_ctx* ctx = c->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream();
+  const int64_t n = c->n;
+  DeviceTemp dx, dc, dn;
+  if (xyz) GA_HIP(hipMalloc(&dx.p, (size_t)n * 3 * sizeof(float)));
+  if (cov33) GA_HIP(hipMalloc(&dc.p, (size_t)n * 9 * sizeof(float)));
+  if (normals3) GA_HIP(hipMalloc(&dn.p, (size_t)n * 3 * sizeof(float)));
+  if (xyz || cov33 || normals3) {
+    unpack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(n, c->pts, c->covA, c->covB, c->normals, (float*)dx.p, (float*)dc.p, (float*)dn.p);
+    GA_HIP(hipGetLastError());
+  }
+  if (xyz) GA_HIP(hipMemcpyAsync(xyz, dx.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (cov33) GA_HIP(hipMemcpyAsync(cov33, dc.p, (size_t)n * 9 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (normals3) GA_HIP(hipMemcpyAsync(normals3, dn.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (neighbors) GA_HIP(hipMemcpyAsync(neighbors, c->neighbors, (size_t)n * c->k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GA_HIP(hipStreamSynchronize(s));
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_set_neighbors(glim_amd_cloud* c, int k, const int32_t* neighbors) {
+  if (!c || k <= 0 || (c->n > 0 && !neighbors)) return GLIM_AMD_ERR_INVALID;
+  glim_amd_ctx* ctx = c->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  if (c->neighbors) {
+    (void)hipFree(c->neighbors);
+    c->neighbors = nullptr;
+  }
+  c->k = k;
+  const size_t bytes = (size_t)(c->n > 0 ? c->n : 1) * k * sizeof(int32_t);
+  GA_HIP(hipMalloc(&c->neighbors, bytes));
+  if (c->n > 0) {
+    GA_HIP(hipMemcpyAsync(c->neighbors, neighbors, (size_t)c->n * k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream()));
+    GA_HIP(hipStreamSynchronize(ctx->stream()));
+  }
+  return GLIM_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// device_math.hpp -- device-side helpers shared by the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "internal.hpp"
+
+namespace glim_amd {
+
+// fast_floor(x) = (int)x - (x < (int)x): the voxel-coordinate rule of the reference
+// (gtsam_points util/fast_floor.hpp; in-tree twin src/glim/viewer/editor/points_selector.cpp:177).
+__device__ __forceinline__ int fast_floor_d(double x) {
+  const int i = __double2int_rz(x);
+  return i - (x < (double)i);
+}
+
+// q = R p + t in FP64 with the exact fma order of oracle/vgicp_oracle.c:orc_transform_point -- this expression is
+// the parity contract that makes voxel coordinates (and hence correspondences) bit-identical to the CPU path.
+__device__ __forceinline__ void transform_point_d(const double* __restrict__ T, double px, double py, double pz, double& qx,
+                                                  double& qy, double& qz) {
+  qx = __fma_rn(T[0], px, __fma_rn(T[1], py, __fma_rn(T[2], pz, T[3])));
+  qy = __fma_rn(T[4], px, __fma_rn(T[5], py, __fma_rn(T[6], pz, T[7])));
+  qz = __fma_rn(T[8], px, __fma_rn(T[9], py, __fma_rn(T[10], pz, T[11])));
+}
+
+// 3 x 21-bit packed voxel coordinate.  Returns EMPTY_KEY when a coordinate is outside [-2^20, 2^20).
+__device__ __forceinline__ unsigned long long pack_key(int cx, int cy, int cz) {
+  const unsigned int ux = (unsigned int)(cx + KEY_OFFSET);
+  const unsigned int uy = (unsigned int)(cy + KEY_OFFSET);
+  const unsigned int uz = (unsigned int)(cz + KEY_OFFSET);
+  if ((ux | uy | uz) >> KEY_BITS) return EMPTY_KEY;
+  return ((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz;
+}
+
+__device__ __forceinline__ void unpack_key(unsigned long long key, int& cx, int& cy, int& cz) {
+  const unsigned int m = (1u << KEY_BITS) - 1u;
+  cx = (int)((key >> (2 * KEY_BITS)) & m) - KEY_OFFSET;
+  cy = (int)((key >> KEY_BITS) & m) - KEY_OFFSET;
+  cz = (int)(key & m) - KEY_OFFSET;
+}
+
+__device__ __forceinline__ unsigned long long voxel_key(double qx, double qy, double qz, double inv_res) {
+  return pack_key(fast_floor_d(qx * inv_res), fast_floor_d(qy * inv_res), fast_floor_d(qz * inv_res));
+}
+
+// 64 -> 32 bit mixer (splitmix64 finaliser); any hash is valid because lookups compare the full key.
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
+  k ^= k >> 30;
+  k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27;
+  k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return (unsigned int)k;
+}
+
+// Linear probe for `key`; returns the slot index or -1.  The table is never full (load <= 1/2).
+__device__ __forceinline__ int find_slot(const VoxelSlot* __restrict__ slots, unsigned int mask, unsigned long long key) {
+  if (key == EMPTY_KEY) return -1;
+  unsigned int s = hash_key(key) & mask;
+  for (;;) {
+    const unsigned long long k = slots[s].key;
+    if (k == key) return (int)s;
+    if (k == EMPTY_KEY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64-lane wavefront sum with DPP (no LDS traffic): quad xor-1, xor-2, row_half_mirror, row_mirror give every lane of a
+// 16-lane row the row sum; row_bcast:15 and row_bcast:31 fold the four rows, the total lands in lane 63.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_f<0x140, 0xF>(v);  // row_mirror
+  v += dpp_f<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+  v += dpp_f<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+}  // namespace glim_amd

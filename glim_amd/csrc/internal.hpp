@@ -1,0 +1,156 @@
+// internal.hpp -- host-side object model behind the C ABI (include/glim_amd.h) and shared device helpers.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, DPP row_bcast reductions, no other target is supported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/glim_amd.h"
+
+namespace glim_amd {
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+void set_hip_error(hipError_t e, const char* what);
+
+#define GA_HIP(call)                                   \
+  do {                                                 \
+    hipError_t _e = (call);                            \
+    if (_e != hipSuccess) {                            \
+      ::glim_amd::set_hip_error(_e, #call);            \
+      return GLIM_AMD_ERR_HIP;                         \
+    }                                                  \
+  } while (0)
+
+#define GA_TRY(call)                 \
+  do {                               \
+    int _rc = (call);                \
+    if (_rc != GLIM_AMD_OK) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// device data layouts
+// ---------------------------------------------------------------------------------------------------------------
+
+// One hash slot of a Gaussian voxel map: 64 bytes, 64-byte aligned, key and statistic in the SAME cache line so a
+// lookup costs one random line (SURVEY.md 8a row a5 stores a 16-B bucket + a 52-B record in two arrays).
+//   key   : packed voxel coordinate (21 bits per axis, offset 2^20), EMPTY_KEY when free
+//   mean  : FP32 mean of the member means
+//   cov   : FP32 mean of the member covariances, symmetric storage c00 c01 c02 c11 c12 c22
+//   count : number of member points
+struct alignas(64) VoxelSlot {
+  unsigned long long key;
+  float mx, my;                 // 16 B
+  float mz, c00, c01, c02;      // 16 B
+  float c11, c12, c22;
+  int count;                    // 16 B
+  int pad[4];                   // 16 B (keeps slots line-aligned)
+};
+static_assert(sizeof(VoxelSlot) == 64, "VoxelSlot must be one 64-byte line");
+
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+constexpr int KEY_BITS = 21;
+constexpr int KEY_OFFSET = 1 << 20;
+
+// Per-factor descriptor consumed by the fused VGICP kernel (device array, rebuilt when the set changes).
+struct FactorDesc {
+  const float4* pts;        // source xyz1
+  const float4* covA;       // c00 c01 c02 c11
+  const float2* covB;       // c12 c22
+  const float4* normals;    // may be null
+  const VoxelSlot* slots;   // target table
+  unsigned int mask;        // table_size - 1
+  int n;                    // source points
+  double inv_res;           // 1 / target resolution
+  unsigned int flags;
+  int first_block;          // index of this factor's first partial row
+  int num_blocks;           // partial rows (= chunks) of this factor
+  int pad;
+};
+
+constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
+constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
+
+}  // namespace glim_amd
+
+// ---------------------------------------------------------------------------------------------------------------
+// C-ABI object definitions (opaque to callers)
+// ---------------------------------------------------------------------------------------------------------------
+struct glim_amd_ctx {
+  int device = 0;
+  int num_cus = 0;
+  bool owns_streams = true;
+  std::vector<hipStream_t> streams;
+  int next_stream = 0;
+  std::mutex mu;
+  hipStream_t stream() const { return streams[0]; }
+  hipStream_t round_robin() {
+    hipStream_t s = streams[next_stream];
+    next_stream = (next_stream + 1) % (int)streams.size();
+    return s;
+  }
+};
+
+struct glim_amd_cloud {
+  glim_amd_ctx* ctx = nullptr;
+  int64_t n = 0;
+  float4* pts = nullptr;
+  float4* covA = nullptr;
+  float2* covB = nullptr;
+  float4* normals = nullptr;
+  int32_t* neighbors = nullptr;
+  int k = 0;
+  bool has_covs = false;
+  bool has_normals = false;
+  size_t bytes() const {
+    size_t b = (size_t)n * sizeof(float4);
+    if (covA) b += (size_t)n * (sizeof(float4) + sizeof(float2));
+    if (normals) b += (size_t)n * sizeof(float4);
+    if (neighbors) b += (size_t)n * k * sizeof(int32_t);
+    return b;
+  }
+};
+
+struct glim_amd_voxelmap {
+  glim_amd_ctx* ctx = nullptr;
+  double resolution = 0.0;
+  double inv_resolution = 0.0;
+  int32_t num_voxels = 0;
+  uint32_t table_size = 0;  // power of two, 0 until insert()
+  glim_amd::VoxelSlot* slots = nullptr;
+};
+
+struct glim_amd_factor_set {
+  glim_amd_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  struct Entry {
+    const glim_amd_voxelmap* target;
+    const glim_amd_cloud* source;
+    uint32_t flags;
+  };
+  std::vector<Entry> entries;
+  bool dirty = true;  // device plan needs a rebuild
+  // device plan
+  int points_per_thread = 1;
+  int total_blocks = 0;
+  glim_amd::FactorDesc* d_descs = nullptr;
+  int2* d_blockmap = nullptr;
+  float* d_partials = nullptr;
+  double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
+  double* d_compact = nullptr;    // n x COMPACT
+  double* h_poses = nullptr;      // pinned
+  double* h_compact = nullptr;    // pinned
+  size_t cap_factors = 0, cap_blocks = 0;
+  std::vector<glim_amd::FactorDesc> h_descs;
+};
+
+namespace glim_amd {
+int factor_set_prepare(glim_amd_factor_set* set);
+void factor_set_release_plan(glim_amd_factor_set* set);
+}  // namespace glim_amd

@@ -1,0 +1,711 @@
+// vgicp.hip -- the VGICP matching-cost factor on gfx950 (kernels K4 linearise, K5 error, K6 overlap) and the factor-set
+// (NonlinearFactorSetGPU) entry points of the C ABI.
+//
+// Replaces gtsam_points::IntegratedVGICPFactorGPU::{linearize,error} + NonlinearFactorSetGPU::linearize + overlap_gpu as
+// called from src/glim/odometry/odometry_estimation_gpu.cpp:144,161,231,248,383-386, src/glim/mapping/sub_mapping.cpp:252,307
+// and src/glim/mapping/global_mapping.cpp:322,335,448,466,860.  The arithmetic follows the CPU factor
+// (gtsam_points::IntegratedVGICPFactor, the parity oracle: SURVEY.md App. B.5):
+//
+//   q = R p + t                      FP64, fixed fma order (bit-exact voxel coordinates / correspondences)
+//   voxel = table[floor(q / res)]    exact 64-bit key compare, linear probing, one 64-byte line per probe
+//   M = (C_B + R C_A R^T)^-1,  r = mu_B - q,  e = r^T M r
+//   H_ss += J_s^T M J_s,  b_s += J_s^T M r,   J_s = [R hat(p) | -R]
+//
+// Two algebraic restructurings keep the kernel HBM-bound (DESIGN.md "K4"):
+//   (1) everything is evaluated in the SOURCE frame: A = R^T M R = (R^T C_B R + C_A)^-1, rs = R^T r, J' = [hat(p) | -I];
+//       then H_ss = J'^T A J' has the block form [[-P A P, P A], [(P A)^T, A]] with P = hat(p) -- 21 + 6 + 1 sums per point.
+//   (2) the target-side blocks of a BINARY factor are never accumulated per point: J_t = -J_s Ad(delta^-1) exactly, hence
+//       H_tt = Ad^T H_ss Ad, H_ts = -Ad^T H_ss, b_t = -Ad^T b_s are recovered in FP64 from the 6x6 source block
+//       (glim_amd_expand_compact).  A binary factor costs the same 28 accumulators as a unary one instead of 122.
+//
+// Reduction: per-thread FP32 accumulators over up to `points_per_thread` points -> 64-lane DPP wave sum -> LDS across the
+// 4 waves of a block -> one 32-float partial row per block -> FP64 fixed-order sum per factor (finalise kernel).
+// The result is bit-reproducible run to run (no floating-point atomics anywhere).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "device_math.hpp"
+#include "internal.hpp"
+
+using namespace glim_amd;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int NACC = 28;  // FP32 accumulators per thread (see layout below); slot 28 of a partial row = inlier count (int bits)
+
+// accumulator layout:  0..5  Hww (00 01 02 11 12 22)   6..14 G = hat(p) A (row-major 3x3 = H_wv)   15..20 A (00 01 02 11 12 22)
+//                      21..23 u x p (= b_w)            24..26 u (b_v = -u)                          27 e
+// compact record:      [count, error, 21 upper-triangular H_ss entries row-major, 6 b_s]
+__constant__ int c_acc_of_upper[21] = {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20};
+
+__device__ __forceinline__ float4 ld16(const void* p) { return *reinterpret_cast<const float4*>(p); }
+
+enum { MODE_LINEARIZE = 0, MODE_ERROR = 1 };
+
+template <int MODE, bool FROZEN>
+__global__ __launch_bounds__(BLOCK) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+                                                       const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
+                                                       float* __restrict__ partials, int ppt) {
+  __shared__ float s_red[4][PARTIAL_STRIDE];
+  const int2 bm = blockmap[blockIdx.x];
+  const int f = bm.x;
+  if (f < 0) return;  // padding block of the XCD-aware map
+  const FactorDesc d = descs[f];
+  const double* Tl = poses_lin + 12 * (size_t)f;
+  const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
+
+  // rotation of the linearisation pose in FP32 (R[r][c])
+  const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
+  const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
+  const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
+  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals != nullptr;
+
+  float acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; j++) acc[j] = 0.f;
+  int inliers = 0;
+
+  const int base = bm.y * (BLOCK * ppt) + threadIdx.x;
+  for (int it = 0; it < ppt; it++) {
+    const int i = base + it * BLOCK;
+    if (i >= d.n) break;
+    const float4 p4 = d.pts[i];
+    const double px = (double)p4.x, py = (double)p4.y, pz = (double)p4.z;
+    double qx, qy, qz;
+    transform_point_d(Tl, px, py, pz, qx, qy, qz);
+    const unsigned long long key = voxel_key(qx, qy, qz, d.inv_res);
+
+    // ---- lookup: exact key match, linear probing; the first 16 B of a slot hold key + mean.xy ----
+    bool hit = false;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned int slot = hash_key(key) & d.mask;
+    if (key != EMPTY_KEY) {
+      for (;;) {
+        s0 = ld16(d.slots + slot);
+        const unsigned long long k =
+          (unsigned long long)__float_as_uint(s0.x) | ((unsigned long long)__float_as_uint(s0.y) << 32);
+        if (k == key) {
+          hit = true;
+          break;
+        }
+        if (k == EMPTY_KEY) break;
+        slot = (slot + 1) & d.mask;
+      }
+    }
+    if (hit && validate) {
+      // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
+      // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
+      const float4 nn = d.normals[i];
+      const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
+      const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
+      const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
+      if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) hit = false;
+    }
+    if (!hit) continue;
+    inliers++;
+
+    const float4 s1 = ld16(reinterpret_cast<const char*>(d.slots + slot) + 16);  // mz c00 c01 c02
+    const float4 s2 = ld16(reinterpret_cast<const char*>(d.slots + slot) + 32);  // c11 c12 c22 count
+    const float4 ca = d.covA[i];
+    const float2 cb = d.covB[i];
+
+    // residual in the target frame (FP64 difference, then FP32), at the evaluation pose
+    double ex = qx, ey = qy, ez = qz;
+    if (FROZEN) transform_point_d(Te, px, py, pz, ex, ey, ez);
+    const float rx = (float)((double)s0.z - ex);
+    const float ry = (float)((double)s0.w - ey);
+    const float rz = (float)((double)s1.x - ez);
+
+    // S = R^T C_B R + C_A   (source frame, symmetric)
+    const float b00 = s1.y, b01 = s1.z, b02 = s1.w, b11 = s2.x, b12 = s2.y, b22 = s2.z;
+    const float w00 = b00 * R00 + b01 * R10 + b02 * R20, w01 = b00 * R01 + b01 * R11 + b02 * R21, w02 = b00 * R02 + b01 * R12 + b02 * R22;
+    const float w10 = b01 * R00 + b11 * R10 + b12 * R20, w11 = b01 * R01 + b11 * R11 + b12 * R21, w12 = b01 * R02 + b11 * R12 + b12 * R22;
+    const float w20 = b02 * R00 + b12 * R10 + b22 * R20, w21 = b02 * R01 + b12 * R11 + b22 * R21, w22 = b02 * R02 + b12 * R12 + b22 * R22;
+    const float S00 = ca.x + R00 * w00 + R10 * w10 + R20 * w20;
+    const float S01 = ca.y + R00 * w01 + R10 * w11 + R20 * w21;
+    const float S02 = ca.z + R00 * w02 + R10 * w12 + R20 * w22;
+    const float S11 = ca.w + R01 * w01 + R11 * w11 + R21 * w21;
+    const float S12 = cb.x + R01 * w02 + R11 * w12 + R21 * w22;
+    const float S22 = cb.y + R02 * w02 + R12 * w12 + R22 * w22;
+
+    // A = S^-1 by cofactors (symmetric)
+    const float k00 = S11 * S22 - S12 * S12;
+    const float k01 = S02 * S12 - S01 * S22;
+    const float k02 = S01 * S12 - S02 * S11;
+    const float det = S00 * k00 + S01 * k01 + S02 * k02;
+    const float idet = 1.0f / det;
+    const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
+    const float A11 = (S00 * S22 - S02 * S02) * idet;
+    const float A12 = (S01 * S02 - S00 * S12) * idet;
+    const float A22 = (S00 * S11 - S01 * S01) * idet;
+
+    // rs = R^T r,  u = A rs,  e = rs . u
+    const float rsx = R00 * rx + R10 * ry + R20 * rz;
+    const float rsy = R01 * rx + R11 * ry + R21 * rz;
+    const float rsz = R02 * rx + R12 * ry + R22 * rz;
+    const float ux = A00 * rsx + A01 * rsy + A02 * rsz;
+    const float uy = A01 * rsx + A11 * rsy + A12 * rsz;
+    const float uz = A02 * rsx + A12 * rsy + A22 * rsz;
+    acc[27] += rsx * ux + rsy * uy + rsz * uz;
+
+    if (MODE == MODE_LINEARIZE) {
+      const float x = p4.x, y = p4.y, z = p4.z;
+      // G = hat(p) A : column j = p x A[:,j]
+      const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
+      const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
+      const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
+      // Hww = -G hat(p) : row i = p x G[i,:]
+      acc[0] += y * g02 - z * g01;
+      acc[1] += z * g00 - x * g02;
+      acc[2] += x * g01 - y * g00;
+      acc[3] += z * g10 - x * g12;
+      acc[4] += x * g11 - y * g10;
+      acc[5] += x * g21 - y * g20;
+      acc[6] += g00; acc[7] += g01; acc[8] += g02;
+      acc[9] += g10; acc[10] += g11; acc[11] += g12;
+      acc[12] += g20; acc[13] += g21; acc[14] += g22;
+      acc[15] += A00; acc[16] += A01; acc[17] += A02; acc[18] += A11; acc[19] += A12; acc[20] += A22;
+      // b_w = u x p,  b_v = -u
+      acc[21] += uy * z - uz * y;
+      acc[22] += uz * x - ux * z;
+      acc[23] += ux * y - uy * x;
+      acc[24] += ux; acc[25] += uy; acc[26] += uz;
+    }
+  }
+
+  // ---- block reduction: DPP wave sums -> LDS -> one partial row ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE == MODE_LINEARIZE) {
+#pragma unroll
+    for (int j = 0; j < NACC; j++) {
+      const float v = wave_sum_to_lane63(acc[j]);
+      if (lane == 63) s_red[wave][j] = v;
+    }
+  } else {
+    const float v = wave_sum_to_lane63(acc[27]);
+    if (lane == 63) s_red[wave][27] = v;
+  }
+  {
+    const float v = wave_sum_to_lane63((float)inliers);  // <= 64 * ppt: exact in FP32
+    if (lane == 63) s_red[wave][28] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < PARTIAL_STRIDE) {
+    const int j = threadIdx.x;
+    float v = 0.f;
+    const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
+    if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
+    partials[(size_t)blockIdx.x * PARTIAL_STRIDE + j] = v;
+  }
+}
+
+// One block of 64 threads per factor: fixed-order FP64 sum of the factor's partial rows -> compact record.
+// The partial row of block b lives at partials[b]; a factor's rows are the blocks whose blockmap entry names it, listed in
+// `rows` (d.first_block .. first_block + num_blocks - 1 index into `rows`).
+__global__ __launch_bounds__(64) void finalize_kernel(const FactorDesc* __restrict__ descs, const int* __restrict__ rows,
+                                                      const float* __restrict__ partials, double* __restrict__ out, long long out_row_offset,
+                                                      int mode) {
+  const int f = blockIdx.x;
+  const int j = threadIdx.x;
+  __shared__ double s_sum[PARTIAL_STRIDE];
+  const int first = descs[f].first_block, nb = descs[f].num_blocks;
+  if (j < PARTIAL_STRIDE) {
+    double s = 0.0;
+    for (int c = 0; c < nb; c++) s += (double)partials[(size_t)rows[first + c] * PARTIAL_STRIDE + j];
+    s_sum[j] = s;
+  }
+  __syncthreads();
+  double* o = out + ((size_t)out_row_offset + f) * COMPACT;
+  if (j == 0) o[0] = s_sum[28];
+  if (j == 1) o[1] = s_sum[27];
+  if (mode == MODE_LINEARIZE) {
+    if (j < 21) o[2 + j] = s_sum[c_acc_of_upper[j]];
+    if (j >= 21 && j < 24) o[2 + j] = s_sum[j];          // b_w = sum u x p
+    if (j >= 24 && j < 27) o[2 + j] = -s_sum[j];         // b_v = -sum u
+  } else if (j >= 2 && j < COMPACT) {
+    o[j] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  const float4 p4 = d.pts[i];
+  double qx, qy, qz;
+  transform_point_d(pose, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
+  const int cx = fast_floor_d(qx * d.inv_res), cy = fast_floor_d(qy * d.inv_res), cz = fast_floor_d(qz * d.inv_res);
+  bool hit = find_slot(d.slots, d.mask, pack_key(cx, cy, cz)) >= 0;
+  if (hit && (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals) {
+    const float4 nn = d.normals[i];
+    const float rnx = (float)pose[0] * nn.x + (float)pose[1] * nn.y + (float)pose[2] * nn.z;
+    const float rny = (float)pose[4] * nn.x + (float)pose[5] * nn.y + (float)pose[6] * nn.z;
+    const float rnz = (float)pose[8] * nn.x + (float)pose[9] * nn.y + (float)pose[10] * nn.z;
+    if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) hit = false;
+  }
+  corr[4 * (size_t)i + 0] = cx;
+  corr[4 * (size_t)i + 1] = cy;
+  corr[4 * (size_t)i + 2] = cz;
+  corr[4 * (size_t)i + 3] = hit ? 1 : -1;
+}
+
+struct OverlapTarget {
+  const VoxelSlot* slots;
+  unsigned int mask;
+  int pad;
+  double inv_res;
+  double T[12];
+};
+
+// K6: a point counts once if ANY (map_j, delta_j) contains it (odometry_estimation_gpu.cpp:224-231).
+__global__ __launch_bounds__(BLOCK) void overlap_kernel(int n, const float4* __restrict__ pts, const OverlapTarget* __restrict__ targets,
+                                                         int num_targets, unsigned int* __restrict__ hits) {
+  int mine = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p4 = pts[i];
+    for (int t = 0; t < num_targets; t++) {
+      double qx, qy, qz;
+      transform_point_d(targets[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
+      if (find_slot(targets[t].slots, targets[t].mask, voxel_key(qx, qy, qz, targets[t].inv_res)) >= 0) {
+        mine++;
+        break;
+      }
+    }
+  }
+  const float v = wave_sum_to_lane63((float)mine);  // per-thread counts are tiny: exact in FP32
+  if ((threadIdx.x & 63) == 63 && v > 0.f) atomicAdd(hits, (unsigned int)v);
+}
+
+void hat3(const double* a, double* H) {
+  H[0] = 0; H[1] = -a[2]; H[2] = a[1];
+  H[3] = a[2]; H[4] = 0; H[5] = -a[0];
+  H[6] = -a[1]; H[7] = a[0]; H[8] = 0;
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------------------------------
+// plan management
+// -----------------------------------------------------------------------------------------------------------------
+namespace glim_amd {
+
+void factor_set_release_plan(glim_amd_factor_set* set) {
+  if (set->d_descs) (void)hipFree(set->d_descs);
+  if (set->d_blockmap) (void)hipFree(set->d_blockmap);
+  if (set->d_partials) (void)hipFree(set->d_partials);
+  if (set->d_poses) (void)hipFree(set->d_poses);
+  if (set->d_compact) (void)hipFree(set->d_compact);
+  if (set->h_poses) (void)hipHostFree(set->h_poses);
+  if (set->h_compact) (void)hipHostFree(set->h_compact);
+  set->d_descs = nullptr;
+  set->d_blockmap = nullptr;
+  set->d_partials = nullptr;
+  set->d_poses = nullptr;
+  set->d_compact = nullptr;
+  set->h_poses = nullptr;
+  set->h_compact = nullptr;
+  set->cap_factors = set->cap_blocks = 0;
+}
+
+// Build the device plan: factor descriptors, chunking, and the XCD-aware block -> (factor, chunk) map.
+// Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"); when the set holds enough
+// factors, all chunks of one factor are given block ids of one residue class so that the factor's voxel table stays in a
+// single XCD's 4 MiB L2.  This is a speed-only choice: any placement is correct.
+int factor_set_prepare(glim_amd_factor_set* set) {
+  if (!set->dirty) return GLIM_AMD_OK;
+  const int nf = (int)set->entries.size();
+  glim_amd_ctx* ctx = set->ctx;
+  long long total_points = 0;
+  for (auto& e : set->entries) total_points += e.source->n;
+  int ppt = 1;
+  if (const char* env = getenv("GLIM_AMD_PPT")) {
+    ppt = std::max(1, std::min(64, atoi(env)));
+  } else {
+    const long long resident_threads = (long long)std::max(1, ctx->num_cus) * 1024;
+    ppt = (int)std::max(1ll, std::min(8ll, total_points / std::max(1ll, resident_threads)));
+  }
+  set->points_per_thread = ppt;
+  const int chunk = BLOCK * ppt;
+
+  set->h_descs.assign(nf, FactorDesc());
+  std::vector<int> nblocks(nf);
+  long long total_blocks = 0;
+  for (int f = 0; f < nf; f++) {
+    const auto& e = set->entries[f];
+    FactorDesc& d = set->h_descs[f];
+    d.pts = e.source->pts;
+    d.covA = e.source->covA;
+    d.covB = e.source->covB;
+    d.normals = e.source->has_normals ? e.source->normals : nullptr;
+    d.slots = e.target->slots;
+    d.mask = e.target->table_size - 1;
+    d.n = (int)e.source->n;
+    d.inv_res = e.target->inv_resolution;
+    d.flags = e.flags;
+    nblocks[f] = std::max(1, (d.n + chunk - 1) / chunk);
+    d.num_blocks = nblocks[f];
+    total_blocks += nblocks[f];
+  }
+
+  // block map
+  std::vector<int2> blockmap;
+  const bool xcd_group = nf >= 16 && getenv("GLIM_AMD_NO_XCD_MAP") == nullptr;
+  if (!xcd_group) {
+    blockmap.reserve((size_t)total_blocks);
+    for (int f = 0; f < nf; f++)
+      for (int c = 0; c < nblocks[f]; c++) blockmap.push_back(make_int2(f, c));
+  } else {
+    std::vector<std::vector<int2>> per_xcd(8);
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < nf; f++) {
+      int x = 0;
+      for (int k = 1; k < 8; k++)
+        if (load[k] < load[x]) x = k;
+      load[x] += nblocks[f];
+      for (int c = 0; c < nblocks[f]; c++) per_xcd[x].push_back(make_int2(f, c));
+    }
+    size_t longest = 0;
+    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+    blockmap.assign(longest * 8, make_int2(-1, 0));
+    for (int x = 0; x < 8; x++)
+      for (size_t j = 0; j < per_xcd[x].size(); j++) blockmap[j * 8 + x] = per_xcd[x][j];
+  }
+  // rows[]: for each factor the list of grid block ids that hold its partials, in chunk order
+  std::vector<int> rows((size_t)total_blocks);
+  {
+    std::vector<int> first(nf);
+    int acc = 0;
+    for (int f = 0; f < nf; f++) {
+      first[f] = acc;
+      set->h_descs[f].first_block = acc;
+      acc += nblocks[f];
+    }
+    for (size_t b = 0; b < blockmap.size(); b++) {
+      if (blockmap[b].x < 0) continue;
+      rows[(size_t)first[blockmap[b].x] + blockmap[b].y] = (int)b;
+    }
+  }
+  set->total_blocks = (int)blockmap.size();
+
+  factor_set_release_plan(set);
+  const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
+  GA_HIP(hipMalloc(&set->d_descs, nfa * sizeof(FactorDesc)));
+  GA_HIP(hipMalloc(&set->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
+  GA_HIP(hipMalloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
+  GA_HIP(hipMalloc(&set->d_poses, nfa * 24 * sizeof(double)));
+  GA_HIP(hipMalloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
+  GA_HIP(hipHostMalloc(&set->h_poses, nfa * 24 * sizeof(double), hipHostMallocDefault));
+  GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocDefault));
+  set->cap_factors = nfa;
+  set->cap_blocks = nba;
+  if (nf > 0) {
+    GA_HIP(hipMemcpyAsync(set->d_descs, set->h_descs.data(), (size_t)nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipMemcpyAsync(set->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipMemcpyAsync(reinterpret_cast<char*>(set->d_blockmap) + nba * sizeof(int2), rows.data(), rows.size() * sizeof(int),
+                          hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipStreamSynchronize(set->stream));
+  }
+  set->dirty = false;
+  return GLIM_AMD_OK;
+}
+
+}  // namespace glim_amd
+
+namespace {
+
+const int* rows_ptr(const glim_amd_factor_set* set) {
+  return reinterpret_cast<const int*>(reinterpret_cast<const char*>(set->d_blockmap) + set->cap_blocks * sizeof(int2));
+}
+
+// enqueue (no sync): poses already in d_poses; writes compact records to `out` rows [row_offset, row_offset + n)
+int launch_linearize(glim_amd_factor_set* set, double* out, long long row_offset) {
+  const int nf = (int)set->entries.size();
+  if (nf == 0) return GLIM_AMD_OK;
+  vgicp_kernel<MODE_LINEARIZE, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+                                                                                     set->d_partials, set->points_per_thread);
+  finalize_kernel<<<nf, 64, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, out, row_offset, MODE_LINEARIZE);
+  GA_HIP(hipGetLastError());
+  return GLIM_AMD_OK;
+}
+
+int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_eval) {
+  const size_t nf = set->entries.size();
+  memcpy(set->h_poses, T_lin, nf * 12 * sizeof(double));
+  if (T_eval) memcpy(set->h_poses + nf * 12, T_eval, nf * 12 * sizeof(double));
+  GA_HIP(hipMemcpyAsync(set->d_poses, set->h_poses, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
+  return GLIM_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glim_amd_factor_set_create(glim_amd_ctx* ctx, glim_amd_factor_set** out) {
+  if (!ctx || !out) return GLIM_AMD_ERR_INVALID;
+  glim_amd_factor_set* s = new glim_amd_factor_set();
+  s->ctx = ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    s->stream = ctx->round_robin();
+  }
+  *out = s;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_destroy(glim_amd_factor_set* set) {
+  if (!set) return GLIM_AMD_OK;
+  (void)hipSetDevice(set->ctx->device);
+  (void)hipStreamSynchronize(set->stream);
+  factor_set_release_plan(set);
+  delete set;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_add(glim_amd_factor_set* set, const glim_amd_voxelmap* target, const glim_amd_cloud* source, uint32_t flags,
+                            int32_t* factor_index) {
+  if (!set || !target || !source) return GLIM_AMD_ERR_INVALID;
+  if (target->ctx != set->ctx || source->ctx != set->ctx) return GLIM_AMD_ERR_INVALID;
+  if (!target->slots || !source->has_covs) return GLIM_AMD_ERR_STATE;
+  if (source->n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;
+  set->entries.push_back({target, source, flags});
+  set->dirty = true;
+  if (factor_index) *factor_index = (int32_t)set->entries.size() - 1;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_clear(glim_amd_factor_set* set) {
+  if (!set) return GLIM_AMD_ERR_INVALID;
+  set->entries.clear();
+  set->dirty = true;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_size(const glim_amd_factor_set* set, int32_t* n) {
+  if (!set || !n) return GLIM_AMD_ERR_INVALID;
+  *n = (int32_t)set->entries.size();
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_expand_compact(const double* c, const double* T, uint32_t flags, glim_amd_linearized6* out) {
+  if (!c || !out) return GLIM_AMD_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->num_inliers = (int64_t)llround(c[0]);
+  out->error = c[1];
+  int k = 2;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      out->H_ss[6 * i + j] = c[k];
+      out->H_ss[6 * j + i] = c[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) out->b_s[i] = c[k++];
+  if ((flags & GLIM_AMD_FACTOR_BINARY) && T) {
+    // Ad = Adjoint(delta^-1) = [R^T 0; -R^T hat(t) R^T]   ([omega; v] ordering)
+    double Rt[9], Ht[9], Ad[36];
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) Rt[3 * r + cc] = T[4 * cc + r];
+    const double t[3] = {T[3], T[7], T[11]};
+    hat3(t, Ht);
+    memset(Ad, 0, sizeof(Ad));
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) {
+        Ad[6 * r + cc] = Rt[3 * r + cc];
+        Ad[6 * (r + 3) + cc + 3] = Rt[3 * r + cc];
+        double s = 0.0;
+        for (int m = 0; m < 3; m++) s += Rt[3 * r + m] * Ht[3 * m + cc];
+        Ad[6 * (r + 3) + cc] = -s;
+      }
+    double AtH[36];  // Ad^T H_ss
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) {
+        double s = 0.0;
+        for (int m = 0; m < 6; m++) s += Ad[6 * m + i] * out->H_ss[6 * m + j];
+        AtH[6 * i + j] = s;
+      }
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j < 6; j++) {
+        double s = 0.0;
+        for (int m = 0; m < 6; m++) s += AtH[6 * i + m] * Ad[6 * m + j];
+        out->H_tt[6 * i + j] = s;
+        out->H_ts[6 * i + j] = -AtH[6 * i + j];
+      }
+      double s = 0.0;
+      for (int m = 0; m < 6; m++) s += Ad[6 * m + i] * out->b_s[m];
+      out->b_t[i] = -s;
+    }
+    // symmetrise H_tt against rounding
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++) {
+        const double s = 0.5 * (out->H_tt[6 * i + j] + out->H_tt[6 * j + i]);
+        out->H_tt[6 * i + j] = out->H_tt[6 * j + i] = s;
+      }
+  }
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T, glim_amd_linearized6* out) {
+  if (!set) return GLIM_AMD_ERR_INVALID;
+  const size_t nf = set->entries.size();
+  if (nf == 0) return GLIM_AMD_OK;
+  if (!T || !out) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  GA_TRY(upload_poses(set, T, nullptr));
+  GA_TRY(launch_linearize(set, set->d_compact, 0));
+  GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  GA_HIP(hipStreamSynchronize(set->stream));
+  for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(set->h_compact + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const double* T, double* out_device, int64_t out_row_offset) {
+  if (!set || !out_device || out_row_offset < 0) return GLIM_AMD_ERR_INVALID;
+  if (set->entries.empty()) return GLIM_AMD_OK;
+  if (!T) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  GA_TRY(upload_poses(set, T, nullptr));
+  return launch_linearize(set, out_device, out_row_offset);
+}
+
+int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, double* errors, int64_t* inliers) {
+  if (!set) return GLIM_AMD_ERR_INVALID;
+  const size_t nf = set->entries.size();
+  if (nf == 0) return GLIM_AMD_OK;
+  if (!T_eval || !errors) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  if (T_lin) {
+    GA_TRY(upload_poses(set, T_lin, T_eval));
+    vgicp_kernel<MODE_ERROR, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
+                                                                                  set->d_blockmap, set->d_partials, set->points_per_thread);
+  } else {
+    GA_TRY(upload_poses(set, T_eval, nullptr));
+    vgicp_kernel<MODE_ERROR, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+                                                                                   set->d_partials, set->points_per_thread);
+  }
+  finalize_kernel<<<(int)nf, 64, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, set->d_compact, 0, MODE_ERROR);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  GA_HIP(hipStreamSynchronize(set->stream));
+  for (size_t f = 0; f < nf; f++) {
+    errors[f] = set->h_compact[f * COMPACT + 1];
+    if (inliers) inliers[f] = (int64_t)llround(set->h_compact[f * COMPACT]);
+  }
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_correspondences(glim_amd_factor_set* set, int32_t fi, const double* T, int32_t* corr) {
+  if (!set || !T || fi < 0 || fi >= (int32_t)set->entries.size()) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  const FactorDesc d = set->h_descs[fi];
+  if (d.n == 0) return GLIM_AMD_OK;
+  if (!corr) return GLIM_AMD_ERR_INVALID;
+  double* d_pose = nullptr;
+  int32_t* d_corr = nullptr;
+  GA_HIP(hipMalloc(&d_pose, 12 * sizeof(double)));
+  hipError_t e = hipMalloc(&d_corr, (size_t)d.n * 4 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pose, T, 12 * sizeof(double), hipMemcpyHostToDevice, set->stream);
+  if (e == hipSuccess) {
+    correspondence_kernel<<<(d.n + BLOCK - 1) / BLOCK, BLOCK, 0, set->stream>>>(d, d_pose, d_corr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(corr, d_corr, (size_t)d.n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, set->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(set->stream);
+  (void)hipFree(d_pose);
+  if (d_corr) (void)hipFree(d_corr);
+  if (e != hipSuccess) {
+    set_hip_error(e, "factor_set_correspondences");
+    return GLIM_AMD_ERR_HIP;
+  }
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int iters, float* ms_kernel, float* ms_linearize) {
+  if (!set || !T || iters <= 0) return GLIM_AMD_ERR_INVALID;
+  const int nf = (int)set->entries.size();
+  if (nf == 0) return GLIM_AMD_ERR_STATE;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  GA_TRY(upload_poses(set, T, nullptr));
+  hipEvent_t e0, e1;
+  GA_HIP(hipEventCreate(&e0));
+  GA_HIP(hipEventCreate(&e1));
+  // warm-up
+  GA_TRY(launch_linearize(set, set->d_compact, 0));
+  GA_HIP(hipStreamSynchronize(set->stream));
+  float ms = 0.f;
+  GA_HIP(hipEventRecord(e0, set->stream));
+  for (int i = 0; i < iters; i++)
+    vgicp_kernel<MODE_LINEARIZE, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+                                                                                       set->d_partials, set->points_per_thread);
+  GA_HIP(hipEventRecord(e1, set->stream));
+  GA_HIP(hipEventSynchronize(e1));
+  GA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_kernel) *ms_kernel = ms / (float)iters;
+  GA_HIP(hipEventRecord(e0, set->stream));
+  for (int i = 0; i < iters; i++) GA_TRY(launch_linearize(set, set->d_compact, 0));
+  GA_HIP(hipEventRecord(e1, set->stream));
+  GA_HIP(hipEventSynchronize(e1));
+  GA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_linearize) *ms_linearize = ms / (float)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T,
+                     const glim_amd_cloud* source, double* overlap) {
+  if (!ctx || num_targets <= 0 || !targets || !T || !source || !overlap) return GLIM_AMD_ERR_INVALID;
+  for (int t = 0; t < num_targets; t++) {
+    if (!targets[t] || targets[t]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
+    if (!targets[t]->slots) return GLIM_AMD_ERR_STATE;
+  }
+  if (source->n == 0) {
+    *overlap = 0.0;
+    return GLIM_AMD_OK;
+  }
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream();
+  std::vector<OverlapTarget> h(num_targets);
+  for (int t = 0; t < num_targets; t++) {
+    h[t].slots = targets[t]->slots;
+    h[t].mask = targets[t]->table_size - 1;
+    h[t].pad = 0;
+    h[t].inv_res = targets[t]->inv_resolution;
+    memcpy(h[t].T, T + 12 * (size_t)t, 12 * sizeof(double));
+  }
+  OverlapTarget* d_t = nullptr;
+  unsigned int* d_hits = nullptr;
+  GA_HIP(hipMalloc(&d_t, (size_t)num_targets * sizeof(OverlapTarget)));
+  hipError_t e = hipMalloc(&d_hits, sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemsetAsync(d_hits, 0, sizeof(unsigned int), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_t, h.data(), (size_t)num_targets * sizeof(OverlapTarget), hipMemcpyHostToDevice, st);
+  unsigned int hits = 0;
+  if (e == hipSuccess) {
+    const int n = (int)source->n;
+    const int blocks = std::min((n + BLOCK - 1) / BLOCK, std::max(1, ctx->num_cus) * 8);
+    overlap_kernel<<<blocks, BLOCK, 0, st>>>(n, source->pts, d_t, num_targets, d_hits);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&hits, d_hits, sizeof(hits), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_t);
+  if (d_hits) (void)hipFree(d_hits);
+  if (e != hipSuccess) {
+    set_hip_error(e, "overlap");
+    return GLIM_AMD_ERR_HIP;
+  }
+  *overlap = (double)hits / (double)source->n;
+  return GLIM_AMD_OK;
+}
+
+}  // extern "C"

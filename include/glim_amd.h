@@ -1,0 +1,162 @@
+/*
+ * glim_amd.h -- C ABI of the MI355X-native (gfx950) VGICP scan-matching hot path for GLIM.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch/Eigen types.  Each entry
+ * point names the reference interface it replaces.  The reference (koide3/glim v1.2.2) reaches this path through
+ * koide3/gtsam_points (un-vendored, CMakeLists.txt:28); the file:line citations are GLIM's call sites of those
+ * gtsam_points symbols, relative to /root/reference.
+ *
+ * Conventions
+ *   - return value: 0 = GLIM_AMD_OK, < 0 = error code (glim_amd_error_string).  Never throws, never aborts.
+ *   - poses: 12 doubles, row-major 3x4 [R | t]  (Eigen::Isometry3d::matrix().topRows<3>()).
+ *     T_target_source = T_target^-1 * T_source for binary factors, fixed_target_pose^-1 * T_source for unary ones.
+ *   - tangent order [omega(3); v(3)] (gtsam::Pose3), right perturbation T (+) xi = T * Exp(xi).
+ *   - host point layouts are the reference's: Eigen::Vector4d points / normals (stride 4 doubles), Eigen::Matrix4d
+ *     covariances (16 doubles, column-major, zero last row/col)   include/glim/preprocess/preprocessed_frame.hpp:31,
+ *     src/glim/common/cloud_covariance_estimation.cpp:96.  Host arrays are borrowed only for the duration of a call.
+ *   - all device work of a context runs on its HIP stream(s); calls are synchronous unless named *_async.
+ *   - handles are owned by the caller; destroy children (clouds, voxel maps, factor sets) before their context.
+ */
+#ifndef GLIM_AMD_H
+#define GLIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLIM_AMD_VERSION 100 /* 0.1.0 */
+
+enum {
+  GLIM_AMD_OK = 0,
+  GLIM_AMD_ERR_INVALID = -1,     /* bad argument */
+  GLIM_AMD_ERR_HIP = -2,         /* HIP runtime failure (glim_amd_last_hip_error) */
+  GLIM_AMD_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+  GLIM_AMD_ERR_RANGE = -4,       /* voxel coordinate outside the +-2^20 key range */
+  GLIM_AMD_ERR_STATE = -5,       /* call not valid in this state (e.g. covariances requested before kNN) */
+  GLIM_AMD_ERR_UNSUPPORTED = -6, /* not implemented in this build */
+  GLIM_AMD_ERR_NOMEM = -7
+};
+
+typedef struct glim_amd_ctx glim_amd_ctx;                 /* device + stream pool (CUDAStream / StreamTempBufferRoundRobin) */
+typedef struct glim_amd_cloud glim_amd_cloud;             /* gtsam_points::PointCloudGPU */
+typedef struct glim_amd_voxelmap glim_amd_voxelmap;       /* gtsam_points::GaussianVoxelMapGPU */
+typedef struct glim_amd_factor_set glim_amd_factor_set;   /* gtsam_points::NonlinearFactorSetGPU of IntegratedVGICPFactorGPU */
+
+/* Result of one factor linearisation -- the FP64 image of gtsam_points' LinearizedSystem6.
+ * H_* row-major 6x6.  gtsam::HessianFactor(k_t, k_s, H_tt, H_ts, -b_t, H_ss, -b_s, error)  (unary: k_s, H_ss, -b_s, error). */
+typedef struct {
+  int64_t num_inliers;
+  double error;
+  double H_tt[36];
+  double H_ss[36];
+  double H_ts[36];
+  double b_t[6];
+  double b_s[6];
+} glim_amd_linearized6;
+
+/* factor flags */
+#define GLIM_AMD_FACTOR_BINARY 0x1             /* fill H_tt, H_ts, b_t (otherwise they are zero: unary factor) */
+#define GLIM_AMD_FACTOR_SURFACE_VALIDATION 0x2 /* IntegratedVGICPFactorGPU::set_enable_surface_validation(true) */
+
+/* ---- library / context --------------------------------------------------------------------------------------- */
+int glim_amd_version(void);
+const char* glim_amd_error_string(int code);
+/* last HIP error text seen by this thread's failing call ("" if none). */
+const char* glim_amd_last_hip_error(void);
+/* number of visible HIP devices (0 on a CPU-only box; never fails). */
+int glim_amd_device_count(void);
+
+/* Replaces gtsam_points::CUDAStream + StreamTempBufferRoundRobin(num_streams)
+ * (src/glim/odometry/odometry_estimation_gpu.cpp:76-77, src/glim/mapping/sub_mapping.cpp:86-87, global_mapping.cpp:110).
+ * external_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create `num_streams` streams. */
+int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim_amd_ctx** out);
+int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
+int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
+/* gtsam_points::cuda_device_names / cuda_mem_get_info (src/glim/util/debug.cpp:84, viewer/memory_monitor.cpp:39). */
+int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t* free_bytes, size_t* total_bytes, int* num_cus);
+
+/* ---- point clouds: PointCloudGPU::clone (odometry_estimation_gpu.cpp:96, sub_mapping.cpp:168,393, global_mapping.cpp:253,260,743) */
+/* points4: n x 4 doubles (required).  covs16: n x 16 doubles or NULL.  normals4: n x 4 doubles or NULL.
+ * Device layout: FP32 SoA -- float4 xyz1, symmetric covariance as float4 (c00 c01 c02 c11) + float2 (c12 c22), float4 normals. */
+int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* covs16, const double* normals4,
+                          glim_amd_cloud** out);
+/* same from compact FP32 arrays: xyz n x 3, cov33 n x 9 (row-major, symmetric) or NULL, normals3 n x 3 or NULL. */
+int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, const float* cov33, const float* normals3,
+                              glim_amd_cloud** out);
+int glim_amd_cloud_destroy(glim_amd_cloud* cloud);
+int glim_amd_cloud_size(const glim_amd_cloud* cloud, int64_t* n);
+/* device bytes held (IntegratedVGICPFactorGPU::memory_usage_gpu accounting, viewer/standard_viewer_mem.cpp:52-56). */
+int glim_amd_cloud_memory_usage(const glim_amd_cloud* cloud, size_t* bytes);
+/* copy back (parity / debug): any pointer may be NULL.  xyz n x 3, cov33 n x 9, normals3 n x 3, neighbors n x k. */
+int glim_amd_cloud_download(const glim_amd_cloud* cloud, float* xyz, float* cov33, float* normals3, int32_t* neighbors);
+
+/* kNN on device: CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221).
+ * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> padded with i.
+ * Result stays on the device inside the cloud (and is copied to neighbors_out, n x k, when not NULL). */
+int glim_amd_cloud_find_neighbors(glim_amd_cloud* cloud, int k, int32_t* neighbors_out);
+/* upload caller-provided neighbours (n x k) instead. */
+int glim_amd_cloud_set_neighbors(glim_amd_cloud* cloud, int k, const int32_t* neighbors);
+/* CloudCovarianceEstimation::estimate (src/glim/common/cloud_covariance_estimation.cpp:43-122, PLANE regularisation :181-196):
+ * fills the cloud's covariances and sensor-facing normals from the first k_neighbors stored neighbours. */
+int glim_amd_cloud_estimate_covariances(glim_amd_cloud* cloud, int k_neighbors);
+
+/* ---- Gaussian voxel maps: GaussianVoxelMapGPU(resolution, ...) + insert(frame)
+ *      (odometry_estimation_gpu.cpp:103-104, sub_mapping.cpp:398-399, global_mapping.cpp:265-266,747-748) ------------ */
+/* The reference's init_num_buckets / max_bucket_scan_count / target_points_drop_rate are accepted for signature
+ * compatibility and ignored: this build is lossless (every point is inserted). */
+int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int init_num_buckets, int max_bucket_scan_count,
+                             double target_points_drop_rate, glim_amd_voxelmap** out);
+/* one-shot build from a cloud that has covariances.  Voxel = mean of member means, mean of member covariances. */
+int glim_amd_voxelmap_insert(glim_amd_voxelmap* vmap, const glim_amd_cloud* cloud);
+int glim_amd_voxelmap_destroy(glim_amd_voxelmap* vmap);
+/* VoxelMapInfo (standard_viewer_mem.cpp:76-77): num_voxels, num_buckets, resolution, device bytes. */
+int glim_amd_voxelmap_info(const glim_amd_voxelmap* vmap, int32_t* num_voxels, int32_t* num_buckets, double* resolution,
+                           size_t* bytes);
+/* copy back all voxels (unspecified order): coords V x 3, counts V, means V x 3, cov33 V x 9.  Any may be NULL. */
+int glim_amd_voxelmap_download(const glim_amd_voxelmap* vmap, int32_t* coords, int32_t* counts, float* means, float* cov33);
+
+/* ---- factor sets: NonlinearFactorSetGPU of IntegratedVGICPFactorGPU
+ *      (odometry_estimation_gpu.cpp:144,161,383-386; sub_mapping.cpp:307; global_mapping.cpp:335,466,860) ------------- */
+int glim_amd_factor_set_create(glim_amd_ctx* ctx, glim_amd_factor_set** out);
+int glim_amd_factor_set_destroy(glim_amd_factor_set* set);
+/* add IntegratedVGICPFactorGPU(target voxel map, source cloud).  The set borrows both handles; keep them alive. */
+int glim_amd_factor_set_add(glim_amd_factor_set* set, const glim_amd_voxelmap* target, const glim_amd_cloud* source, uint32_t flags,
+                            int32_t* factor_index);
+int glim_amd_factor_set_clear(glim_amd_factor_set* set);
+int glim_amd_factor_set_size(const glim_amd_factor_set* set, int32_t* n);
+/* NonlinearFactorSetGPU::linearize: one fused launch over every factor (+ a tiny FP64 finalise), one upload of the
+ * poses, one download of the results.  T_target_source: n x 12.  out: n records. */
+int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T_target_source, glim_amd_linearized6* out);
+/* NonlinearFactorSetGPU::error.  T_lin == NULL: correspondences recomputed at T_eval (CPU-factor semantics, the parity
+ * default); otherwise correspondences and Mahalanobis matrices frozen at T_lin (GPU-factor semantics).  errors: n; inliers: n or NULL. */
+int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, double* errors, int64_t* inliers);
+/* correspondences of one factor at a pose (parity/debug): corr n_points x 4 int32 = {cx, cy, cz, hit ? 1 : -1}. */
+int glim_amd_factor_set_correspondences(glim_amd_factor_set* set, int32_t factor_index, const double* T_target_source, int32_t* corr);
+
+/* Device-resident variant for multi-GPU cost evaluation and benchmarking: results are left on the device in
+ * `out_device` (n x GLIM_AMD_COMPACT_DOUBLES doubles, caller-owned device memory, e.g. a torch tensor) without a host
+ * round trip; the launch is asynchronous on the context stream.  Compact record: [num_inliers, error, 21 upper-triangular
+ * entries of H_ss (row-major), 6 of b_s]; glim_amd_expand_compact turns records into glim_amd_linearized6 on the host. */
+#define GLIM_AMD_COMPACT_DOUBLES 29
+int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const double* T_target_source_host, double* out_device,
+                                               int64_t out_row_offset);
+int glim_amd_expand_compact(const double* compact, const double* T_target_source, uint32_t flags, glim_amd_linearized6* out);
+
+/* Timing aid used by bench.py: runs `iters` back-to-back launches bracketed by HIP events on the set's stream.
+ * ms_vgicp_kernel: average duration of the fused lookup+residual+Jacobian+reduce kernel alone;
+ * ms_linearize: average duration of the whole device-resident linearise (kernel + finalise). */
+int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_vgicp_kernel,
+                                float* ms_linearize);
+
+/* ---- overlap: overlap_gpu / overlap_auto (odometry_estimation_gpu.cpp:231,248,265,279,326; sub_mapping.cpp:252-253;
+ *      global_mapping.cpp:322,448).  Fraction of source points that hit an occupied voxel of ANY target under its delta. */
+int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T_target_source,
+                     const glim_amd_cloud* source, double* overlap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLIM_AMD_H */

@@ -545,7 +545,8 @@ void orc_voxelmap_insert(orc_voxelmap* m, const double* pts, const double* covs,
   for (int i = 0; i < n; i++) {
     int32_t c[3];
     orc_voxel_coord(pts + 4 * (size_t)i, m->inv_resolution, c);
-    orc_voxel* vx = &m->voxels[voxelmap_get_or_create(m, c)];
+    const int vid = voxelmap_get_or_create(m, c); /* may realloc m->voxels: index first, then address */
+    orc_voxel* vx = &m->voxels[vid];
     if (vx->finalized) {
       vx->finalized = 0;
       for (int a = 0; a < 4; a++) vx->mean[a] *= (double)vx->num_points;

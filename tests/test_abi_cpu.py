@@ -1,0 +1,99 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol declared in
+include/glim_amd.h; host-only entry points behave; no compute calls are made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from glim_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(L):
+    from glim_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "glim_amd.h")).read()
+    declared = set(re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_version_and_error_strings(L):
+    assert L.glim_amd_version() >= 100
+    assert L.glim_amd_error_string(0) == b"ok"
+    for code in range(-7, 0):
+        assert L.glim_amd_error_string(code) not in (b"", b"unknown error")
+    assert L.glim_amd_error_string(-99) == b"unknown error"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from glim_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_no_device_is_an_error_code_not_a_fallback(L):
+    from glim_amd import api
+
+    if api.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    assert L.glim_amd_ctx_create(0, 1, None, C.byref(h)) == -3  # GLIM_AMD_ERR_NO_DEVICE
+    with pytest.raises(api.GlimAmdError):
+        api.Context(0, 1)
+
+
+def test_invalid_arguments_return_codes(L):
+    assert L.glim_amd_ctx_create(0, 1, None, None) == -1
+    assert L.glim_amd_ctx_synchronize(None) == -1
+    n = C.c_int64()
+    assert L.glim_amd_cloud_size(None, C.byref(n)) == -1
+    assert L.glim_amd_cloud_destroy(None) == 0
+    assert L.glim_amd_voxelmap_destroy(None) == 0
+    assert L.glim_amd_factor_set_destroy(None) == 0
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py may touch oracle/."""
+    pkg = os.path.join(ROOT, "glim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = "\n".join(line for line in text.splitlines() if not line.strip().startswith(("//", "#", "*", "/*")))
+                assert "import oracle" not in code and "from oracle" not in code and "libvgicp_oracle" not in code, f
+
+
+def test_expand_compact_matches_oracle_binary_blocks(orc, small_pair):
+    """Host-side FP64 expansion of the compact 6x6 source block into the binary factor's H_tt / H_ts / b_t (adjoint identity)."""
+    from glim_amd import api
+
+    t, s = small_pair["target"], small_pair["source"]
+    vm = orc.VoxelMap(0.5).insert(t["points"], t["covs"])
+    T = small_pair["delta"] @ orc.se3_exp([0.01, -0.02, 0.005, 0.05, 0.02, -0.01])
+    ref = orc.vgicp_linearize(vm, s["points"], s["covs"], T)
+    iu = np.triu_indices(6)
+    compact = np.concatenate([[ref["num_inliers"], ref["error"]], ref["H_ss"][iu], ref["b_s"]])
+    got = api.expand_compact(compact, T, api.FACTOR_BINARY)
+    assert got["num_inliers"] == ref["num_inliers"]
+    for k in ("H_tt", "H_ts", "H_ss"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-6 * np.abs(ref[k]).max())
+    np.testing.assert_allclose(got["b_t"], ref["b_t"], rtol=1e-9, atol=1e-9 * np.abs(ref["b_t"]).max())
+    np.testing.assert_allclose(got["b_s"], ref["b_s"], rtol=0, atol=0)
+    un = api.expand_compact(compact, T, 0)
+    assert not np.any(un["H_tt"]) and not np.any(un["H_ts"]) and not np.any(un["b_t"])

@@ -1,0 +1,407 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded, f32-rounded inputs.
+
+Gates (BASELINE.json north_star / SURVEY.md 8d):
+  * correspondences bit-exact as (source i -> voxel integer coordinate | none); num_inliers equal
+  * Gauss-Newton step delta = -(H + lambda I)^-1 b within 1e-4 m / 1e-4 rad of the oracle's, per iteration
+  * kNN index sets exact; covariances within 1e-5 (FP32 storage)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4  # metres / radians per Gauss-Newton iteration (north_star)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from glim_amd import api as _api
+
+    assert _api.device_count() >= 1, "these tests need a GPU and must not fall back"
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    return api.Context(0, 2)
+
+
+def gn_step(L, lam=0.0):
+    return np.linalg.solve(L["H_ss"] + lam * np.eye(6), -L["b_s"])
+
+
+def upload_pair(api, ctx, pair):
+    t, s = pair["target"], pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], t["normals"], ctx=ctx)
+    sg = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], s["normals"], ctx=ctx)
+    return tg, sg
+
+
+def assert_linearization_close(got, ref, binary):
+    assert got["num_inliers"] == ref["num_inliers"]
+    np.testing.assert_allclose(got["error"], ref["error"], rtol=2e-4)
+    scale = np.abs(ref["H_ss"]).max()
+    np.testing.assert_allclose(got["H_ss"], ref["H_ss"], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(got["b_s"], ref["b_s"], rtol=0, atol=2e-4 * np.abs(ref["b_s"]).max() + 1e-6 * scale)
+    if binary:
+        np.testing.assert_allclose(got["H_tt"], ref["H_tt"], rtol=0, atol=2e-4 * np.abs(ref["H_tt"]).max())
+        np.testing.assert_allclose(got["H_ts"], ref["H_ts"], rtol=0, atol=2e-4 * np.abs(ref["H_ts"]).max())
+        np.testing.assert_allclose(got["b_t"], ref["b_t"], rtol=0, atol=2e-4 * np.abs(ref["b_t"]).max() + 1e-6 * scale)
+    else:
+        assert not np.any(got["H_tt"]) and not np.any(got["H_ts"]) and not np.any(got["b_t"])
+    d_got, d_ref = gn_step(got), gn_step(ref)
+    assert np.abs(d_got - d_ref).max() < POSE_TOL, (d_got, d_ref)
+    lam = 1e-6 * np.trace(ref["H_ss"]) / 6
+    assert np.abs(gn_step(got, lam) - gn_step(ref, lam)).max() < POSE_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+
+
+def test_device_is_gfx950(api, ctx):
+    info = ctx.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["num_cus"] >= 200
+
+
+def test_cloud_roundtrip_f64_and_f32_layouts(api, ctx, small_pair):
+    s = small_pair["source"]
+    g64 = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], s["normals"], ctx=ctx)
+    g32 = api.PointCloudGPU.clone(s["points"], s["covs"].astype(np.float32), s["normals"].astype(np.float32), ctx=ctx)
+    for g in (g64, g32):
+        assert g.size() == len(s["points"])
+        xyz, covs, nrm = g.download()
+        np.testing.assert_array_equal(xyz, s["points"])
+        np.testing.assert_array_equal(covs, s["covs"].astype(np.float32))
+        np.testing.assert_array_equal(nrm, s["normals"].astype(np.float32))
+    assert g64.memory_usage_gpu() == len(s["points"]) * (16 + 24 + 16)
+
+
+def test_empty_cloud_and_empty_set(api, ctx, small_pair):
+    e = api.PointCloudGPU.clone(np.zeros((0, 3)), np.zeros((0, 3, 3)), ctx=ctx)
+    assert e.size() == 0
+    fset = api.NonlinearFactorSetGPU(ctx)
+    assert fset.linearize({}) == []
+    t = small_pair["target"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    f = api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, e)
+    fset.add(f)
+    L = fset.linearize({1: np.eye(4)})[0]
+    assert L["num_inliers"] == 0 and L["error"] == 0.0 and not np.any(L["H_ss"]) and not np.any(L["b_s"])
+
+
+@pytest.mark.parametrize("res", [0.25, 0.5, 1.0])
+def test_voxelmap_matches_oracle(api, ctx, orc, small_pair, res):
+    t = small_pair["target"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(tg)
+    ref = orc.VoxelMap(res).insert(t["points"], t["covs"])
+    rc, rn, rm, rC = ref.voxels()
+    info = vm.voxelmap_info()
+    assert info["num_voxels"] == ref.num_voxels()
+    assert info["num_buckets"] >= 2 * info["num_voxels"]  # lossless: load factor <= 1/2
+    gc, gn, gm, gC = vm.voxels()
+    # voxel identity = integer coordinate: identical SETS, identical member counts
+    order_g = np.lexsort(gc.T[::-1])
+    order_r = np.lexsort(rc.T[::-1])
+    np.testing.assert_array_equal(gc[order_g], rc[order_r])
+    np.testing.assert_array_equal(gn[order_g], rn[order_r])
+    assert gn.sum() == len(t["points"])
+    # statistics: mean of means / mean of covs, FP32 storage (<= 1 ulp_f32 of the FP64 oracle value)
+    np.testing.assert_allclose(gm[order_g], rm[order_r], rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(gC[order_g], rC[order_r], rtol=2e-7, atol=1e-7)
+    # bit-reproducible build (fixed-point accumulation): a second build is identical
+    vm2 = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(tg)
+    c2, n2, m2, C2 = vm2.voxels()
+    o2 = np.lexsort(c2.T[::-1])
+    np.testing.assert_array_equal(m2[o2], gm[order_g])
+    np.testing.assert_array_equal(C2[o2], gC[order_g])
+
+
+def test_voxelmap_negative_coordinates_and_range_error(api, ctx):
+    pts = np.array([[-0.1, -0.1, -0.1], [-0.9, -0.2, -0.3], [0.1, 0.1, 0.1], [-1.0, 0.0, 0.0]], dtype=np.float64)
+    covs = np.tile(np.eye(3), (4, 1, 1))
+    g = api.PointCloudGPU.clone(pts, covs, ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(g)
+    coords, counts, means, _ = vm.voxels()
+    got = {tuple(c): n for c, n in zip(coords, counts)}
+    assert got == {(-1, -1, -1): 2, (0, 0, 0): 1, (-1, 0, 0): 1}
+    far = api.PointCloudGPU.clone(np.array([[3e6, 0, 0]], dtype=np.float64), covs[:1], ctx=ctx)
+    with pytest.raises(api.GlimAmdError) as ei:
+        api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(far)
+    assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("res", [0.5, 1.0])
+def test_linearize_matches_oracle(api, ctx, orc, small_pair, binary, res):
+    t, s = small_pair["target"], small_pair["source"]
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(tg)
+    ref_vm = orc.VoxelMap(res).insert(t["points"], t["covs"])
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        xi = rng.normal(size=6) * [0.01, 0.01, 0.01, 0.05, 0.05, 0.05] * (trial > 0)
+        if binary:
+            Tt = orc.se3_exp(rng.normal(size=6) * 0.3)
+            Ts = Tt @ small_pair["delta"] @ orc.se3_exp(xi)
+            factor = api.IntegratedVGICPFactorGPU(0, 1, vm, sg)
+            values = {0: Tt, 1: Ts}
+        else:
+            Tt = orc.se3_exp(rng.normal(size=6) * 0.3)
+            Ts = Tt @ small_pair["delta"] @ orc.se3_exp(xi)
+            factor = api.IntegratedVGICPFactorGPU(Tt, 1, vm, sg)
+            values = {1: Ts}
+        delta = factor.calc_delta(values)
+        fset = api.NonlinearFactorSetGPU(ctx)
+        fset.add(factor)
+        got = fset.linearize(values)[0]
+        ref = orc.vgicp_linearize(ref_vm, s["points"], s["covs"], delta, want_corr=True)
+        assert_linearization_close(got, ref, binary)
+        # correspondences: bit-exact (i -> voxel coordinate | none)
+        corr = fset.correspondences(0, delta)
+        np.testing.assert_array_equal(corr[:, :3], ref["corr"][:, :3])
+        np.testing.assert_array_equal(corr[:, 3] > 0, ref["corr"][:, 3] >= 0)
+        assert factor.linearize(values) is got  # the factor serves the batch result (store_linearized)
+        assert factor.inlier_fraction() == pytest.approx(ref["num_inliers"] / len(s["points"]))
+
+
+def test_linearize_is_bit_reproducible(api, ctx, small_pair):
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+    a = fset.linearize_poses(api.pose12(small_pair["delta"])[None])[0]
+    for _ in range(3):
+        b = fset.linearize_poses(api.pose12(small_pair["delta"])[None])[0]
+        np.testing.assert_array_equal(a["H_ss"], b["H_ss"])
+        np.testing.assert_array_equal(a["b_s"], b["b_s"])
+        assert a["error"] == b["error"]
+
+
+def test_error_matches_oracle_both_semantics(api, ctx, orc, small_pair):
+    t, s = small_pair["target"], small_pair["source"]
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    ref_vm = orc.VoxelMap(0.5).insert(t["points"], t["covs"])
+    f = api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(f)
+    T_lin = small_pair["delta"]
+    T_eval = T_lin @ orc.se3_exp([0.002, -0.001, 0.003, 0.02, -0.03, 0.01])
+    # CPU-factor semantics: correspondences recomputed at the evaluation point
+    e = fset.error({1: T_eval})[0]
+    e_ref, n_ref = orc.vgicp_error(ref_vm, s["points"], s["covs"], T_eval)
+    assert fset.last_error_inliers[0] == n_ref
+    assert e == pytest.approx(e_ref, rel=2e-4)
+    assert f.error({1: T_eval}) == pytest.approx(e_ref, rel=2e-4)
+    # GPU-factor semantics: correspondences frozen at the linearisation point
+    e2 = fset.error({1: T_eval}, values_lin={1: T_lin})[0]
+    e2_ref, n2_ref = orc.vgicp_error(ref_vm, s["points"], s["covs"], T_eval, delta_lin=T_lin)
+    assert fset.last_error_inliers[0] == n2_ref
+    assert e2 == pytest.approx(e2_ref, rel=2e-4)
+
+
+def test_batched_set_equals_individual_factors(api, ctx, orc, small_pair):
+    """NonlinearFactorSetGPU with many factors (>= 16 switches on the XCD-aware block map) == per-factor results."""
+    t, s = small_pair["target"], small_pair["source"]
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
+    refs = [orc.VoxelMap(r).insert(t["points"], t["covs"]) for r in (0.5, 1.0)]
+    rng = np.random.default_rng(7)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    values = {0: np.eye(4)}
+    factors = []
+    for k in range(20):
+        values[k + 1] = small_pair["delta"] @ orc.se3_exp(rng.normal(size=6) * 0.01)
+        f = api.IntegratedVGICPFactorGPU(0, k + 1, vms[k % 2], sg) if k % 3 else api.IntegratedVGICPFactorGPU(np.eye(4), k + 1, vms[k % 2], sg)
+        if k % 5 == 0:
+            f.set_enable_surface_validation(False)
+        factors.append(f)
+        fset.add(f)
+    assert fset.size() == 20
+    out = fset.linearize(values)
+    for k, (f, got) in enumerate(zip(factors, out)):
+        ref = orc.vgicp_linearize(refs[k % 2], s["points"], s["covs"], f.calc_delta(values))
+        assert_linearization_close(got, ref, f.is_binary)
+        single = api.NonlinearFactorSetGPU(ctx)
+        single.add(f.clone())
+        alone = single.linearize(values)[0]
+        assert alone["num_inliers"] == got["num_inliers"]
+        np.testing.assert_allclose(alone["H_ss"], got["H_ss"], rtol=1e-5)
+
+
+def test_points_per_thread_variants_agree(api, ctx, small_pair, monkeypatch):
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    T = api.pose12(small_pair["delta"])[None]
+    results = []
+    for ppt in ("1", "3", "8"):
+        monkeypatch.setenv("GLIM_AMD_PPT", ppt)
+        fset = api.NonlinearFactorSetGPU(ctx)
+        fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        results.append(fset.linearize_poses(T)[0])
+    for r in results[1:]:
+        assert r["num_inliers"] == results[0]["num_inliers"]
+        np.testing.assert_allclose(r["H_ss"], results[0]["H_ss"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(r["b_s"], results[0]["b_s"], rtol=1e-4, atol=1e-3)
+
+
+def test_surface_validation_rejects_back_facing_points(api, ctx, small_pair):
+    t, s = small_pair["target"], small_pair["source"]
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    f = api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg)
+    f.set_enable_surface_validation(True)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(f)
+    delta = small_pair["delta"]
+    got = fset.linearize({1: delta})[0]
+    corr = fset.correspondences(0, delta)
+    # predicate: reject when (R n) . q > 0, evaluated with the same FP32 expression on the host
+    R = delta[:3, :3].astype(np.float32)
+    q = (s["points"].astype(np.float64) @ delta[:3, :3].T + delta[:3, 3]).astype(np.float32)
+    rn = s["normals"].astype(np.float32) @ R.T
+    facing = np.einsum("ij,ij->i", rn, q) <= 0
+    plain = api.NonlinearFactorSetGPU(ctx)
+    plain.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg))
+    hits = plain.correspondences(0, delta)[:, 3] > 0
+    margin = np.abs(np.einsum("ij,ij->i", rn.astype(np.float64), q.astype(np.float64))) > 1e-3
+    np.testing.assert_array_equal((corr[:, 3] > 0)[margin], (hits & facing)[margin])
+    assert got["num_inliers"] == int((corr[:, 3] > 0).sum())
+    assert got["num_inliers"] <= int(hits.sum())
+
+
+def test_overlap_matches_oracle(api, ctx, orc, small_pair):
+    t, s = small_pair["target"], small_pair["source"]
+    tg, sg = upload_pair(api, ctx, small_pair)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    vm1 = api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(tg)
+    ref = orc.VoxelMap(0.5).insert(t["points"], t["covs"])
+    ref1 = orc.VoxelMap(1.0).insert(t["points"], t["covs"])
+    delta = small_pair["delta"]
+    assert api.overlap_gpu(vm, sg, delta) == orc.overlap(ref, s["points"], delta)
+    far = np.eye(4)
+    far[:3, 3] = 1e4
+    assert api.overlap_gpu(vm, sg, far) == 0.0
+    shifted = delta @ orc.se3_exp([0, 0, 0.3, 2.0, 1.0, 0])
+    assert api.overlap_gpu([vm, vm1], sg, [far, shifted]) == orc.overlap([ref, ref1], s["points"], [far, shifted])
+    assert api.overlap_gpu([vm, vm1], sg, [delta, shifted]) == orc.overlap([ref, ref1], s["points"], [delta, shifted])
+
+
+def test_knn_and_covariances_on_device_match_oracle(api, ctx, orc, small_pair):
+    s = small_pair["source"]
+    g = api.PointCloudGPU.clone(s["points"], ctx=ctx)
+    nb = g.find_neighbors(10)
+    ref_nb = s["neighbors"]
+    assert np.all(nb[:, 0] == np.arange(len(nb)))
+    np.testing.assert_array_equal(nb, ref_nb)  # exact, including the (distance, index) order
+    g.estimate_covariances(10)
+    _, covs, normals = g.download()
+    rn, rc = orc.covariances(s["points"], ref_nb)
+    ev = np.linalg.eigvalsh(
+        np.einsum("nki,nkj->nij", s["points"].astype(np.float64)[ref_nb] - s["points"].astype(np.float64)[ref_nb].mean(1, keepdims=True),
+                  s["points"].astype(np.float64)[ref_nb] - s["points"].astype(np.float64)[ref_nb].mean(1, keepdims=True)) / 10)
+    ok = (ev[:, 1] - ev[:, 0]) > 1e-3 * ev[:, 2]  # e0 well conditioned
+    assert ok.mean() > 0.9
+    np.testing.assert_allclose(covs[ok], rc[ok], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(normals[ok], rn[ok], rtol=0, atol=1e-5)
+    # fewer points than k: padded with the query index (cloud_preprocessor.cpp:197)
+    tiny = api.PointCloudGPU.clone(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), ctx=ctx)
+    np.testing.assert_array_equal(tiny.find_neighbors(5), orc.knn(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), 5))
+
+
+def test_gauss_newton_iterations_track_oracle(api, ctx, orc):
+    """config 1 (plumbing): 16k-pt pair, 1.0 m voxels, unary factor, <= 8 iterations; per-iteration pose delta within 1e-4."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(128, 128)
+    Tw = synth.pose(-8.0, -5.0, 1.8, 0.2)
+    xi = np.array([0.01, -0.02, 0.015, 0.10, -0.05, 0.02])
+    tgt = synth.scan(scene, Tw, dirs, 0)
+    src = synth.scan(scene, Tw @ orc.se3_exp(xi), dirs, 1)
+    tg = api.PointCloudGPU.clone(tgt, ctx=ctx)
+    sg = api.PointCloudGPU.clone(src, ctx=ctx)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    _, ct, _ = tg.download()
+    _, cs, _ = sg.download()
+    vm = api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(tg)
+    ref_vm = orc.VoxelMap(1.0).insert(tgt, ct.astype(np.float64))
+    f = api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(f)
+    T = np.eye(4)
+    for it in range(8):
+        got = fset.linearize({1: T})[0]
+        ref = orc.vgicp_linearize(ref_vm, src, cs.astype(np.float64), T)
+        assert got["num_inliers"] == ref["num_inliers"]
+        lam = 1e-6 * np.trace(ref["H_ss"]) / 6
+        d_got, d_ref = gn_step(got, lam), gn_step(ref, lam)
+        assert np.abs(d_got - d_ref).max() < POSE_TOL, (it, d_got, d_ref)
+        T = T @ orc.se3_exp(d_ref)
+        if np.linalg.norm(d_ref[3:]) < 1e-3 and np.linalg.norm(d_ref[:3]) < 1e-3 * np.pi / 180:
+            break
+    err = np.linalg.inv(orc.se3_exp(xi)) @ T
+    assert np.linalg.norm(err[:3, 3]) < 0.02
+
+
+def test_full_size_scan_properties(api, ctx, orc):
+    """BASELINE config 2 size (131 072 points, 0.5 m voxels): inlier count + GN step vs the oracle, and size-independent
+    properties: H symmetric PSD, identity-on-voxel-means gives zero gradient, linearity of H/b in a duplicated cloud."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(128, 1024)
+    poses = synth.arc_trajectory(2)
+    tgt = synth.scan(scene, poses[0], dirs, 0)
+    src = synth.scan(scene, poses[1], dirs, 1)
+    assert len(src) == 131072
+    delta = synth.relative_pose(poses[0], poses[1])
+    tg = api.PointCloudGPU.clone(tgt, ctx=ctx)
+    sg = api.PointCloudGPU.clone(src, ctx=ctx)
+    nbs = []
+    for g in (tg, sg):
+        nbs.append(g.find_neighbors(10))
+        g.estimate_covariances(10)
+    # exact kNN sets at full size vs the oracle's grid search
+    ref_nb = orc.knn(src, 10)
+    np.testing.assert_array_equal(np.sort(nbs[1], 1), np.sort(ref_nb, 1))
+    _, ct, _ = tg.download()
+    _, cs, _ = sg.download()
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    ref_vm = orc.VoxelMap(0.5).insert(tgt, ct.astype(np.float64))
+    assert vm.voxelmap_info()["num_voxels"] == ref_vm.num_voxels()
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+    got = fset.linearize({0: np.eye(4), 1: delta})[0]
+    ref = orc.vgicp_linearize(ref_vm, src, cs.astype(np.float64), delta, want_corr=True)
+    assert_linearization_close(got, ref, True)
+    corr = fset.correspondences(0, delta)
+    np.testing.assert_array_equal(corr[:, :3], ref["corr"][:, :3])
+    np.testing.assert_array_equal(corr[:, 3] > 0, ref["corr"][:, 3] >= 0)
+    # properties
+    np.testing.assert_allclose(got["H_ss"], got["H_ss"].T, rtol=0, atol=0)
+    assert np.linalg.eigvalsh(got["H_ss"]).min() > 0
+    full = np.block([[got["H_tt"], got["H_ts"]], [got["H_ts"].T, got["H_ss"]]])
+    assert np.linalg.eigvalsh(full).min() > -1e-6 * np.abs(full).max()
+    # duplicated source cloud -> exactly twice the inliers, H and b double
+    dup = api.PointCloudGPU.clone(np.concatenate([src, src]), np.concatenate([cs, cs]), ctx=ctx)
+    f2 = api.NonlinearFactorSetGPU(ctx)
+    f2.add(api.IntegratedVGICPFactorGPU(0, 1, vm, dup))
+    got2 = f2.linearize({0: np.eye(4), 1: delta})[0]
+    assert got2["num_inliers"] == 2 * got["num_inliers"]
+    np.testing.assert_allclose(got2["H_ss"], 2 * got["H_ss"], rtol=1e-5)
+    np.testing.assert_allclose(got2["b_s"], 2 * got["b_s"], rtol=1e-4, atol=1e-3)
+    # voxel means against their own map at identity: zero residual
+    coords, counts, means, covs = vm.voxels()
+    mg = api.PointCloudGPU.clone(means, covs, ctx=ctx)
+    f3 = api.NonlinearFactorSetGPU(ctx)
+    f3.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, mg))
+    z = f3.linearize({1: np.eye(4)})[0]
+    assert z["num_inliers"] >= len(means) - 5
+    assert z["error"] < 1e-6 and np.abs(z["b_s"]).max() < 1e-2
