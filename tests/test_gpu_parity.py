@@ -318,7 +318,7 @@ def test_gauss_newton_iterations_track_oracle(api, ctx, orc):
     from glim_amd import synth
 
     scene = synth.Scene.default()
-    dirs = synth.lidar_directions(128, 128)
+    dirs = synth.lidar_directions(64, 256)  # 16 384 rays; denser azimuth keeps the kNN neighbourhoods planar
     Tw = synth.pose(-8.0, -5.0, 1.8, 0.2)
     xi = np.array([0.01, -0.02, 0.015, 0.10, -0.05, 0.02])
     tgt = synth.scan(scene, Tw, dirs, 0)
