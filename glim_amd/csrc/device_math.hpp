@@ -43,25 +43,35 @@ __device__ __forceinline__ unsigned long long voxel_key(double qx, double qy, do
   return pack_key(fast_floor_d(qx * inv_res), fast_floor_d(qy * inv_res), fast_floor_d(qz * inv_res));
 }
 
-// 64 -> 32 bit mixer (splitmix64 finaliser); any hash is valid because lookups compare the full key.
+// 63-bit key -> 32-bit hash with well-mixed HIGH bits (the bucket index is the multiply-shift range reduction
+// (hash * num_buckets) >> 32, so any table size works and no power-of-two rounding wastes memory).  The three 21-bit axis
+// fields are combined with full-rate 24-bit multiply-adds, then one xor-shift-multiply round.  Any hash is valid because
+// lookups compare the full key.
 __device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
-  k ^= k >> 30;
-  k *= 0xbf58476d1ce4e5b9ull;
-  k ^= k >> 27;
-  k *= 0x94d049bb133111ebull;
-  k ^= k >> 31;
-  return (unsigned int)k;
+  const unsigned int m = (1u << KEY_BITS) - 1u;
+  const unsigned int uz = (unsigned int)k & m, uy = (unsigned int)(k >> KEY_BITS) & m, ux = (unsigned int)(k >> (2 * KEY_BITS)) & m;
+  unsigned int h = __umul24(ux, 0x9E3779u) + __umul24(uy, 0x85EBCBu) + __umul24(uz, 0xC2B2AFu);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+__device__ __forceinline__ unsigned int bucket_of(unsigned long long key, unsigned int num_buckets) {
+  return __umulhi(hash_key(key), num_buckets);
 }
 
-// Linear probe for `key`; returns the slot index or -1.  The table is never full (load <= 1/2).
-__device__ __forceinline__ int find_slot(const VoxelSlot* __restrict__ slots, unsigned int mask, unsigned long long key) {
+// Exact lookup: returns 2 * bucket + way, or -1.  Buckets fill way 0 first, then way 1, then spill to the next bucket, so the
+// first EMPTY key met ends the search.  The table always holds free ways (>= 4 ways per key).
+__device__ __forceinline__ int find_slot(const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, unsigned long long key) {
   if (key == EMPTY_KEY) return -1;
-  unsigned int s = hash_key(key) & mask;
+  unsigned int b = bucket_of(key, num_buckets);
   for (;;) {
-    const unsigned long long k = slots[s].key;
-    if (k == key) return (int)s;
-    if (k == EMPTY_KEY) return -1;
-    s = (s + 1) & mask;
+    const unsigned long long k0 = buckets[b].key[0], k1 = buckets[b].key[1];
+    if (k0 == key) return (int)(2 * b);
+    if (k0 == EMPTY_KEY) return -1;
+    if (k1 == key) return (int)(2 * b + 1);
+    if (k1 == EMPTY_KEY) return -1;
+    b = (b + 1 == num_buckets) ? 0u : b + 1;
   }
 }
 

@@ -38,21 +38,22 @@ void set_hip_error(hipError_t e, const char* what);
 // device data layouts
 // ---------------------------------------------------------------------------------------------------------------
 
-// One hash slot of a Gaussian voxel map: 64 bytes, 64-byte aligned, key and statistic in the SAME cache line so a
-// lookup costs one random line (SURVEY.md 8a row a5 stores a 16-B bucket + a 52-B record in two arrays).
-//   key   : packed voxel coordinate (21 bits per axis, offset 2^20), EMPTY_KEY when free
-//   mean  : FP32 mean of the member means
-//   cov   : FP32 mean of the member covariances, symmetric storage c00 c01 c02 c11 c12 c22
-//   count : number of member points
-struct alignas(64) VoxelSlot {
-  unsigned long long key;
-  float mx, my;                 // 16 B
-  float mz, c00, c01, c02;      // 16 B
-  float c11, c12, c22;
-  int count;                    // 16 B
-  int pad[4];                   // 16 B (keeps slots line-aligned)
+// One hash BUCKET of a Gaussian voxel map: 128 bytes, 128-byte aligned (one L2 line), two ways.  A lookup is one 16-byte
+// load of both keys followed by a 48-byte read of the matching record out of the line that load has just brought in, so the
+// dependent read is an on-chip hit and there is no way/collision divergence inside a wavefront; a third key hashing to a
+// full bucket spills to the next bucket (rare at the default 1/3 keys per bucket; exact compare keeps lookups lossless).
+// (SURVEY.md 8a row a5 stores a 16-B bucket + a 52-B record in two arrays: two random lines per lookup.)
+//   key[w]    : packed voxel coordinate (21 bits per axis, offset 2^20), EMPTY_KEY when free
+//   rec[w]    : mx my mz c00 | c01 c02 c11 c12 | c22 count - -
+//               mean of the member means stored RELATIVE TO THE VOXEL CENTRE (coord + 0.5) * resolution (|m| <= res/2: the FP32
+//               image is ~1e-8 m accurate anywhere in the map and mu - q is formed without cancellation); mean of the member
+//               covariances, symmetric storage; number of member points (int bits)
+struct alignas(128) VoxelBucket {
+  unsigned long long key[2];  // 16 B
+  float rec[2][12];           // 2 x 48 B
+  int pad[4];                 // 16 B
 };
-static_assert(sizeof(VoxelSlot) == 64, "VoxelSlot must be one 64-byte line");
+static_assert(sizeof(VoxelBucket) == 128, "VoxelBucket must be one 128-byte line");
 
 constexpr unsigned long long EMPTY_KEY = ~0ull;
 constexpr int KEY_BITS = 21;
@@ -64,14 +65,15 @@ struct FactorDesc {
   const float4* covA;       // c00 c01 c02 c11
   const float2* covB;       // c12 c22
   const float4* normals;    // may be null
-  const VoxelSlot* slots;   // target table
-  unsigned int mask;        // table_size - 1
+  const VoxelBucket* buckets;  // target table
+  unsigned int num_buckets;    // any size >= 1 (range reduction by multiply-shift)
   int n;                    // source points
   double inv_res;           // 1 / target resolution
+  double res;               // target resolution
   unsigned int flags;
   int first_block;          // index of this factor's first partial row
   int num_blocks;           // partial rows (= chunks) of this factor
-  int pad;
+  int ppt;                  // points per thread: chunk = 256 * ppt consecutive points per block
 };
 
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
@@ -122,8 +124,8 @@ struct glim_amd_voxelmap {
   double resolution = 0.0;
   double inv_resolution = 0.0;
   int32_t num_voxels = 0;
-  uint32_t table_size = 0;  // power of two, 0 until insert()
-  glim_amd::VoxelSlot* slots = nullptr;
+  uint32_t num_buckets = 0;  // 0 until insert()
+  glim_amd::VoxelBucket* buckets = nullptr;
 };
 
 struct glim_amd_factor_set {
@@ -138,6 +140,7 @@ struct glim_amd_factor_set {
   bool dirty = true;  // device plan needs a rebuild
   // device plan
   int points_per_thread = 1;
+  int variant_u = 2, variant_minw = 3;  // kernel variant: points in flight per lane, occupancy hint
   int total_blocks = 0;
   glim_amd::FactorDesc* d_descs = nullptr;
   int2* d_blockmap = nullptr;

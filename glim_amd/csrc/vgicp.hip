@@ -7,7 +7,7 @@
 // (gtsam_points::IntegratedVGICPFactor, the parity oracle: SURVEY.md App. B.5):
 //
 //   q = R p + t                      FP64, fixed fma order (bit-exact voxel coordinates / correspondences)
-//   voxel = table[floor(q / res)]    exact 64-bit key compare, linear probing, one 64-byte line per probe
+//   voxel = table[floor(q / res)]    exact 64-bit key compare, two-way 128-byte buckets: one line per lookup
 //   M = (C_B + R C_A R^T)^-1,  r = mu_B - q,  e = r^T M r
 //   H_ss += J_s^T M J_s,  b_s += J_s^T M r,   J_s = [R hat(p) | -R]
 //
@@ -44,10 +44,38 @@ __device__ __forceinline__ float4 ld16(const void* p) { return *reinterpret_cast
 
 enum { MODE_LINEARIZE = 0, MODE_ERROR = 1 };
 
-template <int MODE, bool FROZEN>
-__global__ __launch_bounds__(BLOCK) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
-                                                       const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
-                                                       float* __restrict__ partials, int ppt) {
+// Global-address-space views: the pointers come out of a descriptor loaded from memory, so without the explicit address
+// space hipcc emits FLAT loads (which tick both vmcnt and lgkmcnt and force vmcnt(0) waits); with it, global_load + counted waits.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) v4f_t* gf4_t;
+typedef const __attribute__((address_space(1))) v2f_t* gf2_t;
+__device__ __forceinline__ float4 gld4(const void* p) {
+  const v4f_t v = *reinterpret_cast<gf4_t>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 gld2(const void* p) {
+  const v2f_t v = *reinterpret_cast<gf2_t>(reinterpret_cast<uintptr_t>(p));
+  return make_float2(v.x, v.y);
+}
+
+struct PointIn {
+  float4 p;   // xyz1
+  float4 ca;  // c00 c01 c02 c11
+  float2 cb;  // c12 c22
+};
+
+// MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
+// Mahalanobis matrices frozen at the linearisation pose.  U: points per loop trip.  MINW: occupancy hint (waves per SIMD).
+//
+// The loop is software-pipelined and branch-free on the hot path: the coalesced point/covariance loads of trip t+1 and the
+// 48-byte voxel-slot gathers of trip t are issued back to back BEFORE the algebra of trip t, every lane runs the algebra
+// and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
+// the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
+template <int MODE, bool FROZEN, int U, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+                                                             const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
+                                                             float* __restrict__ partials) {
   __shared__ float s_red[4][PARTIAL_STRIDE];
   const int2 bm = blockmap[blockIdx.x];
   const int f = bm.x;
@@ -61,117 +89,170 @@ __global__ __launch_bounds__(BLOCK) void vgicp_kernel(const FactorDesc* __restri
   const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
   const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
   const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals != nullptr;
+  const float resf = (float)d.res;
+  const int last = d.n - 1;
 
   float acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; j++) acc[j] = 0.f;
   int inliers = 0;
 
+  const int ppt = d.ppt;
   const int base = bm.y * (BLOCK * ppt) + threadIdx.x;
-  for (int it = 0; it < ppt; it++) {
-    const int i = base + it * BLOCK;
-    if (i >= d.n) break;
-    const float4 p4 = d.pts[i];
-    const double px = (double)p4.x, py = (double)p4.y, pz = (double)p4.z;
-    double qx, qy, qz;
-    transform_point_d(Tl, px, py, pz, qx, qy, qz);
-    const unsigned long long key = voxel_key(qx, qy, qz, d.inv_res);
+  if (d.n > 0) {
+    // prologue: points of trip 0 (indices clamped so every load is in bounds; validity is tracked separately)
+    PointIn nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned int i = (unsigned int)min(base + u * BLOCK, last);
+      nxt[u].p = gld4(reinterpret_cast<const char*>(d.pts) + i * 16u);   // uniform base + 32-bit lane offset (n <= 2^28)
+      nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
+      nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+    }
+    for (int it0 = 0; it0 < ppt; it0 += U) {
+      PointIn cur[U];
+      float4 head[U];
+      float qr[U][3];  // q relative to the centre of its voxel (|.| <= res/2): FP32 without cancellation
+      unsigned long long key[U];
+      unsigned int bkt[U];
 
-    // ---- lookup: exact key match, linear probing; the first 16 B of a slot hold key + mean.xy ----
-    bool hit = false;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned int slot = hash_key(key) & d.mask;
-    if (key != EMPTY_KEY) {
-      for (;;) {
-        s0 = ld16(d.slots + slot);
-        const unsigned long long k =
-          (unsigned long long)__float_as_uint(s0.x) | ((unsigned long long)__float_as_uint(s0.y) << 32);
-        if (k == key) {
-          hit = true;
-          break;
+      // ---- FP64 transform -> voxel key -> 16-byte gather of the home bucket's two keys ----
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        cur[u] = nxt[u];
+        const int i = base + (it0 + u) * BLOCK;
+        const bool ok = (it0 + u < ppt) && (i < d.n);
+        double qx, qy, qz;
+        transform_point_d(Tl, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, qx, qy, qz);
+        const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
+        // floor(t) == fast_floor(t) for every in-range coordinate (same integer, bit-exact); v_floor_f64 + one subtraction also
+        // gives the in-voxel fraction for free
+        const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+        const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
+        // out-of-range coordinates saturate in v_cvt_i32_f64 and are rejected by pack_key's unsigned range check
+        key[u] = ok ? pack_key(cx, cy, cz) : EMPTY_KEY;
+        if (FROZEN) {
+          double ex, ey, ez;
+          transform_point_d(Te, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, ex, ey, ez);
+          qr[u][0] = (float)(ex - ((double)cx + 0.5) * d.res);
+          qr[u][1] = (float)(ey - ((double)cy + 0.5) * d.res);
+          qr[u][2] = (float)(ez - ((double)cz + 0.5) * d.res);
+        } else {
+          qr[u][0] = ((float)(tx - fx) - 0.5f) * resf;
+          qr[u][1] = ((float)(ty - fy) - 0.5f) * resf;
+          qr[u][2] = ((float)(tz - fz) - 0.5f) * resf;
         }
-        if (k == EMPTY_KEY) break;
-        slot = (slot + 1) & d.mask;
+        if (validate) {
+          // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
+          // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
+          const float4 nn = gld4(reinterpret_cast<const char*>(d.normals) + (unsigned int)min(i, last) * 16u);
+          const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
+          const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
+          const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
+          if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) key[u] = EMPTY_KEY;
+        }
+        bkt[u] = bucket_of(key[u], d.num_buckets);
+        head[u] = gld4(d.buckets + bkt[u]);  // both keys of the home bucket (always a valid address)
       }
-    }
-    if (hit && validate) {
-      // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
-      // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
-      const float4 nn = d.normals[i];
-      const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
-      const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
-      const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
-      if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) hit = false;
-    }
-    if (!hit) continue;
-    inliers++;
+      // ---- coalesced loads of the NEXT trip, issued behind the gathers (counted vmcnt lets the gathers be consumed first) ----
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned int i = (unsigned int)min(base + (it0 + U + u) * BLOCK, last);
+        nxt[u].p = gld4(reinterpret_cast<const char*>(d.pts) + i * 16u);
+        nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
+        nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+      }
+      // ---- resolve the probe, then the per-point algebra (all lanes; accumulation predicated by hit) ----
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        unsigned long long k0 = (unsigned long long)__float_as_uint(head[u].x) | ((unsigned long long)__float_as_uint(head[u].y) << 32);
+        unsigned long long k1 = (unsigned long long)__float_as_uint(head[u].z) | ((unsigned long long)__float_as_uint(head[u].w) << 32);
+        unsigned int b = bkt[u];
+        if (key[u] != EMPTY_KEY) {
+          // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
+          while (k0 != key[u] && k1 != key[u] && k1 != EMPTY_KEY) {
+            b = (b + 1 == d.num_buckets) ? 0u : b + 1;
+            const float4 h = gld4(d.buckets + b);
+            k0 = (unsigned long long)__float_as_uint(h.x) | ((unsigned long long)__float_as_uint(h.y) << 32);
+            k1 = (unsigned long long)__float_as_uint(h.z) | ((unsigned long long)__float_as_uint(h.w) << 32);
+          }
+        }
+        const bool in1 = (k1 == key[u]);
+        const bool hit = (key[u] != EMPTY_KEY) && (k0 == key[u] || in1);
+        inliers += hit ? 1 : 0;
+        // 48-byte record of the matching way: the line was just fetched by the key load, so this dependent read stays on chip;
+        // every lane reads (way 0 when there is no hit) so the wavefront does not diverge
+        const char* rp = reinterpret_cast<const char*>(d.buckets + b) + (in1 ? 64 : 16);
+        const float4 r0 = gld4(rp);        // mx my mz c00
+        const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
+        const float4 r2 = gld4(rp + 32);   // c22 count - -
+        const float4 ca = cur[u].ca;
+        const float2 cb = cur[u].cb;
 
-    const float4 s1 = ld16(reinterpret_cast<const char*>(d.slots + slot) + 16);  // mz c00 c01 c02
-    const float4 s2 = ld16(reinterpret_cast<const char*>(d.slots + slot) + 32);  // c11 c12 c22 count
-    const float4 ca = d.covA[i];
-    const float2 cb = d.covB[i];
+        // residual mu - q, both relative to the voxel centre
+        const float rx = r0.x - qr[u][0];
+        const float ry = r0.y - qr[u][1];
+        const float rz = r0.z - qr[u][2];
 
-    // residual in the target frame (FP64 difference, then FP32), at the evaluation pose
-    double ex = qx, ey = qy, ez = qz;
-    if (FROZEN) transform_point_d(Te, px, py, pz, ex, ey, ez);
-    const float rx = (float)((double)s0.z - ex);
-    const float ry = (float)((double)s0.w - ey);
-    const float rz = (float)((double)s1.x - ez);
+        // S = R^T C_B R + C_A   (source frame, symmetric).  Non-hit lanes get S = I so the algebra stays finite.
+        const float b00 = hit ? r0.w : 1.f, b01 = hit ? r1.x : 0.f, b02 = hit ? r1.y : 0.f;
+        const float b11 = hit ? r1.z : 1.f, b12 = hit ? r1.w : 0.f, b22 = hit ? r2.x : 1.f;
+        const float w00 = b00 * R00 + b01 * R10 + b02 * R20, w01 = b00 * R01 + b01 * R11 + b02 * R21, w02 = b00 * R02 + b01 * R12 + b02 * R22;
+        const float w10 = b01 * R00 + b11 * R10 + b12 * R20, w11 = b01 * R01 + b11 * R11 + b12 * R21, w12 = b01 * R02 + b11 * R12 + b12 * R22;
+        const float w20 = b02 * R00 + b12 * R10 + b22 * R20, w21 = b02 * R01 + b12 * R11 + b22 * R21, w22 = b02 * R02 + b12 * R12 + b22 * R22;
+        const float S00 = ca.x + R00 * w00 + R10 * w10 + R20 * w20;
+        const float S01 = ca.y + R00 * w01 + R10 * w11 + R20 * w21;
+        const float S02 = ca.z + R00 * w02 + R10 * w12 + R20 * w22;
+        const float S11 = ca.w + R01 * w01 + R11 * w11 + R21 * w21;
+        const float S12 = cb.x + R01 * w02 + R11 * w12 + R21 * w22;
+        const float S22 = cb.y + R02 * w02 + R12 * w12 + R22 * w22;
 
-    // S = R^T C_B R + C_A   (source frame, symmetric)
-    const float b00 = s1.y, b01 = s1.z, b02 = s1.w, b11 = s2.x, b12 = s2.y, b22 = s2.z;
-    const float w00 = b00 * R00 + b01 * R10 + b02 * R20, w01 = b00 * R01 + b01 * R11 + b02 * R21, w02 = b00 * R02 + b01 * R12 + b02 * R22;
-    const float w10 = b01 * R00 + b11 * R10 + b12 * R20, w11 = b01 * R01 + b11 * R11 + b12 * R21, w12 = b01 * R02 + b11 * R12 + b12 * R22;
-    const float w20 = b02 * R00 + b12 * R10 + b22 * R20, w21 = b02 * R01 + b12 * R11 + b22 * R21, w22 = b02 * R02 + b12 * R12 + b22 * R22;
-    const float S00 = ca.x + R00 * w00 + R10 * w10 + R20 * w20;
-    const float S01 = ca.y + R00 * w01 + R10 * w11 + R20 * w21;
-    const float S02 = ca.z + R00 * w02 + R10 * w12 + R20 * w22;
-    const float S11 = ca.w + R01 * w01 + R11 * w11 + R21 * w21;
-    const float S12 = cb.x + R01 * w02 + R11 * w12 + R21 * w22;
-    const float S22 = cb.y + R02 * w02 + R12 * w12 + R22 * w22;
+        // A = S^-1 by cofactors (symmetric); idet = 0 on non-hit lanes zeroes every contribution below
+        const float k00 = S11 * S22 - S12 * S12;
+        const float k01 = S02 * S12 - S01 * S22;
+        const float k02 = S01 * S12 - S02 * S11;
+        const float det = S00 * k00 + S01 * k01 + S02 * k02;
+        float idet = __builtin_amdgcn_rcpf(det);         // 1 ulp hardware reciprocal ...
+        idet = fmaf(fmaf(-det, idet, 1.0f), idet, idet);  // ... + one Newton step (full FP32 accuracy, no division sequence)
+        idet = hit ? idet : 0.f;
+        const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
+        const float A11 = (S00 * S22 - S02 * S02) * idet;
+        const float A12 = (S01 * S02 - S00 * S12) * idet;
+        const float A22 = (S00 * S11 - S01 * S01) * idet;
 
-    // A = S^-1 by cofactors (symmetric)
-    const float k00 = S11 * S22 - S12 * S12;
-    const float k01 = S02 * S12 - S01 * S22;
-    const float k02 = S01 * S12 - S02 * S11;
-    const float det = S00 * k00 + S01 * k01 + S02 * k02;
-    const float idet = 1.0f / det;
-    const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
-    const float A11 = (S00 * S22 - S02 * S02) * idet;
-    const float A12 = (S01 * S02 - S00 * S12) * idet;
-    const float A22 = (S00 * S11 - S01 * S01) * idet;
+        // rs = R^T r,  u = A rs,  e = rs . u
+        const float rsx = R00 * rx + R10 * ry + R20 * rz;
+        const float rsy = R01 * rx + R11 * ry + R21 * rz;
+        const float rsz = R02 * rx + R12 * ry + R22 * rz;
+        const float ux = A00 * rsx + A01 * rsy + A02 * rsz;
+        const float uy = A01 * rsx + A11 * rsy + A12 * rsz;
+        const float uz = A02 * rsx + A12 * rsy + A22 * rsz;
+        acc[27] += rsx * ux + rsy * uy + rsz * uz;
 
-    // rs = R^T r,  u = A rs,  e = rs . u
-    const float rsx = R00 * rx + R10 * ry + R20 * rz;
-    const float rsy = R01 * rx + R11 * ry + R21 * rz;
-    const float rsz = R02 * rx + R12 * ry + R22 * rz;
-    const float ux = A00 * rsx + A01 * rsy + A02 * rsz;
-    const float uy = A01 * rsx + A11 * rsy + A12 * rsz;
-    const float uz = A02 * rsx + A12 * rsy + A22 * rsz;
-    acc[27] += rsx * ux + rsy * uy + rsz * uz;
-
-    if (MODE == MODE_LINEARIZE) {
-      const float x = p4.x, y = p4.y, z = p4.z;
-      // G = hat(p) A : column j = p x A[:,j]
-      const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
-      const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
-      const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
-      // Hww = -G hat(p) : row i = p x G[i,:]
-      acc[0] += y * g02 - z * g01;
-      acc[1] += z * g00 - x * g02;
-      acc[2] += x * g01 - y * g00;
-      acc[3] += z * g10 - x * g12;
-      acc[4] += x * g11 - y * g10;
-      acc[5] += x * g21 - y * g20;
-      acc[6] += g00; acc[7] += g01; acc[8] += g02;
-      acc[9] += g10; acc[10] += g11; acc[11] += g12;
-      acc[12] += g20; acc[13] += g21; acc[14] += g22;
-      acc[15] += A00; acc[16] += A01; acc[17] += A02; acc[18] += A11; acc[19] += A12; acc[20] += A22;
-      // b_w = u x p,  b_v = -u
-      acc[21] += uy * z - uz * y;
-      acc[22] += uz * x - ux * z;
-      acc[23] += ux * y - uy * x;
-      acc[24] += ux; acc[25] += uy; acc[26] += uz;
+        if (MODE == MODE_LINEARIZE) {
+          const float x = cur[u].p.x, y = cur[u].p.y, z = cur[u].p.z;
+          // G = hat(p) A : column j = p x A[:,j]
+          const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
+          const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
+          const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
+          // Hww = -G hat(p) : row i = p x G[i,:]
+          acc[0] += y * g02 - z * g01;
+          acc[1] += z * g00 - x * g02;
+          acc[2] += x * g01 - y * g00;
+          acc[3] += z * g10 - x * g12;
+          acc[4] += x * g11 - y * g10;
+          acc[5] += x * g21 - y * g20;
+          acc[6] += g00; acc[7] += g01; acc[8] += g02;
+          acc[9] += g10; acc[10] += g11; acc[11] += g12;
+          acc[12] += g20; acc[13] += g21; acc[14] += g22;
+          acc[15] += A00; acc[16] += A01; acc[17] += A02; acc[18] += A11; acc[19] += A12; acc[20] += A22;
+          // b_w = u x p,  b_v = -u
+          acc[21] += uy * z - uz * y;
+          acc[22] += uz * x - ux * z;
+          acc[23] += ux * y - uy * x;
+          acc[24] += ux; acc[25] += uy; acc[26] += uz;
+        }
+      }
     }
   }
 
@@ -201,31 +282,39 @@ __global__ __launch_bounds__(BLOCK) void vgicp_kernel(const FactorDesc* __restri
   }
 }
 
-// One block of 64 threads per factor: fixed-order FP64 sum of the factor's partial rows -> compact record.
-// The partial row of block b lives at partials[b]; a factor's rows are the blocks whose blockmap entry names it, listed in
-// `rows` (d.first_block .. first_block + num_blocks - 1 index into `rows`).
-__global__ __launch_bounds__(64) void finalize_kernel(const FactorDesc* __restrict__ descs, const int* __restrict__ rows,
-                                                      const float* __restrict__ partials, double* __restrict__ out, long long out_row_offset,
-                                                      int mode) {
+// One block of 256 threads per factor: fixed-order FP64 sum of the factor's partial rows -> compact record.  Thread (g, j),
+// g = tid / 32, j = tid % 32, sums rows g, g + 8, g + 16, ... of value j; the 8 group sums are then added in group order.
+// The order depends only on the plan, so results are bit-reproducible.  `rows` lists, per factor, the grid block ids that
+// hold its partials (d.first_block .. first_block + num_blocks - 1 index into it).
+__global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const int* __restrict__ rows,
+                                                       const float* __restrict__ partials, double* __restrict__ out, long long out_row_offset,
+                                                       int mode) {
   const int f = blockIdx.x;
-  const int j = threadIdx.x;
+  const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+  __shared__ double s_part[8][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int first = descs[f].first_block, nb = descs[f].num_blocks;
-  if (j < PARTIAL_STRIDE) {
-    double s = 0.0;
-    for (int c = 0; c < nb; c++) s += (double)partials[(size_t)rows[first + c] * PARTIAL_STRIDE + j];
-    s_sum[j] = s;
+  double s = 0.0;
+  for (int c = g; c < nb; c += 8) s += (double)partials[(size_t)rows[first + c] * PARTIAL_STRIDE + j];
+  s_part[g][j] = s;
+  __syncthreads();
+  if (threadIdx.x < PARTIAL_STRIDE) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
+    s_sum[threadIdx.x] = t;
   }
   __syncthreads();
+  const int t = threadIdx.x;
   double* o = out + ((size_t)out_row_offset + f) * COMPACT;
-  if (j == 0) o[0] = s_sum[28];
-  if (j == 1) o[1] = s_sum[27];
+  if (t == 0) o[0] = s_sum[28];
+  if (t == 1) o[1] = s_sum[27];
   if (mode == MODE_LINEARIZE) {
-    if (j < 21) o[2 + j] = s_sum[c_acc_of_upper[j]];
-    if (j >= 21 && j < 24) o[2 + j] = s_sum[j];          // b_w = sum u x p
-    if (j >= 24 && j < 27) o[2 + j] = -s_sum[j];         // b_v = -sum u
-  } else if (j >= 2 && j < COMPACT) {
-    o[j] = 0.0;
+    if (t < 21) o[2 + t] = s_sum[c_acc_of_upper[t]];
+    if (t >= 21 && t < 24) o[2 + t] = s_sum[t];          // b_w = sum u x p
+    if (t >= 24 && t < 27) o[2 + t] = -s_sum[t];         // b_v = -sum u
+  } else if (t >= 2 && t < COMPACT) {
+    o[t] = 0.0;
   }
 }
 
@@ -236,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, con
   double qx, qy, qz;
   transform_point_d(pose, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
   const int cx = fast_floor_d(qx * d.inv_res), cy = fast_floor_d(qy * d.inv_res), cz = fast_floor_d(qz * d.inv_res);
-  bool hit = find_slot(d.slots, d.mask, pack_key(cx, cy, cz)) >= 0;
+  bool hit = find_slot(d.buckets, d.num_buckets, pack_key(cx, cy, cz)) >= 0;
   if (hit && (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals) {
     const float4 nn = d.normals[i];
     const float rnx = (float)pose[0] * nn.x + (float)pose[1] * nn.y + (float)pose[2] * nn.z;
@@ -251,8 +340,8 @@ __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, con
 }
 
 struct OverlapTarget {
-  const VoxelSlot* slots;
-  unsigned int mask;
+  const VoxelBucket* buckets;
+  unsigned int num_buckets;
   int pad;
   double inv_res;
   double T[12];
@@ -267,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void overlap_kernel(int n, const float4* __r
     for (int t = 0; t < num_targets; t++) {
       double qx, qy, qz;
       transform_point_d(targets[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
-      if (find_slot(targets[t].slots, targets[t].mask, voxel_key(qx, qy, qz, targets[t].inv_res)) >= 0) {
+      if (find_slot(targets[t].buckets, targets[t].num_buckets, voxel_key(qx, qy, qz, targets[t].inv_res)) >= 0) {
         mine++;
         break;
       }
@@ -318,15 +407,17 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   glim_amd_ctx* ctx = set->ctx;
   long long total_points = 0;
   for (auto& e : set->entries) total_points += e.source->n;
-  int ppt = 1;
-  if (const char* env = getenv("GLIM_AMD_PPT")) {
-    ppt = std::max(1, std::min(64, atoi(env)));
-  } else {
-    const long long resident_threads = (long long)std::max(1, ctx->num_cus) * 1024;
-    ppt = (int)std::max(1ll, std::min(8ll, total_points / std::max(1ll, resident_threads)));
-  }
-  set->points_per_thread = ppt;
-  const int chunk = BLOCK * ppt;
+  // Grid sizing: aim for ONE resident set of blocks (num_cus x blocks_per_cu) with equal work each, so every lane reduces
+  // its 28 accumulators exactly once and there is no tail wave; each factor gets blocks in proportion to its points.
+  const int blocks_per_cu = 5;  // 96 VGPRs -> 5 waves/SIMD -> 5 blocks of 4 waves per CU
+  long long target_blocks = (long long)std::max(1, ctx->num_cus) * blocks_per_cu;
+  if (const char* env = getenv("GLIM_AMD_TARGET_BLOCKS")) target_blocks = std::max(1, atoi(env));
+  int forced_ppt = 0;
+  if (const char* env = getenv("GLIM_AMD_PPT")) forced_ppt = std::max(1, std::min(256, atoi(env)));
+  set->variant_u = 1;
+  set->variant_minw = 3;
+  if (const char* env = getenv("GLIM_AMD_U")) set->variant_u = atoi(env);
+  if (const char* env = getenv("GLIM_AMD_MINW")) set->variant_minw = atoi(env);
 
   set->h_descs.assign(nf, FactorDesc());
   std::vector<int> nblocks(nf);
@@ -338,15 +429,23 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     d.covA = e.source->covA;
     d.covB = e.source->covB;
     d.normals = e.source->has_normals ? e.source->normals : nullptr;
-    d.slots = e.target->slots;
-    d.mask = e.target->table_size - 1;
+    d.buckets = e.target->buckets;
+    d.num_buckets = e.target->num_buckets;
     d.n = (int)e.source->n;
     d.inv_res = e.target->inv_resolution;
+    d.res = e.target->resolution;
     d.flags = e.flags;
-    nblocks[f] = std::max(1, (d.n + chunk - 1) / chunk);
+    int ppt = forced_ppt;
+    if (!ppt) {
+      const long long share = std::max(1ll, (target_blocks * (long long)d.n + total_points / 2) / std::max(1ll, total_points));
+      ppt = (int)std::max(1ll, std::min(256ll, ((long long)d.n + share * BLOCK - 1) / (share * BLOCK)));
+    }
+    d.ppt = ppt;
+    nblocks[f] = std::max(1, (d.n + BLOCK * ppt - 1) / (BLOCK * ppt));
     d.num_blocks = nblocks[f];
     total_blocks += nblocks[f];
   }
+  set->points_per_thread = nf ? set->h_descs[0].ppt : 1;
 
   // block map
   std::vector<int2> blockmap;
@@ -414,6 +513,24 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 
 namespace {
 
+// kernel-variant dispatch: (U, MINW) chosen per plan (GLIM_AMD_U / GLIM_AMD_MINW override the tuned default)
+template <int U, int W>
+void launch_lin(glim_amd_factor_set* set) {
+  vgicp_kernel<MODE_LINEARIZE, false, U, W><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+                                                                                           set->d_partials);
+}
+
+void launch_vgicp_linearize(glim_amd_factor_set* set) {
+  const int u = set->variant_u, w = set->variant_minw;
+#define GA_CASE(UU, WW) \
+  if (u == UU && w == WW) return launch_lin<UU, WW>(set);
+  GA_CASE(1, 2) GA_CASE(1, 3) GA_CASE(1, 4)
+  GA_CASE(2, 2) GA_CASE(2, 3) GA_CASE(2, 4)
+  GA_CASE(4, 1) GA_CASE(4, 2) GA_CASE(4, 3)
+#undef GA_CASE
+  return launch_lin<2, 3>(set);
+}
+
 const int* rows_ptr(const glim_amd_factor_set* set) {
   return reinterpret_cast<const int*>(reinterpret_cast<const char*>(set->d_blockmap) + set->cap_blocks * sizeof(int2));
 }
@@ -422,9 +539,8 @@ const int* rows_ptr(const glim_amd_factor_set* set) {
 int launch_linearize(glim_amd_factor_set* set, double* out, long long row_offset) {
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
-  vgicp_kernel<MODE_LINEARIZE, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
-                                                                                     set->d_partials, set->points_per_thread);
-  finalize_kernel<<<nf, 64, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, out, row_offset, MODE_LINEARIZE);
+  launch_vgicp_linearize(set);
+  finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, out, row_offset, MODE_LINEARIZE);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
@@ -466,7 +582,7 @@ int glim_amd_factor_set_add(glim_amd_factor_set* set, const glim_amd_voxelmap* t
                             int32_t* factor_index) {
   if (!set || !target || !source) return GLIM_AMD_ERR_INVALID;
   if (target->ctx != set->ctx || source->ctx != set->ctx) return GLIM_AMD_ERR_INVALID;
-  if (!target->slots || !source->has_covs) return GLIM_AMD_ERR_STATE;
+  if (!target->buckets || !source->has_covs) return GLIM_AMD_ERR_STATE;
   if (source->n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;
   set->entries.push_back({target, source, flags});
   set->dirty = true;
@@ -581,14 +697,14 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
   GA_TRY(factor_set_prepare(set));
   if (T_lin) {
     GA_TRY(upload_poses(set, T_lin, T_eval));
-    vgicp_kernel<MODE_ERROR, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
-                                                                                  set->d_blockmap, set->d_partials, set->points_per_thread);
+    vgicp_kernel<MODE_ERROR, true, 2, 3><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
+                                                                                  set->d_blockmap, set->d_partials);
   } else {
     GA_TRY(upload_poses(set, T_eval, nullptr));
-    vgicp_kernel<MODE_ERROR, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
-                                                                                   set->d_partials, set->points_per_thread);
+    vgicp_kernel<MODE_ERROR, false, 2, 3><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+                                                                                   set->d_partials);
   }
-  finalize_kernel<<<(int)nf, 64, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, set->d_compact, 0, MODE_ERROR);
+  finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, set->d_compact, 0, MODE_ERROR);
   GA_HIP(hipGetLastError());
   GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
   GA_HIP(hipStreamSynchronize(set->stream));
@@ -644,8 +760,7 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));
   for (int i = 0; i < iters; i++)
-    vgicp_kernel<MODE_LINEARIZE, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
-                                                                                       set->d_partials, set->points_per_thread);
+    launch_vgicp_linearize(set);
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -666,7 +781,7 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
   if (!ctx || num_targets <= 0 || !targets || !T || !source || !overlap) return GLIM_AMD_ERR_INVALID;
   for (int t = 0; t < num_targets; t++) {
     if (!targets[t] || targets[t]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
-    if (!targets[t]->slots) return GLIM_AMD_ERR_STATE;
+    if (!targets[t]->buckets) return GLIM_AMD_ERR_STATE;
   }
   if (source->n == 0) {
     *overlap = 0.0;
@@ -677,8 +792,8 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
   hipStream_t st = ctx->stream();
   std::vector<OverlapTarget> h(num_targets);
   for (int t = 0; t < num_targets; t++) {
-    h[t].slots = targets[t]->slots;
-    h[t].mask = targets[t]->table_size - 1;
+    h[t].buckets = targets[t]->buckets;
+    h[t].num_buckets = targets[t]->num_buckets;
     h[t].pad = 0;
     h[t].inv_res = targets[t]->inv_resolution;
     memcpy(h[t].T, T + 12 * (size_t)t, 12 * sizeof(double));

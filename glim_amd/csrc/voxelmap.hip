@@ -7,10 +7,12 @@
 // Build (all on the context stream):
 //   1. insert_keys   : every point CASes its packed 64-bit coordinate key into an over-sized scratch table (2N slots,
 //                      never full) and the distinct keys are counted                        -> V
-//   2. move_keys     : the V distinct keys are re-inserted into the final table of 2^ceil(log2(2V)) 64-byte slots
+//   2. move_keys     : the V distinct keys are re-inserted into the final table of 3V two-way 128-byte buckets
 //   3. accumulate    : every point adds its mean / covariance as 64-bit FIXED-POINT integers with atomics -- integer
 //                      addition is associative, so the sums (and the map) are bit-reproducible whatever the atomic order
-//   4. finalise      : sums / count in FP64, stored as FP32 in the slot (key + statistic share one cache line)
+//   4. finalise      : sums / count in FP64, stored as FP32 in the bucket (keys + statistics share one 128-byte line)
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "device_math.hpp"
@@ -28,16 +30,13 @@ __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long* __res
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-__global__ __launch_bounds__(256) void init_slots_kernel(VoxelSlot* __restrict__ slots, unsigned int n) {
-  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  VoxelSlot s;
-  s.key = EMPTY_KEY;
-  s.mx = s.my = s.mz = 0.f;
-  s.c00 = s.c01 = s.c02 = s.c11 = s.c12 = s.c22 = 0.f;
-  s.count = 0;
-  s.pad[0] = s.pad[1] = s.pad[2] = s.pad[3] = 0;
-  slots[i] = s;
+__global__ __launch_bounds__(256) void init_buckets_kernel(VoxelBucket* __restrict__ buckets, unsigned int n) {
+  // one 16-byte store per lane: 8 lanes cover a 128-byte bucket
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * 8) return;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if ((i & 7) == 0) v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // key[0] = key[1] = EMPTY_KEY
+  reinterpret_cast<uint4*>(buckets)[i] = v;
 }
 
 // stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
@@ -65,17 +64,18 @@ __global__ __launch_bounds__(256) void insert_keys_kernel(int n, const float4* _
   }
 }
 
+// Re-insert the distinct keys into the final bucket table: way 0, then way 1, then the next bucket.
 __global__ __launch_bounds__(256) void move_keys_kernel(const unsigned long long* __restrict__ tkeys, unsigned int tsize,
-                                                        VoxelSlot* __restrict__ slots, unsigned int mask) {
+                                                        VoxelBucket* __restrict__ buckets, unsigned int num_buckets) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= tsize) return;
   const unsigned long long key = tkeys[i];
   if (key == EMPTY_KEY) return;
-  unsigned int s = hash_key(key) & mask;
+  unsigned int b = bucket_of(key, num_buckets);
   for (;;) {
-    const unsigned long long prev = atomicCAS(&slots[s].key, EMPTY_KEY, key);
-    if (prev == EMPTY_KEY) return;  // keys in the scratch table are distinct: no equal-key case
-    s = (s + 1) & mask;
+    if (atomicCAS(&buckets[b].key[0], EMPTY_KEY, key) == EMPTY_KEY) return;  // scratch keys are distinct: no equal-key case
+    if (atomicCAS(&buckets[b].key[1], EMPTY_KEY, key) == EMPTY_KEY) return;
+    b = (b + 1 == num_buckets) ? 0u : b + 1;
   }
 }
 
@@ -86,10 +86,11 @@ __device__ __forceinline__ void atomic_add_fixed(long long* p, double v, double 
 
 __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
                                                          const float2* __restrict__ covB, const unsigned long long* __restrict__ pkeys,
-                                                         const VoxelSlot* __restrict__ slots, unsigned int mask, long long* __restrict__ acc) {
+                                                         const VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
+                                                         long long* __restrict__ acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int s = find_slot(slots, mask, pkeys[i]);
+  const int s = find_slot(buckets, num_buckets, pkeys[i]);
   if (s < 0) return;
   const float4 p = pts[i];
   const float4 a = covA[i];
@@ -107,26 +108,34 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
   atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), 1ull);
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(VoxelSlot* __restrict__ slots, unsigned int tsize, const long long* __restrict__ acc) {
+// one thread per (bucket, way)
+__global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
+                                                       const long long* __restrict__ acc, double res) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= tsize) return;
-  if (slots[i].key == EMPTY_KEY) return;
+  if (i >= 2 * num_buckets) return;
+  const unsigned int b = i >> 1, w = i & 1;
+  const unsigned long long key = buckets[b].key[w];
+  if (key == EMPTY_KEY) return;
   const long long* a = acc + (size_t)i * ACC_STRIDE;
   const long long cnt = a[9];
   const double inv_n = 1.0 / (double)cnt;
   const double im = inv_n / MEAN_SCALE, ic = inv_n / COV_SCALE;
-  VoxelSlot s = slots[i];
-  s.mx = (float)((double)a[0] * im);
-  s.my = (float)((double)a[1] * im);
-  s.mz = (float)((double)a[2] * im);
-  s.c00 = (float)((double)a[3] * ic);
-  s.c01 = (float)((double)a[4] * ic);
-  s.c02 = (float)((double)a[5] * ic);
-  s.c11 = (float)((double)a[6] * ic);
-  s.c12 = (float)((double)a[7] * ic);
-  s.c22 = (float)((double)a[8] * ic);
-  s.count = (int)cnt;
-  slots[i] = s;
+  int cx, cy, cz;
+  unpack_key(key, cx, cy, cz);
+  float* r = buckets[b].rec[w];
+  // mean relative to the voxel centre (see VoxelBucket)
+  r[0] = (float)((double)a[0] * im - ((double)cx + 0.5) * res);
+  r[1] = (float)((double)a[1] * im - ((double)cy + 0.5) * res);
+  r[2] = (float)((double)a[2] * im - ((double)cz + 0.5) * res);
+  r[3] = (float)((double)a[3] * ic);  // c00
+  r[4] = (float)((double)a[4] * ic);  // c01
+  r[5] = (float)((double)a[5] * ic);  // c02
+  r[6] = (float)((double)a[6] * ic);  // c11
+  r[7] = (float)((double)a[7] * ic);  // c12
+  r[8] = (float)((double)a[8] * ic);  // c22
+  r[9] = __int_as_float((int)cnt);
+  r[10] = 0.f;
+  r[11] = 0.f;
 }
 
 unsigned int next_pow2(unsigned long long v) {
@@ -160,7 +169,7 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int /*init_nu
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (!m) return GLIM_AMD_OK;
   if (m->ctx) (void)hipSetDevice(m->ctx->device);
-  if (m->slots) (void)hipFree(m->slots);
+  if (m->buckets) (void)hipFree(m->buckets);
   delete m;
   return GLIM_AMD_OK;
 }
@@ -168,7 +177,7 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) {
   if (!m || !cloud || cloud->ctx != m->ctx) return GLIM_AMD_ERR_INVALID;
   if (!cloud->has_covs) return GLIM_AMD_ERR_STATE;
-  if (m->slots) return GLIM_AMD_ERR_UNSUPPORTED;  // GLIM's GPU path builds each map with a single insert()
+  if (m->buckets) return GLIM_AMD_ERR_UNSUPPORTED;  // GLIM's GPU path builds each map with a single insert()
   if (cloud->n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;
   glim_amd_ctx* ctx = m->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
@@ -195,28 +204,33 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
 
   const int num_voxels = h_stats[0];
-  const unsigned int tsize = next_pow2((unsigned long long)(num_voxels > 32 ? num_voxels : 32) * 2);
-  VoxelSlot* slots = nullptr;
-  GA_HIP(hipMalloc(&slots, (size_t)tsize * sizeof(VoxelSlot)));
-  hipError_t e = hipMalloc(&acc.p, (size_t)tsize * ACC_STRIDE * sizeof(long long));
-  if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)tsize * ACC_STRIDE * sizeof(long long), st);
+  // keys per bucket = 1 / bucket_factor (default 1/3: a key misses its home bucket with probability ~0.5 %)
+  unsigned long long bucket_factor = 3;
+  if (const char* env = getenv("GLIM_AMD_BUCKET_FACTOR")) bucket_factor = (unsigned long long)std::max(1, atoi(env));
+  const unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
+  if (nb64 > (1ull << 30)) return GLIM_AMD_ERR_NOMEM;
+  const unsigned int nb = (unsigned int)nb64;
+  VoxelBucket* buckets = nullptr;
+  GA_HIP(hipMalloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
+  hipError_t e = hipMalloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
+  if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long), st);
   if (e == hipSuccess) {
-    init_slots_kernel<<<(tsize + 255) / 256, 256, 0, st>>>(slots, tsize);
-    move_keys_kernel<<<(tsize0 + 255) / 256, 256, 0, st>>>((const unsigned long long*)tkeys.p, tsize0, slots, tsize - 1);
+    init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
+    move_keys_kernel<<<(tsize0 + 255) / 256, 256, 0, st>>>((const unsigned long long*)tkeys.p, tsize0, buckets, nb);
     if (n > 0)
-      accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, slots,
-                                                          tsize - 1, (long long*)acc.p);
-    finalize_kernel<<<(tsize + 255) / 256, 256, 0, st>>>(slots, tsize, (const long long*)acc.p);
+      accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets,
+                                                          nb, (long long*)acc.p);
+    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
     set_hip_error(e, "voxelmap_insert");
-    (void)hipFree(slots);
+    (void)hipFree(buckets);
     return GLIM_AMD_ERR_HIP;
   }
-  m->slots = slots;
-  m->table_size = tsize;
+  m->buckets = buckets;
+  m->num_buckets = nb;
   m->num_voxels = num_voxels;
   return GLIM_AMD_OK;
 }
@@ -224,44 +238,51 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
 int glim_amd_voxelmap_info(const glim_amd_voxelmap* m, int32_t* num_voxels, int32_t* num_buckets, double* resolution, size_t* bytes) {
   if (!m) return GLIM_AMD_ERR_INVALID;
   if (num_voxels) *num_voxels = m->num_voxels;
-  if (num_buckets) *num_buckets = (int32_t)m->table_size;
+  if (num_buckets) *num_buckets = (int32_t)m->num_buckets;
   if (resolution) *resolution = m->resolution;
-  if (bytes) *bytes = (size_t)m->table_size * sizeof(VoxelSlot);
+  if (bytes) *bytes = (size_t)m->num_buckets * sizeof(VoxelBucket);
   return GLIM_AMD_OK;
 }
 
 int glim_amd_voxelmap_download(const glim_amd_voxelmap* m, int32_t* coords, int32_t* counts, float* means, float* cov33) {
   if (!m) return GLIM_AMD_ERR_INVALID;
-  if (!m->slots) return GLIM_AMD_ERR_STATE;
+  if (!m->buckets) return GLIM_AMD_ERR_STATE;
   glim_amd_ctx* ctx = m->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
-  std::vector<VoxelSlot> host(m->table_size);
-  GA_HIP(hipMemcpyAsync(host.data(), m->slots, (size_t)m->table_size * sizeof(VoxelSlot), hipMemcpyDeviceToHost, ctx->stream()));
+  std::vector<VoxelBucket> host(m->num_buckets);
+  GA_HIP(hipMemcpyAsync(host.data(), m->buckets, (size_t)m->num_buckets * sizeof(VoxelBucket), hipMemcpyDeviceToHost, ctx->stream()));
   GA_HIP(hipStreamSynchronize(ctx->stream()));
   const unsigned int msk = (1u << KEY_BITS) - 1u;
   int v = 0;
-  for (const VoxelSlot& s : host) {
-    if (s.key == EMPTY_KEY) continue;
-    if (v >= m->num_voxels) return GLIM_AMD_ERR_STATE;
-    if (coords) {
-      coords[3 * v + 0] = (int)((s.key >> (2 * KEY_BITS)) & msk) - KEY_OFFSET;
-      coords[3 * v + 1] = (int)((s.key >> KEY_BITS) & msk) - KEY_OFFSET;
-      coords[3 * v + 2] = (int)(s.key & msk) - KEY_OFFSET;
+  for (const VoxelBucket& bk : host) {
+    for (int w = 0; w < 2; w++) {
+      const unsigned long long key = bk.key[w];
+      if (key == EMPTY_KEY) continue;
+      if (v >= m->num_voxels) return GLIM_AMD_ERR_STATE;
+      const float* r = bk.rec[w];
+      const int cx = (int)((key >> (2 * KEY_BITS)) & msk) - KEY_OFFSET;
+      const int cy = (int)((key >> KEY_BITS) & msk) - KEY_OFFSET;
+      const int cz = (int)(key & msk) - KEY_OFFSET;
+      if (coords) {
+        coords[3 * v + 0] = cx;
+        coords[3 * v + 1] = cy;
+        coords[3 * v + 2] = cz;
+      }
+      if (counts) memcpy(&counts[v], &r[9], sizeof(int));
+      if (means) {  // stored relative to the voxel centre
+        means[3 * v] = (float)((double)r[0] + ((double)cx + 0.5) * m->resolution);
+        means[3 * v + 1] = (float)((double)r[1] + ((double)cy + 0.5) * m->resolution);
+        means[3 * v + 2] = (float)((double)r[2] + ((double)cz + 0.5) * m->resolution);
+      }
+      if (cov33) {
+        float* c = cov33 + 9 * v;
+        c[0] = r[3]; c[1] = r[4]; c[2] = r[5];
+        c[3] = r[4]; c[4] = r[6]; c[5] = r[7];
+        c[6] = r[5]; c[7] = r[7]; c[8] = r[8];
+      }
+      v++;
     }
-    if (counts) counts[v] = s.count;
-    if (means) {
-      means[3 * v] = s.mx;
-      means[3 * v + 1] = s.my;
-      means[3 * v + 2] = s.mz;
-    }
-    if (cov33) {
-      float* c = cov33 + 9 * v;
-      c[0] = s.c00; c[1] = s.c01; c[2] = s.c02;
-      c[3] = s.c01; c[4] = s.c11; c[5] = s.c12;
-      c[6] = s.c02; c[7] = s.c12; c[8] = s.c22;
-    }
-    v++;
   }
   return v == m->num_voxels ? GLIM_AMD_OK : GLIM_AMD_ERR_STATE;
 }

@@ -404,4 +404,6 @@ def test_full_size_scan_properties(api, ctx, orc):
     f3.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, mg))
     z = f3.linearize({1: np.eye(4)})[0]
     assert z["num_inliers"] >= len(means) - 5
-    assert z["error"] < 1e-6 and np.abs(z["b_s"]).max() < 1e-2
+    # (the downloaded means are rounded to FP32 at ~30 m, i.e. to ~2e-6 m, so the residual is tiny but not exactly zero)
+    assert z["error"] < 1e-3
+    assert np.abs(gn_step(z)).max() < 1e-5
