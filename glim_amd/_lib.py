@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglim_amd.so")
+LIB_PATH = os.environ.get("GLIM_AMD_LIB") or os.path.join(_HERE, "libglim_amd.so")  # GLIM_AMD_LIB: profiling builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 COMPACT_DOUBLES = 29

@@ -47,14 +47,15 @@ __device__ __forceinline__ unsigned long long voxel_key(double qx, double qy, do
 // (hash * num_buckets) >> 32, so any table size works and no power-of-two rounding wastes memory).  The three 21-bit axis
 // fields are combined with full-rate 24-bit multiply-adds, then one xor-shift-multiply round.  Any hash is valid because
 // lookups compare the full key.
-__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
-  const unsigned int m = (1u << KEY_BITS) - 1u;
-  const unsigned int uz = (unsigned int)k & m, uy = (unsigned int)(k >> KEY_BITS) & m, ux = (unsigned int)(k >> (2 * KEY_BITS)) & m;
-  unsigned int h = __umul24(ux, 0x9E3779u) + __umul24(uy, 0x85EBCBu) + __umul24(uz, 0xC2B2AFu);
+__device__ __forceinline__ unsigned int hash_fields(unsigned int ux, unsigned int uy, unsigned int uz) {
+  unsigned int h = __umul24(ux & 0x1fffffu, 0x9E3779u) + __umul24(uy & 0x1fffffu, 0x85EBCBu) + __umul24(uz & 0x1fffffu, 0xC2B2AFu);
   h ^= h >> 15;
   h *= 0x2C1B3C6Du;
   h ^= h >> 13;
   return h;
+}
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
+  return hash_fields((unsigned int)(k >> (2 * KEY_BITS)), (unsigned int)(k >> KEY_BITS), (unsigned int)k);
 }
 __device__ __forceinline__ unsigned int bucket_of(unsigned long long key, unsigned int num_buckets) {
   return __umulhi(hash_key(key), num_buckets);

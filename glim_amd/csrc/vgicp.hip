@@ -32,6 +32,10 @@ using namespace glim_amd;
 
 namespace {
 
+#ifndef GLIM_AMD_ABLATE
+#define GLIM_AMD_ABLATE 0  // profiling-only variants (tools/ablate.sh): 1 no gathers, 2 FP32 transform, 3 no algebra, 4 key gather only, 6 linear (coalesced) bucket index
+#endif
+
 constexpr int BLOCK = 256;
 constexpr int NACC = 28;  // FP32 accumulators per thread (see layout below); slot 28 of a partial row = inlier count (int bits)
 
@@ -48,11 +52,19 @@ enum { MODE_LINEARIZE = 0, MODE_ERROR = 1 };
 // space hipcc emits FLAT loads (which tick both vmcnt and lgkmcnt and force vmcnt(0) waits); with it, global_load + counted waits.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v3f_t __attribute__((ext_vector_type(3)));
 typedef const __attribute__((address_space(1))) v4f_t* gf4_t;
+typedef const __attribute__((address_space(1))) v3f_t* gf3_t;
 typedef const __attribute__((address_space(1))) v2f_t* gf2_t;
 __device__ __forceinline__ float4 gld4(const void* p) {
   const v4f_t v = *reinterpret_cast<gf4_t>(reinterpret_cast<uintptr_t>(p));
   return make_float4(v.x, v.y, v.z, v.w);
+}
+// xyz of a float4 record as ONE 12-byte load: no dead 4th destination register (a dead register gets recycled by the
+// allocator while the load is still in flight, and the write-after-write hazard then stalls the wave on that load)
+__device__ __forceinline__ float4 gld3(const void* p) {
+  const v3f_t v = *reinterpret_cast<gf3_t>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, 1.f);
 }
 __device__ __forceinline__ float2 gld2(const void* p) {
   const v2f_t v = *reinterpret_cast<gf2_t>(reinterpret_cast<uintptr_t>(p));
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const unsigned int i = (unsigned int)min(base + u * BLOCK, last);
-      nxt[u].p = gld4(reinterpret_cast<const char*>(d.pts) + i * 16u);   // uniform base + 32-bit lane offset (n <= 2^28)
+      nxt[u].p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);   // uniform base + 32-bit lane offset (n <= 2^28)
       nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
       nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
     }
@@ -122,15 +134,33 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         cur[u] = nxt[u];
         const int i = base + (it0 + u) * BLOCK;
         const bool ok = (it0 + u < ppt) && (i < d.n);
+#if GLIM_AMD_ABLATE == 2
+        const float qxf = R00 * cur[u].p.x + R01 * cur[u].p.y + R02 * cur[u].p.z + (float)Tl[3];
+        const float qyf = R10 * cur[u].p.x + R11 * cur[u].p.y + R12 * cur[u].p.z + (float)Tl[7];
+        const float qzf = R20 * cur[u].p.x + R21 * cur[u].p.y + R22 * cur[u].p.z + (float)Tl[11];
+        const float ir = (float)d.inv_res;
+        const float tx = qxf * ir, ty = qyf * ir, tz = qzf * ir;
+        const double qx = qxf, qy = qyf, qz = qzf;
+        (void)qx; (void)qy; (void)qz;
+#else
         double qx, qy, qz;
         transform_point_d(Tl, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, qx, qy, qz);
         const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
+#endif
         // floor(t) == fast_floor(t) for every in-range coordinate (same integer, bit-exact); v_floor_f64 + one subtraction also
         // gives the in-voxel fraction for free
+#if GLIM_AMD_ABLATE == 2
+        const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
+        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+#else
         const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
         const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
-        // out-of-range coordinates saturate in v_cvt_i32_f64 and are rejected by pack_key's unsigned range check
-        key[u] = ok ? pack_key(cx, cy, cz) : EMPTY_KEY;
+#endif
+        // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
+        const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
+        const bool valid = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
+        key[u] = valid ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
+        unsigned int hsh = hash_fields(ux, uy, uz);
         if (FROZEN) {
           double ex, ey, ez;
           transform_point_d(Te, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, ex, ey, ez);
@@ -151,14 +181,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
           const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
           if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) key[u] = EMPTY_KEY;
         }
-        bkt[u] = bucket_of(key[u], d.num_buckets);
-        head[u] = gld4(d.buckets + bkt[u]);  // both keys of the home bucket (always a valid address)
+        bkt[u] = __umulhi(hsh, d.num_buckets);
+#if GLIM_AMD_ABLATE == 6
+        bkt[u] = (unsigned int)(base + (it0 + u) * BLOCK) % d.num_buckets;  // coalesced stand-in for the hashed bucket
+        key[u] = EMPTY_KEY - 1;
+#endif
+#if GLIM_AMD_ABLATE == 1
+        head[u] = make_float4(__uint_as_float((unsigned int)key[u]), __uint_as_float((unsigned int)(key[u] >> 32)), 0.f, 0.f);
+#else
+        head[u] = gld4(reinterpret_cast<const char*>(d.buckets) + bkt[u] * 128u);  // both keys of the home bucket (32-bit offset: <= 2^25 buckets)
+#endif
       }
       // ---- coalesced loads of the NEXT trip, issued behind the gathers (counted vmcnt lets the gathers be consumed first) ----
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const unsigned int i = (unsigned int)min(base + (it0 + U + u) * BLOCK, last);
-        nxt[u].p = gld4(reinterpret_cast<const char*>(d.pts) + i * 16u);
+        nxt[u].p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);
         nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
         nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
       }
@@ -172,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
           // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
           while (k0 != key[u] && k1 != key[u] && k1 != EMPTY_KEY) {
             b = (b + 1 == d.num_buckets) ? 0u : b + 1;
-            const float4 h = gld4(d.buckets + b);
+            const float4 h = gld4(reinterpret_cast<const char*>(d.buckets) + b * 128u);
             k0 = (unsigned long long)__float_as_uint(h.x) | ((unsigned long long)__float_as_uint(h.y) << 32);
             k1 = (unsigned long long)__float_as_uint(h.z) | ((unsigned long long)__float_as_uint(h.w) << 32);
           }
@@ -182,10 +220,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         inliers += hit ? 1 : 0;
         // 48-byte record of the matching way: the line was just fetched by the key load, so this dependent read stays on chip;
         // every lane reads (way 0 when there is no hit) so the wavefront does not diverge
-        const char* rp = reinterpret_cast<const char*>(d.buckets + b) + (in1 ? 64 : 16);
+        const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
+#if GLIM_AMD_ABLATE == 1 || GLIM_AMD_ABLATE == 4
+        (void)rp;
+        const float4 r0 = make_float4(0.01f * cur[u].p.x, 0.01f, -0.02f, 1.0f);
+        const float4 r1 = make_float4(0.01f, 0.02f, 0.9f, 0.03f);
+        const float4 r2 = make_float4(0.8f + 0.001f * cur[u].p.y, 0.f, 0.f, 0.f);
+#else
         const float4 r0 = gld4(rp);        // mx my mz c00
         const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
         const float4 r2 = gld4(rp + 32);   // c22 count - -
+#endif
         const float4 ca = cur[u].ca;
         const float2 cb = cur[u].cb;
 
@@ -194,6 +239,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         const float ry = r0.y - qr[u][1];
         const float rz = r0.z - qr[u][2];
 
+#if GLIM_AMD_ABLATE == 3
+        acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2.x + ca.x + ca.y + ca.z + ca.w + cb.x + cb.y + cur[u].p.x;
+        continue;
+#endif
         // S = R^T C_B R + C_A   (source frame, symmetric).  Non-hit lanes get S = I so the algebra stays finite.
         const float b00 = hit ? r0.w : 1.f, b01 = hit ? r1.x : 0.f, b02 = hit ? r1.y : 0.f;
         const float b11 = hit ? r1.z : 1.f, b12 = hit ? r1.w : 0.f, b22 = hit ? r2.x : 1.f;

@@ -208,7 +208,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   unsigned long long bucket_factor = 3;
   if (const char* env = getenv("GLIM_AMD_BUCKET_FACTOR")) bucket_factor = (unsigned long long)std::max(1, atoi(env));
   const unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
-  if (nb64 > (1ull << 30)) return GLIM_AMD_ERR_NOMEM;
+  if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;  // 32-bit byte offsets into the bucket table (4 GiB, ~11 M voxels)
   const unsigned int nb = (unsigned int)nb64;
   VoxelBucket* buckets = nullptr;
   GA_HIP(hipMalloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
