@@ -1,0 +1,157 @@
+// test_compat.cpp -- exercises the C++ mirror of the gtsam_points GPU interface (include/glim_amd/gtsam_points_compat.hpp) the way
+// GLIM's odometry does (odometry_estimation_gpu.cpp:86-107,128-206), and checks the results against the CPU oracle (test-only).
+// Built and run by tests/test_gpu_cpp.py on the GPU box:  g++ -std=c++17 test_compat.cpp -lglim_amd -lvgicp_oracle
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../include/glim_amd/gtsam_points_compat.hpp"
+#include "../../oracle/vgicp_oracle.h"
+
+using namespace glim_amd;
+
+#define REQUIRE(cond)                                                   \
+  do {                                                                  \
+    if (!(cond)) {                                                      \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      return 1;                                                         \
+    }                                                                   \
+  } while (0)
+
+// a corner made of three walls, seen from a sensor pose: n points, f32-representable coordinates (Vector4d layout)
+static std::vector<double> make_scan(int n, double ox, double oy, double yaw, unsigned seed) {
+  std::mt19937_64 rng(seed);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  std::normal_distribution<double> G(0.0, 0.005);
+  std::vector<double> pts(4 * (size_t)n);
+  const double c = std::cos(yaw), s = std::sin(yaw);
+  for (int i = 0; i < n; i++) {
+    double x, y, z;
+    const int wall = i % 3;
+    if (wall == 0) { x = 8.0 * U(rng); y = 6.0 * U(rng); z = -1.5 + G(rng); }        // floor
+    else if (wall == 1) { x = 8.0 + G(rng); y = 6.0 * U(rng); z = -1.5 + 3.0 * U(rng); }  // front wall
+    else { x = 8.0 * U(rng); y = 6.0 + G(rng); z = -1.5 + 3.0 * U(rng); }               // side wall
+    const double wx = x - ox, wy = y - oy;  // world -> sensor frame (T_world_sensor^-1)
+    pts[4 * i + 0] = (double)(float)(c * wx + s * wy);
+    pts[4 * i + 1] = (double)(float)(-s * wx + c * wy);
+    pts[4 * i + 2] = (double)(float)z;
+    pts[4 * i + 3] = 1.0;
+  }
+  return pts;
+}
+
+static Isometry3d pose2d(double x, double y, double yaw) {
+  Isometry3d T;
+  T.m = {std::cos(yaw), -std::sin(yaw), 0, x, std::sin(yaw), std::cos(yaw), 0, y, 0, 0, 1, 0};
+  return T;
+}
+
+static double max_rel_diff(const double* a, const double* b, int n) {
+  double num = 0, den = 1e-300;
+  for (int i = 0; i < n; i++) {
+    num = std::fmax(num, std::fabs(a[i] - b[i]));
+    den = std::fmax(den, std::fabs(b[i]));
+  }
+  return num / den;
+}
+
+int main() {
+  if (glim_amd_device_count() < 1) {
+    std::fprintf(stderr, "no HIP device: this test must run on the GPU box\n");
+    return 2;
+  }
+  const int n = 20000, k = 10;
+  const Isometry3d T_world_a = pose2d(1.0, 1.0, 0.05), T_world_b = pose2d(1.3, 1.1, 0.08);
+  const std::vector<double> pa = make_scan(n, 1.0, 1.0, 0.05, 1), pb = make_scan(n, 1.3, 1.1, 0.08, 2);
+
+  // -- OdometryEstimationGPU::create_frame: clone, (kNN + covariance on the device), two voxel-map levels
+  auto fa = PointCloudGPU::clone(pa.data(), nullptr, nullptr, n);
+  auto fb = PointCloudGPU::clone(pb.data(), nullptr, nullptr, n);
+  const std::vector<int> nb_b = fb->find_neighbors(k);
+  fa->find_neighbors(k);
+  fa->estimate_covariances(k);
+  fb->estimate_covariances(k);
+  std::vector<GaussianVoxelMapGPU::Ptr> maps;
+  for (int level = 0; level < 2; level++) {
+    auto vm = std::make_shared<GaussianVoxelMapGPU>(0.5f * std::pow(2.0f, (float)level), 8192 * 2, 10, 1e-3);
+    vm->insert(*fa);
+    REQUIRE(vm->voxelmap_info().num_voxels > 100);
+    maps.push_back(vm);
+  }
+
+  // -- create_factors: binary factor per level (+ one unary), batched through NonlinearFactorSetGPU
+  const Key X0 = 0, X1 = 1;
+  Values values;
+  values[X0] = T_world_a;
+  values[X1] = T_world_b;
+  NonlinearFactorSetGPU set;
+  std::vector<IntegratedVGICPFactorGPU::shared_ptr> factors;
+  for (auto& vm : maps) {
+    auto f = std::make_shared<IntegratedVGICPFactorGPU>(X0, X1, vm, fb);
+    factors.push_back(f);
+    set.add(f);
+  }
+  auto unary = std::make_shared<IntegratedVGICPFactorGPU>(T_world_a, X1, maps[0], fb);
+  factors.push_back(unary);
+  set.add(unary);
+  REQUIRE(set.size() == 3);
+  set.linearize(values);
+
+  // -- oracle on the same inputs: kNN sets, covariances, voxel map, factor
+  std::vector<int32_t> onb((size_t)n * k);
+  orc_knn_grid(pb.data(), n, k, 0.0, onb.data(), 0);
+  for (size_t i = 0; i < onb.size(); i++) REQUIRE(onb[i] == nb_b[i]);
+  std::vector<double> na(4 * (size_t)n), ca(16 * (size_t)n), nbv(4 * (size_t)n), cb(16 * (size_t)n);
+  std::vector<int32_t> onb_a((size_t)n * k);
+  orc_knn_grid(pa.data(), n, k, 0.0, onb_a.data(), 0);
+  orc_covariance_estimate(pa.data(), n, onb_a.data(), k, k, na.data(), ca.data(), 0);
+  orc_covariance_estimate(pb.data(), n, onb.data(), k, k, nbv.data(), cb.data(), 0);
+  for (auto& v : ca) v = (double)(float)v;  // the device stores FP32 covariances
+  for (auto& v : cb) v = (double)(float)v;
+  const Isometry3d delta = factors[0]->calc_delta(values);
+  for (int level = 0; level < 2; level++) {
+    orc_voxelmap* om = orc_voxelmap_create(0.5 * std::pow(2.0, level));
+    orc_voxelmap_insert(om, pa.data(), ca.data(), n);
+    REQUIRE(orc_voxelmap_num_voxels(om) == maps[level]->voxelmap_info().num_voxels);
+    orc_linearized6 ref;
+    orc_vgicp_linearize(om, pb.data(), cb.data(), n, delta.m.data(), 0, &ref, nullptr);
+    const LinearizedSystem6& got = factors[level]->linearized();
+    REQUIRE(got.num_inliers == ref.num_inliers);
+    REQUIRE(got.num_inliers > n / 2);
+    REQUIRE(max_rel_diff(got.H_ss, ref.H_ss, 36) < 2e-4);
+    REQUIRE(max_rel_diff(got.H_tt, ref.H_tt, 36) < 2e-4);
+    REQUIRE(max_rel_diff(got.H_ts, ref.H_ts, 36) < 2e-4);
+    REQUIRE(max_rel_diff(got.b_s, ref.b_s, 6) < 1e-3);
+    REQUIRE(std::fabs(got.error - ref.error) < 2e-4 * ref.error);
+    double dg[6], dr[6];
+    REQUIRE(orc_solve6(got.H_ss, got.b_s, 0.0, dg) == 0);
+    REQUIRE(orc_solve6(ref.H_ss, ref.b_s, 0.0, dr) == 0);
+    for (int i = 0; i < 6; i++) REQUIRE(std::fabs(dg[i] - dr[i]) < 1e-4);
+    if (level == 0) {
+      // unary factor with the target pose fixed == source block of the binary one, no target blocks
+      const LinearizedSystem6& u = unary->linearized();
+      REQUIRE(u.num_inliers == got.num_inliers);
+      REQUIRE(max_rel_diff(u.H_ss, got.H_ss, 36) < 1e-12);
+      for (int i = 0; i < 36; i++) REQUIRE(u.H_tt[i] == 0.0 && u.H_ts[i] == 0.0);
+      // slow path (factor linearised on its own) == batch result; error() == linearised error at the same point
+      auto solo = factors[0]->clone();
+      const LinearizedSystem6 s = solo->linearize(values);
+      REQUIRE(s.num_inliers == got.num_inliers);
+      REQUIRE(max_rel_diff(s.H_ss, got.H_ss, 36) < 1e-6);
+      REQUIRE(std::fabs(solo->error(values) - got.error) < 1e-6 * got.error);
+      // overlap_gpu == inlier fraction (odometry_estimation_gpu.cpp:248); multi-target form counts any hit
+      const double ov = overlap_gpu(maps[0], fb, delta);
+      REQUIRE(std::fabs(ov - (double)got.num_inliers / n) < 1e-12);
+      Isometry3d far = delta;
+      far.m[3] += 1e4;
+      REQUIRE(overlap_gpu(maps[0], fb, far) == 0.0);
+      REQUIRE(std::fabs(overlap_gpu({maps[0], maps[1]}, fb, {far, delta}) - overlap_gpu(maps[1], fb, delta)) < 1e-12);
+      REQUIRE(std::fabs(factors[0]->inlier_fraction() - ov) < 1e-12);
+    }
+    orc_voxelmap_destroy(om);
+  }
+  std::printf("test_compat OK: %d points, inliers level0 = %lld\n", n, (long long)factors[0]->linearized().num_inliers);
+  return 0;
+}

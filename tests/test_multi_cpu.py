@@ -1,0 +1,102 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes shard a factor list, all-reduce the [n x 29] block array and expand it.
+
+The per-factor compute is stood in by the CPU oracle here (tests may use it); on the GPU box the same ShardedCostEvaluator is
+fed by the HIP NonlinearFactorSetGPU (bench.py --gpus N).  What this covers: shard boundaries, row placement, the collective,
+the compact layout and the FP64 expansion of binary blocks -- i.e. everything of the distributed path that is not the kernel.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_are_contiguous_and_balanced():
+    from glim_amd import multi
+
+    rng = np.random.default_rng(0)
+    for n, w in [(0, 2), (1, 2), (5, 8), (17, 2), (100, 8), (32640, 8)]:
+        costs = rng.integers(1000, 70000, size=n)
+        b = multi.shard_bounds(costs, w)
+        assert b[0] == 0 and b[-1] == n and len(b) == w + 1
+        assert all(b[i] <= b[i + 1] for i in range(w))
+        if n >= 4 * w:
+            loads = [costs[b[i]:b[i + 1]].sum() for i in range(w)]
+            assert max(loads) <= 1.25 * (costs.sum() / w) + costs.max()
+    assert multi.shard_bounds([1] * 8, 8) == list(range(9))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from glim_amd import api, multi, synth
+    from oracle import oracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank builds the same replicated problem: 4 small scans, all ordered pairs as binary factors
+        scene = synth.Scene.default()
+        dirs = synth.lidar_directions(16, 64)
+        poses = synth.arc_trajectory(4)
+        scans, covs, maps = [], [], []
+        for i, T in enumerate(poses):
+            p = synth.scan(scene, T, dirs, i)
+            _, c = orc.covariances(p, orc.knn(p, 10))
+            c = c.astype(np.float32).astype(np.float64)
+            scans.append(p)
+            covs.append(c)
+            maps.append(orc.VoxelMap(1.0).insert(p, c))
+        pairs = [(i, j) for i in range(4) for j in range(4) if i != j]
+        deltas = [synth.relative_pose(poses[i], poses[j]) for i, j in pairs]
+        costs = [len(scans[j]) for _, j in pairs]
+        ev = multi.ShardedCostEvaluator(costs, rank, world)
+        rows = [multi.compact_from_linearized(orc.vgicp_linearize(maps[pairs[f][0]], scans[pairs[f][1]], covs[pairs[f][1]], deltas[f]))
+                for f in ev.owned()]
+        blocks = ev.evaluate_host(np.array(rows).reshape(-1, multi.COMPACT)).numpy()
+        # every rank must now hold every factor; compare with the unsharded evaluation
+        worst = 0.0
+        for f, (i, j) in enumerate(pairs):
+            ref = orc.vgicp_linearize(maps[i], scans[j], covs[j], deltas[f])
+            got = api.expand_compact(blocks[f], deltas[f], api.FACTOR_BINARY)
+            assert got["num_inliers"] == ref["num_inliers"]
+            for k in ("H_tt", "H_ss", "H_ts", "b_t", "b_s"):
+                worst = max(worst, float(np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)))
+        q.put((rank, ev.lo, ev.hi, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_equals_unsharded_gloo_world2():
+    import torch.multiprocessing as mp
+
+    from glim_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 12  # contiguous shards covering all 12 factors
+    assert all(r[3] < 1e-9 for r in res)
