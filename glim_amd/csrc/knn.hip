@@ -1,14 +1,24 @@
-// knn.hip -- kernel K2: exact k-nearest-neighbour search on the device.
+// knn.hip -- kernel group K2: exact k-nearest-neighbour search on the device.
 // Replaces CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221, a nanoflann kd-tree):
 // for every point the k nearest points among ALL points including itself (buffers pre-filled with i, :197), ascending
 // squared distance; ties are ordered by ascending index (the oracle's rule; the reference leaves exact ties to the kd-tree).
 //
 // Distances are evaluated in FP64 as (dx*dx + dy*dy) + dz*dz on the FP32-representable inputs -- the same expression, in
-// the same order and without fma contraction, as oracle/vgicp_oracle.c:sqdist3 -- so neighbour SETS are bit-identical.
+// the same order and without fma contraction, as oracle/vgicp_oracle.c:sqdist3 -- so neighbour lists are bit-identical.
 //
-// Round-1 implementation: LDS-tiled exhaustive scan (every query against every point), one query per lane, tile of 1024
-// candidates staged as FP64 SoA in LDS and read as wave-uniform broadcasts.  O(N^2) but exact and branch-light:
-// 131 072 points = 1.7e10 pair tests.  A grid-hashed search for the 300k-point stream (BASELINE config 5) is the next step.
+// Two implementations, same result:
+//   * grid (default): points are counting-sorted into a hashed uniform grid (cell edge h picked from the data so that an
+//     occupied cell holds a few points); every query scans the cells of growing Chebyshev rings around its own cell and
+//     stops as soon as its k-th best distance is provably inside the scanned cube ((ring-1) h + distance to the nearest wall
+//     of the own cell); queries are processed in cell order so a wavefront walks the same cells.  Queries that would need
+//     more than MAX_RING rings (isolated points) are finished by the exhaustive kernel.
+//   * exhaustive: LDS-tiled scan of every point (tiny clouds, and the fallback above).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "device_math.hpp"
 #include "internal.hpp"
 
 using namespace glim_amd;
@@ -16,6 +26,7 @@ using namespace glim_amd;
 namespace {
 
 constexpr int TILE = 1024;
+constexpr int MAX_RING = 6;
 
 template <int K>
 struct TopK {
@@ -46,11 +57,19 @@ struct TopK {
   }
 };
 
+__device__ __forceinline__ double sqdist(double qx, double qy, double qz, double x, double y, double z) {
+  const double dx = qx - x, dy = qy - y, dz = qz - z;
+  return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// ---- exhaustive scan.  `queries` (optional): list of point indices to answer; otherwise every point. ----
 template <int K>
-__global__ __launch_bounds__(256) void knn_bruteforce_kernel(int n, const float4* __restrict__ pts, int k, int32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void knn_bruteforce_kernel(int n, const float4* __restrict__ pts, int k, int32_t* __restrict__ out,
+                                                             const int* __restrict__ queries, int num_queries) {
   __shared__ double s_x[TILE], s_y[TILE], s_z[TILE];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < num_queries;
+  const int i = live ? (queries ? queries[t] : t) : 0;
   double qx = 0, qy = 0, qz = 0;
   if (live) {
     const float4 p = pts[i];
@@ -58,7 +77,6 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(int n, const float4
   }
   TopK<K> best;
   best.init(i);
-  int found = 0;
   for (int t0 = 0; t0 < n; t0 += TILE) {
     const int tn = min(TILE, n - t0);
     __syncthreads();
@@ -67,26 +85,262 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(int n, const float4
       s_x[j] = p.x; s_y[j] = p.y; s_z[j] = p.z;
     }
     __syncthreads();
-    if (live) {
-      for (int j = 0; j < tn; j++) {
-        const double dx = qx - s_x[j], dy = qy - s_y[j], dz = qz - s_z[j];
-        const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-        best.push(d2, t0 + j);
-      }
-      found += tn;
-    }
+    if (live)
+      for (int j = 0; j < tn; j++) best.push(sqdist(qx, qy, qz, s_x[j], s_y[j], s_z[j]), t0 + j);
   }
   if (live) {
-    const int valid = min(found, K);
+    const int valid = min(n, K);
 #pragma unroll
     for (int j = 0; j < K; j++)
       if (j < k) out[(size_t)i * k + j] = (j < valid) ? best.idx[j] : i;
   }
 }
 
+// ---- grid build ----
+// stats: [0] occupied cells, [1] out-of-range points, [2] unresolved queries
+__global__ __launch_bounds__(256) void grid_insert_kernel(int n, const float4* __restrict__ pts, double inv_h, unsigned long long* __restrict__ keys,
+                                                          unsigned int mask, int* __restrict__ counts, int* __restrict__ slot_of, int* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const unsigned long long key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_h);
+  if (key == EMPTY_KEY) {
+    atomicAdd(&stats[1], 1);
+    slot_of[i] = -1;
+    return;
+  }
+  unsigned int s = hash_key(key) & mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&keys[s], EMPTY_KEY, key);
+    if (prev == EMPTY_KEY) atomicAdd(&stats[0], 1);
+    if (prev == EMPTY_KEY || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicAdd(&counts[s], 1);
+  slot_of[i] = (int)s;
+}
+
+// exclusive scan of counts[T] -> starts[T] (single block, 1024 threads, contiguous chunks)
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int* __restrict__ starts, unsigned int T) {
+  __shared__ int s_sum[1024];
+  const unsigned int per = (T + 1023u) / 1024u;
+  const unsigned int b = threadIdx.x * per, e = min(T, b + per);
+  int sum = 0;
+  for (unsigned int i = b; i < e; i++) sum += counts[i];
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (threadIdx.x >= (unsigned)off) ? s_sum[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_sum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_sum[threadIdx.x] - sum;
+  for (unsigned int i = b; i < e; i++) {
+    starts[i] = run;
+    run += counts[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ slot_of,
+                                                           const int* __restrict__ starts, int* __restrict__ cursor, float4* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = slot_of[i];
+  if (s < 0) return;
+  const int pos = starts[s] + atomicAdd(&cursor[s], 1);
+  const float4 p = pts[i];
+  sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ---- grid query: one lane per point, in cell order ----
 template <int K>
-void launch_knn(hipStream_t st, int n, const float4* pts, int k, int32_t* out) {
-  knn_bruteforce_kernel<K><<<(n + 255) / 256, 256, 0, st>>>(n, pts, k, out);
+__global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __restrict__ sorted, double h, double inv_h,
+                                                       const unsigned long long* __restrict__ keys, unsigned int mask, const int* __restrict__ starts,
+                                                       const int* __restrict__ counts, int k, int32_t* __restrict__ out, int* __restrict__ unresolved,
+                                                       int* __restrict__ stats) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const float4 q4 = sorted[s];
+  const int self = __float_as_int(q4.w);
+  const double qx = q4.x, qy = q4.y, qz = q4.z;
+  const double tx = qx * inv_h, ty = qy * inv_h, tz = qz * inv_h;
+  const int cx = fast_floor_d(tx), cy = fast_floor_d(ty), cz = fast_floor_d(tz);
+  // distance from the query to the nearest wall of its own cell (>= 0; conservative under rounding)
+  double margin = fmin(fmin(tx - (double)cx, (double)(cx + 1) - tx), fmin(fmin(ty - (double)cy, (double)(cy + 1) - ty), fmin(tz - (double)cz, (double)(cz + 1) - tz)));
+  margin = fmax(0.0, margin * h * 0.999999);
+  TopK<K> best;
+  best.init(self);
+  bool done = false;
+  for (int ring = 0; ring <= MAX_RING; ring++) {
+    if (ring >= 1) {
+      const double reach = (double)(ring - 1) * h * 0.999999 + margin;  // every unscanned point is at least this far
+      if (best.d[K - 1] < reach * reach) {                               // strict: an unscanned tie could carry a smaller index
+        done = true;
+        break;
+      }
+    }
+    for (int dz = -ring; dz <= ring; dz++)
+      for (int dy = -ring; dy <= ring; dy++) {
+        const bool shell_yz = (abs(dz) == ring) || (abs(dy) == ring);
+        for (int dx = -ring; dx <= ring; dx += (shell_yz || ring == 0) ? 1 : 2 * ring) {
+          const unsigned long long key = pack_key(cx + dx, cy + dy, cz + dz);
+          if (key == EMPTY_KEY) continue;
+          unsigned int sl = hash_key(key) & mask;
+          int found = -1;
+          for (;;) {
+            const unsigned long long kk = keys[sl];
+            if (kk == key) {
+              found = (int)sl;
+              break;
+            }
+            if (kk == EMPTY_KEY) break;
+            sl = (sl + 1) & mask;
+          }
+          if (found < 0) continue;
+          const int b = starts[found], e = b + counts[found];
+          for (int j = b; j < e; j++) {
+            const float4 c = sorted[j];
+            best.push(sqdist(qx, qy, qz, (double)c.x, (double)c.y, (double)c.z), __float_as_int(c.w));
+          }
+        }
+      }
+  }
+  if (!done) {
+    // the (2 MAX_RING + 1)^3 cube was scanned: accept only if that already proves the result, else hand over to the exhaustive kernel
+    const double reach = (double)MAX_RING * h * 0.999999 + margin;
+    done = best.d[K - 1] < reach * reach;
+  }
+  if (!done) {
+    unresolved[atomicAdd(&stats[2], 1)] = self;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < K; j++)
+    if (j < k) out[(size_t)self * k + j] = best.idx[j];  // fewer than k points in the whole cloud never reaches here (n > k enforced)
+}
+
+// bounding box by ordered-int atomics: bb[0..2] = min, bb[3..5] = max (as order-preserving ints)
+__device__ __forceinline__ int ordered(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void bbox_kernel(int n, const float4* __restrict__ pts, int* __restrict__ bb) {
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    const int v[3] = {ordered(p.x), ordered(p.y), ordered(p.z)};
+    for (int a = 0; a < 3; a++) {
+      lo[a] = min(lo[a], v[a]);
+      hi[a] = max(hi[a], v[a]);
+    }
+  }
+  for (int a = 0; a < 3; a++) {
+    atomicMin(&bb[a], lo[a]);
+    atomicMax(&bb[3 + a], hi[a]);
+  }
+}
+float unordered(int i) {
+  const int j = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &j, sizeof(f));
+  return f;
+}
+
+template <int K>
+void launch_brute(hipStream_t st, int n, const float4* pts, int k, int32_t* out, const int* queries, int nq) {
+  if (nq > 0) knn_bruteforce_kernel<K><<<(nq + 255) / 256, 256, 0, st>>>(n, pts, k, out, queries, nq);
+}
+template <int K>
+void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const unsigned long long* keys, unsigned int mask, const int* starts,
+                 const int* counts, int k, int32_t* out, int* unresolved, int* stats) {
+  knn_grid_kernel<K><<<(n + 255) / 256, 256, 0, st>>>(n, sorted, h, 1.0 / h, keys, mask, starts, counts, k, out, unresolved, stats);
+}
+
+#define DISPATCH_K(FN, ...)                      \
+  do {                                           \
+    if (k <= 8) FN<8>(__VA_ARGS__);              \
+    else if (k <= 10) FN<10>(__VA_ARGS__);       \
+    else if (k <= 16) FN<16>(__VA_ARGS__);       \
+    else if (k <= 24) FN<24>(__VA_ARGS__);       \
+    else FN<32>(__VA_ARGS__);                    \
+  } while (0)
+
+struct DeviceTemp {
+  void* p = nullptr;
+  ~DeviceTemp() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+unsigned int next_pow2(unsigned long long v) {
+  unsigned long long p = 1;
+  while (p < v) p <<= 1;
+  return (unsigned int)p;
+}
+
+int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out) {
+  // ---- cell edge from the data: a surface-like cloud of n points in its bounding box, ~3 points per occupied cell ----
+  DeviceTemp bb, keys, counts, starts, cursor, slot_of, sorted, stats, unresolved;
+  GA_HIP(hipMalloc(&bb.p, 6 * sizeof(int)));
+  const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+  bbox_kernel<<<std::min((n + 255) / 256, 1024), 256, 0, st>>>(n, pts, (int*)bb.p);
+  int h_bb[6];
+  GA_HIP(hipMemcpyAsync(h_bb, bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+  double ext[3];
+  for (int a = 0; a < 3; a++) ext[a] = std::max(1e-6, (double)unordered(h_bb[3 + a]) - (double)unordered(h_bb[a]));
+  const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+  double h = std::sqrt(3.0 * 2.0 * area / (double)n);
+  if (const char* env = getenv("GLIM_AMD_KNN_CELL")) h = atof(env);
+  const double max_abs = std::max({std::fabs((double)unordered(h_bb[0])), std::fabs((double)unordered(h_bb[1])), std::fabs((double)unordered(h_bb[2])),
+                                   std::fabs((double)unordered(h_bb[3])), std::fabs((double)unordered(h_bb[4])), std::fabs((double)unordered(h_bb[5]))});
+  h = std::max(h, max_abs / 1.0e6 + 1e-9);  // keep cell coordinates inside the 21-bit key range
+
+  const unsigned int T = next_pow2((unsigned long long)n * 2);
+  GA_HIP(hipMalloc(&keys.p, (size_t)T * sizeof(unsigned long long)));
+  GA_HIP(hipMalloc(&counts.p, (size_t)T * sizeof(int)));
+  GA_HIP(hipMalloc(&starts.p, (size_t)T * sizeof(int)));
+  GA_HIP(hipMalloc(&cursor.p, (size_t)T * sizeof(int)));
+  GA_HIP(hipMalloc(&slot_of.p, (size_t)n * sizeof(int)));
+  GA_HIP(hipMalloc(&sorted.p, (size_t)n * sizeof(float4)));
+  GA_HIP(hipMalloc(&stats.p, 4 * sizeof(int)));
+  GA_HIP(hipMalloc(&unresolved.p, (size_t)n * sizeof(int)));
+
+  int h_stats[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 4; attempt++) {
+    GA_HIP(hipMemsetAsync(keys.p, 0xff, (size_t)T * sizeof(unsigned long long), st));
+    GA_HIP(hipMemsetAsync(counts.p, 0, (size_t)T * sizeof(int), st));
+    GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
+    grid_insert_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, 1.0 / h, (unsigned long long*)keys.p, T - 1, (int*)counts.p, (int*)slot_of.p, (int*)stats.p);
+    GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    if (h_stats[1] != 0) {  // a coordinate fell outside the key range: coarsen
+      h *= 4.0;
+      continue;
+    }
+    const double per_cell = (double)n / std::max(1, h_stats[0]);
+    if (getenv("GLIM_AMD_KNN_CELL")) break;
+    if (per_cell > 8.0 && attempt < 3) h *= 0.5;
+    else if (per_cell < 1.5 && attempt < 3) h *= 2.0;
+    else break;
+  }
+  if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
+  GA_HIP(hipMemsetAsync(cursor.p, 0, (size_t)T * sizeof(int), st));
+  scan_kernel<<<1, 1024, 0, st>>>((const int*)counts.p, (int*)starts.p, T);
+  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, (const int*)slot_of.p, (const int*)starts.p, (int*)cursor.p, (float4*)sorted.p);
+  DISPATCH_K(launch_grid, st, n, (const float4*)sorted.p, h, (const unsigned long long*)keys.p, T - 1, (const int*)starts.p, (const int*)counts.p, k, out,
+             (int*)unresolved.p, (int*)stats.p);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+  if (h_stats[2] > 0) {  // isolated points: finish exactly with the exhaustive kernel
+    DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)unresolved.p, h_stats[2]);
+    GA_HIP(hipGetLastError());
+    GA_HIP(hipStreamSynchronize(st));
+  }
+  return GLIM_AMD_OK;
 }
 
 }  // namespace
@@ -106,14 +360,16 @@ int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_o
   c->k = k;
   GA_HIP(hipMalloc(&c->neighbors, (size_t)(c->n > 0 ? c->n : 1) * k * sizeof(int32_t)));
   if (c->n == 0) return GLIM_AMD_OK;
+  if (c->n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
   const int n = (int)c->n;
   hipStream_t st = ctx->stream();
-  if (k <= 8) launch_knn<8>(st, n, c->pts, k, c->neighbors);
-  else if (k <= 10) launch_knn<10>(st, n, c->pts, k, c->neighbors);
-  else if (k <= 16) launch_knn<16>(st, n, c->pts, k, c->neighbors);
-  else if (k <= 24) launch_knn<24>(st, n, c->pts, k, c->neighbors);
-  else launch_knn<32>(st, n, c->pts, k, c->neighbors);
-  GA_HIP(hipGetLastError());
+  const bool brute = n <= 2048 || n <= 2 * k || getenv("GLIM_AMD_KNN_BRUTE") != nullptr;
+  if (brute) {
+    DISPATCH_K(launch_brute, st, n, c->pts, k, c->neighbors, (const int*)nullptr, n);
+    GA_HIP(hipGetLastError());
+  } else {
+    GA_TRY(knn_grid(ctx, st, n, c->pts, k, c->neighbors));
+  }
   if (neighbors_out) GA_HIP(hipMemcpyAsync(neighbors_out, c->neighbors, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GA_HIP(hipStreamSynchronize(st));
   return GLIM_AMD_OK;
