@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- VGICP linearize() throughput on MI355X (BASELINE.json metric M1; configs[1]).
+"""bench.py -- VGICP linearize() throughput on MI355X (BASELINE.json metric; default workload = configs[1]).
 
 Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 launched through torch.distributed.run, one
 rank per GPU over RCCL.  Prints ONE JSON line on rank 0.
 
-Workload ("odometry128k"): F distinct VGICP factors per GPU, each a 131 072-point spinning-LiDAR scan (128 rings x 1024
-azimuths, synthetic analytic scene) matched against the 0.5 m Gaussian voxel map of the previous scan on a 0.5 m / 2 deg
-arc.  One STEP = one NonlinearFactorSetGPU::linearize over all F factors with inputs resident in HBM: pose upload (96 B per
-factor), the fused lookup + Mahalanobis residual + 6-DoF Jacobian + reduction kernel, the FP64 finalise, results left on the
-device.  F = 64 by default so that the working set (~0.5 GB) exceeds the 256 MiB Infinity Cache and the kernel really
-streams from HBM.  value = factors linearised per second over the whole job.
-
+Default workload "odometry128k" (BASELINE configs[1], metric M1): F distinct VGICP factors per GPU, each a 131 072-point
+spinning-LiDAR scan (128 rings x 1024 azimuths, synthetic analytic scene) matched against the 0.5 m Gaussian voxel map of the
+previous scan on a 0.5 m / 2 deg arc.  One STEP = one NonlinearFactorSetGPU::linearize over all F factors with inputs resident
+in HBM: pose upload (96 B per factor), the fused lookup + Mahalanobis residual + 6-DoF Jacobian + reduction kernel, the FP64
+finalise, results left on the device.  F = 64 so that the working set (~0.5 GB) exceeds the 256 MiB Infinity Cache and the
+kernel really streams from HBM.  value = factors linearised per second over the whole job.
 N > 1 (weak scaling): every rank owns its own F factors (the factor list of a multi-scan cost is sharded, point data never
-crosses GPUs); each step ends with one RCCL all-reduce (sum) of the dense [N*F x 29] per-factor H/b/error block array, the
-exchange step BASELINE.json's north_star names.
+crosses GPUs); each step ends with one RCCL all-reduce (sum) of the dense [N*F x 29] per-factor H/b/error block array.
 
-Also reported: `roofline` for the dominant kernel (HIP-event timed inside this process), `cpu_baseline` (the FP64 OpenMP
-oracle on the host cores, bounded sample), the synchronous single-factor loop rate, and the parity of one factor's
-Gauss-Newton step against the oracle.
+Other workloads (parity-test configurations of BASELINE.json, selectable for evidence; never the default line):
+  --workload submap20    configs[2]: 20 keyframes x 65 536 pts, 190 pairs x 2 voxel levels = 380 binary factors per bundle
+  --workload global256   configs[3]: 256 submaps x 65 536 pts, all 32 640 pairs, 1.0 m voxels, pair list sharded over the
+                         ranks + RCCL all-reduce (strong scaling; metric M2 = seconds per cost evaluation)
+  --workload rgbd300k    configs[4]: 307 200-pt depth frames, per frame upload -> kNN -> covariance -> 0.1 m voxel map -> one
+                         unary linearise against the previous frame (sustained frames/s, p50/p99 latency)
+
+Also reported: `roofline` for the dominant kernel (HIP-event timed inside this process on the stream the kernel runs on),
+`cpu_baseline` (the FP64 OpenMP oracle on the usable host cores, bounded sample), the synchronous single-factor loop rate, and
+the parity of one factor's Gauss-Newton step against the oracle.
 """
 import argparse
 import json
@@ -38,34 +43,6 @@ HBM_ACHIEVABLE_GBS = 6290.0
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
-
-
-def build_workload(api, ctx, n_factors, rank, rings, azimuths, resolution, k=10):
-    """F (target voxel map, source cloud, pose) triples; everything (kNN, covariances, voxel maps) built on the device."""
-    from glim_amd import synth
-
-    scene = synth.Scene.default()
-    dirs = synth.lidar_directions(rings, azimuths)
-    # each rank walks its own stretch of the trajectory
-    poses = synth.arc_trajectory(n_factors + 1, start=(-12.0 + 0.7 * rank, -7.0 + 0.9 * rank, 1.8), yaw0_deg=10.0 + 7.0 * rank)
-    clouds, vmaps, host_scans = [], [], []
-    t0 = time.time()
-    for i, T in enumerate(poses):
-        pts = synth.scan(scene, T, dirs, frame_id=1000 * rank + i)
-        host_scans.append(pts)
-        g = api.PointCloudGPU.clone(pts, ctx=ctx)
-        g.find_neighbors(k, download=False)
-        g.estimate_covariances(k)
-        clouds.append(g)
-        if i < n_factors:
-            vmaps.append(api.GaussianVoxelMapGPU(resolution, ctx=ctx).insert(g))
-    log(f"generated {len(poses)} scans of {len(host_scans[0])} pts in {time.time() - t0:.1f}s")
-    fset = api.NonlinearFactorSetGPU(ctx)
-    deltas = []
-    for i in range(n_factors):
-        fset.add(api.IntegratedVGICPFactorGPU(i, i + 1, vmaps[i], clouds[i + 1]))  # binary factor: target i, source i+1
-        deltas.append(api.pose12(synth.relative_pose(poses[i], poses[i + 1])))
-    return {"fset": fset, "clouds": clouds, "vmaps": vmaps, "deltas": np.stack(deltas), "scans": host_scans, "poses": poses}
 
 
 def effective_cores():
@@ -95,20 +72,51 @@ def measured_traffic(workload_tag):
     return best
 
 
-def cpu_baseline_and_parity(api, wl, resolution, budget_s=12.0):
+def make_frames(api, ctx, poses, rings, azimuths, frame_id0=0, k=10):
+    """Synthetic scans uploaded to the device with kNN + covariances computed there."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(rings, azimuths)
+    clouds = []
+    for i, T in enumerate(poses):
+        g = api.PointCloudGPU.clone(synth.scan(scene, T, dirs, frame_id=frame_id0 + i), ctx=ctx)
+        g.find_neighbors(k, download=False)
+        g.estimate_covariances(k)
+        clouds.append(g)
+    return clouds
+
+
+def algorithmic_bytes(n_pts, n_vox):
+    """B_lin = 48 N + 68 V + 488 per factor."""
+    return float(sum(48 * n + 68 * v + 488 for n, v in zip(n_pts, n_vox)))
+
+
+def roofline_of(fset, poses, n_pts, n_vox, iters, traffic=None):
+    ms_kernel, ms_lin = fset.profile(poses, iters=iters)
+    algo = algorithmic_bytes(n_pts, n_vox)
+    achieved = algo / (ms_kernel * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": "vgicp_kernel<LINEARIZE>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,
+        "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+        "algorithmic_bytes_per_launch": algo, "kernel_ms": ms_kernel, "linearize_ms": ms_lin,
+    }
+
+
+def cpu_baseline_and_parity(api, target_cloud, source_cloud, delta12, resolution, gpu_result, budget_s=12.0):
     """Time the FP64 OpenMP oracle (restatement of gtsam_points::IntegratedVGICPFactor::linearize) on one factor of the same
     workload and check the GPU Gauss-Newton step against it."""
     import ctypes as C
 
     from oracle import oracle as orc
 
-    clouds = wl["clouds"]
-    tgt_xyz, tgt_cov, _ = clouds[0].download(normals=False)
-    src_xyz, src_cov, _ = clouds[1].download(normals=False)
+    tgt_xyz, tgt_cov, _ = target_cloud.download(normals=False)
+    src_xyz, src_cov, _ = source_cloud.download(normals=False)
     vm = orc.VoxelMap(resolution).insert(tgt_xyz, tgt_cov.astype(np.float64))
     p4 = orc.points4(src_xyz)
     c16 = orc.covs16(src_cov.astype(np.float64))
-    T = np.ascontiguousarray(wl["deltas"][0])
+    T = np.ascontiguousarray(delta12)
     L = orc.Linearized6()
     lib = orc.lib()
     cores = min(orc.max_threads(), effective_cores())
@@ -131,20 +139,293 @@ def cpu_baseline_and_parity(api, wl, resolution, budget_s=12.0):
             rate_all, n_all, cores = r2, n2, cores // 2
     rate_ref, _ = run(min(2, cores), budget_s / 4)  # the reference's shipped num_threads (config_odometry_cpu.json:36)
     ref = orc._lin_to_dict(L)
-    got = wl["fset"].linearize_poses(wl["deltas"])[0]
-    d_got = np.linalg.solve(got["H_ss"], -got["b_s"])
+    d_got = np.linalg.solve(gpu_result["H_ss"], -gpu_result["b_s"])
     d_ref = np.linalg.solve(ref["H_ss"], -ref["b_s"])
     parity = {
-        "inliers_equal": bool(got["num_inliers"] == ref["num_inliers"]),
+        "inliers_equal": bool(gpu_result["num_inliers"] == ref["num_inliers"]),
         "max_pose_delta_err": float(np.abs(d_got - d_ref).max()),
         "tolerance": 1e-4,
     }
     base = {
         "value": rate_all, "unit": "calls/s", "cores": cores, "kind": "port",
-        "sample": f"{n_all} linearize() calls of one {len(p4)}-pt factor (oracle/vgicp_oracle.c, OpenMP guided,8, all usable host cores = min(affinity, cgroup quota))",
+        "sample": f"{n_all} linearize() calls of one {len(p4)}-pt factor (oracle/vgicp_oracle.c, OpenMP guided,8, usable host cores = min(affinity, cgroup quota))",
         "value_2_threads": rate_ref,
     }
     return base, parity
+
+
+class Dist:
+    """torch.distributed plumbing (RCCL on GPU boxes)."""
+
+    def __init__(self, gpus):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if gpus > 1 and self.world != gpus:
+            raise SystemExit(f"--gpus {gpus} needs WORLD_SIZE={gpus} (launch with torch.distributed.run)")
+        assert torch.cuda.is_available(), "bench.py needs a GPU; the product path has no CPU fallback"
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def barrier_sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(D, step, steps, warmup):
+    for i in range(warmup):
+        step(i)
+    D.barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    D.barrier_sync()
+    return D.max_over_ranks(time.perf_counter() - t0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_odometry128k(args, D, api, ctx):
+    from glim_amd import synth
+    from glim_amd.se3 import se3_exp
+
+    torch = D.torch
+    F, rank, world = args.factors, D.rank, D.world
+    poses = synth.arc_trajectory(F + 1, start=(-12.0 + 0.7 * rank, -7.0 + 0.9 * rank, 1.8), yaw0_deg=10.0 + 7.0 * rank)
+    t0 = time.time()
+    clouds = make_frames(api, ctx, poses, args.rings, args.azimuths, frame_id0=1000 * rank)
+    vmaps = [api.GaussianVoxelMapGPU(args.resolution, ctx=ctx).insert(c) for c in clouds[:F]]
+    log(f"generated {F + 1} scans of {clouds[0].size()} pts (kNN, covariances, voxel maps on the device) in {time.time() - t0:.1f}s")
+    fset = api.NonlinearFactorSetGPU(ctx)
+    deltas = []
+    for i in range(F):
+        fset.add(api.IntegratedVGICPFactorGPU(i, i + 1, vmaps[i], clouds[i + 1]))  # binary factor: target i, source i+1
+        deltas.append(api.pose12(synth.relative_pose(poses[i], poses[i + 1])))
+    deltas = np.stack(deltas)
+    n_pts = [c.size() for c in clouds[1:]]
+    n_vox = [v.voxelmap_info()["num_voxels"] for v in vmaps]
+
+    # a few linearisation points per factor (the optimiser moves the poses between calls)
+    rng = np.random.default_rng(1234 + rank)
+    pose_sets = []
+    for s in range(4):
+        P = np.empty((F, 12))
+        for f in range(F):
+            Dm = np.eye(4)
+            Dm[:3, :4] = deltas[f].reshape(3, 4)
+            P[f] = api.pose12(Dm @ se3_exp(rng.normal(size=6) * [2e-3, 2e-3, 2e-3, 1e-2, 1e-2, 1e-2] * (s > 0)))
+        pose_sets.append(P)
+    out = torch.zeros(world * F, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+
+    def step(i):
+        if world > 1:
+            out.zero_()  # non-owned rows must be zero before the sum
+        fset.linearize_device_async(pose_sets[i % len(pose_sets)], out.data_ptr(), rank * F)
+        if world > 1:
+            D.dist.all_reduce(out)  # RCCL sum over xGMI of the [world*F x 29] block array
+
+    elapsed = timed_steps(D, step, args.steps, args.warmup)
+    value = world * F * args.steps / elapsed
+    traffic = measured_traffic("odometry128k F=%d" % F) if (args.rings, args.azimuths) == (128, 1024) else None
+    result = None
+    roofline = roofline_of(fset, pose_sets[0], n_pts, n_vox, max(10, args.steps), traffic)
+    if rank == 0:
+        # synchronous single-factor loop (upload pose, launch, 232-B readback, host sync per call)
+        single = api.NonlinearFactorSetGPU(ctx)
+        single.add(api.IntegratedVGICPFactorGPU(0, 1, vmaps[0], clouds[1]))
+        T1 = deltas[:1]
+        for _ in range(20):
+            single.linearize_poses(T1)
+        t1 = time.perf_counter()
+        n_sync = 300
+        for _ in range(n_sync):
+            got = single.linearize_poses(T1)[0]
+        sync_rate = n_sync / (time.perf_counter() - t1)
+        result = {
+            "metric": "vgicp_linearize_calls_per_s", "value": value, "unit": "calls/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1] odometry128k: 131072-pt spinning-LiDAR scans vs 0.5 m voxel maps, batched VGICP linearize",
+                "factors_per_gpu": F, "points_per_factor": int(np.mean(n_pts)), "voxels_per_factor": int(np.mean(n_vox)),
+                "voxel_resolution_m": args.resolution, "factor_type": "binary",
+                "collective": "rccl_all_reduce[world*F x 29] f64" if world > 1 else "none", "device": ctx.device_info()["name"],
+            },
+            "roofline": roofline, "sync_single_factor_calls_per_s": sync_rate,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline_and_parity(api, clouds[0], clouds[1], deltas[0], args.resolution, got)
+            result["cpu_baseline"] = base
+            result["parity"] = parity
+            result["speedup_vs_cpu_baseline"] = value / base["value"]
+    return result
+
+
+def run_submap20(args, D, api, ctx):
+    """configs[2]: SubMappingGPU local bundle (sub_mapping.cpp:276-315): all pairs of 20 keyframes x 2 voxel levels."""
+    from glim_amd import synth
+
+    K = 20
+    poses = synth.arc_trajectory(K, step=0.5, yaw_step_deg=1.5)
+    clouds = make_frames(api, ctx, poses, 64, 1024)
+    levels = (0.25, 0.5)  # config_sub_mapping_gpu.json:48-50
+    vmaps = [[api.GaussianVoxelMapGPU(r, ctx=ctx).insert(c) for r in levels] for c in clouds]
+    fset = api.NonlinearFactorSetGPU(ctx)
+    deltas, n_pts, n_vox = [], [], []
+    for i in range(K):
+        for j in range(i + 1, K):
+            for lv in range(len(levels)):
+                fset.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i][lv], clouds[j]))
+                deltas.append(api.pose12(synth.relative_pose(poses[i], poses[j])))
+                n_pts.append(clouds[j].size())
+                n_vox.append(vmaps[i][lv].voxelmap_info()["num_voxels"])
+    deltas = np.stack(deltas)
+    nf = len(deltas)
+    out = D.torch.zeros(nf, api._lib.COMPACT_DOUBLES, dtype=D.torch.float64, device="cuda")
+    elapsed = timed_steps(D, lambda i: fset.linearize_device_async(deltas, out.data_ptr(), 0), args.steps, args.warmup)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fset.linearize_poses(deltas)  # one LM iteration = linearise (host round trip) ...
+        errs = fset_error(fset, deltas)  # ... + error for the accept/reject test
+    lm_ms = (time.perf_counter() - t0) / 5 * 1e3
+    inl = float(np.mean([r["num_inliers"] for r in fset.linearize_poses(deltas)]) / np.mean(n_pts))
+    return {
+        "metric": "vgicp_linearize_calls_per_s", "value": nf * args.steps / elapsed, "unit": "calls/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2] submap20: 20 keyframes x 65536 pts, 190 pairs x 2 levels (0.25/0.5 m) = 380 binary factors",
+                   "factors": nf, "bundle_linearize_ms": elapsed / args.steps * 1e3, "lm_iteration_ms_incl_host_roundtrip": lm_ms,
+                   "mean_inlier_fraction": inl, "sum_error": float(np.sum(errs))},
+        "roofline": roofline_of(fset, deltas, n_pts, n_vox, max(5, args.steps)),
+    }
+
+
+def fset_error(fset, deltas):
+    import ctypes as C
+
+    n = len(deltas)
+    err = np.zeros(n)
+    T = np.ascontiguousarray(deltas)
+    from glim_amd.api import check, lib
+
+    check(lib().glim_amd_factor_set_error(fset._h, None, T.ctypes.data_as(C.POINTER(C.c_double)), err.ctypes.data_as(C.POINTER(C.c_double)), None),
+          "glim_amd_factor_set_error")
+    return err
+
+
+def run_global256(args, D, api, ctx):
+    """configs[3] / metric M2: all-pairs matching cost over 256 submaps, pair list sharded over the ranks, RCCL all-reduce."""
+    from glim_amd import multi, synth
+
+    torch = D.torch
+    S = args.submaps
+    side = int(round(S ** 0.5))
+    poses = synth.grid_trajectory(side, side, spacing=2.0)[:S]
+    t0 = time.time()
+    clouds = make_frames(api, ctx, poses, 64, 1024)  # replicated on every rank
+    vmaps = [api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(c) for c in clouds]  # global_mapping.cpp:59 default resolution
+    log(f"replicated {S} submaps of {clouds[0].size()} pts per rank in {time.time() - t0:.1f}s")
+    pairs = [(i, j) for i in range(S) for j in range(i + 1, S)]
+    costs = [clouds[j].size() for _, j in pairs]
+    ev = multi.ShardedCostEvaluator(costs, D.rank, D.world)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
+    for f in ev.owned():
+        i, j = pairs[f]
+        fset.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i], clouds[j]))
+    blocks = torch.zeros(len(pairs), api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+    local_poses = deltas[ev.lo:ev.hi]
+
+    def step(_):
+        if D.world > 1:
+            blocks.zero_()
+        fset.linearize_device_async(local_poses, blocks.data_ptr(), ev.lo)
+        multi.allreduce_blocks(blocks)
+
+    elapsed = timed_steps(D, step, args.steps, args.warmup)
+    host = blocks.cpu().numpy()
+    n_pts = [costs[f] for f in ev.owned()]
+    n_vox = [vmaps[pairs[f][0]].voxelmap_info()["num_voxels"] for f in ev.owned()]
+    roof = roofline_of(fset, local_poses, n_pts, n_vox, max(3, args.steps))
+    if D.rank != 0:
+        return None
+    sec = elapsed / args.steps
+    return {
+        "metric": "multi_scan_cost_eval_s", "value": sec, "unit": "s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3] global256: {S} submaps x 65536 pts, all {len(pairs)} pairs, 1.0 m voxels, binary factors",
+                   "pairs": len(pairs), "pairs_this_rank": ev.hi - ev.lo, "mean_inlier_fraction": float(host[:, 0].mean() / np.mean(costs)),
+                   "total_error": float(host[:, 1].sum()), "factor_linearizations_per_s": len(pairs) / sec,
+                   "collective": f"rccl_all_reduce[{len(pairs)} x 29] f64 ({len(pairs) * 29 * 8 / 1e6:.1f} MB)" if D.world > 1 else "none"},
+        "roofline": roof,
+    }
+
+
+def run_rgbd300k(args, D, api, ctx):
+    """configs[4]: dense depth stream, everything per frame on the device (PCIe upload included: frames arrive from the host)."""
+    from glim_amd import synth
+
+    room = synth.Scene.small_room()
+    dirs = synth.pinhole_directions(640, 480, 70, 55)
+    n_distinct = 6
+    frames, poses = [], []
+    for i in range(n_distinct):
+        T = synth.pose(-2.5 + 0.05 * i, -1.5 + 0.02 * i, 1.4, 0.5 + 0.01 * i)
+        frames.append(synth.scan(room, T, dirs, i, sigma=0.002, max_range=8.0, min_range=0.3))
+        poses.append(T)
+    log(f"{n_distinct} distinct depth frames of {len(frames[0])} pts")
+    n_frames = args.frames
+    prev_map, prev_pose, lat, inl = None, None, [], []
+    D.barrier_sync()
+    t_all = time.perf_counter()
+    for fidx in range(n_frames + 3):
+        if fidx == 3:
+            D.torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            lat = []
+        t0 = time.perf_counter()
+        pts, T = frames[fidx % n_distinct], poses[fidx % n_distinct]
+        g = api.PointCloudGPU.clone(pts, ctx=ctx)  # H2D upload + pack
+        g.find_neighbors(10, download=False)  # K2
+        g.estimate_covariances(10)  # K1
+        vm = api.GaussianVoxelMapGPU(0.1, ctx=ctx).insert(g)  # K3
+        if prev_map is not None:
+            f = api.IntegratedVGICPFactorGPU(prev_pose, 1, prev_map, g)  # unary factor against the previous frame
+            fs = api.NonlinearFactorSetGPU(ctx)
+            fs.add(f)
+            r = fs.linearize({1: T})[0]  # K4 + host read-back
+            inl.append(r["num_inliers"] / len(pts))
+        prev_map, prev_pose = vm, T
+        lat.append(time.perf_counter() - t0)
+    D.torch.cuda.synchronize()
+    total = time.perf_counter() - t_all
+    lat = np.array(lat) * 1e3
+    return {
+        "metric": "rgbd_frames_per_s", "value": n_frames / total, "unit": "frames/s", "n_gpus": 1, "steps": n_frames, "warmup": 3,
+        "ms_per_step": total / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4] rgbd300k: 640x480 depth frames, upload + kNN(k=10) + covariance + 0.1 m voxel map + 1 unary linearize per frame",
+                   "points_per_frame": int(len(frames[0])), "latency_ms_p50": float(np.percentile(lat, 50)), "latency_ms_p99": float(np.percentile(lat, 99)),
+                   "mean_inlier_fraction": float(np.mean(inl)), "target_fps": 30},
+    }
 
 
 def main():
@@ -152,133 +433,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--factors", type=int, default=64, help="factors per GPU per step")
+    ap.add_argument("--workload", default="odometry128k", choices=["odometry128k", "submap20", "global256", "rgbd300k"])
+    ap.add_argument("--factors", type=int, default=64, help="odometry128k: factors per GPU per step")
     ap.add_argument("--rings", type=int, default=128)
     ap.add_argument("--azimuths", type=int, default=1024)
     ap.add_argument("--resolution", type=float, default=0.5)
+    ap.add_argument("--submaps", type=int, default=256, help="global256: number of submaps")
+    ap.add_argument("--frames", type=int, default=300, help="rgbd300k: frames in the timed stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-    assert torch.cuda.is_available(), "bench.py needs a GPU; the product path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    D = Dist(args.gpus)
     from glim_amd import api
 
     # run on torch's current stream so that torch.cuda.synchronize(), RCCL and our kernels are ordered together
-    stream = torch.cuda.current_stream()
-    ctx = api.Context(local_rank, 1, external_stream=stream.cuda_stream)
-    info = ctx.device_info()
-    wl = build_workload(api, ctx, args.factors, rank, args.rings, args.azimuths, args.resolution)
-    fset, F = wl["fset"], args.factors
-    n_pts = [c.size() for c in wl["clouds"][1:]]
-    n_vox = [v.voxelmap_info()["num_voxels"] for v in wl["vmaps"]]
-
-    # a few linearisation points per factor (the optimiser moves the poses between calls)
-    rng = np.random.default_rng(1234 + rank)
-    from glim_amd.se3 import se3_exp
-
-    pose_sets = []
-    for s in range(4):
-        P = np.empty((F, 12))
-        for f in range(F):
-            D = np.eye(4)
-            D[:3, :4] = wl["deltas"][f].reshape(3, 4)
-            P[f] = api.pose12(D @ se3_exp(rng.normal(size=6) * [2e-3, 2e-3, 2e-3, 1e-2, 1e-2, 1e-2] * (s > 0)))
-        pose_sets.append(P)
-
-    out = torch.zeros(world * F, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
-
-    def step(i):
-        fset.linearize_device_async(pose_sets[i % len(pose_sets)], out.data_ptr(), rank * F)
-        if world > 1:
-            dist.all_reduce(out)  # RCCL sum over xGMI of the [world*F x 29] block array (non-owned rows are zero)
-            # (each rank's own rows were just overwritten; the others are re-zeroed below for the next step)
-
-    def rezero():
-        if world > 1:
-            out.zero_()
-
-    for i in range(args.warmup):
-        rezero()
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        rezero()
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * F * args.steps / elapsed
-
-    # roofline of the dominant kernel, HIP events on the stream the kernel runs on (inside the library)
-    ms_kernel, ms_lin = fset.profile(pose_sets[0], iters=max(10, args.steps))
-    algo_bytes = float(sum(48 * n + 68 * v + 488 for n, v in zip(n_pts, n_vox)))  # B_lin = 48 N + 68 V + 488 per factor
-    achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
-    traffic = measured_traffic("odometry128k F=%d" % F) if (args.rings, args.azimuths) == (128, 1024) else None
-    roofline = {
-        "bound": "hbm", "kernel": "vgicp_kernel<LINEARIZE>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,
-        "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
-        "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": ms_kernel, "linearize_ms": ms_lin,
-    }
-
-    result = None
-    if rank == 0:
-        # synchronous single-factor loop (upload pose, launch, 232-B readback, host sync per call)
-        single = api.NonlinearFactorSetGPU(ctx)
-        single.add(api.IntegratedVGICPFactorGPU(0, 1, wl["vmaps"][0], wl["clouds"][1]))
-        T1 = wl["deltas"][:1]
-        for _ in range(20):
-            single.linearize_poses(T1)
-        t1 = time.perf_counter()
-        n_sync = 300
-        for _ in range(n_sync):
-            single.linearize_poses(T1)
-        sync_rate = n_sync / (time.perf_counter() - t1)
-
-        result = {
-            "metric": "vgicp_linearize_calls_per_s", "value": value, "unit": "calls/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "configs[1] odometry128k: 131072-pt spinning-LiDAR scans vs 0.5 m voxel maps, batched VGICP linearize",
-                "factors_per_gpu": F, "points_per_factor": int(np.mean(n_pts)), "voxels_per_factor": int(np.mean(n_vox)),
-                "voxel_resolution_m": args.resolution, "factor_type": "binary", "collective": "rccl_all_reduce[world*F x 29] f64" if world > 1 else "none",
-                "device": info["name"],
-            },
-            "roofline": roofline,
-            "sync_single_factor_calls_per_s": sync_rate,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline_and_parity(api, wl, args.resolution)
-            result["cpu_baseline"] = base
-            result["parity"] = parity
-            result["speedup_vs_cpu_baseline"] = value / base["value"]
+    ctx = api.Context(D.local_rank, 1, external_stream=D.torch.cuda.current_stream().cuda_stream)
+    runner = {"odometry128k": run_odometry128k, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k}[args.workload]
+    result = runner(args, D, api, ctx)
+    if D.rank == 0 and result is not None:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.finish()
 
 
 if __name__ == "__main__":

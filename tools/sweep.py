@@ -14,7 +14,12 @@ from glim_amd import api  # noqa: E402
 
 F = int(os.environ.get("SWEEP_FACTORS", "64"))
 ctx = api.Context(0, 1)
-wl = bench.build_workload(api, ctx, F, 0, 128, 1024, 0.5)
+from glim_amd import synth  # noqa: E402
+
+_poses = synth.arc_trajectory(F + 1, start=(-12.0, -7.0, 1.8), yaw0_deg=10.0)
+_clouds = bench.make_frames(api, ctx, _poses, 128, 1024)
+wl = {"clouds": _clouds, "vmaps": [api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(c) for c in _clouds[:F]],
+      "deltas": np.stack([api.pose12(synth.relative_pose(_poses[i], _poses[i + 1])) for i in range(F)])}
 n_pts = [c.size() for c in wl["clouds"][1:]]
 n_vox = [v.voxelmap_info()["num_voxels"] for v in wl["vmaps"]]
 algo = float(sum(48 * n + 68 * v + 488 for n, v in zip(n_pts, n_vox)))
