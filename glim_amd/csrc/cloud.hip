@@ -175,6 +175,8 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->covB) (void)hipFree(c->covB);
   if (c->normals) (void)hipFree(c->normals);
   if (c->neighbors) (void)hipFree(c->neighbors);
+  if (c->pn4) (void)hipFree(c->pn4);
+  if (c->n2) (void)hipFree(c->n2);
   delete c;
   return GLIM_AMD_OK;
 }

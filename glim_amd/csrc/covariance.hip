@@ -88,7 +88,7 @@ __device__ V3 smallest_eigenvector(double m00, double m01, double m02, double m1
 
 __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __restrict__ pts, const int32_t* __restrict__ nbrs, int k_corr,
                                                          int k_nbr, float4* __restrict__ covA, float2* __restrict__ covB,
-                                                         float4* __restrict__ normals) {
+                                                         float4* __restrict__ normals, float4* __restrict__ pn4, float2* __restrict__ n2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
@@ -115,6 +115,9 @@ __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __
     e.x = -e.x; e.y = -e.y; e.z = -e.z;
   }
   normals[i] = make_float4((float)e.x, (float)e.y, (float)e.z, 0.0f);
+  // plane-form stream for the factor kernel (24 B per point): xyz + the unit normal the covariance is a function of
+  pn4[i] = make_float4(p.x, p.y, p.z, (float)e.x);
+  n2[i] = make_float2((float)e.y, (float)e.z);
 }
 
 }  // namespace
@@ -132,14 +135,17 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->covA) GA_HIP(hipMalloc(&c->covA, nn * sizeof(float4)));
   if (!c->covB) GA_HIP(hipMalloc(&c->covB, nn * sizeof(float2)));
   if (!c->normals) GA_HIP(hipMalloc(&c->normals, nn * sizeof(float4)));
+  if (!c->pn4) GA_HIP(hipMalloc(&c->pn4, nn * sizeof(float4)));
+  if (!c->n2) GA_HIP(hipMalloc(&c->n2, nn * sizeof(float2)));
   if (c->n > 0) {
     const int n = (int)c->n;
-    covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals);
+    covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals, c->pn4, c->n2);
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(ctx->stream()));
   }
   c->has_covs = true;
   c->has_normals = true;
+  c->plane_form = true;
   return GLIM_AMD_OK;
 }
 

@@ -65,6 +65,8 @@ struct FactorDesc {
   const float4* covA;       // c00 c01 c02 c11
   const float2* covB;       // c12 c22
   const float4* normals;    // may be null
+  const float4* pn4;        // plane-form stream: x y z nx   (null unless the cloud is plane-form)
+  const float2* n2;         //                    ny nz
   const VoxelBucket* buckets;  // target table
   unsigned int num_buckets;    // any size >= 1 (range reduction by multiply-shift)
   int n;                    // source points
@@ -106,6 +108,9 @@ struct glim_amd_cloud {
   float4* covA = nullptr;
   float2* covB = nullptr;
   float4* normals = nullptr;
+  float4* pn4 = nullptr;  // plane-form stream (x y z nx), see load_point<PLANE> in vgicp.hip
+  float2* n2 = nullptr;   //                   (ny nz)
+  bool plane_form = false;
   int32_t* neighbors = nullptr;
   int k = 0;
   bool has_covs = false;
@@ -115,6 +120,7 @@ struct glim_amd_cloud {
     if (covA) b += (size_t)n * (sizeof(float4) + sizeof(float2));
     if (normals) b += (size_t)n * sizeof(float4);
     if (neighbors) b += (size_t)n * k * sizeof(int32_t);
+    if (pn4) b += (size_t)n * (sizeof(float4) + sizeof(float2));
     return b;
   }
 };
@@ -140,6 +146,7 @@ struct glim_amd_factor_set {
   bool dirty = true;  // device plan needs a rebuild
   // device plan
   int points_per_thread = 1;
+  bool plane_form = false;  // every source cloud of the set is plane-form -> 24 B/pt kernel
   int variant_u = 2, variant_minw = 3;  // kernel variant: points in flight per lane, occupancy hint
   int total_blocks = 0;
   glim_amd::FactorDesc* d_descs = nullptr;

@@ -72,10 +72,28 @@ __device__ __forceinline__ float2 gld2(const void* p) {
 }
 
 struct PointIn {
-  float4 p;   // xyz1
-  float4 ca;  // c00 c01 c02 c11
-  float2 cb;  // c12 c22
+  float4 p;   // xyz1            (PLANE: x y z nx)
+  float4 ca;  // c00 c01 c02 c11 (PLANE: unused)
+  float2 cb;  // c12 c22         (PLANE: ny nz)
 };
+
+// PLANE = the source cloud's covariances are the PLANE-regularised form C = I - (1 - 1e-3) n n^T produced by
+// glim_amd_cloud_estimate_covariances (the only form GLIM's CloudCovarianceEstimation emits, cloud_covariance_estimation.cpp:20,
+// :181-196): the factor then streams 24 B per point (xyz + unit normal) instead of 40 B and rebuilds C in registers.
+template <bool PLANE>
+__device__ __forceinline__ PointIn load_point(const FactorDesc& d, unsigned int i) {
+  PointIn r;
+  if (PLANE) {
+    r.p = gld4(reinterpret_cast<const char*>(d.pn4) + i * 16u);  // uniform base + 32-bit lane offset (n <= 2^28)
+    r.cb = gld2(reinterpret_cast<const char*>(d.n2) + i * 8u);
+    r.ca = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    r.p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);
+    r.ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
+    r.cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+  }
+  return r;
+}
 
 // MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
 // Mahalanobis matrices frozen at the linearisation pose.  U: points per loop trip.  MINW: occupancy hint (waves per SIMD).
@@ -84,7 +102,7 @@ struct PointIn {
 // 48-byte voxel-slot gathers of trip t are issued back to back BEFORE the algebra of trip t, every lane runs the algebra
 // and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
 // the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
-template <int MODE, bool FROZEN, int U, int MINW>
+template <int MODE, bool FROZEN, int U, int MINW, bool PLANE>
 __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                              const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
                                                              float* __restrict__ partials) {
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
   const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
   const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
-  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals != nullptr;
+  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.normals != nullptr);
   const float resf = (float)d.res;
   const int last = d.n - 1;
 
@@ -116,10 +134,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
     PointIn nxt[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const unsigned int i = (unsigned int)min(base + u * BLOCK, last);
-      nxt[u].p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);   // uniform base + 32-bit lane offset (n <= 2^28)
-      nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
-      nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+      nxt[u] = load_point<PLANE>(d, (unsigned int)min(base + u * BLOCK, last));
     }
     for (int it0 = 0; it0 < ppt; it0 += U) {
       PointIn cur[U];
@@ -175,7 +190,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         if (validate) {
           // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
           // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
-          const float4 nn = gld4(reinterpret_cast<const char*>(d.normals) + (unsigned int)min(i, last) * 16u);
+          const float4 nn = PLANE ? make_float4(cur[u].p.w, cur[u].cb.x, cur[u].cb.y, 0.f)
+                                  : gld4(reinterpret_cast<const char*>(d.normals) + (unsigned int)min(i, last) * 16u);
           const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
           const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
           const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
@@ -195,10 +211,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
       // ---- coalesced loads of the NEXT trip, issued behind the gathers (counted vmcnt lets the gathers be consumed first) ----
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const unsigned int i = (unsigned int)min(base + (it0 + U + u) * BLOCK, last);
-        nxt[u].p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);
-        nxt[u].ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
-        nxt[u].cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+        nxt[u] = load_point<PLANE>(d, (unsigned int)min(base + (it0 + U + u) * BLOCK, last));
       }
       // ---- resolve the probe, then the per-point algebra (all lanes; accumulation predicated by hit) ----
 #pragma unroll
@@ -231,8 +244,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
         const float4 r2 = gld4(rp + 32);   // c22 count - -
 #endif
-        const float4 ca = cur[u].ca;
-        const float2 cb = cur[u].cb;
+        float4 ca = cur[u].ca;
+        float2 cb = cur[u].cb;
+        if (PLANE) {  // C_A = I - (1 - 1e-3) n n^T rebuilt from the streamed unit normal
+          const float w = 0.999f, nx = cur[u].p.w, ny = cur[u].cb.x, nz = cur[u].cb.y;
+          const float wx = w * nx, wy = w * ny;
+          ca = make_float4(1.f - wx * nx, -wx * ny, -wx * nz, 1.f - wy * ny);
+          cb = make_float2(-wy * nz, 1.f - w * nz * nz);
+        }
 
         // residual mu - q, both relative to the voxel centre
         const float rx = r0.x - qr[u][0];
@@ -469,6 +488,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   if (const char* env = getenv("GLIM_AMD_MINW")) set->variant_minw = atoi(env);
 
   set->h_descs.assign(nf, FactorDesc());
+  bool all_plane = nf > 0 && getenv("GLIM_AMD_NO_PLANE") == nullptr;
   std::vector<int> nblocks(nf);
   long long total_blocks = 0;
   for (int f = 0; f < nf; f++) {
@@ -478,6 +498,9 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     d.covA = e.source->covA;
     d.covB = e.source->covB;
     d.normals = e.source->has_normals ? e.source->normals : nullptr;
+    d.pn4 = e.source->pn4;
+    d.n2 = e.source->n2;
+    all_plane = all_plane && e.source->plane_form && e.source->pn4 && e.source->n2;
     d.buckets = e.target->buckets;
     d.num_buckets = e.target->num_buckets;
     d.n = (int)e.source->n;
@@ -495,6 +518,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     total_blocks += nblocks[f];
   }
   set->points_per_thread = nf ? set->h_descs[0].ppt : 1;
+  set->plane_form = all_plane;
 
   // block map
   std::vector<int2> blockmap;
@@ -565,7 +589,12 @@ namespace {
 // kernel-variant dispatch: (U, MINW) chosen per plan (GLIM_AMD_U / GLIM_AMD_MINW override the tuned default)
 template <int U, int W>
 void launch_lin(glim_amd_factor_set* set) {
-  vgicp_kernel<MODE_LINEARIZE, false, U, W><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+  if (set->plane_form) {
+    vgicp_kernel<MODE_LINEARIZE, false, U, W, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses,
+                                                                                                   set->d_blockmap, set->d_partials);
+    return;
+  }
+  vgicp_kernel<MODE_LINEARIZE, false, U, W, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
                                                                                            set->d_partials);
 }
 
@@ -746,11 +775,11 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
   GA_TRY(factor_set_prepare(set));
   if (T_lin) {
     GA_TRY(upload_poses(set, T_lin, T_eval));
-    vgicp_kernel<MODE_ERROR, true, 2, 3><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
+    vgicp_kernel<MODE_ERROR, true, 1, 3, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
                                                                                   set->d_blockmap, set->d_partials);
   } else {
     GA_TRY(upload_poses(set, T_eval, nullptr));
-    vgicp_kernel<MODE_ERROR, false, 2, 3><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
+    vgicp_kernel<MODE_ERROR, false, 1, 3, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
                                                                                    set->d_partials);
   }
   finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, set->d_compact, 0, MODE_ERROR);

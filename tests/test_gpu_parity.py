@@ -395,8 +395,11 @@ def test_full_size_scan_properties(api, ctx, orc):
     f2.add(api.IntegratedVGICPFactorGPU(0, 1, vm, dup))
     got2 = f2.linearize({0: np.eye(4), 1: delta})[0]
     assert got2["num_inliers"] == 2 * got["num_inliers"]
-    np.testing.assert_allclose(got2["H_ss"], 2 * got["H_ss"], rtol=1e-5)
-    np.testing.assert_allclose(got2["b_s"], 2 * got["b_s"], rtol=1e-4, atol=1e-3)
+    # (the duplicate was uploaded with explicit FP32 covariances -> general kernel; the original is plane-form -> 24 B/pt kernel:
+    #  the two evaluate C_A from differently rounded images of the same matrix, hence the 1e-5-level tolerance)
+    np.testing.assert_allclose(got2["H_ss"], 2 * got["H_ss"], rtol=0, atol=2e-5 * np.abs(got["H_ss"]).max())
+    np.testing.assert_allclose(got2["b_s"], 2 * got["b_s"], rtol=0, atol=2e-4 * np.abs(got["b_s"]).max() + 1e-3)
+    assert np.abs(gn_step(got2) - gn_step(got)).max() < 1e-6
     # voxel means against their own map at identity: zero residual
     coords, counts, means, covs = vm.voxels()
     mg = api.PointCloudGPU.clone(means, covs, ctx=ctx)
@@ -407,3 +410,41 @@ def test_full_size_scan_properties(api, ctx, orc):
     # (the downloaded means are rounded to FP32 at ~30 m, i.e. to ~2e-6 m, so the residual is tiny but not exactly zero)
     assert z["error"] < 1e-3
     assert np.abs(gn_step(z)).max() < 1e-5
+
+
+def test_plane_form_kernel_matches_general_kernel_and_oracle(api, ctx, orc, monkeypatch):
+    """Clouds whose covariances were estimated on the device are plane-form (C = I - 0.999 n n^T) and take the 24 B/pt kernel;
+    the same cloud through the general 40 B/pt kernel (GLIM_AMD_NO_PLANE) and the oracle must agree."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(64, 512)
+    poses = synth.arc_trajectory(2)
+    tgt, src = synth.scan(scene, poses[0], dirs, 0), synth.scan(scene, poses[1], dirs, 1)
+    delta = synth.relative_pose(poses[0], poses[1]) @ orc.se3_exp([0.004, -0.003, 0.002, 0.03, 0.02, -0.01])
+    tg, sg = api.PointCloudGPU.clone(tgt, ctx=ctx), api.PointCloudGPU.clone(src, ctx=ctx)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    _, ct, _ = tg.download()
+    _, cs, ns = sg.download()
+    # the streamed normals reproduce the stored covariance: C = I - 0.999 n n^T within FP32 rounding
+    np.testing.assert_allclose(cs, np.eye(3)[None] - 0.999 * ns[:, :, None] * ns[:, None, :], atol=3e-7)
+    ref = orc.vgicp_linearize(orc.VoxelMap(0.5).insert(tgt, ct.astype(np.float64)), src, cs.astype(np.float64), delta, want_corr=True)
+    results = {}
+    for mode in ("plane", "general"):
+        if mode == "general":
+            monkeypatch.setenv("GLIM_AMD_NO_PLANE", "1")
+        for sv in (False, True):
+            f = api.IntegratedVGICPFactorGPU(0, 1, vm, sg)
+            f.set_enable_surface_validation(sv)
+            fset = api.NonlinearFactorSetGPU(ctx)
+            fset.add(f)
+            results[(mode, sv)] = fset.linearize({0: np.eye(4), 1: delta})[0]
+    monkeypatch.delenv("GLIM_AMD_NO_PLANE")
+    for mode in ("plane", "general"):
+        assert_linearization_close(results[(mode, False)], ref, True)
+    # surface validation reads the normals from the plane-form stream in one kernel and from the normal array in the other
+    assert results[("plane", True)]["num_inliers"] == results[("general", True)]["num_inliers"] <= ref["num_inliers"]
+    assert np.abs(gn_step(results[("plane", True)]) - gn_step(results[("general", True)])).max() < 1e-5
