@@ -392,6 +392,13 @@ class NonlinearFactorSetGPU:
         check(lib().glim_amd_factor_set_profile(self._h, _dp(T), int(iters), C.byref(a), C.byref(b)), "glim_amd_factor_set_profile")
         return a.value, b.value
 
+    def profile_sync(self, T_target_source, iters=200):
+        """milliseconds per synchronous linearize() call measured inside the library (no binding overhead)."""
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
+        a = C.c_float()
+        check(lib().glim_amd_factor_set_profile_sync(self._h, _dp(T), int(iters), C.byref(a)), "glim_amd_factor_set_profile_sync")
+        return a.value
+
     def close(self):
         if self._h:
             lib().glim_amd_factor_set_destroy(self._h)

@@ -155,7 +155,8 @@ struct glim_amd_factor_set {
   double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
   double* d_compact = nullptr;    // n x COMPACT
   double* h_poses = nullptr;      // pinned
-  double* h_compact = nullptr;    // pinned
+  double* h_compact = nullptr;    // pinned, host-mapped
+  double* h_compact_dev = nullptr;  // device view of h_compact (small sets: results land in host memory, no D2H copy)
   size_t cap_factors = 0, cap_blocks = 0;
   std::vector<glim_amd::FactorDesc> h_descs;
 };

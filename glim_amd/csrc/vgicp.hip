@@ -22,6 +22,7 @@
 // 4 waves of a block -> one 32-float partial row per block -> FP64 fixed-order sum per factor (finalise kernel).
 // The result is bit-reproducible run to run (no floating-point atomics anywhere).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -462,6 +463,7 @@ void factor_set_release_plan(glim_amd_factor_set* set) {
   set->d_compact = nullptr;
   set->h_poses = nullptr;
   set->h_compact = nullptr;
+  set->h_compact_dev = nullptr;
   set->cap_factors = set->cap_blocks = 0;
 }
 
@@ -568,7 +570,12 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   GA_HIP(hipMalloc(&set->d_poses, nfa * 24 * sizeof(double)));
   GA_HIP(hipMalloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
   GA_HIP(hipHostMalloc(&set->h_poses, nfa * 24 * sizeof(double), hipHostMallocDefault));
-  GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocDefault));
+  GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocMapped));
+  set->h_compact_dev = nullptr;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_compact_dev), set->h_compact, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    set->h_compact_dev = nullptr;
+  }
   set->cap_factors = nfa;
   set->cap_blocks = nba;
   if (nf > 0) {
@@ -747,10 +754,29 @@ int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T, gli
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
   GA_TRY(upload_poses(set, T, nullptr));
-  GA_TRY(launch_linearize(set, set->d_compact, 0));
-  GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  if (set->h_compact_dev && nf <= 1024) {
+    // small sets (the per-frame odometry case): the finalise kernel writes the 232-B records straight into host-mapped pinned
+    // memory, so the call costs one pose copy + two launches + one stream sync and no device-to-host copy
+    GA_TRY(launch_linearize(set, set->h_compact_dev, 0));
+  } else {
+    GA_TRY(launch_linearize(set, set->d_compact, 0));
+    GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  }
   GA_HIP(hipStreamSynchronize(set->stream));
   for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(set->h_compact + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T, int iters, float* ms_per_call) {
+  if (!set || !T || iters <= 0 || !ms_per_call) return GLIM_AMD_ERR_INVALID;
+  const size_t nf = set->entries.size();
+  if (nf == 0) return GLIM_AMD_ERR_STATE;
+  std::vector<glim_amd_linearized6> out(nf);
+  for (int i = 0; i < 5; i++) GA_TRY(glim_amd_factor_set_linearize(set, T, out.data()));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_factor_set_linearize(set, T, out.data()));
+  const auto t1 = std::chrono::steady_clock::now();
+  *ms_per_call = (float)(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
   return GLIM_AMD_OK;
 }
 
@@ -832,8 +858,8 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   hipEvent_t e0, e1;
   GA_HIP(hipEventCreate(&e0));
   GA_HIP(hipEventCreate(&e1));
-  // warm-up
-  GA_TRY(launch_linearize(set, set->d_compact, 0));
+  // warm-up (clocks, caches, TLBs)
+  for (int i = 0; i < 10; i++) GA_TRY(launch_linearize(set, set->d_compact, 0));
   GA_HIP(hipStreamSynchronize(set->stream));
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));

@@ -151,6 +151,10 @@ int glim_amd_expand_compact(const double* compact, const double* T_target_source
 int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_vgicp_kernel,
                                 float* ms_linearize);
 
+/* wall-clock milliseconds per synchronous glim_amd_factor_set_linearize call (pose upload, launches, result in host memory),
+ * measured inside the library so that no binding overhead is included. */
+int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_per_call);
+
 /* ---- overlap: overlap_gpu / overlap_auto (odometry_estimation_gpu.cpp:231,248,265,279,326; sub_mapping.cpp:252-253;
  *      global_mapping.cpp:322,448).  Fraction of source points that hit an occupied voxel of ANY target under its delta. */
 int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T_target_source,
