@@ -120,25 +120,84 @@ __global__ __launch_bounds__(256) void grid_insert_kernel(int n, const float4* _
   slot_of[i] = (int)s;
 }
 
-// exclusive scan of counts[T] -> starts[T] (single block, 1024 threads, contiguous chunks)
-__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int* __restrict__ starts, unsigned int T) {
-  __shared__ int s_sum[1024];
-  const unsigned int per = (T + 1023u) / 1024u;
-  const unsigned int b = threadIdx.x * per, e = min(T, b + per);
-  int sum = 0;
-  for (unsigned int i = b; i < e; i++) sum += counts[i];
-  s_sum[threadIdx.x] = sum;
+// exclusive scan of counts[T] -> starts[T] in three launches: per-tile sums, scan of the tile sums (one block), per-tile scan
+// with the tile offset.  A tile is SCAN_TILE consecutive entries read coalesced (lane-contiguous int4).
+constexpr int SCAN_TILE = 4096;  // 1024 threads x int4
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* s_tmp, int* total) {
+  // wave-level inclusive scan by shuffles, then a scan of the 16 wave sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) s_tmp[wave] = inc;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = (threadIdx.x >= (unsigned)off) ? s_sum[threadIdx.x - off] : 0;
-    __syncthreads();
-    s_sum[threadIdx.x] += v;
+  if (threadIdx.x < 16) {
+    int w = s_tmp[threadIdx.x];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int t = __shfl_up(w, off, 16);
+      if ((int)threadIdx.x >= off) w += t;
+    }
+    s_tmp[16 + threadIdx.x] = w;  // inclusive scan of wave sums
+  }
+  __syncthreads();
+  const int wave_off = wave ? s_tmp[16 + wave - 1] : 0;
+  if (total) *total = s_tmp[31];
+  return wave_off + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void scan_tile_sums_kernel(const int* __restrict__ counts, unsigned int T, int* __restrict__ tile_sums) {
+  __shared__ int s_tmp[32];
+  const unsigned int i = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (i + 3 < T) c = *reinterpret_cast<const int4*>(counts + i);
+  else {
+    if (i < T) c.x = counts[i];
+    if (i + 1 < T) c.y = counts[i + 1];
+    if (i + 2 < T) c.z = counts[i + 2];
+  }
+  int total = 0;
+  block_exclusive_scan_1024(c.x + c.y + c.z + c.w, s_tmp, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_tile_offsets_kernel(int* __restrict__ tile_sums, int num_tiles) {
+  // exclusive scan of the tile sums in place (num_tiles <= 1024 * chunk handled by a serial carry over chunks of 1024)
+  __shared__ int s_tmp[32];
+  int carry = 0;
+  for (int base = 0; base < num_tiles; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const int v = i < num_tiles ? tile_sums[i] : 0;
+    int total = 0;
+    const int ex = block_exclusive_scan_1024(v, s_tmp, &total);
+    if (i < num_tiles) tile_sums[i] = carry + ex;
+    carry += total;
     __syncthreads();
   }
-  int run = s_sum[threadIdx.x] - sum;
-  for (unsigned int i = b; i < e; i++) {
-    starts[i] = run;
-    run += counts[i];
+}
+
+__global__ __launch_bounds__(1024) void scan_apply_kernel(const int* __restrict__ counts, unsigned int T, const int* __restrict__ tile_offsets,
+                                                          int* __restrict__ starts) {
+  __shared__ int s_tmp[32];
+  const unsigned int i = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int4 c = make_int4(0, 0, 0, 0);
+  if (i + 3 < T) c = *reinterpret_cast<const int4*>(counts + i);
+  else {
+    if (i < T) c.x = counts[i];
+    if (i + 1 < T) c.y = counts[i + 1];
+    if (i + 2 < T) c.z = counts[i + 2];
+  }
+  const int ex = tile_offsets[blockIdx.x] + block_exclusive_scan_1024(c.x + c.y + c.z + c.w, s_tmp, nullptr);
+  const int4 o = make_int4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+  if (i + 3 < T) *reinterpret_cast<int4*>(starts + i) = o;
+  else {
+    if (i < T) starts[i] = o.x;
+    if (i + 1 < T) starts[i + 1] = o.y;
+    if (i + 2 < T) starts[i + 2] = o.z;
   }
 }
 
@@ -158,10 +217,19 @@ template <int K>
 __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __restrict__ sorted, double h, double inv_h,
                                                        const unsigned long long* __restrict__ keys, unsigned int mask, const int* __restrict__ starts,
                                                        const int* __restrict__ counts, int k, int32_t* __restrict__ out, int* __restrict__ unresolved,
-                                                       int* __restrict__ stats) {
+                                                       int* __restrict__ stats, const float4* __restrict__ pts, const int* __restrict__ queries,
+                                                       int num_queries) {
+  // first pass: one lane per point in cell order (queries == nullptr); retry passes on a coarser grid: the listed points only
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const float4 q4 = sorted[s];
+  if (s >= (queries ? num_queries : n)) return;
+  float4 q4;
+  if (queries) {
+    const int qi = queries[s];
+    const float4 p = pts[qi];
+    q4 = make_float4(p.x, p.y, p.z, __int_as_float(qi));
+  } else {
+    q4 = sorted[s];
+  }
   const int self = __float_as_int(q4.w);
   const double qx = q4.x, qy = q4.y, qz = q4.z;
   const double tx = qx * inv_h, ty = qy * inv_h, tz = qz * inv_h;
@@ -235,10 +303,19 @@ __global__ __launch_bounds__(256) void bbox_kernel(int n, const float4* __restri
       hi[a] = max(hi[a], v[a]);
     }
   }
+  // wave-level min/max first: one set of atomics per wavefront instead of one per lane
   for (int a = 0; a < 3; a++) {
-    atomicMin(&bb[a], lo[a]);
-    atomicMax(&bb[3 + a], hi[a]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
+    }
   }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&bb[a], lo[a]);
+      atomicMax(&bb[3 + a], hi[a]);
+    }
 }
 float unordered(int i) {
   const int j = i >= 0 ? i : i ^ 0x7fffffff;
@@ -253,8 +330,10 @@ void launch_brute(hipStream_t st, int n, const float4* pts, int k, int32_t* out,
 }
 template <int K>
 void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const unsigned long long* keys, unsigned int mask, const int* starts,
-                 const int* counts, int k, int32_t* out, int* unresolved, int* stats) {
-  knn_grid_kernel<K><<<(n + 255) / 256, 256, 0, st>>>(n, sorted, h, 1.0 / h, keys, mask, starts, counts, k, out, unresolved, stats);
+                 const int* counts, int k, int32_t* out, int* unresolved, int* stats, const float4* pts, const int* queries, int nq) {
+  const int work = queries ? nq : n;
+  if (work > 0)
+    knn_grid_kernel<K><<<(work + 255) / 256, 256, 0, st>>>(n, sorted, h, 1.0 / h, keys, mask, starts, counts, k, out, unresolved, stats, pts, queries, nq);
 }
 
 #define DISPATCH_K(FN, ...)                      \
@@ -279,9 +358,38 @@ unsigned int next_pow2(unsigned long long v) {
   return (unsigned int)p;
 }
 
+// counting sort of all points into the hashed grid of cell edge h (keys/counts/starts/sorted are rebuilt)
+struct GridBuffers {
+  DeviceTemp keys, counts, starts, cursor, slot_of, sorted, stats, tile_sums;
+  unsigned int T = 0;
+};
+
+int build_grid(hipStream_t st, int n, const float4* pts, double h, GridBuffers& g, int* h_stats) {
+  GA_HIP(hipMemsetAsync(g.keys.p, 0xff, (size_t)g.T * sizeof(unsigned long long), st));
+  GA_HIP(hipMemsetAsync(g.counts.p, 0, (size_t)g.T * sizeof(int), st));
+  GA_HIP(hipMemsetAsync(g.stats.p, 0, 4 * sizeof(int), st));
+  grid_insert_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, 1.0 / h, (unsigned long long*)g.keys.p, g.T - 1, (int*)g.counts.p, (int*)g.slot_of.p,
+                                                      (int*)g.stats.p);
+  GA_HIP(hipMemcpyAsync(h_stats, g.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+  return GLIM_AMD_OK;
+}
+
+int sort_into_grid(hipStream_t st, int n, const float4* pts, GridBuffers& g) {
+  const int tiles = (int)((g.T + SCAN_TILE - 1) / SCAN_TILE);
+  GA_HIP(hipMemsetAsync(g.cursor.p, 0, (size_t)g.T * sizeof(int), st));
+  scan_tile_sums_kernel<<<tiles, 1024, 0, st>>>((const int*)g.counts.p, g.T, (int*)g.tile_sums.p);
+  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>((int*)g.tile_sums.p, tiles);
+  scan_apply_kernel<<<tiles, 1024, 0, st>>>((const int*)g.counts.p, g.T, (const int*)g.tile_sums.p, (int*)g.starts.p);
+  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, (const int*)g.slot_of.p, (const int*)g.starts.p, (int*)g.cursor.p, (float4*)g.sorted.p);
+  GA_HIP(hipGetLastError());
+  return GLIM_AMD_OK;
+}
+
 int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out) {
   // ---- cell edge from the data: a surface-like cloud of n points in its bounding box, ~3 points per occupied cell ----
-  DeviceTemp bb, keys, counts, starts, cursor, slot_of, sorted, stats, unresolved;
+  DeviceTemp bb, unresolved_a, unresolved_b;
+  GridBuffers g;
   GA_HIP(hipMalloc(&bb.p, 6 * sizeof(int)));
   const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
@@ -296,50 +404,63 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   if (const char* env = getenv("GLIM_AMD_KNN_CELL")) h = atof(env);
   const double max_abs = std::max({std::fabs((double)unordered(h_bb[0])), std::fabs((double)unordered(h_bb[1])), std::fabs((double)unordered(h_bb[2])),
                                    std::fabs((double)unordered(h_bb[3])), std::fabs((double)unordered(h_bb[4])), std::fabs((double)unordered(h_bb[5]))});
-  h = std::max(h, max_abs / 1.0e6 + 1e-9);  // keep cell coordinates inside the 21-bit key range
+  const double h_min = max_abs / 1.0e6 + 1e-9;  // keep cell coordinates inside the 21-bit key range
+  h = std::max(h, h_min);
+  const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
 
-  const unsigned int T = next_pow2((unsigned long long)n * 2);
-  GA_HIP(hipMalloc(&keys.p, (size_t)T * sizeof(unsigned long long)));
-  GA_HIP(hipMalloc(&counts.p, (size_t)T * sizeof(int)));
-  GA_HIP(hipMalloc(&starts.p, (size_t)T * sizeof(int)));
-  GA_HIP(hipMalloc(&cursor.p, (size_t)T * sizeof(int)));
-  GA_HIP(hipMalloc(&slot_of.p, (size_t)n * sizeof(int)));
-  GA_HIP(hipMalloc(&sorted.p, (size_t)n * sizeof(float4)));
-  GA_HIP(hipMalloc(&stats.p, 4 * sizeof(int)));
-  GA_HIP(hipMalloc(&unresolved.p, (size_t)n * sizeof(int)));
+  g.T = next_pow2((unsigned long long)n * 2);
+  GA_HIP(hipMalloc(&g.keys.p, (size_t)g.T * sizeof(unsigned long long)));
+  GA_HIP(hipMalloc(&g.counts.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(hipMalloc(&g.starts.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(hipMalloc(&g.cursor.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(hipMalloc(&g.slot_of.p, (size_t)n * sizeof(int)));
+  GA_HIP(hipMalloc(&g.sorted.p, (size_t)n * sizeof(float4)));
+  GA_HIP(hipMalloc(&g.stats.p, 4 * sizeof(int)));
+  GA_HIP(hipMalloc(&g.tile_sums.p, (size_t)((g.T + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(int)));
+  GA_HIP(hipMalloc(&unresolved_a.p, (size_t)n * sizeof(int)));
+  GA_HIP(hipMalloc(&unresolved_b.p, (size_t)n * sizeof(int)));
 
   int h_stats[4] = {0, 0, 0, 0};
   for (int attempt = 0; attempt < 4; attempt++) {
-    GA_HIP(hipMemsetAsync(keys.p, 0xff, (size_t)T * sizeof(unsigned long long), st));
-    GA_HIP(hipMemsetAsync(counts.p, 0, (size_t)T * sizeof(int), st));
-    GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
-    grid_insert_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, 1.0 / h, (unsigned long long*)keys.p, T - 1, (int*)counts.p, (int*)slot_of.p, (int*)stats.p);
-    GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_TRY(build_grid(st, n, pts, h, g, h_stats));
     if (h_stats[1] != 0) {  // a coordinate fell outside the key range: coarsen
       h *= 4.0;
       continue;
     }
     const double per_cell = (double)n / std::max(1, h_stats[0]);
     if (getenv("GLIM_AMD_KNN_CELL")) break;
-    if (per_cell > 8.0 && attempt < 3) h *= 0.5;
+    if (per_cell > 8.0 && attempt < 3 && h * 0.5 >= h_min) h *= 0.5;
     else if (per_cell < 1.5 && attempt < 3) h *= 2.0;
     else break;
   }
   if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
-  GA_HIP(hipMemsetAsync(cursor.p, 0, (size_t)T * sizeof(int), st));
-  scan_kernel<<<1, 1024, 0, st>>>((const int*)counts.p, (int*)starts.p, T);
-  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, (const int*)slot_of.p, (const int*)starts.p, (int*)cursor.p, (float4*)sorted.p);
-  DISPATCH_K(launch_grid, st, n, (const float4*)sorted.p, h, (const unsigned long long*)keys.p, T - 1, (const int*)starts.p, (const int*)counts.p, k, out,
-             (int*)unresolved.p, (int*)stats.p);
-  GA_HIP(hipGetLastError());
-  GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
-  if (h_stats[2] > 0) {  // isolated points: finish exactly with the exhaustive kernel
-    DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)unresolved.p, h_stats[2]);
+
+  // level 0: every point, in cell order.  Levels 1..: the points the previous level could not prove (sparse regions) are
+  // re-run on a 4x coarser grid; once the scanned cube covers the whole bounding box the result is exact by construction.
+  int* todo = (int*)unresolved_a.p;
+  int* next = (int*)unresolved_b.p;
+  int num_todo = 0;
+  for (int level = 0; level < 12; level++) {
+    if (level > 0) {
+      h *= 4.0;
+      GA_TRY(build_grid(st, n, pts, h, g, h_stats));
+      if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
+    }
+    GA_TRY(sort_into_grid(st, n, pts, g));
+    GA_HIP(hipMemsetAsync((int*)g.stats.p + 2, 0, sizeof(int), st));
+    DISPATCH_K(launch_grid, st, n, (const float4*)g.sorted.p, h, (const unsigned long long*)g.keys.p, g.T - 1, (const int*)g.starts.p,
+               (const int*)g.counts.p, k, out, next, (int*)g.stats.p, pts, level > 0 ? todo : (const int*)nullptr, num_todo);
     GA_HIP(hipGetLastError());
+    GA_HIP(hipMemcpyAsync(h_stats, g.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     GA_HIP(hipStreamSynchronize(st));
+    num_todo = h_stats[2];
+    if (num_todo == 0) return GLIM_AMD_OK;
+    std::swap(todo, next);
+    if ((double)MAX_RING * h > diag) break;  // the next cube would cover everything anyway: finish exhaustively
   }
+  DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)todo, num_todo);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipStreamSynchronize(st));
   return GLIM_AMD_OK;
 }
 
