@@ -116,6 +116,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
   const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
 
   // rotation of the linearisation pose in FP32 (R[r][c])
+  // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
   const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
   const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
