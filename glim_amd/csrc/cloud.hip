@@ -73,12 +73,12 @@ int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_
   c->ctx = ctx;
   c->n = n;
   const size_t nn = (size_t)(n > 0 ? n : 1);
-  hipError_t e = hipMalloc(&c->pts, nn * sizeof(float4));
-  if (e == hipSuccess && covs) e = hipMalloc(&c->covA, nn * sizeof(float4));
-  if (e == hipSuccess && covs) e = hipMalloc(&c->covB, nn * sizeof(float2));
-  if (e == hipSuccess && normals) e = hipMalloc(&c->normals, nn * sizeof(float4));
+  hipError_t e = pool_malloc(&c->pts, nn * sizeof(float4));
+  if (e == hipSuccess && covs) e = pool_malloc(&c->covA, nn * sizeof(float4));
+  if (e == hipSuccess && covs) e = pool_malloc(&c->covB, nn * sizeof(float2));
+  if (e == hipSuccess && normals) e = pool_malloc(&c->normals, nn * sizeof(float4));
   if (e != hipSuccess) {
-    set_hip_error(e, "hipMalloc(cloud)");
+    set_hip_error(e, "pool_malloc(cloud)");
     glim_amd_cloud_destroy(c);
     return e == hipErrorOutOfMemory ? GLIM_AMD_ERR_NOMEM : GLIM_AMD_ERR_HIP;
   }
@@ -91,7 +91,7 @@ int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_
 struct DeviceTemp {
   void* p = nullptr;
   ~DeviceTemp() {
-    if (p) (void)hipFree(p);
+    if (p) (void)pool_free(p);
   }
 };
 
@@ -110,9 +110,9 @@ int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
   if (n > 0) {
     hipStream_t s = ctx->stream();
     DeviceTemp dp, dc, dn;
-    hipError_t e = hipMalloc(&dp.p, (size_t)n * 4 * sizeof(double));
-    if (e == hipSuccess && covs16) e = hipMalloc(&dc.p, (size_t)n * 16 * sizeof(double));
-    if (e == hipSuccess && normals4) e = hipMalloc(&dn.p, (size_t)n * 4 * sizeof(double));
+    hipError_t e = pool_malloc(&dp.p, (size_t)n * 4 * sizeof(double));
+    if (e == hipSuccess && covs16) e = pool_malloc(&dc.p, (size_t)n * 16 * sizeof(double));
+    if (e == hipSuccess && normals4) e = pool_malloc(&dn.p, (size_t)n * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(dp.p, points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && covs16) e = hipMemcpyAsync(dc.p, covs16, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && normals4) e = hipMemcpyAsync(dn.p, normals4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
@@ -144,9 +144,9 @@ int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, co
   if (n > 0) {
     hipStream_t s = ctx->stream();
     DeviceTemp dp, dc, dn;
-    hipError_t e = hipMalloc(&dp.p, (size_t)n * 3 * sizeof(float));
-    if (e == hipSuccess && cov33) e = hipMalloc(&dc.p, (size_t)n * 9 * sizeof(float));
-    if (e == hipSuccess && normals3) e = hipMalloc(&dn.p, (size_t)n * 3 * sizeof(float));
+    hipError_t e = pool_malloc(&dp.p, (size_t)n * 3 * sizeof(float));
+    if (e == hipSuccess && cov33) e = pool_malloc(&dc.p, (size_t)n * 9 * sizeof(float));
+    if (e == hipSuccess && normals3) e = pool_malloc(&dn.p, (size_t)n * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(dp.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && cov33) e = hipMemcpyAsync(dc.p, cov33, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && normals3) e = hipMemcpyAsync(dn.p, normals3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s);
@@ -170,13 +170,13 @@ int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, co
 int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (!c) return GLIM_AMD_OK;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  if (c->pts) (void)hipFree(c->pts);
-  if (c->covA) (void)hipFree(c->covA);
-  if (c->covB) (void)hipFree(c->covB);
-  if (c->normals) (void)hipFree(c->normals);
-  if (c->neighbors) (void)hipFree(c->neighbors);
-  if (c->pn4) (void)hipFree(c->pn4);
-  if (c->n2) (void)hipFree(c->n2);
+  if (c->pts) (void)pool_free(c->pts);
+  if (c->covA) (void)pool_free(c->covA);
+  if (c->covB) (void)pool_free(c->covB);
+  if (c->normals) (void)pool_free(c->normals);
+  if (c->neighbors) (void)pool_free(c->neighbors);
+  if (c->pn4) (void)pool_free(c->pn4);
+  if (c->n2) (void)pool_free(c->n2);
   delete c;
   return GLIM_AMD_OK;
 }
@@ -205,9 +205,9 @@ int glim_amd_cloud_download(const glim_amd_cloud* c, float* xyz, float* cov33, f
   hipStream_t s = ctx->stream();
   const int64_t n = c->n;
   DeviceTemp dx, dc, dn;
-  if (xyz) GA_HIP(hipMalloc(&dx.p, (size_t)n * 3 * sizeof(float)));
-  if (cov33) GA_HIP(hipMalloc(&dc.p, (size_t)n * 9 * sizeof(float)));
-  if (normals3) GA_HIP(hipMalloc(&dn.p, (size_t)n * 3 * sizeof(float)));
+  if (xyz) GA_HIP(pool_malloc(&dx.p, (size_t)n * 3 * sizeof(float)));
+  if (cov33) GA_HIP(pool_malloc(&dc.p, (size_t)n * 9 * sizeof(float)));
+  if (normals3) GA_HIP(pool_malloc(&dn.p, (size_t)n * 3 * sizeof(float)));
   if (xyz || cov33 || normals3) {
     unpack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(n, c->pts, c->covA, c->covB, c->normals, (float*)dx.p, (float*)dc.p, (float*)dn.p);
     GA_HIP(hipGetLastError());
@@ -226,12 +226,12 @@ int glim_amd_cloud_set_neighbors(glim_amd_cloud* c, int k, const int32_t* neighb
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   if (c->neighbors) {
-    (void)hipFree(c->neighbors);
+    (void)pool_free(c->neighbors);
     c->neighbors = nullptr;
   }
   c->k = k;
   const size_t bytes = (size_t)(c->n > 0 ? c->n : 1) * k * sizeof(int32_t);
-  GA_HIP(hipMalloc(&c->neighbors, bytes));
+  GA_HIP(pool_malloc(&c->neighbors, bytes));
   if (c->n > 0) {
     GA_HIP(hipMemcpyAsync(c->neighbors, neighbors, (size_t)c->n * k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream()));
     GA_HIP(hipStreamSynchronize(ctx->stream()));

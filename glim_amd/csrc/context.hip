@@ -1,9 +1,12 @@
 // context.hip -- library, error and context entry points of the C ABI (include/glim_amd.h).
+#include <atomic>
+
 #include "internal.hpp"
 
 namespace glim_amd {
 
 static thread_local char g_hip_error[512] = "";
+static std::atomic<int> g_live_contexts{0};
 
 void set_hip_error(hipError_t e, const char* what) {
   snprintf(g_hip_error, sizeof(g_hip_error), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
@@ -73,6 +76,7 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
       ctx->streams.push_back(s);
     }
   }
+  g_live_contexts++;
   *out = ctx;
   return GLIM_AMD_OK;
 }
@@ -83,6 +87,7 @@ int glim_amd_ctx_destroy(glim_amd_ctx* ctx) {
   for (auto s : ctx->streams) (void)hipStreamSynchronize(s);
   if (ctx->owns_streams)
     for (auto s : ctx->streams) (void)hipStreamDestroy(s);
+  if (--g_live_contexts == 0) pool_trim(ctx->device);  // last context gone: give the cached device memory back
   delete ctx;
   return GLIM_AMD_OK;
 }
@@ -111,3 +116,99 @@ int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device memory pool (per device, process-wide): hipMalloc / hipFree cost 10-100+ us each and hipFree synchronises the
+// device, which is what made the per-frame path (upload -> kNN -> covariance -> voxel map) jittery (p99 46 ms on the 300k-point
+// stream).  Freed blocks are cached by size and handed back to later requests of a similar size; every API call that frees
+// scratch has synchronised its stream before returning, so re-use is ordered.  GLIM_AMD_NO_POOL=1 disables the cache.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <map>
+#include <unordered_map>
+
+namespace glim_amd {
+
+namespace {
+struct DevicePool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> live;
+  size_t cached_bytes = 0;
+};
+DevicePool& pool_of(int device) {
+  // intentionally leaked: contexts held in static storage by callers may be destroyed after any static of this library
+  static DevicePool* pools = new DevicePool[64];
+  return pools[(device >= 0 && device < 64) ? device : 0];
+}
+constexpr size_t kMaxCachedBytes = 32ull << 30;
+bool pool_disabled() {
+  static const bool off = getenv("GLIM_AMD_NO_POOL") != nullptr;
+  return off;
+}
+}  // namespace
+
+hipError_t pool_malloc_impl(void** p, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevicePool& P = pool_of(dev);
+  if (!pool_disabled()) {
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.free_blocks.lower_bound(want);
+    if (it != P.free_blocks.end() && it->first <= want + want / 2 + 4096) {
+      *p = it->second;
+      P.live[*p] = it->first;
+      P.cached_bytes -= it->first;
+      P.free_blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess && !pool_disabled()) {  // out of memory: drop the cache and retry once
+    (void)hipGetLastError();
+    pool_trim(dev);
+    e = hipMalloc(p, want);
+  }
+  if (e == hipSuccess && !pool_disabled()) {
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.live[*p] = want;
+  }
+  return e;
+}
+
+hipError_t pool_free(void* p) {
+  if (!p) return hipSuccess;
+  if (pool_disabled()) return hipFree(p);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DevicePool& P = pool_of(dev);
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return hipFree(p);  // not ours (allocated before the pool was enabled)
+    sz = it->second;
+    P.live.erase(it);
+    if (P.cached_bytes + sz <= kMaxCachedBytes) {
+      P.free_blocks.emplace(sz, p);
+      P.cached_bytes += sz;
+      return hipSuccess;
+    }
+  }
+  return hipFree(p);
+}
+
+void pool_trim(int device) {
+  DevicePool& P = pool_of(device);
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (auto& kv : P.free_blocks) blocks.push_back(kv.second);
+    P.free_blocks.clear();
+    P.cached_bytes = 0;
+  }
+  for (void* b : blocks) (void)hipFree(b);
+}
+
+}  // namespace glim_amd

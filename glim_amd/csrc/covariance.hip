@@ -132,11 +132,11 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   const size_t nn = (size_t)(c->n > 0 ? c->n : 1);
-  if (!c->covA) GA_HIP(hipMalloc(&c->covA, nn * sizeof(float4)));
-  if (!c->covB) GA_HIP(hipMalloc(&c->covB, nn * sizeof(float2)));
-  if (!c->normals) GA_HIP(hipMalloc(&c->normals, nn * sizeof(float4)));
-  if (!c->pn4) GA_HIP(hipMalloc(&c->pn4, nn * sizeof(float4)));
-  if (!c->n2) GA_HIP(hipMalloc(&c->n2, nn * sizeof(float2)));
+  if (!c->covA) GA_HIP(pool_malloc(&c->covA, nn * sizeof(float4)));
+  if (!c->covB) GA_HIP(pool_malloc(&c->covB, nn * sizeof(float2)));
+  if (!c->normals) GA_HIP(pool_malloc(&c->normals, nn * sizeof(float4)));
+  if (!c->pn4) GA_HIP(pool_malloc(&c->pn4, nn * sizeof(float4)));
+  if (!c->n2) GA_HIP(pool_malloc(&c->n2, nn * sizeof(float2)));
   if (c->n > 0) {
     const int n = (int)c->n;
     covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals, c->pn4, c->n2);

@@ -19,6 +19,15 @@ namespace glim_amd {
 // ---------------------------------------------------------------------------------------------------------------
 void set_hip_error(hipError_t e, const char* what);
 
+// device memory pool (context.hip): drop-in for hipMalloc / hipFree on the current device
+hipError_t pool_malloc_impl(void** p, size_t bytes);
+hipError_t pool_free(void* p);
+void pool_trim(int device);
+template <class T>
+inline hipError_t pool_malloc(T** p, size_t bytes) {
+  return pool_malloc_impl(reinterpret_cast<void**>(p), bytes);
+}
+
 #define GA_HIP(call)                                   \
   do {                                                 \
     hipError_t _e = (call);                            \

@@ -348,7 +348,7 @@ void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const un
 struct DeviceTemp {
   void* p = nullptr;
   ~DeviceTemp() {
-    if (p) (void)hipFree(p);
+    if (p) (void)pool_free(p);
   }
 };
 
@@ -390,7 +390,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   // ---- cell edge from the data: a surface-like cloud of n points in its bounding box, ~3 points per occupied cell ----
   DeviceTemp bb, unresolved_a, unresolved_b;
   GridBuffers g;
-  GA_HIP(hipMalloc(&bb.p, 6 * sizeof(int)));
+  GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
   bbox_kernel<<<std::min((n + 255) / 256, 1024), 256, 0, st>>>(n, pts, (int*)bb.p);
@@ -409,16 +409,16 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
 
   g.T = next_pow2((unsigned long long)n * 2);
-  GA_HIP(hipMalloc(&g.keys.p, (size_t)g.T * sizeof(unsigned long long)));
-  GA_HIP(hipMalloc(&g.counts.p, (size_t)g.T * sizeof(int)));
-  GA_HIP(hipMalloc(&g.starts.p, (size_t)g.T * sizeof(int)));
-  GA_HIP(hipMalloc(&g.cursor.p, (size_t)g.T * sizeof(int)));
-  GA_HIP(hipMalloc(&g.slot_of.p, (size_t)n * sizeof(int)));
-  GA_HIP(hipMalloc(&g.sorted.p, (size_t)n * sizeof(float4)));
-  GA_HIP(hipMalloc(&g.stats.p, 4 * sizeof(int)));
-  GA_HIP(hipMalloc(&g.tile_sums.p, (size_t)((g.T + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(int)));
-  GA_HIP(hipMalloc(&unresolved_a.p, (size_t)n * sizeof(int)));
-  GA_HIP(hipMalloc(&unresolved_b.p, (size_t)n * sizeof(int)));
+  GA_HIP(pool_malloc(&g.keys.p, (size_t)g.T * sizeof(unsigned long long)));
+  GA_HIP(pool_malloc(&g.counts.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(pool_malloc(&g.starts.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(pool_malloc(&g.cursor.p, (size_t)g.T * sizeof(int)));
+  GA_HIP(pool_malloc(&g.slot_of.p, (size_t)n * sizeof(int)));
+  GA_HIP(pool_malloc(&g.sorted.p, (size_t)n * sizeof(float4)));
+  GA_HIP(pool_malloc(&g.stats.p, 4 * sizeof(int)));
+  GA_HIP(pool_malloc(&g.tile_sums.p, (size_t)((g.T + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&unresolved_a.p, (size_t)n * sizeof(int)));
+  GA_HIP(pool_malloc(&unresolved_b.p, (size_t)n * sizeof(int)));
 
   int h_stats[4] = {0, 0, 0, 0};
   for (int attempt = 0; attempt < 4; attempt++) {
@@ -475,11 +475,11 @@ int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_o
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   if (c->neighbors) {
-    (void)hipFree(c->neighbors);
+    (void)pool_free(c->neighbors);
     c->neighbors = nullptr;
   }
   c->k = k;
-  GA_HIP(hipMalloc(&c->neighbors, (size_t)(c->n > 0 ? c->n : 1) * k * sizeof(int32_t)));
+  GA_HIP(pool_malloc(&c->neighbors, (size_t)(c->n > 0 ? c->n : 1) * k * sizeof(int32_t)));
   if (c->n == 0) return GLIM_AMD_OK;
   if (c->n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
   const int n = (int)c->n;

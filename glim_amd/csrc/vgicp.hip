@@ -450,11 +450,11 @@ void hat3(const double* a, double* H) {
 namespace glim_amd {
 
 void factor_set_release_plan(glim_amd_factor_set* set) {
-  if (set->d_descs) (void)hipFree(set->d_descs);
-  if (set->d_blockmap) (void)hipFree(set->d_blockmap);
-  if (set->d_partials) (void)hipFree(set->d_partials);
-  if (set->d_poses) (void)hipFree(set->d_poses);
-  if (set->d_compact) (void)hipFree(set->d_compact);
+  if (set->d_descs) (void)pool_free(set->d_descs);
+  if (set->d_blockmap) (void)pool_free(set->d_blockmap);
+  if (set->d_partials) (void)pool_free(set->d_partials);
+  if (set->d_poses) (void)pool_free(set->d_poses);
+  if (set->d_compact) (void)pool_free(set->d_compact);
   if (set->h_poses) (void)hipHostFree(set->h_poses);
   if (set->h_compact) (void)hipHostFree(set->h_compact);
   set->d_descs = nullptr;
@@ -565,11 +565,11 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 
   factor_set_release_plan(set);
   const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
-  GA_HIP(hipMalloc(&set->d_descs, nfa * sizeof(FactorDesc)));
-  GA_HIP(hipMalloc(&set->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
-  GA_HIP(hipMalloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
-  GA_HIP(hipMalloc(&set->d_poses, nfa * 24 * sizeof(double)));
-  GA_HIP(hipMalloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
+  GA_HIP(pool_malloc(&set->d_descs, nfa * sizeof(FactorDesc)));
+  GA_HIP(pool_malloc(&set->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
+  GA_HIP(pool_malloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
+  GA_HIP(pool_malloc(&set->d_poses, nfa * 24 * sizeof(double)));
+  GA_HIP(pool_malloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
   GA_HIP(hipHostMalloc(&set->h_poses, nfa * 24 * sizeof(double), hipHostMallocDefault));
   GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocMapped));
   set->h_compact_dev = nullptr;
@@ -830,8 +830,8 @@ int glim_amd_factor_set_correspondences(glim_amd_factor_set* set, int32_t fi, co
   if (!corr) return GLIM_AMD_ERR_INVALID;
   double* d_pose = nullptr;
   int32_t* d_corr = nullptr;
-  GA_HIP(hipMalloc(&d_pose, 12 * sizeof(double)));
-  hipError_t e = hipMalloc(&d_corr, (size_t)d.n * 4 * sizeof(int32_t));
+  GA_HIP(pool_malloc(&d_pose, 12 * sizeof(double)));
+  hipError_t e = pool_malloc(&d_corr, (size_t)d.n * 4 * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemcpyAsync(d_pose, T, 12 * sizeof(double), hipMemcpyHostToDevice, set->stream);
   if (e == hipSuccess) {
     correspondence_kernel<<<(d.n + BLOCK - 1) / BLOCK, BLOCK, 0, set->stream>>>(d, d_pose, d_corr);
@@ -839,8 +839,8 @@ int glim_amd_factor_set_correspondences(glim_amd_factor_set* set, int32_t fi, co
   }
   if (e == hipSuccess) e = hipMemcpyAsync(corr, d_corr, (size_t)d.n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, set->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(set->stream);
-  (void)hipFree(d_pose);
-  if (d_corr) (void)hipFree(d_corr);
+  (void)pool_free(d_pose);
+  if (d_corr) (void)pool_free(d_corr);
   if (e != hipSuccess) {
     set_hip_error(e, "factor_set_correspondences");
     return GLIM_AMD_ERR_HIP;
@@ -905,8 +905,8 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
   }
   OverlapTarget* d_t = nullptr;
   unsigned int* d_hits = nullptr;
-  GA_HIP(hipMalloc(&d_t, (size_t)num_targets * sizeof(OverlapTarget)));
-  hipError_t e = hipMalloc(&d_hits, sizeof(unsigned int));
+  GA_HIP(pool_malloc(&d_t, (size_t)num_targets * sizeof(OverlapTarget)));
+  hipError_t e = pool_malloc(&d_hits, sizeof(unsigned int));
   if (e == hipSuccess) e = hipMemsetAsync(d_hits, 0, sizeof(unsigned int), st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_t, h.data(), (size_t)num_targets * sizeof(OverlapTarget), hipMemcpyHostToDevice, st);
   unsigned int hits = 0;
@@ -918,8 +918,8 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&hits, d_hits, sizeof(hits), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_t);
-  if (d_hits) (void)hipFree(d_hits);
+  (void)pool_free(d_t);
+  if (d_hits) (void)pool_free(d_hits);
   if (e != hipSuccess) {
     set_hip_error(e, "overlap");
     return GLIM_AMD_ERR_HIP;

@@ -147,7 +147,7 @@ unsigned int next_pow2(unsigned long long v) {
 struct DeviceTemp {
   void* p = nullptr;
   ~DeviceTemp() {
-    if (p) (void)hipFree(p);
+    if (p) (void)pool_free(p);
   }
 };
 
@@ -169,7 +169,7 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int /*init_nu
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (!m) return GLIM_AMD_OK;
   if (m->ctx) (void)hipSetDevice(m->ctx->device);
-  if (m->buckets) (void)hipFree(m->buckets);
+  if (m->buckets) (void)pool_free(m->buckets);
   delete m;
   return GLIM_AMD_OK;
 }
@@ -187,9 +187,9 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
 
   DeviceTemp tkeys, pkeys, stats, acc;
   const unsigned int tsize0 = next_pow2((unsigned long long)(n > 32 ? n : 32) * 2);
-  GA_HIP(hipMalloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
-  GA_HIP(hipMalloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
-  GA_HIP(hipMalloc(&stats.p, 2 * sizeof(int)));
+  GA_HIP(pool_malloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
+  GA_HIP(pool_malloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
+  GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
   GA_HIP(hipMemsetAsync(stats.p, 0, 2 * sizeof(int), st));
   fill_u64_kernel<<<1024, 256, 0, st>>>((unsigned long long*)tkeys.p, tsize0, EMPTY_KEY);
   GA_HIP(hipGetLastError());
@@ -211,8 +211,8 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;  // 32-bit byte offsets into the bucket table (4 GiB, ~11 M voxels)
   const unsigned int nb = (unsigned int)nb64;
   VoxelBucket* buckets = nullptr;
-  GA_HIP(hipMalloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
-  hipError_t e = hipMalloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
+  GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
+  hipError_t e = pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
   if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long), st);
   if (e == hipSuccess) {
     init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
@@ -226,7 +226,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
     set_hip_error(e, "voxelmap_insert");
-    (void)hipFree(buckets);
+    (void)pool_free(buckets);
     return GLIM_AMD_ERR_HIP;
   }
   m->buckets = buckets;
