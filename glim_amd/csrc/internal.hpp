@@ -87,6 +87,14 @@ struct FactorDesc {
   int ppt;                  // points per thread: chunk = 256 * ppt consecutive points per block
 };
 
+// Pose of a single-factor set passed by value in the kernel arguments: the synchronous per-factor call then needs no
+// host-to-device copy at all (valid == 0: poses are read from the device array as usual).
+struct InlinePose {
+  double m[12];
+  int valid;
+  int pad;
+};
+
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
 constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
 
@@ -165,6 +173,14 @@ struct glim_amd_factor_set {
   double* d_compact = nullptr;    // n x COMPACT
   double* h_poses = nullptr;      // pinned
   double* h_compact = nullptr;    // pinned, host-mapped
+  int* d_tickets = nullptr;          // per-factor block arrival counters (fused finalisation)
+  bool fused_finalize = true;
+  int* d_done = nullptr;             // finalise-block arrival counter (polling fast path)
+  unsigned int* h_flag = nullptr;    // host-mapped completion word, written by the last finalise block
+  unsigned int* h_flag_dev = nullptr;
+  unsigned int poll_seq = 0;
+  bool poll = false;
+  glim_amd::InlinePose inline_pose{};  // single-factor sets: the pose rides in the kernel arguments
   double* h_compact_dev = nullptr;  // device view of h_compact (small sets: results land in host memory, no D2H copy)
   size_t cap_factors = 0, cap_blocks = 0;
   std::vector<glim_amd::FactorDesc> h_descs;

@@ -22,6 +22,7 @@
 // 4 waves of a block -> one 32-float partial row per block -> FP64 fixed-order sum per factor (finalise kernel).
 // The result is bit-reproducible run to run (no floating-point atomics anywhere).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -96,6 +97,64 @@ __device__ __forceinline__ PointIn load_point(const FactorDesc& d, unsigned int 
   return r;
 }
 
+// Arguments of the per-factor finalisation (shared by the fused tail of vgicp_kernel and the stand-alone finalize_kernel).
+struct FinalizeArgs {
+  const int* rows;           // per factor: the grid block ids that hold its partial rows, in chunk order
+  int* tickets;              // per factor: arrival counter of its blocks (fused path; zero between launches)
+  double* out;               // compact records
+  long long out_row_offset;
+  int* done_counter;         // finished factors of this launch (polling fast path)
+  unsigned int* host_flag;   // host-mapped completion word or null
+  unsigned int seq;
+  int num_factors;
+  int fused;                 // 1: the last block of a factor finalises it inside vgicp_kernel; 0: finalize_kernel does
+};
+
+// Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 256 threads of ONE block.  Thread (g, j),
+// g = tid / 32, j = tid % 32, sums rows g, g + 8, g + 16, ... of value j; the 8 group sums are then added in group order.  The
+// order depends only on the plan, so results are bit-reproducible whichever block happens to run this.
+__device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
+                                                double (*s_part)[PARTIAL_STRIDE], double* s_sum) {
+  const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int first = d.first_block, nb = d.num_blocks;
+  double s = 0.0;
+  for (int c = g; c < nb; c += 8) s += (double)partials[(size_t)fa.rows[first + c] * PARTIAL_STRIDE + j];
+  s_part[g][j] = s;
+  __syncthreads();
+  if (threadIdx.x < PARTIAL_STRIDE) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
+    s_sum[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
+  if (t == 0) o[0] = s_sum[28];
+  if (t == 1) o[1] = s_sum[27];
+  if (mode == MODE_LINEARIZE) {
+    if (t < 21) o[2 + t] = s_sum[c_acc_of_upper[t]];
+    if (t >= 21 && t < 24) o[2 + t] = s_sum[t];          // b_w = sum u x p
+    if (t >= 24 && t < 27) o[2 + t] = -s_sum[t];         // b_v = -sum u
+  } else if (t >= 2 && t < COMPACT) {
+    o[t] = 0.0;
+  }
+  if (fa.host_flag) {
+    // completion flag for the polling fast path: every finalising block makes its record visible system-wide, the one that
+    // completes the launch publishes `seq` into host-mapped memory (the host spins on it instead of a stream synchronise)
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+      const int prev = atomicAdd(fa.done_counter, 1);
+      if (prev == fa.num_factors - 1) {
+        *fa.done_counter = 0;
+        __threadfence_system();
+        __hip_atomic_store(fa.host_flag, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
 // Mahalanobis matrices frozen at the linearisation pose.  U: points per loop trip.  MINW: occupancy hint (waves per SIMD).
 //
@@ -103,16 +162,20 @@ __device__ __forceinline__ PointIn load_point(const FactorDesc& d, unsigned int 
 // 48-byte voxel-slot gathers of trip t are issued back to back BEFORE the algebra of trip t, every lane runs the algebra
 // and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
 // the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
-template <int MODE, bool FROZEN, int U, int MINW, bool PLANE>
+template <int MODE, bool FROZEN, int U, int MINW, bool PLANE, bool INLINE>
 __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                              const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
-                                                             float* __restrict__ partials) {
+                                                             float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa) {
   __shared__ float s_red[4][PARTIAL_STRIDE];
+  __shared__ double s_part[8][PARTIAL_STRIDE];
+  __shared__ double s_sum[PARTIAL_STRIDE];
+  __shared__ int s_last;
   const int2 bm = blockmap[blockIdx.x];
   const int f = bm.x;
   if (f < 0) return;  // padding block of the XCD-aware map
   const FactorDesc d = descs[f];
-  const double* Tl = poses_lin + 12 * (size_t)f;
+  // INLINE (single-factor sets): the pose is read from the kernel arguments (scalar registers), no device pose array involved
+  const double* Tl = INLINE ? ip.m : poses_lin + 12 * (size_t)f;
   const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
 
   // rotation of the linearisation pose in FP32 (R[r][c])
@@ -350,42 +413,38 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
     if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
     partials[(size_t)blockIdx.x * PARTIAL_STRIDE + j] = v;
   }
+  if (!fa.fused) return;
+
+  // ---- fused finalisation: the LAST block of this factor to arrive sums the factor's partial rows (fixed order) ----
+  // Placement-independent hand-off (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", cdna_hip_programming.md G16): the
+  // storing wave drains its stores, one lane issues an agent-scope release (L2 write-back) and takes a ticket with a relaxed
+  // agent-scope atomic; the block that draws the last ticket issues one agent-scope acquire (drops its stale L1 lines) before
+  // any lane reads the other blocks' rows with plain loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(fa.tickets + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last_one = (ticket == d.num_blocks - 1);
+    if (last_one) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(fa.tickets + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    s_last = last_one;
+  }
+  __syncthreads();
+  if (s_last) finalize_factor(d, f, partials, fa, MODE, s_part, s_sum);
 }
 
-// One block of 256 threads per factor: fixed-order FP64 sum of the factor's partial rows -> compact record.  Thread (g, j),
-// g = tid / 32, j = tid % 32, sums rows g, g + 8, g + 16, ... of value j; the 8 group sums are then added in group order.
-// The order depends only on the plan, so results are bit-reproducible.  `rows` lists, per factor, the grid block ids that
-// hold its partials (d.first_block .. first_block + num_blocks - 1 index into it).
-__global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const int* __restrict__ rows,
-                                                       const float* __restrict__ partials, double* __restrict__ out, long long out_row_offset,
+// Stand-alone finalisation (default): one block of 256 threads per factor.
+__global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
                                                        int mode) {
-  const int f = blockIdx.x;
-  const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
   __shared__ double s_part[8][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
-  const int first = descs[f].first_block, nb = descs[f].num_blocks;
-  double s = 0.0;
-  for (int c = g; c < nb; c += 8) s += (double)partials[(size_t)rows[first + c] * PARTIAL_STRIDE + j];
-  s_part[g][j] = s;
-  __syncthreads();
-  if (threadIdx.x < PARTIAL_STRIDE) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
-    s_sum[threadIdx.x] = t;
-  }
-  __syncthreads();
-  const int t = threadIdx.x;
-  double* o = out + ((size_t)out_row_offset + f) * COMPACT;
-  if (t == 0) o[0] = s_sum[28];
-  if (t == 1) o[1] = s_sum[27];
-  if (mode == MODE_LINEARIZE) {
-    if (t < 21) o[2 + t] = s_sum[c_acc_of_upper[t]];
-    if (t >= 21 && t < 24) o[2 + t] = s_sum[t];          // b_w = sum u x p
-    if (t >= 24 && t < 27) o[2 + t] = -s_sum[t];         // b_v = -sum u
-  } else if (t >= 2 && t < COMPACT) {
-    o[t] = 0.0;
-  }
+  const int f = blockIdx.x;
+  const FactorDesc d = descs[f];
+  finalize_factor(d, f, partials, fa, mode, s_part, s_sum);
 }
 
 __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
@@ -455,6 +514,10 @@ void factor_set_release_plan(glim_amd_factor_set* set) {
   if (set->d_partials) (void)pool_free(set->d_partials);
   if (set->d_poses) (void)pool_free(set->d_poses);
   if (set->d_compact) (void)pool_free(set->d_compact);
+  if (set->d_done) (void)pool_free(set->d_done);
+  set->d_done = nullptr;
+  if (set->d_tickets) (void)pool_free(set->d_tickets);
+  set->d_tickets = nullptr;
   if (set->h_poses) (void)hipHostFree(set->h_poses);
   if (set->h_compact) (void)hipHostFree(set->h_compact);
   set->d_descs = nullptr;
@@ -570,6 +633,28 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   GA_HIP(pool_malloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
   GA_HIP(pool_malloc(&set->d_poses, nfa * 24 * sizeof(double)));
   GA_HIP(pool_malloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
+  GA_HIP(pool_malloc(&set->d_tickets, nfa * sizeof(int)));
+  GA_HIP(hipMemsetAsync(set->d_tickets, 0, nfa * sizeof(int), set->stream));
+  // Fused in-kernel finalisation was measured SLOWER on MI355X (64 x 131k-pt factors: 122 us vs 77 us + 3 us finalise kernel;
+  // single factor: 39 us vs 34.5 us per synchronous call): one agent-scope release per block (L2 write-back) costs more than the
+  // kernel boundary it removes.  Kept as an opt-in experiment.
+  set->fused_finalize = getenv("GLIM_AMD_FUSED_FINALIZE") != nullptr;
+  GA_HIP(pool_malloc(&set->d_done, sizeof(int)));
+  GA_HIP(hipMemsetAsync(set->d_done, 0, sizeof(int), set->stream));
+  if (!set->h_flag) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&set->h_flag), 64, hipHostMallocMapped) == hipSuccess) {
+      *set->h_flag = 0;
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_flag_dev), set->h_flag, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(set->h_flag);
+        set->h_flag = nullptr;
+        set->h_flag_dev = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      set->h_flag = nullptr;
+    }
+  }
   GA_HIP(hipHostMalloc(&set->h_poses, nfa * 24 * sizeof(double), hipHostMallocDefault));
   GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocMapped));
   set->h_compact_dev = nullptr;
@@ -595,44 +680,72 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 namespace {
 
 // kernel-variant dispatch: (U, MINW) chosen per plan (GLIM_AMD_U / GLIM_AMD_MINW override the tuned default)
+template <int U, int W, bool PLANE, bool INLINE>
+void launch_lin2(glim_amd_factor_set* set, const FinalizeArgs& fa) {
+  vgicp_kernel<MODE_LINEARIZE, false, U, W, PLANE, INLINE><<<set->total_blocks, BLOCK, 0, set->stream>>>(
+    set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, set->inline_pose, fa);
+}
 template <int U, int W>
-void launch_lin(glim_amd_factor_set* set) {
+void launch_lin(glim_amd_factor_set* set, const FinalizeArgs& fa) {
+  const bool inl = set->inline_pose.valid != 0;
   if (set->plane_form) {
-    vgicp_kernel<MODE_LINEARIZE, false, U, W, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses,
-                                                                                                   set->d_blockmap, set->d_partials);
-    return;
+    if (inl) launch_lin2<U, W, true, true>(set, fa);
+    else launch_lin2<U, W, true, false>(set, fa);
+  } else {
+    if (inl) launch_lin2<U, W, false, true>(set, fa);
+    else launch_lin2<U, W, false, false>(set, fa);
   }
-  vgicp_kernel<MODE_LINEARIZE, false, U, W, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
-                                                                                           set->d_partials);
 }
 
-void launch_vgicp_linearize(glim_amd_factor_set* set) {
+struct FinalizeArgs;
+void launch_vgicp_linearize(glim_amd_factor_set* set, const FinalizeArgs& fa) {
   const int u = set->variant_u, w = set->variant_minw;
 #define GA_CASE(UU, WW) \
-  if (u == UU && w == WW) return launch_lin<UU, WW>(set);
-  GA_CASE(1, 2) GA_CASE(1, 3) GA_CASE(1, 4)
-  GA_CASE(2, 2) GA_CASE(2, 3) GA_CASE(2, 4)
-  GA_CASE(4, 1) GA_CASE(4, 2) GA_CASE(4, 3)
+  if (u == UU && w == WW) return launch_lin<UU, WW>(set, fa);
+  GA_CASE(1, 3) GA_CASE(1, 4) GA_CASE(2, 3) GA_CASE(2, 4)
 #undef GA_CASE
-  return launch_lin<2, 3>(set);
+  return launch_lin<1, 3>(set, fa);
 }
 
 const int* rows_ptr(const glim_amd_factor_set* set) {
   return reinterpret_cast<const int*>(reinterpret_cast<const char*>(set->d_blockmap) + set->cap_blocks * sizeof(int2));
 }
 
-// enqueue (no sync): poses already in d_poses; writes compact records to `out` rows [row_offset, row_offset + n)
+FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long long row_offset, bool poll) {
+  FinalizeArgs fa;
+  fa.rows = rows_ptr(set);
+  fa.tickets = set->d_tickets;
+  fa.out = out;
+  fa.out_row_offset = row_offset;
+  fa.done_counter = set->d_done;
+  fa.host_flag = poll ? set->h_flag_dev : nullptr;
+  fa.seq = set->poll_seq;
+  fa.num_factors = (int)set->entries.size();
+  fa.fused = set->fused_finalize ? 1 : 0;
+  return fa;
+}
+
+// enqueue (no sync): poses already in d_poses / the inline pose; writes compact records to `out` rows [row_offset, row_offset + n).
+// Two launches by default (main kernel + FP64 finalise); GLIM_AMD_FUSED_FINALIZE=1 lets the last block of every factor finalise
+// it in-kernel instead (measured slower, see factor_set_prepare).
 int launch_linearize(glim_amd_factor_set* set, double* out, long long row_offset) {
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
-  launch_vgicp_linearize(set);
-  finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, out, row_offset, MODE_LINEARIZE);
+  const FinalizeArgs fa = finalize_args(set, out, row_offset, set->poll);
+  launch_vgicp_linearize(set, fa);
+  if (!fa.fused) finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_LINEARIZE);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
 
 int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_eval) {
   const size_t nf = set->entries.size();
+  set->inline_pose.valid = 0;
+  if (nf == 1 && !T_eval && getenv("GLIM_AMD_NO_INLINE_POSE") == nullptr) {  // single factor: the pose rides in the kernel arguments
+    memcpy(set->inline_pose.m, T_lin, 12 * sizeof(double));
+    set->inline_pose.valid = 1;
+    return GLIM_AMD_OK;
+  }
   memcpy(set->h_poses, T_lin, nf * 12 * sizeof(double));
   if (T_eval) memcpy(set->h_poses + nf * 12, T_eval, nf * 12 * sizeof(double));
   GA_HIP(hipMemcpyAsync(set->d_poses, set->h_poses, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
@@ -757,13 +870,34 @@ int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T, gli
   GA_TRY(upload_poses(set, T, nullptr));
   if (set->h_compact_dev && nf <= 1024) {
     // small sets (the per-frame odometry case): the finalise kernel writes the 232-B records straight into host-mapped pinned
-    // memory, so the call costs one pose copy + two launches + one stream sync and no device-to-host copy
-    GA_TRY(launch_linearize(set, set->h_compact_dev, 0));
+    // memory and then publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of paying a
+    // stream-synchronise round trip.  No device-to-host copy, and for a single factor no host-to-device copy either.
+    const bool poll = set->h_flag && getenv("GLIM_AMD_NO_POLL") == nullptr;
+    set->poll = poll;
+    set->poll_seq++;
+    const int rc = launch_linearize(set, set->h_compact_dev, 0);
+    set->poll = false;
+    GA_TRY(rc);
+    bool done = false;
+    if (poll) {
+      const auto t0 = std::chrono::steady_clock::now();
+      volatile unsigned int* flag = set->h_flag;
+      for (unsigned long spins = 0;; spins++) {
+        if (*flag == set->poll_seq) {
+          done = true;
+          break;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // fall back
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!done) GA_HIP(hipStreamSynchronize(set->stream));
   } else {
     GA_TRY(launch_linearize(set, set->d_compact, 0));
     GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+    GA_HIP(hipStreamSynchronize(set->stream));
   }
-  GA_HIP(hipStreamSynchronize(set->stream));
   for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(set->h_compact + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
   return GLIM_AMD_OK;
 }
@@ -800,16 +934,21 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
   std::lock_guard<std::mutex> lock(set->ctx->mu);
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
+  const FinalizeArgs fa = finalize_args(set, set->d_compact, 0, false);
   if (T_lin) {
     GA_TRY(upload_poses(set, T_lin, T_eval));
-    vgicp_kernel<MODE_ERROR, true, 1, 3, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses + nf * 12,
-                                                                                  set->d_blockmap, set->d_partials);
+    vgicp_kernel<MODE_ERROR, true, 1, 3, false, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(
+      set->d_descs, set->d_poses, set->d_poses + nf * 12, set->d_blockmap, set->d_partials, InlinePose{}, fa);
   } else {
     GA_TRY(upload_poses(set, T_eval, nullptr));
-    vgicp_kernel<MODE_ERROR, false, 1, 3, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(set->d_descs, set->d_poses, set->d_poses, set->d_blockmap,
-                                                                                   set->d_partials);
+    if (set->inline_pose.valid)
+      vgicp_kernel<MODE_ERROR, false, 1, 3, false, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(
+        set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, set->inline_pose, fa);
+    else
+      vgicp_kernel<MODE_ERROR, false, 1, 3, false, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(
+        set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, InlinePose{}, fa);
   }
-  finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, rows_ptr(set), set->d_partials, set->d_compact, 0, MODE_ERROR);
+  if (!fa.fused) finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_ERROR);
   GA_HIP(hipGetLastError());
   GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
   GA_HIP(hipStreamSynchronize(set->stream));
@@ -864,8 +1003,9 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   GA_HIP(hipStreamSynchronize(set->stream));
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));
+  const FinalizeArgs fa_prof = finalize_args(set, set->d_compact, 0, false);
   for (int i = 0; i < iters; i++)
-    launch_vgicp_linearize(set);
+    launch_vgicp_linearize(set, fa_prof);
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
