@@ -39,19 +39,43 @@ __global__ __launch_bounds__(256) void init_buckets_kernel(VoxelBucket* __restri
   reinterpret_cast<uint4*>(buckets)[i] = v;
 }
 
+// Wavefront-level grouping of equal keys: consecutive points of a scan usually fall into the same voxel, and 64 lanes hammering
+// one table word with atomics serialise in the L2.  Every distinct key of the wavefront elects ONE leader lane; `group` is the
+// ballot of the lanes sharing this lane's key.  The loop is wave-uniform (one trip per distinct key, ~10 on LiDAR scans).
+__device__ __forceinline__ bool wave_group_by_key(unsigned long long key, bool valid, unsigned long long& group) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long remaining = __ballot(valid);
+  bool leader = false;
+  group = 0ull;
+  while (remaining) {
+    const int l = __ffsll((long long)remaining) - 1;
+    const unsigned int klo = __shfl((unsigned int)key, l, 64), khi = __shfl((unsigned int)(key >> 32), l, 64);
+    const unsigned long long kl = ((unsigned long long)khi << 32) | klo;
+    const bool mine = valid && key == kl;
+    const unsigned long long same = __ballot(mine);
+    if (mine) {
+      group = same;
+      leader = (lane == l);
+    }
+    remaining &= ~same;
+  }
+  return leader;
+}
+
 // stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
 __global__ __launch_bounds__(256) void insert_keys_kernel(int n, const float4* __restrict__ pts, double inv_res,
                                                           unsigned long long* __restrict__ tkeys, unsigned int tmask,
                                                           unsigned long long* __restrict__ pkeys, int* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  const unsigned long long key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
-  pkeys[i] = key;
-  if (key == EMPTY_KEY) {
-    atomicAdd(&stats[1], 1);
-    return;
+  unsigned long long key = EMPTY_KEY;
+  if (i < n) {
+    const float4 p = pts[i];
+    key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
+    pkeys[i] = key;
+    if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
   }
+  unsigned long long group;
+  if (!wave_group_by_key(key, key != EMPTY_KEY, group)) return;  // one CAS chain per distinct key of the wavefront
   unsigned int s = hash_key(key) & tmask;
   for (;;) {
     const unsigned long long prev = atomicCAS(&tkeys[s], EMPTY_KEY, key);
@@ -79,33 +103,57 @@ __global__ __launch_bounds__(256) void move_keys_kernel(const unsigned long long
   }
 }
 
-__device__ __forceinline__ void atomic_add_fixed(long long* p, double v, double scale) {
-  const long long q = __double2ll_rn(v * scale);
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+  const unsigned int lo = __shfl((unsigned int)v, src, 64), hi = __shfl((unsigned int)((unsigned long long)v >> 32), src, 64);
+  return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// Every point contributes 9 fixed-point sums + a count to its voxel.  Lanes of a wavefront that share a voxel are summed in
+// registers first (integer adds: order-free, so still bit-reproducible) and only the group leader touches memory: ~10 leaders x 10
+// atomics per wavefront instead of 64 x 10.
 __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
                                                          const float2* __restrict__ covB, const unsigned long long* __restrict__ pkeys,
                                                          const VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
                                                          long long* __restrict__ acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int s = find_slot(buckets, num_buckets, pkeys[i]);
+  unsigned long long key = EMPTY_KEY;
+  long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < n) {
+    key = pkeys[i];
+    const float4 p = pts[i];
+    const float4 a = covA[i];
+    const float2 b = covB[i];
+    v[0] = __double2ll_rn((double)p.x * MEAN_SCALE);
+    v[1] = __double2ll_rn((double)p.y * MEAN_SCALE);
+    v[2] = __double2ll_rn((double)p.z * MEAN_SCALE);
+    v[3] = __double2ll_rn((double)a.x * COV_SCALE);
+    v[4] = __double2ll_rn((double)a.y * COV_SCALE);
+    v[5] = __double2ll_rn((double)a.z * COV_SCALE);
+    v[6] = __double2ll_rn((double)a.w * COV_SCALE);
+    v[7] = __double2ll_rn((double)b.x * COV_SCALE);
+    v[8] = __double2ll_rn((double)b.y * COV_SCALE);
+  }
+  unsigned long long group;
+  const bool leader = wave_group_by_key(key, key != EMPTY_KEY, group);
+  // leaders gather their group's values member by member (every lane takes part in the shuffles; trips = largest group)
+  long long sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rest = leader ? group : 0ull;
+  while (__ballot(rest != 0ull)) {
+    const int src = rest ? (__ffsll((long long)rest) - 1) : 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const long long t = shfl_ll(v[j], src);
+      if (rest) sum[j] += t;
+    }
+    rest &= rest - 1ull;
+  }
+  if (!leader) return;
+  const int s = find_slot(buckets, num_buckets, key);
   if (s < 0) return;
-  const float4 p = pts[i];
-  const float4 a = covA[i];
-  const float2 b = covB[i];
   long long* dst = acc + (size_t)s * ACC_STRIDE;
-  atomic_add_fixed(dst + 0, (double)p.x, MEAN_SCALE);
-  atomic_add_fixed(dst + 1, (double)p.y, MEAN_SCALE);
-  atomic_add_fixed(dst + 2, (double)p.z, MEAN_SCALE);
-  atomic_add_fixed(dst + 3, (double)a.x, COV_SCALE);
-  atomic_add_fixed(dst + 4, (double)a.y, COV_SCALE);
-  atomic_add_fixed(dst + 5, (double)a.z, COV_SCALE);
-  atomic_add_fixed(dst + 6, (double)a.w, COV_SCALE);
-  atomic_add_fixed(dst + 7, (double)b.x, COV_SCALE);
-  atomic_add_fixed(dst + 8, (double)b.y, COV_SCALE);
-  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), 1ull);
+#pragma unroll
+  for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)sum[j]);
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
 }
 
 // one thread per (bucket, way)
