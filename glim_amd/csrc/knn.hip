@@ -26,7 +26,10 @@ using namespace glim_amd;
 namespace {
 
 constexpr int TILE = 1024;
-constexpr int MAX_RING = 6;
+#ifndef GLIM_AMD_KNN_MAX_RING
+#define GLIM_AMD_KNN_MAX_RING 6
+#endif
+constexpr int MAX_RING = GLIM_AMD_KNN_MAX_RING;
 
 template <int K>
 struct TopK {
@@ -400,7 +403,9 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   double ext[3];
   for (int a = 0; a < 3; a++) ext[a] = std::max(1e-6, (double)unordered(h_bb[3 + a]) - (double)unordered(h_bb[a]));
   const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
-  double h = std::sqrt(3.0 * 2.0 * area / (double)n);
+  double ppc = 3.0;  // target points per occupied cell of the level-0 grid
+  if (const char* env = getenv("GLIM_AMD_KNN_PPC")) ppc = std::max(0.25, atof(env));
+  double h = std::sqrt(ppc * 2.0 * area / (double)n);
   if (const char* env = getenv("GLIM_AMD_KNN_CELL")) h = atof(env);
   const double max_abs = std::max({std::fabs((double)unordered(h_bb[0])), std::fabs((double)unordered(h_bb[1])), std::fabs((double)unordered(h_bb[2])),
                                    std::fabs((double)unordered(h_bb[3])), std::fabs((double)unordered(h_bb[4])), std::fabs((double)unordered(h_bb[5]))});
@@ -429,8 +434,8 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
     }
     const double per_cell = (double)n / std::max(1, h_stats[0]);
     if (getenv("GLIM_AMD_KNN_CELL")) break;
-    if (per_cell > 8.0 && attempt < 3 && h * 0.5 >= h_min) h *= 0.5;
-    else if (per_cell < 1.5 && attempt < 3) h *= 2.0;
+    if (per_cell > 2.7 * ppc && attempt < 3 && h * 0.5 >= h_min) h *= 0.5;
+    else if (per_cell < 0.5 * ppc && attempt < 3) h *= 2.0;
     else break;
   }
   if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
