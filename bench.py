@@ -214,7 +214,14 @@ def run_odometry128k(args, D, api, ctx):
 
     torch = D.torch
     F, rank, world = args.factors, D.rank, D.world
-    poses = synth.arc_trajectory(F + 1, start=(-12.0 + 0.7 * rank, -7.0 + 0.9 * rank, 1.8), yaw0_deg=10.0 + 7.0 * rank)
+    # 0.5 m / 2 deg per frame = a circle of radius 14.3 m; its centre is kept near the middle of the 60 x 40 m room (shifted a
+    # little per rank) so that every one of the F + 1 scans stays inside and returns all 131 072 points
+    import math
+
+    yaw0 = math.radians(10.0 + 7.0 * rank)
+    radius = 0.5 / math.radians(2.0)
+    cx, cy = 1.5 * (rank % 4) - 2.0, 1.0 * (rank // 4) - 0.5
+    poses = synth.arc_trajectory(F + 1, start=(cx + radius * math.sin(yaw0), cy - radius * math.cos(yaw0), 1.8), yaw0_deg=math.degrees(yaw0))
     t0 = time.time()
     clouds = make_frames(api, ctx, poses, args.rings, args.azimuths, frame_id0=1000 * rank)
     vmaps = [api.GaussianVoxelMapGPU(args.resolution, ctx=ctx).insert(c) for c in clouds[:F]]
