@@ -64,6 +64,7 @@ SYMBOLS = {
     "glim_amd_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
     "glim_amd_cloud_create": (_i, [_vp, _i64, _dp, _dp, _dp, _pp]),
     "glim_amd_cloud_create_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _pp]),
+    "glim_amd_cloud_create_deskewed": (_i, [_vp, _i64, _dp, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
     "glim_amd_cloud_destroy": (_i, [_vp]),
     "glim_amd_cloud_size": (_i, [_vp, _lp]),
     "glim_amd_cloud_memory_usage": (_i, [_vp, C.POINTER(_sz)]),

@@ -123,6 +123,30 @@ class PointCloudGPU:
             check(lib().glim_amd_cloud_create(ctx._h, n, _dp(p4), _dp(c16), _dp(n4), C.byref(h)), "glim_amd_cloud_create")
         return PointCloudGPU(h, ctx)
 
+    @staticmethod
+    def clone_deskewed(points, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None, ctx=None):
+        """CloudDeskewing::deskew (cloud_deskewing.cpp) fused with PointCloudGPU::clone: IMU-pose form when imu_times / imu_poses are
+        given, constant-velocity form otherwise."""
+        ctx = ctx or default_context()
+        points = np.asarray(points, dtype=np.float64)
+        n = points.shape[0]
+        p4 = np.ones((n, 4), dtype=np.float64)
+        p4[:, :3] = points[:, :3]
+        t = np.ascontiguousarray(times, dtype=np.float64).reshape(n)
+        Til = pose12(T_imu_lidar)
+        it = ip = None
+        n_imu = 0
+        if imu_times is not None and len(imu_times) > 0:
+            it = np.ascontiguousarray(imu_times, dtype=np.float64)
+            ip = np.ascontiguousarray(np.stack([pose12(P) for P in imu_poses]))
+            n_imu = len(it)
+        lv = None if linear_vel is None else np.ascontiguousarray(linear_vel, dtype=np.float64)
+        av = None if angular_vel is None else np.ascontiguousarray(angular_vel, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().glim_amd_cloud_create_deskewed(ctx._h, n, _dp(p4), _dp(t), _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av),
+                                                   C.byref(h)), "glim_amd_cloud_create_deskewed")
+        return PointCloudGPU(h, ctx)
+
     def size(self):
         n = C.c_int64()
         check(lib().glim_amd_cloud_size(self._h, C.byref(n)), "glim_amd_cloud_size")
@@ -381,9 +405,14 @@ class NonlinearFactorSetGPU:
         return corr
 
     def linearize_device_async(self, T_target_source, out_device_ptr, row_offset=0):
-        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
-        check(lib().glim_amd_factor_set_linearize_device_async(self._h, _dp(T), C.c_void_p(out_device_ptr), int(row_offset)),
-              "glim_amd_factor_set_linearize_device_async")
+        T = T_target_source
+        if not (isinstance(T, np.ndarray) and T.dtype == np.float64 and T.flags.c_contiguous and T.size == 12 * len(self.factors)):
+            T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
+        # raw addresses: building ctypes pointer objects costs several microseconds per call, which matters in launch-rate loops
+        rc = lib().glim_amd_factor_set_linearize_device_async(self._h, C.cast(T.ctypes.data, C.POINTER(C.c_double)), C.c_void_p(out_device_ptr),
+                                                              int(row_offset))
+        if rc != 0:
+            check(rc, "glim_amd_factor_set_linearize_device_async")
 
     def profile(self, T_target_source, iters=20):
         """(ms per fused VGICP kernel launch, ms per device-resident linearise) measured with HIP events on the set's stream."""

@@ -1,0 +1,243 @@
+// deskew.hip -- motion-undistortion of a scan fused with the device upload.
+// Replaces glim::CloudDeskewing::deskew (src/glim/common/cloud_deskewing.cpp:11-53 constant velocity, :55-133 IMU poses) as
+// called between preprocessing and covariance estimation (src/glim/odometry/odometry_estimation_imu.cpp:313-316,
+// src/glim/mapping/sub_mapping.cpp:356-372) followed by PointCloudGPU::clone: one kernel reads the raw Vector4d points and
+// writes the deskewed FP32 SoA cloud, so the deskewed FP64 copy never exists on the host.
+//
+// The reference quantises time into a table (a new entry whenever a point is more than 0.1 ms after the last entry, :24-36,
+// :72-84) and computes ONE rigid transform T_lidar0_lidar1 per entry; every point is moved by the transform of its entry.
+// The table (a few hundred 3x4 matrices) and the per-point entry index are built on the host exactly like the reference does
+// -- a serial pass over n time stamps plus <= ~1000 small pose compositions -- and the per-point work (the data-parallel
+// part: n gathers of a 96-byte matrix + one FP64 3x4 transform + the FP32 pack) runs on the device.
+#include <cmath>
+#include <vector>
+
+#include "internal.hpp"
+
+using namespace glim_amd;
+
+namespace {
+
+struct Pose {
+  double m[12];  // row-major 3x4 [R | t]
+};
+
+Pose compose(const Pose& A, const Pose& B) {
+  Pose C;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) C.m[4 * r + c] = A.m[4 * r + 0] * B.m[c] + A.m[4 * r + 1] * B.m[4 + c] + A.m[4 * r + 2] * B.m[8 + c];
+    C.m[4 * r + 3] = A.m[4 * r + 0] * B.m[3] + A.m[4 * r + 1] * B.m[7] + A.m[4 * r + 2] * B.m[11] + A.m[4 * r + 3];
+  }
+  return C;
+}
+
+Pose inverse(const Pose& A) {
+  Pose I;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) I.m[4 * r + c] = A.m[4 * c + r];
+  for (int r = 0; r < 3; r++) I.m[4 * r + 3] = -(I.m[4 * r + 0] * A.m[3] + I.m[4 * r + 1] * A.m[7] + I.m[4 * r + 2] * A.m[11]);
+  return I;
+}
+
+// gtsam::Pose3::Expmap([omega; v])
+Pose se3_exp(const double* xi) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double W2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+  double a, b, c;
+  if (th < 1e-8) {
+    a = 1.0 - th2 / 6.0;
+    b = 0.5 - th2 / 24.0;
+    c = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    a = std::sin(th) / th;
+    b = (1.0 - std::cos(th)) / th2;
+    c = (th - std::sin(th)) / (th2 * th);
+  }
+  Pose T;
+  for (int r = 0; r < 3; r++) {
+    double V[3];
+    for (int cc = 0; cc < 3; cc++) {
+      const double I = (r == cc) ? 1.0 : 0.0;
+      T.m[4 * r + cc] = I + a * W[3 * r + cc] + b * W2[3 * r + cc];
+      V[cc] = I + b * W[3 * r + cc] + c * W2[3 * r + cc];
+    }
+    T.m[4 * r + 3] = V[0] * xi[3] + V[1] * xi[4] + V[2] * xi[5];
+  }
+  return T;
+}
+
+// Eigen::Quaterniond(Matrix3d), ::slerp, ::toRotationMatrix (the routines cloud_deskewing.cpp:113-119 calls); q = (x, y, z, w)
+void quat_from_rot(const Pose& T, double* q) {
+  double m[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) m[r][c] = T.m[4 * r + c];
+  double t = m[0][0] + m[1][1] + m[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t;
+    q[1] = (m[0][2] - m[2][0]) * t;
+    q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t;
+    q[j] = (m[j][i] + m[i][j]) * t;
+    q[k] = (m[k][i] + m[i][k]) * t;
+  }
+}
+
+void quat_slerp(const double* a, double t, const double* b, double* out) {
+  const double one = 1.0 - 2.220446049250313e-16;
+  const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  const double absD = std::fabs(d);
+  double s0, s1;
+  if (absD >= one) {
+    s0 = 1.0 - t;
+    s1 = t;
+  } else {
+    const double theta = std::acos(absD), sinTheta = std::sin(theta);
+    s0 = std::sin((1.0 - t) * theta) / sinTheta;
+    s1 = std::sin(t * theta) / sinTheta;
+  }
+  if (d < 0.0) s1 = -s1;
+  for (int i = 0; i < 4; i++) out[i] = s0 * a[i] + s1 * b[i];
+}
+
+void quat_to_rot(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+
+// one thread per point: q = T[entry(i)] p  in FP64, packed to the FP32 SoA cloud
+__global__ __launch_bounds__(256) void deskew_pack_kernel(int64_t n, const double* __restrict__ points4, const int* __restrict__ entry,
+                                                          const double* __restrict__ table, float4* __restrict__ pts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = reinterpret_cast<const double4*>(points4)[i];
+  const double* T = table + 12 * (size_t)entry[i];
+  const double x = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3] * p.w;
+  const double y = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7] * p.w;
+  const double z = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11] * p.w;
+  pts[i] = make_float4((float)x, (float)y, (float)z, 1.0f);
+}
+
+struct DeviceTemp {
+  void* p = nullptr;
+  ~DeviceTemp() {
+    if (p) (void)pool_free(p);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
+                                   int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
+                                   const double* angular_vel3, glim_amd_cloud** out) {
+  if (!ctx || !out || n < 0 || !T_imu_lidar12 || (n > 0 && (!points4 || !times))) return GLIM_AMD_ERR_INVALID;
+  if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  if (n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
+
+  // ---- host: time table + one transform per entry (cloud_deskewing.cpp:22-45 / :70-124) ----
+  const double time_eps = 1e-4;
+  std::vector<double> table;
+  std::vector<int> entry((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    if (table.empty() || times[i] - table.back() > time_eps) table.push_back(times[i]);
+    entry[(size_t)i] = (int)table.size() - 1;
+  }
+  Pose T_imu_lidar, T_lidar_imu;
+  memcpy(T_imu_lidar.m, T_imu_lidar12, sizeof(T_imu_lidar.m));
+  T_lidar_imu = inverse(T_imu_lidar);
+  std::vector<Pose> TT(table.size());
+  if (n_imu == 0) {
+    const double zero[3] = {0, 0, 0};
+    const double* lv = linear_vel3 ? linear_vel3 : zero;
+    const double* av = angular_vel3 ? angular_vel3 : zero;
+    for (size_t i = 0; i < table.size(); i++) {
+      const double dt = table[i];
+      const double xi[6] = {dt * av[0], dt * av[1], dt * av[2], dt * lv[0], dt * lv[1], dt * lv[2]};
+      TT[i] = compose(compose(T_lidar_imu, inverse(se3_exp(xi))), T_imu_lidar);
+    }
+  } else {
+    int cursor = 0;
+    Pose T_imu0_world{};
+    for (size_t i = 0; i < table.size(); i++) {
+      const double time = stamp + table[i];
+      while (cursor < n_imu - 1 && imu_times[cursor + 1] < time) cursor++;
+      Pose L, Rp;
+      memcpy(L.m, imu_poses12 + 12 * (size_t)cursor, sizeof(L.m));
+      if (i == 0) T_imu0_world = inverse(L);
+      Pose T_world_imu1 = L;
+      if (cursor + 1 < n_imu) {
+        memcpy(Rp.m, imu_poses12 + 12 * (size_t)(cursor + 1), sizeof(Rp.m));
+        const double t0 = imu_times[cursor], t1 = imu_times[cursor + 1];
+        const double p = std::max(0.0, std::min(1.0, (time - t0) / (t1 - t0)));
+        double ql[4], qr[4], qs[4], R[9];
+        quat_from_rot(L, ql);
+        quat_from_rot(Rp, qr);
+        quat_slerp(ql, p, qr, qs);
+        quat_to_rot(qs, R);
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 3; c++) T_world_imu1.m[4 * r + c] = R[3 * r + c];
+          T_world_imu1.m[4 * r + 3] = (1.0 - p) * L.m[4 * r + 3] + p * Rp.m[4 * r + 3];
+        }
+      }
+      TT[i] = compose(compose(T_lidar_imu, compose(T_imu0_world, T_world_imu1)), T_imu_lidar);
+    }
+  }
+
+  // ---- device: upload raw points, entry indices and the table; transform + pack ----
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  glim_amd_cloud* c = new glim_amd_cloud();
+  c->ctx = ctx;
+  c->n = n;
+  hipError_t e = pool_malloc(&c->pts, (size_t)(n > 0 ? n : 1) * sizeof(float4));
+  if (e != hipSuccess) {
+    set_hip_error(e, "pool_malloc(deskewed cloud)");
+    delete c;
+    return GLIM_AMD_ERR_HIP;
+  }
+  if (n > 0) {
+    hipStream_t s = ctx->stream();
+    DeviceTemp dp, de, dt;
+    e = pool_malloc(&dp.p, (size_t)n * 4 * sizeof(double));
+    if (e == hipSuccess) e = pool_malloc(&de.p, (size_t)n * sizeof(int));
+    if (e == hipSuccess) e = pool_malloc(&dt.p, TT.size() * sizeof(Pose));
+    if (e == hipSuccess) e = hipMemcpyAsync(dp.p, points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(de.p, entry.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dt.p, TT.data(), TT.size() * sizeof(Pose), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, (const double*)dp.p, (const int*)de.p, (const double*)dt.p, c->pts);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      set_hip_error(e, "cloud_create_deskewed");
+      glim_amd_cloud_destroy(c);
+      return GLIM_AMD_ERR_HIP;
+    }
+  }
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+}  // extern "C"

@@ -209,7 +209,7 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int /*init_nu
   glim_amd_voxelmap* m = new glim_amd_voxelmap();
   m->ctx = ctx;
   m->resolution = resolution;
-  m->inv_resolution = 1.0 / resolution;  // same FP64 expression as the oracle (orc_voxelmap_create)
+  m->inv_resolution = 1.0 / resolution;  // same FP64 expression as the CPU restatement (parity contract)
   *out = m;
   return GLIM_AMD_OK;
 }

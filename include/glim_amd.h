@@ -93,6 +93,15 @@ int glim_amd_cloud_memory_usage(const glim_amd_cloud* cloud, size_t* bytes);
 /* copy back (parity / debug): any pointer may be NULL.  xyz n x 3, cov33 n x 9, normals3 n x 3, neighbors n x k. */
 int glim_amd_cloud_download(const glim_amd_cloud* cloud, float* xyz, float* cov33, float* normals3, int32_t* neighbors);
 
+/* CloudDeskewing::deskew fused with the upload: src/glim/common/cloud_deskewing.cpp:11-53 (constant
+ * velocity: n_imu == 0, linear_vel3 / angular_vel3, NULL = zero) and :55-133 (IMU poses: imu_times[n_imu], imu_poses12[n_imu x 12]
+ * = T_world_imu row-major 3x4, `stamp` = scan start time), as called at src/glim/odometry/odometry_estimation_imu.cpp:313-316.
+ * points4: n x Vector4d, times: n per-point offsets from the scan start (as the preprocessor leaves them: ascending), T_imu_lidar12:
+ * extrinsic.  The result is a device cloud of the deskewed points (no covariances yet). */
+int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
+                                   int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
+                                   const double* angular_vel3, glim_amd_cloud** out);
+
 /* kNN on device: CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221).
  * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> padded with i.
  * Result stays on the device inside the cloud (and is copied to neighbors_out, n x k, when not NULL). */

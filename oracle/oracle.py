@@ -80,6 +80,10 @@ def lib():
         L.orc_solve6.argtypes = [dp, dp, C.c_double, dp]
         L.orc_gn_align.restype = C.c_int
         L.orc_gn_align.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp]
+        L.orc_deskew_constvel.restype = C.c_int
+        L.orc_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
+        L.orc_deskew_imu.restype = C.c_int
+        L.orc_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -312,3 +316,21 @@ def gn_align(vmap, src_xyz, src_covs33, T_init, max_iters=8, lam=0.0, num_thread
     deltas = np.zeros((max_iters, 6))
     it = lib().orc_gn_align(vmap._h, _dp(p4), _dp(c16), p4.shape[0], _dp(T), max_iters, float(lam), num_threads, _dp(deltas))
     return pose44(T), deltas[:it].copy()
+
+
+def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=(0, 0, 0), angular_vel=(0, 0, 0)):
+    """CloudDeskewing::deskew (cloud_deskewing.cpp): IMU-pose form when imu_times/imu_poses are given, else constant velocity.
+    Returns N x 3 float64."""
+    p4 = points4(points_xyz)
+    n = p4.shape[0]
+    t = _f64(times, (n,))
+    Til = pose12(T_imu_lidar)
+    out = np.zeros((n, 4))
+    if imu_times is not None and len(imu_times) > 0:
+        it = _f64(imu_times, (-1,))
+        ip = np.ascontiguousarray(np.stack([pose12(P) for P in imu_poses]))
+        lib().orc_deskew_imu(_dp(Til), _dp(it), _dp(ip), len(it), float(stamp), _dp(t), _dp(p4), n, _dp(out))
+    else:
+        lv, av = _f64(linear_vel, (3,)), _f64(angular_vel, (3,))
+        lib().orc_deskew_constvel(_dp(Til), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _dp(out))
+    return out[:, :3].copy()

@@ -845,3 +845,161 @@ int orc_gn_align(const orc_voxelmap* target, const double* pts, const double* co
   }
   return it;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* deskewing -- src/glim/common/cloud_deskewing.cpp:11-53 (constant velocity) and :55-133 (IMU poses)  */
+/* (the step between preprocessing and covariance estimation,                  */
+/*  src/glim/odometry/odometry_estimation_imu.cpp:313-316)                                           */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* time table: a new entry whenever times[i] - table.back() > 1e-4; time_indices[i] = current last entry (:24-36, :72-84) */
+static int build_time_table(const double* times, int n, double** table_out, int32_t* indices) {
+  const double time_eps = 1e-4;
+  double* table = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    if (m == 0 || times[i] - table[m - 1] > time_eps) table[m++] = times[i];
+    indices[i] = m - 1;
+  }
+  *table_out = table;
+  return m;
+}
+
+/* Eigen::Quaterniond(Matrix3d) -- Eigen 3.4 quaternionbase_assign_impl<Other,3,3> (w,x,y,z in q[3],q[0..2]) */
+static void quat_from_rot(const double* T12, double* q /* x y z w */) {
+  double m[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) m[r][c] = T12[4 * r + c];
+  double t = m[0][0] + m[1][1] + m[2][2];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t;
+    q[1] = (m[0][2] - m[2][0]) * t;
+    q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t;
+    q[j] = (m[j][i] + m[i][j]) * t;
+    q[k] = (m[k][i] + m[i][k]) * t;
+  }
+}
+
+/* Eigen::Quaterniond::slerp (Eigen 3.4) */
+static void quat_slerp(const double* a, double t, const double* b, double* out) {
+  const double one = 1.0 - 2.220446049250313e-16;
+  const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  const double absD = fabs(d);
+  double scale0, scale1;
+  if (absD >= one) {
+    scale0 = 1.0 - t;
+    scale1 = t;
+  } else {
+    const double theta = acos(absD);
+    const double sinTheta = sin(theta);
+    scale0 = sin((1.0 - t) * theta) / sinTheta;
+    scale1 = sin(t * theta) / sinTheta;
+  }
+  if (d < 0.0) scale1 = -scale1;
+  for (int i = 0; i < 4; i++) out[i] = scale0 * a[i] + scale1 * b[i];
+}
+
+/* Eigen::Quaterniond::toRotationMatrix */
+static void quat_to_rot(const double* q, double* R /* row-major 3x3 */) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+static void apply_pose(const double* T, const double* p4, double* out4) {
+  for (int r = 0; r < 3; r++) out4[r] = ((T[4 * r + 0] * p4[0] + T[4 * r + 1] * p4[1]) + T[4 * r + 2] * p4[2]) + T[4 * r + 3] * p4[3];
+  out4[3] = p4[3];
+}
+
+int orc_deskew_constvel(const double* T_imu_lidar, const double* linear_vel, const double* angular_vel, const double* times,
+                        const double* points4, int n, double* out4) {
+  if (n <= 0) return 0;
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  double* table = NULL;
+  const int m = build_time_table(times, n, &table, idx);
+  double T_lidar_imu[12];
+  orc_pose_inverse(T_imu_lidar, T_lidar_imu);
+  double* TT = (double*)malloc(sizeof(double) * 12 * (size_t)m);
+  for (int i = 0; i < m; i++) {
+    const double dt = table[i];
+    const double xi[6] = {dt * angular_vel[0], dt * angular_vel[1], dt * angular_vel[2], dt * linear_vel[0], dt * linear_vel[1], dt * linear_vel[2]};
+    double T_imu1_imu0[12], inv[12], tmp[12];
+    orc_se3_exp(xi, T_imu1_imu0);                 /* :43 */
+    orc_pose_inverse(T_imu1_imu0, inv);
+    orc_pose_compose(T_lidar_imu, inv, tmp);      /* :44  T_lidar_imu * T_imu1_imu0^-1 * T_imu_lidar */
+    orc_pose_compose(tmp, T_imu_lidar, TT + 12 * (size_t)i);
+  }
+  for (int i = 0; i < n; i++) apply_pose(TT + 12 * (size_t)idx[i], points4 + 4 * (size_t)i, out4 + 4 * (size_t)i); /* :47-51 */
+  free(TT);
+  free(table);
+  free(idx);
+  return 0;
+}
+
+int orc_deskew_imu(const double* T_imu_lidar, const double* imu_times, const double* imu_poses12, int n_imu, double stamp,
+                   const double* times, const double* points4, int n, double* out4) {
+  if (n <= 0) return 0;
+  if (n_imu <= 0) { /* :66-68 */
+    const double zero[3] = {0, 0, 0};
+    return orc_deskew_constvel(T_imu_lidar, zero, zero, times, points4, n, out4);
+  }
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  double* table = NULL;
+  const int m = build_time_table(times, n, &table, idx);
+  double T_lidar_imu[12];
+  orc_pose_inverse(T_imu_lidar, T_lidar_imu);
+  double* TT = (double*)malloc(sizeof(double) * 12 * (size_t)m);
+  int cursor = 0;
+  double T_imu0_world[12];
+  for (int i = 0; i < m; i++) {
+    const double time = stamp + table[i];
+    while (cursor < n_imu - 1 && imu_times[cursor + 1] < time) cursor++; /* :95-97 */
+    if (i == 0) orc_pose_inverse(imu_poses12 + 12 * (size_t)cursor, T_imu0_world); /* :99-102 */
+    double T_world_imu1[12];
+    if (cursor + 1 >= n_imu) {
+      memcpy(T_world_imu1, imu_poses12 + 12 * (size_t)cursor, sizeof(double) * 12); /* :105-106 */
+    } else {
+      const double t0 = imu_times[cursor], t1 = imu_times[cursor + 1];
+      double p = (time - t0) / (t1 - t0);
+      p = p < 1.0 ? p : 1.0; /* std::max(0, std::min(1, .)) :111 */
+      p = p > 0.0 ? p : 0.0;
+      const double* L = imu_poses12 + 12 * (size_t)cursor;
+      const double* Rr = imu_poses12 + 12 * (size_t)(cursor + 1);
+      double ql[4], qr[4], qs[4], R[9];
+      quat_from_rot(L, ql);
+      quat_from_rot(Rr, qr);
+      quat_slerp(ql, p, qr, qs);
+      quat_to_rot(qs, R);
+      for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T_world_imu1[4 * r + c] = R[3 * r + c];
+        T_world_imu1[4 * r + 3] = (1.0 - p) * L[4 * r + 3] + p * Rr[4 * r + 3]; /* :118 */
+      }
+    }
+    double T_imu0_imu1[12], tmp[12];
+    orc_pose_compose(T_imu0_world, T_world_imu1, T_imu0_imu1);  /* :122 */
+    orc_pose_compose(T_lidar_imu, T_imu0_imu1, tmp);            /* :123 */
+    orc_pose_compose(tmp, T_imu_lidar, TT + 12 * (size_t)i);
+  }
+  for (int i = 0; i < n; i++) apply_pose(TT + 12 * (size_t)idx[i], points4 + 4 * (size_t)i, out4 + 4 * (size_t)i); /* :127-130 */
+  free(TT);
+  free(table);
+  free(idx);
+  return 0;
+}

@@ -128,6 +128,14 @@ int orc_solve6(const double* H36, const double* b6, double lambda, double* x6);
 int orc_gn_align(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
                  double* T12_inout, int max_iters, double lambda, int num_threads, double* deltas_out);
 
+/* ---- deskewing  src/glim/common/cloud_deskewing.cpp:11-53 (constant velocity), :55-133 (IMU poses) ---- */
+/* points4 / out4: n x 4 doubles; times: n (relative to the scan start, ascending as the preprocessor leaves them);
+ * imu_poses12: n_imu row-major 3x4 T_world_imu; T_imu_lidar12: extrinsic.  Returns 0. */
+int orc_deskew_constvel(const double* T_imu_lidar12, const double* linear_vel3, const double* angular_vel3, const double* times,
+                        const double* points4, int n, double* out4);
+int orc_deskew_imu(const double* T_imu_lidar12, const double* imu_times, const double* imu_poses12, int n_imu, double stamp,
+                   const double* times, const double* points4, int n, double* out4);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

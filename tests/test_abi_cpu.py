@@ -76,6 +76,7 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 code = "\n".join(line for line in text.splitlines() if not line.strip().startswith(("//", "#", "*", "/*")))
+                assert "orc_" not in code, f
                 assert "import oracle" not in code and "from oracle" not in code and "libvgicp_oracle" not in code, f
 
 
