@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libvgicp_oracle.so")
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(os.path.join(_HERE, f)) for f in ("vgicp_oracle.c", "vgicp_oracle.h")
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("vgicp_oracle.c", "preprocess_oracle.c", "vgicp_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -32,6 +32,47 @@ class Linearized6(C.Structure):
         ("b_t", C.c_double * 6),
         ("b_s", C.c_double * 6),
     ]
+
+
+class PreprocessParams(C.Structure):
+    """orc_preprocess_params (defaults: the shipped config/config_preprocess.json)."""
+
+    _fields_ = [
+        ("distance_near_thresh", C.c_double),
+        ("distance_far_thresh", C.c_double),
+        ("use_random_grid_downsampling", C.c_int32),
+        ("downsample_target", C.c_int32),
+        ("downsample_resolution", C.c_double),
+        ("downsample_rate", C.c_double),
+        ("global_shutter", C.c_int32),
+        ("enable_outlier_removal", C.c_int32),
+        ("outlier_removal_k", C.c_int32),
+        ("outlier_std_mul_factor", C.c_double),
+        ("enable_cropbox_filter", C.c_int32),
+        ("crop_bbox_frame_imu", C.c_int32),
+        ("crop_bbox_min", C.c_double * 3),
+        ("crop_bbox_max", C.c_double * 3),
+        ("T_imu_lidar", C.c_double * 12),
+        ("k_correspondences", C.c_int32),
+        ("voxelgrid_block_size", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+def preprocess_params(**kw):
+    p = PreprocessParams()
+    d = dict(
+        distance_near_thresh=0.5, distance_far_thresh=100.0, use_random_grid_downsampling=1, downsample_target=10000,
+        downsample_resolution=1.0, downsample_rate=0.1, global_shutter=0, enable_outlier_removal=0, outlier_removal_k=10,
+        outlier_std_mul_factor=1.0, enable_cropbox_filter=0, crop_bbox_frame_imu=0, k_correspondences=10, voxelgrid_block_size=1024, seed=0,
+    )
+    d.update({k: v for k, v in kw.items() if k not in ("crop_bbox_min", "crop_bbox_max", "T_imu_lidar")})
+    for k, v in d.items():
+        setattr(p, k, v)
+    p.crop_bbox_min[:] = list(kw.get("crop_bbox_min", (-1.0, -1.0, -1.0)))
+    p.crop_bbox_max[:] = list(kw.get("crop_bbox_max", (1.0, 1.0, 1.0)))
+    p.T_imu_lidar[:] = list(pose12(kw.get("T_imu_lidar", np.eye(4))))
+    return p
 
 
 _lib = None
@@ -84,6 +125,21 @@ def lib():
         L.orc_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
         L.orc_deskew_imu.restype = C.c_int
         L.orc_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
+        pp = C.POINTER(PreprocessParams)
+        L.orc_sample_hash.restype = C.c_uint64
+        L.orc_sample_hash.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_sampling_key.restype = C.c_uint64
+        L.orc_sampling_key.argtypes = [dp, C.c_double]
+        L.orc_voxelgrid_sampling.restype = C.c_int
+        L.orc_voxelgrid_sampling.argtypes = [dp, dp, dp, C.c_int, C.c_double, C.c_int, dp, dp, dp]
+        L.orc_randomgrid_sampling.restype = C.c_int
+        L.orc_randomgrid_sampling.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_uint64, ip]
+        L.orc_find_inliers.restype = C.c_int
+        L.orc_find_inliers.argtypes = [dp, C.c_int, C.c_int, C.c_double, ip, C.c_int]
+        L.orc_preprocess_keep.restype = C.c_int
+        L.orc_preprocess_keep.argtypes = [dp, pp]
+        L.orc_preprocess.restype = C.c_int
+        L.orc_preprocess.argtypes = [dp, dp, dp, C.c_int, pp, dp, dp, dp, ip, C.c_int]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -334,3 +390,47 @@ def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp
         lv, av = _f64(linear_vel, (3,)), _f64(angular_vel, (3,))
         lib().orc_deskew_constvel(_dp(Til), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _dp(out))
     return out[:, :3].copy()
+
+
+# ---- scan preprocessing ----------------------------------------------------------
+
+
+def voxelgrid_sampling(points_xyz, times, intensities, resolution, block_size=1024):
+    p4 = points4(points_xyz)
+    n = p4.shape[0]
+    t = _f64(times, (n,))
+    it = _f64(intensities, (n,)) if intensities is not None else None
+    op, ot, oi = np.zeros((max(n, 1), 4)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    m = lib().orc_voxelgrid_sampling(_dp(p4), _dp(t), _dp(it) if it is not None else None, n, float(resolution), int(block_size), _dp(op), _dp(ot), _dp(oi))
+    return op[:m, :3].copy(), ot[:m].copy(), (oi[:m].copy() if it is not None else None)
+
+
+def randomgrid_sampling(points_xyz, resolution, rate, seed=0):
+    p4 = points4(points_xyz)
+    n = p4.shape[0]
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    m = lib().orc_randomgrid_sampling(_dp(p4), n, float(resolution), float(rate), int(seed), _ip(idx))
+    return idx[:m].copy()
+
+
+def find_inliers(points_xyz, k, std_mul, num_threads=0):
+    p4 = points4(points_xyz)
+    n = p4.shape[0]
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    m = lib().orc_find_inliers(_dp(p4), n, int(k), float(std_mul), _ip(idx), int(num_threads))
+    return idx[:m].copy()
+
+
+def preprocess(points_xyz, times, intensities=None, params=None, neighbors=True, num_threads=0):
+    """CloudPreprocessor::preprocess_impl.  Returns dict(points N'x3, times, intensities|None, neighbors|None)."""
+    prm = params if params is not None else preprocess_params()
+    p4 = points4(points_xyz)
+    n = p4.shape[0]
+    t = _f64(times, (n,))
+    it = _f64(intensities, (n,)) if intensities is not None else None
+    op, ot, oi = np.zeros((max(n, 1), 4)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    nb = np.zeros((max(n, 1), prm.k_correspondences), dtype=np.int32) if neighbors else None
+    m = lib().orc_preprocess(_dp(p4), _dp(t), _dp(it) if it is not None else None, n, C.byref(prm), _dp(op), _dp(ot), _dp(oi),
+                             _ip(nb) if nb is not None else None, int(num_threads))
+    return dict(points=op[:m, :3].copy(), times=ot[:m].copy(), intensities=oi[:m].copy() if it is not None else None,
+                neighbors=nb[:m].copy() if nb is not None else None)

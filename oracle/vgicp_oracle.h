@@ -136,6 +136,35 @@ int orc_deskew_constvel(const double* T_imu_lidar12, const double* linear_vel3, 
 int orc_deskew_imu(const double* T_imu_lidar12, const double* imu_times, const double* imu_poses12, int n_imu, double stamp,
                    const double* times, const double* points4, int n, double* out4);
 
+/* ---- scan preprocessing  src/glim/preprocess/cloud_preprocessor.cpp:92-188; see preprocess_oracle.c ---- */
+typedef struct orc_preprocess_params {
+  double distance_near_thresh, distance_far_thresh; /* cloud_preprocessor.cpp:26-27 */
+  int32_t use_random_grid_downsampling;             /* :28 */
+  int32_t downsample_target;                        /* :30  (> 0: rate = target / n, :105) */
+  double downsample_resolution, downsample_rate;    /* :29, :31 */
+  int32_t global_shutter;                           /* :24 */
+  int32_t enable_outlier_removal, outlier_removal_k; /* :32-33 */
+  double outlier_std_mul_factor;                    /* :34 */
+  int32_t enable_cropbox_filter, crop_bbox_frame_imu; /* :36, :45 */
+  double crop_bbox_min[3], crop_bbox_max[3];        /* :46-47 */
+  double T_imu_lidar[12];                           /* :43 */
+  int32_t k_correspondences;                        /* :56 */
+  int32_t voxelgrid_block_size;                     /* (!) 1024 upstream, 0 = voxels are never split */
+  uint64_t seed;                                    /* counter-based sampler seed (replaces the std::mt19937 of :67) */
+} orc_preprocess_params;
+
+uint64_t orc_sample_hash(uint64_t seed, uint64_t index);
+uint64_t orc_sampling_key(const double* p4, double inv_res);
+/* out_* sized for n entries; return the number of output points */
+int orc_voxelgrid_sampling(const double* points4, const double* times, const double* intensities, int n, double resolution, int block_size,
+                           double* out_points4, double* out_times, double* out_intensities);
+int orc_randomgrid_sampling(const double* points4, int n, double resolution, double rate, uint64_t seed, int32_t* out_indices);
+int orc_find_inliers(const double* points4, int n, int k, double std_mul, int32_t* out_indices, int num_threads);
+int orc_preprocess_keep(const double* p4, const orc_preprocess_params* prm);
+/* the whole CloudPreprocessor::preprocess_impl; out_neighbors (optional): n x k_correspondences */
+int orc_preprocess(const double* points4, const double* times, const double* intensities, int n, const orc_preprocess_params* prm,
+                   double* out_points4, double* out_times, double* out_intensities, int32_t* out_neighbors, int num_threads);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus
