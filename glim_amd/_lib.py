@@ -32,6 +32,31 @@ class Linearized6(C.Structure):
     ]
 
 
+class PreprocessParams(C.Structure):
+    """glim_amd_preprocess_params (include/glim_amd.h) == CloudPreprocessorParams (cloud_preprocessor.cpp:20-61)."""
+
+    _fields_ = [
+        ("distance_near_thresh", C.c_double),
+        ("distance_far_thresh", C.c_double),
+        ("use_random_grid_downsampling", C.c_int32),
+        ("downsample_target", C.c_int32),
+        ("downsample_resolution", C.c_double),
+        ("downsample_rate", C.c_double),
+        ("global_shutter", C.c_int32),
+        ("enable_outlier_removal", C.c_int32),
+        ("outlier_removal_k", C.c_int32),
+        ("outlier_std_mul_factor", C.c_double),
+        ("enable_cropbox_filter", C.c_int32),
+        ("crop_bbox_frame_imu", C.c_int32),
+        ("crop_bbox_min", C.c_double * 3),
+        ("crop_bbox_max", C.c_double * 3),
+        ("T_imu_lidar", C.c_double * 12),
+        ("k_correspondences", C.c_int32),
+        ("voxelgrid_block_size", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
 class GlimAmdError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -65,6 +90,11 @@ SYMBOLS = {
     "glim_amd_cloud_create": (_i, [_vp, _i64, _dp, _dp, _dp, _pp]),
     "glim_amd_cloud_create_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _pp]),
     "glim_amd_cloud_create_deskewed": (_i, [_vp, _i64, _dp, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_preprocess_default_params": (_i, [C.POINTER(PreprocessParams)]),
+    "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
+    "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
+    "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_debug_sort_pairs": (_i, [_vp, _i64, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "glim_amd_cloud_destroy": (_i, [_vp]),
     "glim_amd_cloud_size": (_i, [_vp, _lp]),
     "glim_amd_cloud_memory_usage": (_i, [_vp, C.POINTER(_sz)]),

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FACTOR_BINARY, FACTOR_SURFACE_VALIDATION, GlimAmdError, Linearized6, check, lib  # noqa: F401
+from ._lib import FACTOR_BINARY, FACTOR_SURFACE_VALIDATION, GlimAmdError, Linearized6, PreprocessParams, check, lib  # noqa: F401
 
 _default_ctx = None
 
@@ -146,6 +146,51 @@ class PointCloudGPU:
         check(lib().glim_amd_cloud_create_deskewed(ctx._h, n, _dp(p4), _dp(t), _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av),
                                                    C.byref(h)), "glim_amd_cloud_create_deskewed")
         return PointCloudGPU(h, ctx)
+
+    @staticmethod
+    def preprocess(points, times, intensities=None, params=None, ctx=None):
+        """CloudPreprocessor::preprocess (cloud_preprocessor.cpp:92-188) on the device: returns the preprocessed cloud (points, times,
+        intensities, kNN resident in HBM); `download_frame()` gives the PreprocessedFrame fields."""
+        ctx = ctx or default_context()
+        prm = params if params is not None else preprocess_params()
+        points = np.asarray(points, dtype=np.float64)
+        n = points.shape[0]
+        p4 = np.ones((n, 4), dtype=np.float64)
+        p4[:, : points.shape[1]] = points
+        t = np.ascontiguousarray(times, dtype=np.float64).reshape(n)
+        it = None if intensities is None else np.ascontiguousarray(intensities, dtype=np.float64).reshape(n)
+        h = C.c_void_p()
+        check(lib().glim_amd_preprocess(ctx._h, n, _dp(p4), _dp(t), _dp(it), C.byref(prm), C.byref(h)), "glim_amd_preprocess")
+        g = PointCloudGPU(h, ctx)
+        g._k = prm.k_correspondences
+        g._has_intensities = it is not None
+        return g
+
+    def download_frame(self):
+        """PreprocessedFrame fields (include/glim/preprocess/preprocessed_frame.hpp:26-39) of a preprocessed cloud."""
+        n, k = self.size(), getattr(self, "_k", 0)
+        p4, t = np.zeros((n, 4)), np.zeros(n)
+        it = np.zeros(n) if getattr(self, "_has_intensities", False) else None
+        nb = np.zeros((n, k), dtype=np.int32) if k > 0 else None
+        check(lib().glim_amd_cloud_download_frame(self._h, _dp(p4), _dp(t), _dp(it), _ip(nb)), "glim_amd_cloud_download_frame")
+        return dict(points=p4[:, :3].copy(), times=t, intensities=it, neighbors=nb, k_neighbors=k)
+
+    def deskew(self, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None):
+        """CloudDeskewing::deskew of a preprocessed cloud that is already on the device; the raw-scan neighbours are carried over."""
+        Til = pose12(T_imu_lidar)
+        it = ip = None
+        n_imu = 0
+        if imu_times is not None and len(imu_times) > 0:
+            it = np.ascontiguousarray(imu_times, dtype=np.float64)
+            ip = np.ascontiguousarray(np.stack([pose12(P) for P in imu_poses]))
+            n_imu = len(it)
+        lv = None if linear_vel is None else np.ascontiguousarray(linear_vel, dtype=np.float64)
+        av = None if angular_vel is None else np.ascontiguousarray(angular_vel, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().glim_amd_cloud_deskew(self._h, _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av), C.byref(h)), "glim_amd_cloud_deskew")
+        g = PointCloudGPU(h, self.ctx)
+        g._k = getattr(self, "_k", 0)
+        return g
 
     def size(self):
         n = C.c_int64()
@@ -438,6 +483,32 @@ class NonlinearFactorSetGPU:
             self.close()
         except Exception:
             pass
+
+
+def preprocess_params(**kw):
+    """glim_amd_preprocess_params with the shipped defaults (config/config_preprocess.json), fields overridden by keyword."""
+    p = PreprocessParams()
+    check(lib().glim_amd_preprocess_default_params(C.byref(p)), "glim_amd_preprocess_default_params")
+    for k, v in kw.items():
+        if k in ("crop_bbox_min", "crop_bbox_max"):
+            getattr(p, k)[:] = [float(x) for x in v]
+        elif k == "T_imu_lidar":
+            p.T_imu_lidar[:] = list(pose12(v))
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def debug_sort_pairs(keys, vals=None, bits=64, ctx=None):
+    """The stable device radix sort behind the preprocessing (parity / debug)."""
+    ctx = ctx or default_context()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    v = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint32)
+    ko, vo = np.zeros_like(k), np.zeros(len(k), dtype=np.uint32)
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    check(lib().glim_amd_debug_sort_pairs(ctx._h, len(k), int(bits), k.ctypes.data_as(u64p), None if v is None else v.ctypes.data_as(u32p),
+                                          ko.ctypes.data_as(u64p), vo.ctypes.data_as(u32p)), "glim_amd_debug_sort_pairs")
+    return ko, vo
 
 
 def expand_compact(compact, T_target_source, flags):

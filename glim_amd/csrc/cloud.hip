@@ -88,13 +88,6 @@ int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_
   return GLIM_AMD_OK;
 }
 
-struct DeviceTemp {
-  void* p = nullptr;
-  ~DeviceTemp() {
-    if (p) (void)pool_free(p);
-  }
-};
-
 }  // namespace
 
 extern "C" {
@@ -177,6 +170,9 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->neighbors) (void)pool_free(c->neighbors);
   if (c->pn4) (void)pool_free(c->pn4);
   if (c->n2) (void)pool_free(c->n2);
+  if (c->pts64) (void)pool_free(c->pts64);
+  if (c->times) (void)pool_free(c->times);
+  if (c->intensities) (void)pool_free(c->intensities);
   delete c;
   return GLIM_AMD_OK;
 }

@@ -136,29 +136,12 @@ __global__ __launch_bounds__(256) void deskew_pack_kernel(int64_t n, const doubl
   pts[i] = make_float4((float)x, (float)y, (float)z, 1.0f);
 }
 
-struct DeviceTemp {
-  void* p = nullptr;
-  ~DeviceTemp() {
-    if (p) (void)pool_free(p);
-  }
-};
-
-}  // namespace
-
-extern "C" {
-
-int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
-                                   int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
-                                   const double* angular_vel3, glim_amd_cloud** out) {
-  if (!ctx || !out || n < 0 || !T_imu_lidar12 || (n > 0 && (!points4 || !times))) return GLIM_AMD_ERR_INVALID;
-  if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
-  *out = nullptr;
-  if (n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
-
-  // ---- host: time table + one transform per entry (cloud_deskewing.cpp:22-45 / :70-124) ----
+// host: time table + one transform per entry (cloud_deskewing.cpp:22-45 / :70-124)
+void build_deskew_table(int64_t n, const double* times, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
+                        double stamp, const double* linear_vel3, const double* angular_vel3, std::vector<int>& entry, std::vector<Pose>& TT) {
   const double time_eps = 1e-4;
   std::vector<double> table;
-  std::vector<int> entry((size_t)n);
+  entry.resize((size_t)n);
   for (int64_t i = 0; i < n; i++) {
     if (table.empty() || times[i] - table.back() > time_eps) table.push_back(times[i]);
     entry[(size_t)i] = (int)table.size() - 1;
@@ -166,7 +149,7 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
   Pose T_imu_lidar, T_lidar_imu;
   memcpy(T_imu_lidar.m, T_imu_lidar12, sizeof(T_imu_lidar.m));
   T_lidar_imu = inverse(T_imu_lidar);
-  std::vector<Pose> TT(table.size());
+  TT.resize(table.size());
   if (n_imu == 0) {
     const double zero[3] = {0, 0, 0};
     const double* lv = linear_vel3 ? linear_vel3 : zero;
@@ -203,10 +186,12 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
       TT[i] = compose(compose(T_lidar_imu, compose(T_imu0_world, T_world_imu1)), T_imu_lidar);
     }
   }
+}
 
-  // ---- device: upload raw points, entry indices and the table; transform + pack ----
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  GA_HIP(hipSetDevice(ctx->device));
+// device: (upload the raw points unless they are already resident,) entry indices and the table; transform + pack.
+// Caller holds ctx->mu.
+int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const double* d_points4, const std::vector<int>& entry, const std::vector<Pose>& TT,
+               glim_amd_cloud** out) {
   glim_amd_cloud* c = new glim_amd_cloud();
   c->ctx = ctx;
   c->n = n;
@@ -219,22 +204,74 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
   if (n > 0) {
     hipStream_t s = ctx->stream();
     DeviceTemp dp, de, dt;
-    e = pool_malloc(&dp.p, (size_t)n * 4 * sizeof(double));
+    if (!d_points4) {
+      e = pool_malloc(&dp.p, (size_t)n * 4 * sizeof(double));
+      if (e == hipSuccess) e = hipMemcpyAsync(dp.p, h_points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
+      d_points4 = (const double*)dp.p;
+    }
     if (e == hipSuccess) e = pool_malloc(&de.p, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = pool_malloc(&dt.p, TT.size() * sizeof(Pose));
-    if (e == hipSuccess) e = hipMemcpyAsync(dp.p, points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(de.p, entry.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(dt.p, TT.data(), TT.size() * sizeof(Pose), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, (const double*)dp.p, (const int*)de.p, (const double*)dt.p, c->pts);
+      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, d_points4, (const int*)de.p, (const double*)dt.p, c->pts);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
-      set_hip_error(e, "cloud_create_deskewed");
+      set_hip_error(e, "cloud deskew");
       glim_amd_cloud_destroy(c);
       return GLIM_AMD_ERR_HIP;
     }
+  }
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
+                                   int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
+                                   const double* angular_vel3, glim_amd_cloud** out) {
+  if (!ctx || !out || n < 0 || !T_imu_lidar12 || (n > 0 && (!points4 || !times))) return GLIM_AMD_ERR_INVALID;
+  if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  if (n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
+  std::vector<int> entry;
+  std::vector<Pose> TT;
+  build_deskew_table(n, times, T_imu_lidar12, n_imu, imu_times, imu_poses12, stamp, linear_vel3, angular_vel3, entry, TT);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  return run_deskew(ctx, n, points4, nullptr, entry, TT, out);
+}
+
+int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
+                          double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out) {
+  if (!pre || !out || !T_imu_lidar12) return GLIM_AMD_ERR_INVALID;
+  if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  if (!pre->pts64 || !pre->times || (int64_t)pre->h_times.size() != pre->n) return GLIM_AMD_ERR_STATE;  // not a preprocessed cloud
+  glim_amd_ctx* ctx = pre->ctx;
+  const int64_t n = pre->n;
+  std::vector<int> entry;
+  std::vector<Pose> TT;
+  build_deskew_table(n, pre->h_times.data(), T_imu_lidar12, n_imu, imu_times, imu_poses12, stamp, linear_vel3, angular_vel3, entry, TT);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  glim_amd_cloud* c = nullptr;
+  GA_TRY(run_deskew(ctx, n, nullptr, reinterpret_cast<const double*>(pre->pts64), entry, TT, &c));
+  if (pre->neighbors && n > 0) {  // the neighbour lists found on the raw scan are carried over (odometry_estimation_imu.cpp:320)
+    hipError_t e = pool_malloc(&c->neighbors, (size_t)n * pre->k * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(c->neighbors, pre->neighbors, (size_t)n * pre->k * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
+    if (e != hipSuccess) {
+      set_hip_error(e, "cloud_deskew(neighbors)");
+      glim_amd_cloud_destroy(c);
+      return GLIM_AMD_ERR_HIP;
+    }
+    c->k = pre->k;
   }
   *out = c;
   return GLIM_AMD_OK;

@@ -28,6 +28,26 @@ inline hipError_t pool_malloc(T** p, size_t bytes) {
   return pool_malloc_impl(reinterpret_cast<void**>(p), bytes);
 }
 
+// RAII holder of a pool allocation used as kernel scratch
+struct DeviceTemp {
+  void* p = nullptr;
+  DeviceTemp() = default;
+  DeviceTemp(const DeviceTemp&) = delete;
+  DeviceTemp& operator=(const DeviceTemp&) = delete;
+  ~DeviceTemp() {
+    if (p) (void)pool_free(p);
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
+size_t radix_sort_scratch_bytes(int n);
+hipError_t radix_sort_pairs(hipStream_t st, int n, int bits, unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
+                            unsigned int* vals_b, bool vals_a_is_iota, int* scratch, unsigned long long** keys_sorted, unsigned int** vals_sorted);
+
 #define GA_HIP(call)                                   \
   do {                                                 \
     hipError_t _e = (call);                            \
@@ -132,8 +152,16 @@ struct glim_amd_cloud {
   int k = 0;
   bool has_covs = false;
   bool has_normals = false;
+  // scan-preprocessing outputs (preprocess.hip): the exact FP64 points `pts` was rounded from, and per-point time / intensity
+  double4* pts64 = nullptr;
+  double* times = nullptr;
+  double* intensities = nullptr;
+  std::vector<double> h_times;  // host copy of `times` (the deskewing time table is built from it)
   size_t bytes() const {
     size_t b = (size_t)n * sizeof(float4);
+    if (pts64) b += (size_t)n * sizeof(double4);
+    if (times) b += (size_t)n * sizeof(double);
+    if (intensities) b += (size_t)n * sizeof(double);
     if (covA) b += (size_t)n * (sizeof(float4) + sizeof(float2));
     if (normals) b += (size_t)n * sizeof(float4);
     if (neighbors) b += (size_t)n * k * sizeof(int32_t);

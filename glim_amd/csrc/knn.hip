@@ -20,6 +20,7 @@
 
 #include "device_math.hpp"
 #include "internal.hpp"
+#include "scan.hpp"
 
 using namespace glim_amd;
 
@@ -121,87 +122,6 @@ __global__ __launch_bounds__(256) void grid_insert_kernel(int n, const float4* _
   }
   atomicAdd(&counts[s], 1);
   slot_of[i] = (int)s;
-}
-
-// exclusive scan of counts[T] -> starts[T] in three launches: per-tile sums, scan of the tile sums (one block), per-tile scan
-// with the tile offset.  A tile is SCAN_TILE consecutive entries read coalesced (lane-contiguous int4).
-constexpr int SCAN_TILE = 4096;  // 1024 threads x int4
-
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* s_tmp, int* total) {
-  // wave-level inclusive scan by shuffles, then a scan of the 16 wave sums
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) s_tmp[wave] = inc;
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    int w = s_tmp[threadIdx.x];
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-      const int t = __shfl_up(w, off, 16);
-      if ((int)threadIdx.x >= off) w += t;
-    }
-    s_tmp[16 + threadIdx.x] = w;  // inclusive scan of wave sums
-  }
-  __syncthreads();
-  const int wave_off = wave ? s_tmp[16 + wave - 1] : 0;
-  if (total) *total = s_tmp[31];
-  return wave_off + inc - v;
-}
-
-__global__ __launch_bounds__(1024) void scan_tile_sums_kernel(const int* __restrict__ counts, unsigned int T, int* __restrict__ tile_sums) {
-  __shared__ int s_tmp[32];
-  const unsigned int i = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-  int4 c = make_int4(0, 0, 0, 0);
-  if (i + 3 < T) c = *reinterpret_cast<const int4*>(counts + i);
-  else {
-    if (i < T) c.x = counts[i];
-    if (i + 1 < T) c.y = counts[i + 1];
-    if (i + 2 < T) c.z = counts[i + 2];
-  }
-  int total = 0;
-  block_exclusive_scan_1024(c.x + c.y + c.z + c.w, s_tmp, &total);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void scan_tile_offsets_kernel(int* __restrict__ tile_sums, int num_tiles) {
-  // exclusive scan of the tile sums in place (num_tiles <= 1024 * chunk handled by a serial carry over chunks of 1024)
-  __shared__ int s_tmp[32];
-  int carry = 0;
-  for (int base = 0; base < num_tiles; base += 1024) {
-    const int i = base + (int)threadIdx.x;
-    const int v = i < num_tiles ? tile_sums[i] : 0;
-    int total = 0;
-    const int ex = block_exclusive_scan_1024(v, s_tmp, &total);
-    if (i < num_tiles) tile_sums[i] = carry + ex;
-    carry += total;
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(1024) void scan_apply_kernel(const int* __restrict__ counts, unsigned int T, const int* __restrict__ tile_offsets,
-                                                          int* __restrict__ starts) {
-  __shared__ int s_tmp[32];
-  const unsigned int i = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
-  int4 c = make_int4(0, 0, 0, 0);
-  if (i + 3 < T) c = *reinterpret_cast<const int4*>(counts + i);
-  else {
-    if (i < T) c.x = counts[i];
-    if (i + 1 < T) c.y = counts[i + 1];
-    if (i + 2 < T) c.z = counts[i + 2];
-  }
-  const int ex = tile_offsets[blockIdx.x] + block_exclusive_scan_1024(c.x + c.y + c.z + c.w, s_tmp, nullptr);
-  const int4 o = make_int4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
-  if (i + 3 < T) *reinterpret_cast<int4*>(starts + i) = o;
-  else {
-    if (i < T) starts[i] = o.x;
-    if (i + 1 < T) starts[i + 1] = o.y;
-    if (i + 2 < T) starts[i + 2] = o.z;
-  }
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ slot_of,
@@ -348,13 +268,6 @@ void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const un
     else FN<32>(__VA_ARGS__);                    \
   } while (0)
 
-struct DeviceTemp {
-  void* p = nullptr;
-  ~DeviceTemp() {
-    if (p) (void)pool_free(p);
-  }
-};
-
 unsigned int next_pow2(unsigned long long v) {
   unsigned long long p = 1;
   while (p < v) p <<= 1;
@@ -379,11 +292,8 @@ int build_grid(hipStream_t st, int n, const float4* pts, double h, GridBuffers& 
 }
 
 int sort_into_grid(hipStream_t st, int n, const float4* pts, GridBuffers& g) {
-  const int tiles = (int)((g.T + SCAN_TILE - 1) / SCAN_TILE);
   GA_HIP(hipMemsetAsync(g.cursor.p, 0, (size_t)g.T * sizeof(int), st));
-  scan_tile_sums_kernel<<<tiles, 1024, 0, st>>>((const int*)g.counts.p, g.T, (int*)g.tile_sums.p);
-  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>((int*)g.tile_sums.p, tiles);
-  scan_apply_kernel<<<tiles, 1024, 0, st>>>((const int*)g.counts.p, g.T, (const int*)g.tile_sums.p, (int*)g.starts.p);
+  GA_HIP(exclusive_scan_int(st, (const int*)g.counts.p, g.T, (int*)g.tile_sums.p, (int*)g.starts.p));
   grid_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, (const int*)g.slot_of.p, (const int*)g.starts.p, (int*)g.cursor.p, (float4*)g.sorted.p);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
@@ -421,7 +331,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   GA_HIP(pool_malloc(&g.slot_of.p, (size_t)n * sizeof(int)));
   GA_HIP(pool_malloc(&g.sorted.p, (size_t)n * sizeof(float4)));
   GA_HIP(pool_malloc(&g.stats.p, 4 * sizeof(int)));
-  GA_HIP(pool_malloc(&g.tile_sums.p, (size_t)((g.T + SCAN_TILE - 1) / SCAN_TILE + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&g.tile_sums.p, scan_scratch_ints(g.T) * sizeof(int)));
   GA_HIP(pool_malloc(&unresolved_a.p, (size_t)n * sizeof(int)));
   GA_HIP(pool_malloc(&unresolved_b.p, (size_t)n * sizeof(int)));
 

@@ -1,0 +1,646 @@
+// preprocess.hip -- scan preprocessing on the device.
+//
+// Replaces glim::CloudPreprocessor::preprocess_impl (src/glim/preprocess/cloud_preprocessor.cpp:92-188) together with the three
+// gtsam_points routines it calls (voxelgrid_sampling / randomgrid_sampling :104-109, remove_outliers :162-164): one upload of the
+// raw scan, then every stage runs on the device and hands its result to the next one in HBM -- downsampling, range + cropbox
+// filter, sort by time, outlier removal, kNN (knn.hip).  The host only reads back a few counters that size the next stage.
+//
+// Exactness contract (oracle/preprocess_oracle.c states the same rules on the CPU; tests/test_preprocess.py checks them):
+//   * voxel coordinates: fast_floor(p * (1/res)) in FP64 -> identical voxel membership;
+//   * order inside a voxel / between equal time stamps: ascending original index.  The reference sorts with unstable sorts, so its
+//     order is implementation defined; the device gets the index order from a STABLE radix sort (sort.hip);
+//   * voxel-grid means: one thread walks its run of the sorted order and adds sequentially in FP64 -- the same additions in the
+//     same order as the CPU loop, hence bit-identical means (a parallel tree sum would not be);
+//   * random-grid sampling: counter-based generator h = splitmix64(seed, index) instead of the reference's sequential
+//     std::mt19937 stream (which no data-parallel implementation can replay): inside a voxel the points with the smallest
+//     (h >> 32, index) survive, the global 1.2x cap keeps the smallest (h & 0xffffffff, index);
+//   * predicates (range, cropbox) are evaluated in FP64 in one fixed operation order without contraction.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "internal.hpp"
+#include "device_math.hpp"
+#include "scan.hpp"
+
+using namespace glim_amd;
+
+namespace {
+
+using u64 = unsigned long long;
+using u32 = unsigned int;
+
+constexpr u64 INVALID_VKEY = ~0ull;
+
+// == orc_sample_hash (splitmix64 of seed + (index + 1) * golden)
+__host__ __device__ inline u64 sample_hash(u64 seed, u64 index) {
+  u64 z = seed + (index + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- K9a: voxel key (x lowest, 21 bits per axis, offset 2^20) + bounding box of the valid coordinates ----
+__global__ __launch_bounds__(256) void pp_key_kernel(int n, const double4* __restrict__ p4, double inv_res, u64* __restrict__ vkey,
+                                                     int* __restrict__ bb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int c[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  bool valid = false;
+  if (i < n) {
+    const double4 p = p4[i];
+    const double t[3] = {p.x * inv_res, p.y * inv_res, p.z * inv_res};
+    valid = isfinite(p.w);
+#pragma unroll
+    for (int a = 0; a < 3; a++) valid = valid && (t[a] >= -1048576.0 && t[a] < 1048576.0);  // false for NaN / inf
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) c[a] = fast_floor_d(t[a]) + KEY_OFFSET;
+    }
+    vkey[i] = valid ? ((u64)c[0] | ((u64)c[1] << 21) | ((u64)c[2] << 42)) : INVALID_VKEY;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const int lo = wave_min_i(c[a]);
+    const int hi = wave_max_i(valid ? c[a] : (int)0x80000000);
+    if ((threadIdx.x & 63) == 0) {
+      if (lo != 0x7fffffff) atomicMin(&bb[a], lo);
+      if (hi != (int)0x80000000) atomicMax(&bb[3 + a], hi);
+    }
+  }
+}
+
+// ---- K9b: key compacted to the bounding box: ((z - zmin) << (bx + by)) | ((y - ymin) << bx) | (x - xmin); invalid -> 1 << vbits ----
+__global__ __launch_bounds__(256) void pp_compact_key_kernel(int n, const u64* __restrict__ vkey, int xmin, int ymin, int zmin, int bx, int by,
+                                                             int vbits, u64* __restrict__ ckey) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 k = vkey[i];
+  if (k == INVALID_VKEY) {
+    ckey[i] = 1ull << vbits;
+    return;
+  }
+  const u64 x = (k & 0x1FFFFFull) - (u64)xmin, y = ((k >> 21) & 0x1FFFFFull) - (u64)ymin, z = ((k >> 42) & 0x1FFFFFull) - (u64)zmin;
+  ckey[i] = (z << (bx + by)) | (y << bx) | x;
+}
+
+__global__ __launch_bounds__(256) void pp_hash_key_kernel(int n, u64 seed, u64* __restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] = sample_hash(seed, (u64)i) >> 32;
+}
+
+__global__ __launch_bounds__(256) void pp_gather_key_kernel(int n, const u32* __restrict__ vals, const u64* __restrict__ ckey, u64* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) out[j] = ckey[vals[j]];
+}
+
+// counters[0] = number of distinct valid keys in the sorted order, counters[1] = number of valid entries
+__global__ __launch_bounds__(256) void pp_count_voxels_kernel(int n, const u64* __restrict__ k, u64 invalid, int* __restrict__ counters) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = j < n && k[j] != invalid;
+  const bool head = valid && (j == 0 || k[j - 1] != k[j]);
+  const int heads = wave_sum_i(head ? 1 : 0), valids = wave_sum_i(valid ? 1 : 0);
+  if ((threadIdx.x & 63) == 0) {
+    if (heads) atomicAdd(&counters[0], heads);
+    if (valids) atomicAdd(&counters[1], valids);
+  }
+}
+
+// randomgrid_sampling: rank inside the voxel < points_per_voxel  <=>  the entry ppv places earlier belongs to another voxel
+__global__ __launch_bounds__(256) void pp_select_kernel(int n, double rate, const u64* __restrict__ k, const u32* __restrict__ v, u64 invalid,
+                                                        int* __restrict__ counters, int* __restrict__ sel) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int num_voxels = counters[0];
+  bool keep = false;
+  if (j < n && num_voxels > 0) {
+    const long long ppv = (long long)ceil((rate * (double)n) / (double)num_voxels);
+    const u64 key = k[j];
+    keep = key != invalid && ((long long)j < ppv || k[j - ppv] != key);
+    if (keep) sel[v[j]] = 1;
+  }
+  const int cnt = wave_sum_i(keep ? 1 : 0);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[2], cnt);
+}
+
+__global__ __launch_bounds__(256) void pp_cap_key_kernel(int n, u64 seed, const int* __restrict__ sel, u64* __restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] = sel[i] ? (sample_hash(seed, (u64)i) & 0xFFFFFFFFull) : (1ull << 32);
+}
+
+__global__ __launch_bounds__(256) void pp_cap_apply_kernel(int n, int max_num, const u32* __restrict__ v, int* __restrict__ sel) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n && j >= max_num) sel[v[j]] = 0;
+}
+
+// ---- voxelgrid_sampling: run heads of the sorted order (key change, or a multiple of block_size), then one thread per run ----
+__global__ __launch_bounds__(256) void pp_head_flag_kernel(int n, const u64* __restrict__ k, u64 invalid, int block_size, int* __restrict__ heads,
+                                                           int* __restrict__ n_valid) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > n) return;
+  if (j == n) {
+    heads[n] = 0;
+    return;
+  }
+  const bool valid = k[j] != invalid;
+  heads[j] = valid && (j == 0 || k[j - 1] != k[j] || (block_size > 0 && j % block_size == 0));
+  if (valid && (j == n - 1 || k[j + 1] == invalid)) *n_valid = j + 1;
+}
+
+__global__ __launch_bounds__(256) void pp_seg_start_kernel(int n, const int* __restrict__ heads, const int* __restrict__ seg, const int* __restrict__ n_valid,
+                                                           int* __restrict__ seg_start) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > n) return;
+  if (j == n) seg_start[seg[n]] = *n_valid;
+  else if (heads[j]) seg_start[seg[j]] = j;
+}
+
+__global__ __launch_bounds__(256) void pp_segment_mean_kernel(int m, const int* __restrict__ seg_start, const u32* __restrict__ v,
+                                                              const double4* __restrict__ p4, const double* __restrict__ times,
+                                                              const double* __restrict__ inten, double4* __restrict__ outP, double* __restrict__ outT,
+                                                              double* __restrict__ outI) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  const int begin = seg_start[s], end = seg_start[s + 1];
+  double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0, st = 0.0, si = 0.0;
+  for (int j = begin; j < end; j++) {  // sequential: the same additions in the same order as the CPU loop
+    const u32 i = v[j];
+    const double4 p = p4[i];
+    sx += p.x;
+    sy += p.y;
+    sz += p.z;
+    sw += p.w;
+    st += times[i];
+    if (inten) si += inten[i];
+  }
+  outP[s] = make_double4(sx / sw, sy / sw, sz / sw, sw / sw);
+  outT[s] = st / sw;
+  if (inten) outI[s] = si / sw;
+}
+
+// ---- range / finite / cropbox predicate (cloud_preprocessor.cpp:122-128, :146-160) ----
+struct FilterParams {
+  double near2, far2;
+  int crop, crop_imu;
+  double bmin[3], bmax[3], T[12];
+};
+
+__global__ __launch_bounds__(256) void pp_filter_flag_kernel(int m, const double4* __restrict__ P, const int* __restrict__ sel, FilterParams fp,
+                                                             int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > m) return;
+  if (i == m) {
+    flags[m] = 0;
+    return;
+  }
+  bool keep = sel ? sel[i] != 0 : true;
+  if (keep) {
+    const double4 p = P[i];
+    const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w);
+    const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(p.x, p.x), __dmul_rn(p.z, p.z)), __dmul_rn(p.y, p.y));
+    keep = d2 > fp.near2 && d2 < fp.far2 && finite;
+    if (keep && fp.crop) {
+      double q[3] = {p.x, p.y, p.z};
+      if (fp.crop_imu) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          q[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(fp.T[4 * r], p.x), __dmul_rn(fp.T[4 * r + 1], p.y)), __dmul_rn(fp.T[4 * r + 2], p.z)),
+                           fp.T[4 * r + 3]);
+      }
+      bool inside = true;
+#pragma unroll
+      for (int a = 0; a < 3; a++) inside = inside && q[a] >= fp.bmin[a] && q[a] <= fp.bmax[a];
+      keep = !inside;
+    }
+  }
+  flags[i] = keep ? 1 : 0;
+}
+
+// order-preserving image of a double for an unsigned radix sort; -0.0 counts as +0.0 (they compare equal on the CPU)
+__device__ __forceinline__ u64 orderable(double t) {
+  const u64 b = (u64)__double_as_longlong(t + 0.0);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void pp_compact_time_kernel(int m, const int* __restrict__ flags, const int* __restrict__ pos,
+                                                              const double* __restrict__ T, u64* __restrict__ tkeys, u32* __restrict__ tvals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m || !flags[i]) return;
+  tkeys[pos[i]] = orderable(T[i]);
+  tvals[pos[i]] = (u32)i;
+}
+
+__global__ __launch_bounds__(256) void pp_gather_out_kernel(int f, const u32* __restrict__ idx, const double4* __restrict__ P, const double* __restrict__ T,
+                                                            const double* __restrict__ I, int zero_times, float4* __restrict__ pts,
+                                                            double4* __restrict__ pts64, double* __restrict__ times, double* __restrict__ inten) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= f) return;
+  const u32 i = idx[j];
+  const double4 p = P[i];
+  pts64[j] = p;
+  pts[j] = make_float4((float)p.x, (float)p.y, (float)p.z, 1.0f);
+  times[j] = zero_times ? 0.0 : T[i];
+  if (inten) inten[j] = I[i];
+}
+
+// ---- statistical outlier removal (gtsam_points::remove_outliers): mean distance to the k nearest neighbours ----
+__global__ __launch_bounds__(256) void pp_mean_dist_kernel(int f, const double4* __restrict__ P, const int* __restrict__ nb, int k,
+                                                           double* __restrict__ d, double* __restrict__ partial) {
+  __shared__ double s_sum[4], s_sq[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double di = 0.0;
+  if (i < f) {
+    const double4 p = P[i];
+    double s = 0.0;
+    for (int j = 0; j < k; j++) {
+      const double4 q = P[nb[(size_t)i * k + j]];
+      const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+      s += __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+    }
+    di = s / (double)k;
+    d[i] = di;
+  }
+  // deterministic block sums of d and d^2 (fixed butterfly order), one partial pair per block
+  double a = di, b = __dmul_rn(di, di);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[threadIdx.x >> 6] = a;
+    s_sq[threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    partial[2 * blockIdx.x + 1] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
+  }
+}
+
+__global__ void pp_outlier_thresh_kernel(int f, int blocks, const double* __restrict__ partial, double std_mul, double* __restrict__ thresh) {
+  double sum = 0.0, sq = 0.0;
+  for (int b = 0; b < blocks; b++) {  // block order: deterministic
+    sum += partial[2 * b];
+    sq += partial[2 * b + 1];
+  }
+  const double mean = sum / (double)f;
+  const double var = sq / (double)f - __dmul_rn(mean, mean);
+  *thresh = mean + std_mul * sqrt(var > 0.0 ? var : 0.0);
+}
+
+__global__ __launch_bounds__(256) void pp_inlier_flag_kernel(int f, const double* __restrict__ d, const double* __restrict__ thresh,
+                                                             int* __restrict__ flags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > f) return;
+  flags[i] = (i < f && d[i] < *thresh) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void pp_compact_index_kernel(int m, const int* __restrict__ flags, const int* __restrict__ pos, u32* __restrict__ idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m && flags[i]) idx[pos[i]] = (u32)i;
+}
+
+inline int grid_for(int n) { return (n + 255) / 256; }
+inline int bits_for(int range) {
+  int b = 0;
+  while (range > 0) {
+    b++;
+    range >>= 1;
+  }
+  return b;
+}
+
+struct CloudGuard {
+  glim_amd_cloud* c = nullptr;
+  ~CloudGuard() {
+    if (c) glim_amd_cloud_destroy(c);
+  }
+  glim_amd_cloud* release() {
+    glim_amd_cloud* r = c;
+    c = nullptr;
+    return r;
+  }
+};
+
+// Allocates the output arrays of a preprocessed cloud of f points.
+int alloc_frame_cloud(glim_amd_ctx* ctx, int f, bool with_intensities, glim_amd_cloud** out) {
+  glim_amd_cloud* c = new glim_amd_cloud();
+  c->ctx = ctx;
+  c->n = f;
+  const size_t nn = (size_t)(f > 0 ? f : 1);
+  hipError_t e = pool_malloc(&c->pts, nn * sizeof(float4));
+  if (e == hipSuccess) e = pool_malloc(&c->pts64, nn * sizeof(double4));
+  if (e == hipSuccess) e = pool_malloc(&c->times, nn * sizeof(double));
+  if (e == hipSuccess && with_intensities) e = pool_malloc(&c->intensities, nn * sizeof(double));
+  if (e != hipSuccess) {
+    set_hip_error(e, "pool_malloc(preprocessed cloud)");
+    glim_amd_cloud_destroy(c);
+    return e == hipErrorOutOfMemory ? GLIM_AMD_ERR_NOMEM : GLIM_AMD_ERR_HIP;
+  }
+  *out = c;
+  return GLIM_AMD_OK;
+}
+
+// Sort scratch shared by the stages of one call (sized for the raw scan).
+struct SortBuffers {
+  DeviceTemp ka, kb, va, vb, hist;
+  int alloc(int n) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    GA_HIP(pool_malloc(&ka.p, nn * sizeof(u64)));
+    GA_HIP(pool_malloc(&kb.p, nn * sizeof(u64)));
+    GA_HIP(pool_malloc(&va.p, nn * sizeof(u32)));
+    GA_HIP(pool_malloc(&vb.p, nn * sizeof(u32)));
+    GA_HIP(pool_malloc(&hist.p, radix_sort_scratch_bytes(n)));
+    return GLIM_AMD_OK;
+  }
+};
+
+// Stage A (downsampling) on the raw device arrays.  Random grid: fills `sel` (n ints, 1 = survives) and leaves P/T/I = the raw
+// arrays; voxel grid: writes the averaged arrays (avgP/avgT/avgI, *m entries).
+int downsample_random(hipStream_t st, int n, const double4* p4, const u64* ckey, int vbits, double rate, u64 seed, SortBuffers& sb, int* counters,
+                      int* h_counters, int* sel) {
+  u64* ks = nullptr;
+  u32* vs = nullptr;
+  // sort 1: by hash (ties by index through stability); sort 2: by voxel -> inside every voxel ascending (hash, index)
+  pp_hash_key_kernel<<<grid_for(n), 256, 0, st>>>(n, seed, sb.ka.as<u64>());
+  GA_HIP(radix_sort_pairs(st, n, 32, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), true, sb.hist.as<int>(), &ks, &vs));
+  // after 4 passes the pairs are back in (ka, va); gather the voxel keys into kb, keeping the permutation in va
+  u64* k2 = (ks == sb.ka.as<u64>()) ? sb.kb.as<u64>() : sb.ka.as<u64>();
+  u32* v_other = (vs == sb.va.as<u32>()) ? sb.vb.as<u32>() : sb.va.as<u32>();
+  pp_gather_key_kernel<<<grid_for(n), 256, 0, st>>>(n, vs, ckey, k2);
+  u64* k_other = (k2 == sb.ka.as<u64>()) ? sb.kb.as<u64>() : sb.ka.as<u64>();
+  GA_HIP(radix_sort_pairs(st, n, vbits + 1, k2, vs, k_other, v_other, false, sb.hist.as<int>(), &ks, &vs));
+  const u64 invalid = 1ull << vbits;
+  GA_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+  GA_HIP(hipMemsetAsync(sel, 0, (size_t)n * sizeof(int), st));
+  pp_count_voxels_kernel<<<grid_for(n), 256, 0, st>>>(n, ks, invalid, counters);
+  pp_select_kernel<<<grid_for(n), 256, 0, st>>>(n, rate, ks, vs, invalid, counters, sel);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipMemcpyAsync(h_counters, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+  const long long max_num_points = (long long)((double)n * rate * 1.2);
+  if ((long long)h_counters[2] > max_num_points) {
+    pp_cap_key_kernel<<<grid_for(n), 256, 0, st>>>(n, seed, sel, sb.ka.as<u64>());
+    GA_HIP(radix_sort_pairs(st, n, 33, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), true, sb.hist.as<int>(), &ks, &vs));
+    pp_cap_apply_kernel<<<grid_for(n), 256, 0, st>>>(n, (int)max_num_points, vs, sel);
+    GA_HIP(hipGetLastError());
+  }
+  return GLIM_AMD_OK;
+}
+
+int downsample_voxelgrid(hipStream_t st, int n, const double4* p4, const double* times, const double* inten, const u64* ckey, int vbits, int block_size,
+                         SortBuffers& sb, int* counters, int* h_counters, DeviceTemp& avgP, DeviceTemp& avgT, DeviceTemp& avgI, int* m_out) {
+  u64* ks = nullptr;
+  u32* vs = nullptr;
+  GA_HIP(hipMemcpyAsync(sb.ka.p, ckey, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+  GA_HIP(radix_sort_pairs(st, n, vbits + 1, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), true, sb.hist.as<int>(), &ks, &vs));
+  DeviceTemp heads, seg, tiles, seg_start;
+  GA_HIP(pool_malloc(&heads.p, (size_t)(n + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&seg.p, (size_t)(n + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)n + 1) * sizeof(int)));
+  GA_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
+  pp_head_flag_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, ks, 1ull << vbits, block_size, heads.as<int>(), counters + 1);
+  GA_HIP(exclusive_scan_int(st, heads.as<int>(), (unsigned int)n + 1, tiles.as<int>(), seg.as<int>()));
+  GA_HIP(hipMemcpyAsync(h_counters, seg.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+  const int m = h_counters[0];
+  *m_out = m;
+  const size_t mm = (size_t)(m > 0 ? m : 1);
+  GA_HIP(pool_malloc(&avgP.p, mm * sizeof(double4)));
+  GA_HIP(pool_malloc(&avgT.p, mm * sizeof(double)));
+  if (inten) GA_HIP(pool_malloc(&avgI.p, mm * sizeof(double)));
+  if (m == 0) return GLIM_AMD_OK;
+  GA_HIP(pool_malloc(&seg_start.p, (size_t)(m + 1) * sizeof(int)));
+  pp_seg_start_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, heads.as<int>(), seg.as<int>(), counters + 1, seg_start.as<int>());
+  pp_segment_mean_kernel<<<grid_for(m), 256, 0, st>>>(m, seg_start.as<int>(), vs, p4, times, inten, avgP.as<double4>(), avgT.as<double>(),
+                                                      avgI.as<double>());
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipStreamSynchronize(st));  // the scratch of this scope is released on return
+  return GLIM_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int glim_amd_preprocess_default_params(glim_amd_preprocess_params* p) {
+  if (!p) return GLIM_AMD_ERR_INVALID;
+  memset(p, 0, sizeof(*p));
+  p->distance_near_thresh = 0.5;
+  p->distance_far_thresh = 100.0;
+  p->use_random_grid_downsampling = 1;
+  p->downsample_target = 10000;
+  p->downsample_resolution = 1.0;
+  p->downsample_rate = 0.1;
+  p->outlier_removal_k = 10;
+  p->outlier_std_mul_factor = 1.0;
+  for (int a = 0; a < 3; a++) {
+    p->crop_bbox_min[a] = -1.0;
+    p->crop_bbox_max[a] = 1.0;
+    p->T_imu_lidar[5 * a] = 1.0;
+  }
+  p->k_correspondences = 10;
+  p->voxelgrid_block_size = 1024;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, const double* times, const double* intensities,
+                        const glim_amd_preprocess_params* prm, glim_amd_cloud** out) {
+  if (!ctx || !out || !prm || n64 < 0 || (n64 > 0 && (!points4 || !times))) return GLIM_AMD_ERR_INVALID;
+  if (n64 > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
+  if (!(prm->downsample_resolution > 0.0) || prm->k_correspondences < 0 || prm->k_correspondences > 32) return GLIM_AMD_ERR_INVALID;
+  if (prm->enable_outlier_removal && (prm->outlier_removal_k <= 0 || prm->outlier_removal_k > 32)) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  const int n = (int)n64;
+  const bool has_int = intensities != nullptr;
+  CloudGuard result;
+
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GA_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream();
+    if (n == 0) {
+      GA_TRY(alloc_frame_cloud(ctx, 0, has_int, &result.c));
+    } else {
+      // ---- upload the raw scan ----
+      DeviceTemp d_p4, d_t, d_i, d_vkey, d_ckey, d_bb, d_counters, d_sel;
+      GA_HIP(pool_malloc(&d_p4.p, (size_t)n * sizeof(double4)));
+      GA_HIP(pool_malloc(&d_t.p, (size_t)n * sizeof(double)));
+      if (has_int) GA_HIP(pool_malloc(&d_i.p, (size_t)n * sizeof(double)));
+      GA_HIP(pool_malloc(&d_vkey.p, (size_t)n * sizeof(u64)));
+      GA_HIP(pool_malloc(&d_ckey.p, (size_t)n * sizeof(u64)));
+      GA_HIP(pool_malloc(&d_bb.p, 6 * sizeof(int)));
+      GA_HIP(pool_malloc(&d_counters.p, 4 * sizeof(int)));
+      GA_HIP(hipMemcpyAsync(d_p4.p, points4, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, st));
+      GA_HIP(hipMemcpyAsync(d_t.p, times, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+      if (has_int) GA_HIP(hipMemcpyAsync(d_i.p, intensities, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+      SortBuffers sb;
+      GA_TRY(sb.alloc(n));
+      int h_counters[4] = {0, 0, 0, 0};
+
+      // ---- downsampling (cloud_preprocessor.cpp:103-109) ----
+      const double rate = prm->downsample_target > 0 ? (double)prm->downsample_target / (double)n : prm->downsample_rate;
+      const bool random = prm->use_random_grid_downsampling != 0;
+      const bool sample_all = random && rate >= 0.99;  // randomgrid_sampling returns the cloud unchanged
+      const double4* P = d_p4.as<double4>();
+      const double* T = d_t.as<double>();
+      const double* I = has_int ? d_i.as<double>() : nullptr;
+      const int* sel = nullptr;
+      DeviceTemp avgP, avgT, avgI;
+      int m = n;
+      if (!sample_all) {
+        const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        int h_bb[6];
+        GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+        pp_key_kernel<<<grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
+        GA_HIP(hipGetLastError());
+        GA_HIP(hipMemcpyAsync(h_bb, d_bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
+        GA_HIP(hipStreamSynchronize(st));
+        int bx = 0, by = 0, bz = 0;
+        if (h_bb[0] <= h_bb[3]) {
+          bx = bits_for(h_bb[3] - h_bb[0]);
+          by = bits_for(h_bb[4] - h_bb[1]);
+          bz = bits_for(h_bb[5] - h_bb[2]);
+        } else {
+          h_bb[0] = h_bb[1] = h_bb[2] = 0;  // no valid point at all
+        }
+        const int vbits = bx + by + bz;
+        pp_compact_key_kernel<<<grid_for(n), 256, 0, st>>>(n, d_vkey.as<u64>(), h_bb[0], h_bb[1], h_bb[2], bx, by, vbits, d_ckey.as<u64>());
+        GA_HIP(hipGetLastError());
+        if (random) {
+          GA_HIP(pool_malloc(&d_sel.p, (size_t)n * sizeof(int)));
+          GA_TRY(downsample_random(st, n, P, d_ckey.as<u64>(), vbits, rate, prm->seed, sb, d_counters.as<int>(), h_counters, d_sel.as<int>()));
+          sel = d_sel.as<int>();
+        } else {
+          GA_TRY(downsample_voxelgrid(st, n, P, T, I, d_ckey.as<u64>(), vbits, prm->voxelgrid_block_size, sb, d_counters.as<int>(), h_counters, avgP,
+                                      avgT, avgI, &m));
+          P = avgP.as<double4>();
+          T = avgT.as<double>();
+          I = has_int ? avgI.as<double>() : nullptr;
+        }
+      }
+
+      // ---- range + cropbox filter (:117-128, :143-160), compaction, sort by time (:134-136), global shutter (:138-140) ----
+      int f = 0;
+      u32* order = nullptr;
+      DeviceTemp flags, pos, tiles;
+      if (m > 0) {
+        FilterParams fp;
+        fp.near2 = prm->distance_near_thresh * prm->distance_near_thresh;
+        fp.far2 = prm->distance_far_thresh * prm->distance_far_thresh;
+        fp.crop = prm->enable_cropbox_filter;
+        fp.crop_imu = prm->crop_bbox_frame_imu;
+        for (int a = 0; a < 3; a++) {
+          fp.bmin[a] = prm->crop_bbox_min[a];
+          fp.bmax[a] = prm->crop_bbox_max[a];
+        }
+        memcpy(fp.T, prm->T_imu_lidar, sizeof(fp.T));
+        GA_HIP(pool_malloc(&flags.p, (size_t)(m + 1) * sizeof(int)));
+        GA_HIP(pool_malloc(&pos.p, (size_t)(m + 1) * sizeof(int)));
+        GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)m + 1) * sizeof(int)));
+        pp_filter_flag_kernel<<<grid_for(m + 1), 256, 0, st>>>(m, P, sel, fp, flags.as<int>());
+        GA_HIP(exclusive_scan_int(st, flags.as<int>(), (unsigned int)m + 1, tiles.as<int>(), pos.as<int>()));
+        pp_compact_time_kernel<<<grid_for(m), 256, 0, st>>>(m, flags.as<int>(), pos.as<int>(), T, sb.ka.as<u64>(), sb.va.as<u32>());
+        GA_HIP(hipGetLastError());
+        GA_HIP(hipMemcpyAsync(h_counters, pos.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, st));
+        GA_HIP(hipStreamSynchronize(st));
+        f = h_counters[0];
+        u64* ks = nullptr;
+        GA_HIP(radix_sort_pairs(st, f, 64, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), false, sb.hist.as<int>(), &ks, &order));
+      }
+      GA_TRY(alloc_frame_cloud(ctx, f, has_int, &result.c));
+      glim_amd_cloud* c = result.c;
+      if (f > 0) {
+        pp_gather_out_kernel<<<grid_for(f), 256, 0, st>>>(f, order, P, T, I, prm->global_shutter, c->pts, c->pts64, c->times, c->intensities);
+        GA_HIP(hipGetLastError());
+      }
+      GA_HIP(hipStreamSynchronize(st));  // scratch of this scope is released below
+    }
+  }
+
+  // ---- statistical outlier removal (:162-164): kNN on the filtered cloud, mean neighbour distance, global threshold ----
+  if (prm->enable_outlier_removal && result.c->n > 0) {
+    glim_amd_cloud* c = result.c;
+    const int f = (int)c->n, k = prm->outlier_removal_k;
+    GA_TRY(glim_amd_cloud_find_neighbors(c, k, nullptr));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GA_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream();
+    const int blocks = grid_for(f);
+    DeviceTemp d, partial, thresh, flags, pos, tiles, idx;
+    GA_HIP(pool_malloc(&d.p, (size_t)f * sizeof(double)));
+    GA_HIP(pool_malloc(&partial.p, (size_t)blocks * 2 * sizeof(double)));
+    GA_HIP(pool_malloc(&thresh.p, sizeof(double)));
+    GA_HIP(pool_malloc(&flags.p, (size_t)(f + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&pos.p, (size_t)(f + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)f + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&idx.p, (size_t)f * sizeof(u32)));
+    pp_mean_dist_kernel<<<blocks, 256, 0, st>>>(f, c->pts64, c->neighbors, k, d.as<double>(), partial.as<double>());
+    pp_outlier_thresh_kernel<<<1, 1, 0, st>>>(f, blocks, partial.as<double>(), prm->outlier_std_mul_factor, thresh.as<double>());
+    pp_inlier_flag_kernel<<<grid_for(f + 1), 256, 0, st>>>(f, d.as<double>(), thresh.as<double>(), flags.as<int>());
+    GA_HIP(exclusive_scan_int(st, flags.as<int>(), (unsigned int)f + 1, tiles.as<int>(), pos.as<int>()));
+    pp_compact_index_kernel<<<grid_for(f), 256, 0, st>>>(f, flags.as<int>(), pos.as<int>(), idx.as<u32>());
+    GA_HIP(hipGetLastError());
+    int kept = 0;
+    GA_HIP(hipMemcpyAsync(&kept, pos.as<int>() + f, sizeof(int), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    CloudGuard filtered;
+    GA_TRY(alloc_frame_cloud(ctx, kept, has_int, &filtered.c));
+    if (kept > 0) {
+      pp_gather_out_kernel<<<grid_for(kept), 256, 0, st>>>(kept, idx.as<u32>(), c->pts64, c->times, c->intensities, 0, filtered.c->pts, filtered.c->pts64,
+                                                          filtered.c->times, filtered.c->intensities);
+      GA_HIP(hipGetLastError());
+    }
+    GA_HIP(hipStreamSynchronize(st));
+    std::swap(result.c, filtered.c);  // the unfiltered cloud is destroyed with `filtered`
+  }
+
+  // ---- host copy of the time stamps (deskewing builds its time table from them) + kNN for the covariances (:183-184) ----
+  {
+    glim_amd_cloud* c = result.c;
+    if (c->n > 0) {
+      std::lock_guard<std::mutex> lock(ctx->mu);
+      GA_HIP(hipSetDevice(ctx->device));
+      c->h_times.resize((size_t)c->n);
+      GA_HIP(hipMemcpyAsync(c->h_times.data(), c->times, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream()));
+      GA_HIP(hipStreamSynchronize(ctx->stream()));
+    }
+    if (prm->k_correspondences > 0) GA_TRY(glim_amd_cloud_find_neighbors(c, prm->k_correspondences, nullptr));
+  }
+  *out = result.release();
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_download_frame(const glim_amd_cloud* c, double* points4, double* times, double* intensities, int32_t* neighbors) {
+  if (!c) return GLIM_AMD_ERR_INVALID;
+  if ((points4 && !c->pts64) || (times && !c->times) || (intensities && !c->intensities) || (neighbors && !c->neighbors)) return GLIM_AMD_ERR_STATE;
+  if (c->n == 0) return GLIM_AMD_OK;
+  glim_amd_ctx* ctx = c->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream();
+  const size_t n = (size_t)c->n;
+  if (points4) GA_HIP(hipMemcpyAsync(points4, c->pts64, n * sizeof(double4), hipMemcpyDeviceToHost, s));
+  if (times) GA_HIP(hipMemcpyAsync(times, c->times, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (intensities) GA_HIP(hipMemcpyAsync(intensities, c->intensities, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (neighbors) GA_HIP(hipMemcpyAsync(neighbors, c->neighbors, n * (size_t)c->k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  GA_HIP(hipStreamSynchronize(s));
+  return GLIM_AMD_OK;
+}
+
+}  // extern "C"

@@ -192,13 +192,6 @@ unsigned int next_pow2(unsigned long long v) {
   return (unsigned int)p;
 }
 
-struct DeviceTemp {
-  void* p = nullptr;
-  ~DeviceTemp() {
-    if (p) (void)pool_free(p);
-  }
-};
-
 }  // namespace
 
 extern "C" {

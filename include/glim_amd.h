@@ -102,6 +102,45 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
                                    int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
                                    const double* angular_vel3, glim_amd_cloud** out);
 
+/* ---- scan preprocessing on device: CloudPreprocessor::preprocess_impl,
+ * src/glim/preprocess/cloud_preprocessor.cpp:92-188 -- downsampling (gtsam_points::randomgrid_sampling / voxelgrid_sampling,
+ * :104-109), range filter (:117-128), sort by time (:134-136), global shutter (:138-140), cropbox (:143-160), statistical outlier
+ * removal (:162-164) and the kNN for the covariances (:183-184), without a host round trip between the stages. */
+typedef struct glim_amd_preprocess_params { /* CloudPreprocessorParams, cloud_preprocessor.cpp:20-61; config/config_preprocess.json */
+  double distance_near_thresh, distance_far_thresh;
+  int32_t use_random_grid_downsampling;
+  int32_t downsample_target; /* random_downsample_target: > 0 -> rate = target / n (:105) */
+  double downsample_resolution, downsample_rate;
+  int32_t global_shutter; /* config_sensors global_shutter_lidar (:24) */
+  int32_t enable_outlier_removal, outlier_removal_k;
+  double outlier_std_mul_factor;
+  int32_t enable_cropbox_filter, crop_bbox_frame_imu; /* crop_bbox_frame == "imu" */
+  double crop_bbox_min[3], crop_bbox_max[3];
+  double T_imu_lidar[12]; /* row-major 3x4, used by the "imu" cropbox only */
+  int32_t k_correspondences;
+  int32_t voxelgrid_block_size; /* gtsam_points averages voxels inside blocks of 1024 sorted points; 0 = never split a voxel */
+  uint64_t seed;                /* the reference draws from a std::mt19937 (:67); here: seed of the counter-based sampler */
+} glim_amd_preprocess_params;
+/* shipped defaults (config/config_preprocess.json) */
+int glim_amd_preprocess_default_params(glim_amd_preprocess_params* params);
+/* points4: n x Vector4d (RawPoints::points), times: n (RawPoints::times), intensities: n or NULL.  The result is a device
+ * cloud holding the surviving points (FP32 for the factor path + the exact FP64 values), their times, intensities and -- when
+ * k_correspondences > 0 -- their k nearest neighbours: everything PreprocessedFrame carries
+ * (include/glim/preprocess/preprocessed_frame.hpp:26-39). */
+int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* intensities,
+                        const glim_amd_preprocess_params* params, glim_amd_cloud** out);
+/* PreprocessedFrame fields of a preprocessed cloud back on the host; any pointer may be NULL.  points4 n x 4 (w = 1), times n,
+ * intensities n (GLIM_AMD_ERR_STATE if the scan had none), neighbors n x k. */
+int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, double* times, double* intensities, int32_t* neighbors);
+/* CloudDeskewing::deskew applied to a preprocessed cloud that is already on the device (same arguments as
+ * glim_amd_cloud_create_deskewed).  The new cloud shares nothing with `pre`; the neighbour lists found on the raw scan are
+ * carried over, as the reference does (odometry_estimation_imu.cpp:313-320: deskew, then covariances from raw_frame->neighbors). */
+int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
+                          const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out);
+/* parity / debug only: the stable device radix sort behind the preprocessing (sorts by the low `bits` key bits; vals_in NULL = 0..n-1). */
+int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                              uint32_t* vals_out);
+
 /* kNN on device: CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221).
  * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> padded with i.
  * Result stays on the device inside the cloud (and is copied to neighbors_out, n x k, when not NULL). */
