@@ -17,6 +17,7 @@ Other workloads (parity-test configurations of BASELINE.json, selectable for evi
   --workload submap20    configs[2]: 20 keyframes x 65 536 pts, 190 pairs x 2 voxel levels = 380 binary factors per bundle
   --workload global256   configs[3]: 256 submaps x 65 536 pts, all 32 640 pairs, 1.0 m voxels, pair list sharded over the
                          ranks + RCCL all-reduce (strong scaling; metric M2 = seconds per cost evaluation)
+  --workload frontend128k  SURVEY 8f ranks 1-2: raw scan -> preprocess -> deskew -> covariance -> voxel map -> factor, per frame
   --workload rgbd300k    configs[4]: 307 200-pt depth frames, per frame upload -> kNN -> covariance -> 0.1 m voxel map -> one
                          unary linearise against the previous frame (sustained frames/s, p50/p99 latency)
 
@@ -451,18 +452,97 @@ def run_rgbd300k(args, D, api, ctx):
     }
 
 
+def run_frontend128k(args, D, api, ctx):
+    """the per-scan front end GLIM runs before the factors, on the device end to end -- raw 131 072-pt scan ->
+    CloudPreprocessor::preprocess (random-grid sampling to `--target` points, range filter, time sort, kNN) -> CloudDeskewing::deskew ->
+    covariances -> 0.5 m voxel map -> one VGICP linearize against the previous frame.  PCIe upload of the raw scan included."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(args.rings, args.azimuths)
+    traj = synth.arc_trajectory(6, step=0.3, yaw_step_deg=1.0)
+    rng = np.random.default_rng(7)
+    raws = []
+    for i, T in enumerate(traj):
+        pts = synth.scan(scene, T, dirs, i).astype(np.float64)
+        p4 = np.ones((len(pts), 4))
+        p4[:, :3] = pts
+        raws.append((p4, np.sort(rng.uniform(0.0, 0.1, len(pts))), rng.uniform(0, 255, len(pts)), T))
+    prm_kw = dict(downsample_target=args.target, downsample_resolution=0.5 if args.target > 20000 else 1.0)
+    Til = np.eye(4)
+    lv, av = np.array([3.0, 0.0, 0.0]), np.array([0.0, 0.0, 0.17])
+    n_frames = args.frames
+    prev_map, prev_pose, lat, kept, stage = None, None, [], [], np.zeros(5)
+    D.barrier_sync()
+    t_all = time.perf_counter()
+    for fidx in range(n_frames + 3):
+        if fidx == 3:
+            D.torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            lat, stage = [], np.zeros(5)
+        p4, times, inten, T = raws[fidx % len(raws)]
+        t0 = time.perf_counter()
+        pre = api.PointCloudGPU.preprocess(p4, times, inten, api.preprocess_params(seed=fidx, **prm_kw), ctx=ctx)
+        t1 = time.perf_counter()
+        g = pre.deskew(Til, linear_vel=lv, angular_vel=av)
+        t2 = time.perf_counter()
+        g.estimate_covariances(10)
+        t3 = time.perf_counter()
+        vm = api.GaussianVoxelMapGPU(args.resolution, ctx=ctx).insert(g)
+        t4 = time.perf_counter()
+        if prev_map is not None:
+            fs = api.NonlinearFactorSetGPU(ctx)
+            fs.add(api.IntegratedVGICPFactorGPU(prev_pose, 1, prev_map, g))
+            fs.linearize({1: T})
+        t5 = time.perf_counter()
+        prev_map, prev_pose = vm, T
+        lat.append(t5 - t0)
+        stage += np.array([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4])
+        kept.append(g.size())
+    D.torch.cuda.synchronize()
+    total = time.perf_counter() - t_all
+    lat = np.array(lat) * 1e3
+    result = {
+        "metric": "lidar_frontend_frames_per_s", "value": n_frames / total, "unit": "frames/s", "n_gpus": 1, "steps": n_frames, "warmup": 3,
+        "ms_per_step": total / n_frames * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"8f frontend128k: raw {len(raws[0][0])}-pt scans, preprocess (random grid -> {args.target}) + deskew + covariance + "
+                               f"{args.resolution} m voxel map + 1 unary linearize per frame",
+                   "points_per_frame_raw": int(len(raws[0][0])), "points_per_frame_kept": int(np.mean(kept)),
+                   "latency_ms_p50": float(np.percentile(lat, 50)), "latency_ms_p99": float(np.percentile(lat, 99)),
+                   "stage_ms": dict(zip(["preprocess", "deskew", "covariance", "voxelmap", "linearize"], (stage / n_frames * 1e3).round(4).tolist()))},
+    }
+    if not args.no_cpu_baseline and D.rank == 0:
+        from oracle import oracle as orc
+
+        p4, times, inten, _ = raws[0]
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 5.0:
+            ref = orc.preprocess(p4[:, :3], times, inten, orc.preprocess_params(seed=0, **prm_kw))
+            d = orc.deskew(ref["points"], ref["times"], Til, linear_vel=lv, angular_vel=av)
+            orc.covariances(d, ref["neighbors"])
+            reps += 1
+        cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        got = api.PointCloudGPU.preprocess(p4, times, inten, api.preprocess_params(seed=0, **prm_kw), ctx=ctx).download_frame()
+        assert np.array_equal(got["points"], ref["points"]) and np.array_equal(got["neighbors"], ref["neighbors"]), "device preprocessing != oracle"
+        result["cpu_baseline"] = {"value": 1e3 / cpu_ms, "unit": "frames/s", "cores": effective_cores(), "kind": "port",
+                                  "sample": f"{reps} frames: oracle preprocess + deskew + covariances (no voxel map / factor), {cpu_ms:.1f} ms per frame"}
+        log(f"parity: device preprocessing == oracle on frame 0 ({len(ref['points'])} points, bit-exact points and neighbours)")
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="odometry128k", choices=["odometry128k", "submap20", "global256", "rgbd300k"])
+    ap.add_argument("--workload", default="odometry128k", choices=["odometry128k", "submap20", "global256", "rgbd300k", "frontend128k"])
     ap.add_argument("--factors", type=int, default=128, help="odometry128k: factors per GPU per step")
     ap.add_argument("--rings", type=int, default=128)
     ap.add_argument("--azimuths", type=int, default=1024)
     ap.add_argument("--resolution", type=float, default=0.5)
     ap.add_argument("--submaps", type=int, default=256, help="global256: number of submaps")
-    ap.add_argument("--frames", type=int, default=300, help="rgbd300k: frames in the timed stream")
+    ap.add_argument("--frames", type=int, default=300, help="rgbd300k / frontend128k: frames in the timed stream")
+    ap.add_argument("--target", type=int, default=10000, help="frontend128k: random_downsample_target (config_preprocess.json ships 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -477,7 +557,8 @@ def main():
 
     # run on torch's current stream so that torch.cuda.synchronize(), RCCL and our kernels are ordered together
     ctx = api.Context(D.local_rank, 1, external_stream=D.torch.cuda.current_stream().cuda_stream)
-    runner = {"odometry128k": run_odometry128k, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k}[args.workload]
+    runner = {"odometry128k": run_odometry128k, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k,
+              "frontend128k": run_frontend128k}[args.workload]
     result = runner(args, D, api, ctx)
     D.finish()
     sys.stdout.flush()

@@ -164,6 +164,8 @@ hipError_t pool_malloc_impl(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
+  static const bool trace = getenv("GLIM_AMD_POOL_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[glim_amd pool] miss: hipMalloc(%zu)\n", want);
   hipError_t e = hipMalloc(p, want);
   if (e != hipSuccess && !pool_disabled()) {  // out of memory: drop the cache and retry once
     (void)hipGetLastError();
@@ -199,7 +201,76 @@ hipError_t pool_free(void* p) {
   return hipFree(p);
 }
 
+// Pinned, device-mapped host memory (completion flags, pose / result staging of a factor set): hipHostMalloc / hipHostFree cost
+// 100+ us each, and GLIM builds a fresh NonlinearFactorSetGPU for every linearisation, so these blocks are cached by size too.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> live;
+  size_t cached_bytes = 0;
+};
+PinnedPool& pinned_pool() {
+  static PinnedPool* pool = new PinnedPool();  // leaked on purpose, like the device pools
+  return *pool;
+}
+constexpr size_t kMaxCachedPinnedBytes = 256ull << 20;
+}  // namespace
+
+hipError_t pinned_malloc_impl(void** p, size_t bytes) {
+  size_t want = 256;
+  while (want < bytes) want <<= 1;  // power-of-two size classes: a set that grows by one factor still hits the cache
+  PinnedPool& P = pinned_pool();
+  if (!pool_disabled()) {
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.free_blocks.find(want);
+    if (it != P.free_blocks.end()) {
+      *p = it->second;
+      P.live[*p] = want;
+      P.cached_bytes -= want;
+      P.free_blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipHostMalloc(p, want, hipHostMallocMapped);
+  if (e == hipSuccess && !pool_disabled()) {
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.live[*p] = want;
+  }
+  return e;
+}
+
+hipError_t pinned_free(void* p) {
+  if (!p) return hipSuccess;
+  if (pool_disabled()) return hipHostFree(p);
+  PinnedPool& P = pinned_pool();
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return hipHostFree(p);
+    const size_t sz = it->second;
+    P.live.erase(it);
+    if (P.cached_bytes + sz <= kMaxCachedPinnedBytes) {
+      P.free_blocks.emplace(sz, p);
+      P.cached_bytes += sz;
+      return hipSuccess;
+    }
+  }
+  return hipHostFree(p);
+}
+
 void pool_trim(int device) {
+  {
+    PinnedPool& H = pinned_pool();
+    std::vector<void*> blocks;
+    {
+      std::lock_guard<std::mutex> lock(H.mu);
+      for (auto& kv : H.free_blocks) blocks.push_back(kv.second);
+      H.free_blocks.clear();
+      H.cached_bytes = 0;
+    }
+    for (void* b : blocks) (void)hipHostFree(b);
+  }
   DevicePool& P = pool_of(device);
   std::vector<void*> blocks;
   {

@@ -101,4 +101,38 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// block-level integer reductions (blocks of <= 1024 threads): wavefront butterflies, then one LDS round; the result is
+// valid in thread 0.  Used so that a kernel issues ONE set of global atomics per block: atomics of many wavefronts on
+// the same address serialise in L2 (measured ~10 ns each on MI355X -- 12 000 of them cost more than the kernel body).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// OP: 0 = min, 1 = max, 2 = sum.  s_tmp: >= 16 ints of LDS per call site (a __syncthreads() separates consecutive calls).
+template <int OP>
+__device__ __forceinline__ int block_reduce_i(int v, int* s_tmp) {
+  v = OP == 0 ? wave_min_i(v) : (OP == 1 ? wave_max_i(v) : wave_sum_i(v));
+  const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) s_tmp[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < waves; w++) v = OP == 0 ? min(v, s_tmp[w]) : (OP == 1 ? max(v, s_tmp[w]) : v + s_tmp[w]);
+  }
+  __syncthreads();
+  return v;
+}
+
 }  // namespace glim_amd

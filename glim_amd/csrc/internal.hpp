@@ -23,6 +23,13 @@ void set_hip_error(hipError_t e, const char* what);
 hipError_t pool_malloc_impl(void** p, size_t bytes);
 hipError_t pool_free(void* p);
 void pool_trim(int device);
+// pinned + device-mapped host memory, cached by size class (context.hip)
+hipError_t pinned_malloc_impl(void** p, size_t bytes);
+hipError_t pinned_free(void* p);
+template <class T>
+inline hipError_t pinned_malloc(T** p, size_t bytes) {
+  return pinned_malloc_impl(reinterpret_cast<void**>(p), bytes);
+}
 template <class T>
 inline hipError_t pool_malloc(T** p, size_t bytes) {
   return pool_malloc_impl(reinterpret_cast<void**>(p), bytes);

@@ -226,15 +226,13 @@ __global__ __launch_bounds__(256) void bbox_kernel(int n, const float4* __restri
       hi[a] = max(hi[a], v[a]);
     }
   }
-  // wave-level min/max first: one set of atomics per wavefront instead of one per lane
+  // one set of atomics per BLOCK (same-address atomics serialise in L2)
+  __shared__ int s_tmp[16];
   for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
-      hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
-    }
+    lo[a] = block_reduce_i<0>(lo[a], s_tmp);
+    hi[a] = block_reduce_i<1>(hi[a], s_tmp);
   }
-  if ((threadIdx.x & 63) == 0)
+  if (threadIdx.x == 0)
     for (int a = 0; a < 3; a++) {
       atomicMin(&bb[a], lo[a]);
       atomicMax(&bb[3 + a], hi[a]);
@@ -306,7 +304,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
-  bbox_kernel<<<std::min((n + 255) / 256, 1024), 256, 0, st>>>(n, pts, (int*)bb.p);
+  bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, (int*)bb.p);
   int h_bb[6];
   GA_HIP(hipMemcpyAsync(h_bb, bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
   GA_HIP(hipStreamSynchronize(st));

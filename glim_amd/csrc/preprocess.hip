@@ -40,47 +40,40 @@ __host__ __device__ inline u64 sample_hash(u64 seed, u64 index) {
   return z ^ (z >> 31);
 }
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // ---- K9a: voxel key (x lowest, 21 bits per axis, offset 2^20) + bounding box of the valid coordinates ----
 __global__ __launch_bounds__(256) void pp_key_kernel(int n, const double4* __restrict__ p4, double inv_res, u64* __restrict__ vkey,
                                                      int* __restrict__ bb) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  int c[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-  bool valid = false;
-  if (i < n) {
+  __shared__ int s_tmp[16];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const double4 p = p4[i];
     const double t[3] = {p.x * inv_res, p.y * inv_res, p.z * inv_res};
-    valid = isfinite(p.w);
+    bool valid = isfinite(p.w);
 #pragma unroll
     for (int a = 0; a < 3; a++) valid = valid && (t[a] >= -1048576.0 && t[a] < 1048576.0);  // false for NaN / inf
+    u64 key = INVALID_VKEY;
     if (valid) {
+      int c[3];
 #pragma unroll
-      for (int a = 0; a < 3; a++) c[a] = fast_floor_d(t[a]) + KEY_OFFSET;
+      for (int a = 0; a < 3; a++) {
+        c[a] = fast_floor_d(t[a]) + KEY_OFFSET;
+        lo[a] = min(lo[a], c[a]);
+        hi[a] = max(hi[a], c[a]);
+      }
+      key = (u64)c[0] | ((u64)c[1] << 21) | ((u64)c[2] << 42);
     }
-    vkey[i] = valid ? ((u64)c[0] | ((u64)c[1] << 21) | ((u64)c[2] << 42)) : INVALID_VKEY;
+    vkey[i] = key;
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    const int lo = wave_min_i(c[a]);
-    const int hi = wave_max_i(valid ? c[a] : (int)0x80000000);
-    if ((threadIdx.x & 63) == 0) {
-      if (lo != 0x7fffffff) atomicMin(&bb[a], lo);
-      if (hi != (int)0x80000000) atomicMax(&bb[3 + a], hi);
+    lo[a] = block_reduce_i<0>(lo[a], s_tmp);
+    hi[a] = block_reduce_i<1>(hi[a], s_tmp);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (lo[a] != 0x7fffffff) atomicMin(&bb[a], lo[a]);
+      if (hi[a] != (int)0x80000000) atomicMax(&bb[3 + a], hi[a]);
     }
   }
 }
@@ -111,11 +104,17 @@ __global__ __launch_bounds__(256) void pp_gather_key_kernel(int n, const u32* __
 
 // counters[0] = number of distinct valid keys in the sorted order, counters[1] = number of valid entries
 __global__ __launch_bounds__(256) void pp_count_voxels_kernel(int n, const u64* __restrict__ k, u64 invalid, int* __restrict__ counters) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = j < n && k[j] != invalid;
-  const bool head = valid && (j == 0 || k[j - 1] != k[j]);
-  const int heads = wave_sum_i(head ? 1 : 0), valids = wave_sum_i(valid ? 1 : 0);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ int s_tmp[16];
+  int heads = 0, valids = 0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const u64 key = k[j];
+    const bool valid = key != invalid;
+    valids += valid;
+    heads += valid && (j == 0 || k[j - 1] != key);
+  }
+  heads = block_reduce_i<2>(heads, s_tmp);
+  valids = block_reduce_i<2>(valids, s_tmp);
+  if (threadIdx.x == 0) {
     if (heads) atomicAdd(&counters[0], heads);
     if (valids) atomicAdd(&counters[1], valids);
   }
@@ -124,17 +123,21 @@ __global__ __launch_bounds__(256) void pp_count_voxels_kernel(int n, const u64* 
 // randomgrid_sampling: rank inside the voxel < points_per_voxel  <=>  the entry ppv places earlier belongs to another voxel
 __global__ __launch_bounds__(256) void pp_select_kernel(int n, double rate, const u64* __restrict__ k, const u32* __restrict__ v, u64 invalid,
                                                         int* __restrict__ counters, int* __restrict__ sel) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  __shared__ int s_tmp[16];
   const int num_voxels = counters[0];
-  bool keep = false;
-  if (j < n && num_voxels > 0) {
+  int kept = 0;
+  if (num_voxels > 0) {
     const long long ppv = (long long)ceil((rate * (double)n) / (double)num_voxels);
-    const u64 key = k[j];
-    keep = key != invalid && ((long long)j < ppv || k[j - ppv] != key);
-    if (keep) sel[v[j]] = 1;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+      const u64 key = k[j];
+      if (key != invalid && ((long long)j < ppv || k[j - ppv] != key)) {
+        sel[v[j]] = 1;
+        kept++;
+      }
+    }
   }
-  const int cnt = wave_sum_i(keep ? 1 : 0);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counters[2], cnt);
+  kept = block_reduce_i<2>(kept, s_tmp);
+  if (threadIdx.x == 0 && kept) atomicAdd(&counters[2], kept);
 }
 
 __global__ __launch_bounds__(256) void pp_cap_key_kernel(int n, u64 seed, const int* __restrict__ sel, u64* __restrict__ keys) {
@@ -169,27 +172,38 @@ __global__ __launch_bounds__(256) void pp_seg_start_kernel(int n, const int* __r
   else if (heads[j]) seg_start[seg[j]] = j;
 }
 
-__global__ __launch_bounds__(256) void pp_segment_mean_kernel(int m, const int* __restrict__ seg_start, const u32* __restrict__ v,
-                                                              const double4* __restrict__ p4, const double* __restrict__ times,
-                                                              const double* __restrict__ inten, double4* __restrict__ outP, double* __restrict__ outT,
-                                                              double* __restrict__ outI) {
+// the raw arrays permuted into the sorted order, so that the sequential walk below streams consecutive memory
+__global__ __launch_bounds__(256) void pp_gather_sorted_kernel(int n, const u32* __restrict__ v, const double4* __restrict__ p4,
+                                                               const double* __restrict__ times, const double* __restrict__ inten,
+                                                               double4* __restrict__ sP, double* __restrict__ sT, double* __restrict__ sI) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const u32 i = v[j];
+  sP[j] = p4[i];
+  sT[j] = times[i];
+  if (inten) sI[j] = inten[i];
+}
+
+__global__ __launch_bounds__(256) void pp_segment_mean_kernel(int m, const int* __restrict__ seg_start, const double4* __restrict__ sP,
+                                                              const double* __restrict__ sT, const double* __restrict__ sI, double4* __restrict__ outP,
+                                                              double* __restrict__ outT, double* __restrict__ outI) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= m) return;
   const int begin = seg_start[s], end = seg_start[s + 1];
   double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0, st = 0.0, si = 0.0;
+#pragma unroll 4
   for (int j = begin; j < end; j++) {  // sequential: the same additions in the same order as the CPU loop
-    const u32 i = v[j];
-    const double4 p = p4[i];
+    const double4 p = sP[j];
     sx += p.x;
     sy += p.y;
     sz += p.z;
     sw += p.w;
-    st += times[i];
-    if (inten) si += inten[i];
+    st += sT[j];
+    if (sI) si += sI[j];
   }
   outP[s] = make_double4(sx / sw, sy / sw, sz / sw, sw / sw);
   outT[s] = st / sw;
-  if (inten) outI[s] = si / sw;
+  if (sI) outI[s] = si / sw;
 }
 
 // ---- range / finite / cropbox predicate (cloud_preprocessor.cpp:122-128, :146-160) ----
@@ -316,6 +330,8 @@ __global__ __launch_bounds__(256) void pp_compact_index_kernel(int m, const int*
 }
 
 inline int grid_for(int n) { return (n + 255) / 256; }
+// grid-stride kernels that end in one set of atomics per block: few, fat blocks
+inline int reduce_grid_for(int n) { return std::max(1, std::min((n + 2047) / 2048, 128)); }
 inline int bits_for(int range) {
   int b = 0;
   while (range > 0) {
@@ -388,8 +404,8 @@ int downsample_random(hipStream_t st, int n, const double4* p4, const u64* ckey,
   const u64 invalid = 1ull << vbits;
   GA_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
   GA_HIP(hipMemsetAsync(sel, 0, (size_t)n * sizeof(int), st));
-  pp_count_voxels_kernel<<<grid_for(n), 256, 0, st>>>(n, ks, invalid, counters);
-  pp_select_kernel<<<grid_for(n), 256, 0, st>>>(n, rate, ks, vs, invalid, counters, sel);
+  pp_count_voxels_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, ks, invalid, counters);
+  pp_select_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, rate, ks, vs, invalid, counters, sel);
   GA_HIP(hipGetLastError());
   GA_HIP(hipMemcpyAsync(h_counters, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   GA_HIP(hipStreamSynchronize(st));
@@ -427,8 +443,13 @@ int downsample_voxelgrid(hipStream_t st, int n, const double4* p4, const double*
   if (m == 0) return GLIM_AMD_OK;
   GA_HIP(pool_malloc(&seg_start.p, (size_t)(m + 1) * sizeof(int)));
   pp_seg_start_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, heads.as<int>(), seg.as<int>(), counters + 1, seg_start.as<int>());
-  pp_segment_mean_kernel<<<grid_for(m), 256, 0, st>>>(m, seg_start.as<int>(), vs, p4, times, inten, avgP.as<double4>(), avgT.as<double>(),
-                                                      avgI.as<double>());
+  DeviceTemp sP, sT, sI;
+  GA_HIP(pool_malloc(&sP.p, (size_t)n * sizeof(double4)));
+  GA_HIP(pool_malloc(&sT.p, (size_t)n * sizeof(double)));
+  if (inten) GA_HIP(pool_malloc(&sI.p, (size_t)n * sizeof(double)));
+  pp_gather_sorted_kernel<<<grid_for(n), 256, 0, st>>>(n, vs, p4, times, inten, sP.as<double4>(), sT.as<double>(), sI.as<double>());
+  pp_segment_mean_kernel<<<grid_for(m), 256, 0, st>>>(m, seg_start.as<int>(), sP.as<double4>(), sT.as<double>(), sI.as<double>(), avgP.as<double4>(),
+                                                      avgT.as<double>(), avgI.as<double>());
   GA_HIP(hipGetLastError());
   GA_HIP(hipStreamSynchronize(st));  // the scratch of this scope is released on return
   return GLIM_AMD_OK;
@@ -507,7 +528,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
         int h_bb[6];
         GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
-        pp_key_kernel<<<grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
+        pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
         GA_HIP(hipGetLastError());
         GA_HIP(hipMemcpyAsync(h_bb, d_bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
         GA_HIP(hipStreamSynchronize(st));

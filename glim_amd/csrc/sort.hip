@@ -5,15 +5,18 @@
 // (std::sort, cloud_preprocessor.cpp:135).  Stability is what makes the device result reproduce the oracle's
 // (key, original index) order exactly.
 //
-// One pass = 8 key bits, three launches:
-//   rs_hist     every block owns a tile of RS_TILE consecutive pairs and counts its 256 digit values in LDS;
+// One pass = 8 key bits, two launches (three for very large inputs):
+//   rs_hist     every block owns a tile of 256 x ROUNDS consecutive pairs and counts its 256 digit values in LDS;
 //               hist[digit][block] (digit-major) goes to global memory
-//   rs_offsets  ONE block turns the 256 x B table into global exclusive offsets (digit-major order == the output order of
-//               a stable sort: all pairs with a smaller digit first, then the same digit in earlier blocks)
-//   rs_scatter  every block re-reads its tile in 8 rounds of 256 threads; inside a round the rank of a pair among the equal
-//               digits is  (equal digits in earlier rounds)  +  (equal digits in earlier waves of this round)  +
+//   rs_scatter  thread d of every block first derives the block's global offset for digit d from row d of that table (digit-major
+//               order == the output order of a stable sort: all pairs with a smaller digit first, then the same digit in
+//               earlier blocks) -- the table has <= 256 columns and sits in L2, so re-deriving it per block is cheaper than
+//               a separate single-block scan launch; above 256 blocks a separate rs_offsets launch does it once.
+//               The block then re-reads its tile in ROUNDS rounds of 256 threads; inside a round the rank of a pair among
+//               the equal digits is  (equal digits in earlier rounds)  +  (equal digits in earlier waves of this round)  +
 //               (equal digits in lower lanes of this wave); the last term comes from 8 ballots (one per digit bit), so the
 //               order inside a tile is exactly the index order
+// ROUNDS (1, 2, 4, 8) is the smallest tile that keeps the grid at <= 256 blocks: small inputs still spread over the chip.
 // Only the key bits the caller declares significant are sorted (`bits`): voxel keys are compacted to the bounding box of the
 // scan first (~20 bits instead of 63), so a 131 072-point scan needs 3 passes, not 8.
 #include "internal.hpp"
@@ -23,32 +26,32 @@ using namespace glim_amd;
 namespace {
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_ROUNDS = 8;
-constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;
+constexpr int RS_FUSED_MAX_BLOCKS = 256;
 
+template <int ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long long* __restrict__ keys, int n, int shift, int mask, int* __restrict__ hist,
-                                                             int B) {
+                                                             int stride) {
   __shared__ int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const int base = blockIdx.x * RS_TILE;
+  const int base = blockIdx.x * (RS_THREADS * ROUNDS);
 #pragma unroll
-  for (int r = 0; r < RS_ROUNDS; r++) {
+  for (int r = 0; r < ROUNDS; r++) {
     const int i = base + r * RS_THREADS + (int)threadIdx.x;
     if (i < n) atomicAdd(&h[(int)(keys[i] >> shift) & mask], 1);
   }
   __syncthreads();
-  hist[threadIdx.x * B + blockIdx.x] = h[threadIdx.x];
+  hist[threadIdx.x * stride + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of E = 256 * B ints in place by one block of 1024 threads (thread t owns a run of consecutive entries)
+// exclusive scan of E = 256 * stride ints in place by one block of 1024 threads (thread t owns a run of consecutive entries);
+// only used when the grid has more than RS_FUSED_MAX_BLOCKS blocks
 __global__ __launch_bounds__(1024) void rs_offsets_kernel(int* __restrict__ hist, int E) {
   __shared__ int s_wave[16];
   const int per = (E + 1023) / 1024;
   const int begin = (int)threadIdx.x * per, end = min(E, begin + per);
   int sum = 0;
   for (int i = begin; i < end; i++) sum += hist[i];
-  // block exclusive scan of the 1024 thread sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = sum;
 #pragma unroll
@@ -68,19 +71,47 @@ __global__ __launch_bounds__(1024) void rs_offsets_kernel(int* __restrict__ hist
   }
 }
 
+template <int ROUNDS, bool FUSED>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in,
                                                                 unsigned long long* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int n,
-                                                                int shift, int mask, const int* __restrict__ offsets, int B) {
+                                                                int shift, int mask, const int* __restrict__ table, int stride) {
   __shared__ int wave_cnt[RS_THREADS / 64][256];
   __shared__ int running[256];
+  __shared__ int s_wave[RS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  running[tid] = offsets[tid * B + blockIdx.x];
+  if (FUSED) {
+    // row `tid` of the histogram table (stride is a multiple of 4, padding columns are zero): digit total and the part in earlier blocks
+    const int4* row = reinterpret_cast<const int4*>(table + (size_t)tid * stride);
+    int total = 0, before = 0;
+    const int my4 = (int)blockIdx.x >> 2, my_r = (int)blockIdx.x & 3;
+    for (int c = 0; c < stride / 4; c++) {
+      const int4 v = row[c];
+      const int s4 = (v.x + v.y) + (v.z + v.w);
+      total += s4;
+      if (c < my4) before += s4;
+      else if (c == my4) before += (my_r > 0 ? v.x : 0) + (my_r > 1 ? v.y : 0) + (my_r > 2 ? v.z : 0);
+    }
+    int inc = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    running[tid] = wave_off + inc - total + before;
+  } else {
+    running[tid] = table[(size_t)tid * stride + blockIdx.x];
+  }
 #pragma unroll
   for (int w = 0; w < RS_THREADS / 64; w++) wave_cnt[w][tid] = 0;
   __syncthreads();
-  const int base = blockIdx.x * RS_TILE;
+  const int base = blockIdx.x * (RS_THREADS * ROUNDS);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  for (int r = 0; r < RS_ROUNDS; r++) {
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
     const int i = base + r * RS_THREADS + tid;
     const bool valid = i < n;
     const unsigned long long key = valid ? keys_in[i] : 0ull;
@@ -103,41 +134,77 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned l
       keys_out[dst] = key;
       vals_out[dst] = val;
     }
-    __syncthreads();
-    int add = 0;
+    if (r + 1 < ROUNDS) {
+      __syncthreads();
+      int add = 0;
 #pragma unroll
-    for (int w = 0; w < RS_THREADS / 64; w++) {
-      add += wave_cnt[w][tid];
-      wave_cnt[w][tid] = 0;
+      for (int w = 0; w < RS_THREADS / 64; w++) {
+        add += wave_cnt[w][tid];
+        wave_cnt[w][tid] = 0;
+      }
+      running[tid] += add;
+      __syncthreads();
     }
-    running[tid] += add;
-    __syncthreads();
   }
+}
+
+template <int ROUNDS>
+void launch_pass(hipStream_t st, int B, int stride, const unsigned long long* kin, const unsigned int* vin, unsigned long long* kout, unsigned int* vout, int n,
+                 int shift, int mask, int* table) {
+  rs_hist_kernel<ROUNDS><<<B, RS_THREADS, 0, st>>>(kin, n, shift, mask, table, stride);
+  if (B <= RS_FUSED_MAX_BLOCKS) {
+    rs_scatter_kernel<ROUNDS, true><<<B, RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, mask, table, stride);
+  } else {
+    rs_offsets_kernel<<<1, 1024, 0, st>>>(table, 256 * stride);
+    rs_scatter_kernel<ROUNDS, false><<<B, RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, mask, table, stride);
+  }
+}
+
+inline int pick_rounds(int n) {
+  for (int r = 1; r < 8; r <<= 1)
+    if ((n + RS_THREADS * r - 1) / (RS_THREADS * r) <= RS_FUSED_MAX_BLOCKS) return r;
+  return 8;
+}
+inline int table_stride(int n) {
+  const int r = pick_rounds(n);
+  const int B = (n + RS_THREADS * r - 1) / (RS_THREADS * r);
+  return (B + 3) & ~3;
 }
 
 }  // namespace
 
 namespace glim_amd {
 
-size_t radix_sort_scratch_bytes(int n) { return (size_t)256 * (size_t)((n + RS_TILE - 1) / RS_TILE + 1) * sizeof(int); }
+// (sized so that the same scratch also serves any smaller sort: a smaller input may pick a smaller tile and up to 256 blocks)
+size_t radix_sort_scratch_bytes(int n) { return (size_t)256 * (size_t)std::max(table_stride(n > 0 ? n : 1), RS_FUSED_MAX_BLOCKS) * sizeof(int); }
 
 // Sorts n pairs by the low `bits` bits of the key, stable.  Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); the
 // sorted pairs end up in (*keys_sorted, *vals_sorted), which is one of the two.  vals_a_is_iota: the values are 0..n-1 and
-// vals_a does not need to be initialised.  Enqueues on `st`; no synchronisation.
+// vals_a does not need to be initialised.  `scratch`: radix_sort_scratch_bytes(n' >= n).  Enqueues on `st`; no synchronisation.
 hipError_t radix_sort_pairs(hipStream_t st, int n, int bits, unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
                             unsigned int* vals_b, bool vals_a_is_iota, int* scratch, unsigned long long** keys_sorted, unsigned int** vals_sorted) {
   unsigned long long *kin = keys_a, *kout = keys_b;
   unsigned int *vin = vals_a, *vout = vals_b;
   if (n > 0) {
-    const int B = (n + RS_TILE - 1) / RS_TILE;
+    const int rounds = pick_rounds(n);
+    const int B = (n + RS_THREADS * rounds - 1) / (RS_THREADS * rounds);
+    const int stride = table_stride(n);
+    if (stride != B) {  // the padding columns of the table are read by the fused offset computation: keep them zero
+      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)256 * stride * sizeof(int), st);
+      if (e != hipSuccess) return e;
+    }
     const int passes = bits <= 0 ? 1 : (bits + 7) / 8;  // bits == 0: one identity pass (materialises iota values)
     for (int p = 0; p < passes; p++) {
       const int shift = 8 * p;
       const int rem = bits - shift;
       const int mask = rem >= 8 ? 255 : (rem <= 0 ? 0 : (1 << rem) - 1);  // key bits above `bits` are ignored
-      rs_hist_kernel<<<B, RS_THREADS, 0, st>>>(kin, n, shift, mask, scratch, B);
-      rs_offsets_kernel<<<1, 1024, 0, st>>>(scratch, 256 * B);
-      rs_scatter_kernel<<<B, RS_THREADS, 0, st>>>(kin, (p == 0 && vals_a_is_iota) ? nullptr : vin, kout, vout, n, shift, mask, scratch, B);
+      const unsigned int* v = (p == 0 && vals_a_is_iota) ? nullptr : vin;
+      switch (rounds) {
+        case 1: launch_pass<1>(st, B, stride, kin, v, kout, vout, n, shift, mask, scratch); break;
+        case 2: launch_pass<2>(st, B, stride, kin, v, kout, vout, n, shift, mask, scratch); break;
+        case 4: launch_pass<4>(st, B, stride, kin, v, kout, vout, n, shift, mask, scratch); break;
+        default: launch_pass<8>(st, B, stride, kin, v, kout, vout, n, shift, mask, scratch); break;
+      }
       std::swap(kin, kout);
       std::swap(vin, vout);
     }

@@ -518,8 +518,8 @@ void factor_set_release_plan(glim_amd_factor_set* set) {
   set->d_done = nullptr;
   if (set->d_tickets) (void)pool_free(set->d_tickets);
   set->d_tickets = nullptr;
-  if (set->h_poses) (void)hipHostFree(set->h_poses);
-  if (set->h_compact) (void)hipHostFree(set->h_compact);
+  if (set->h_poses) (void)pinned_free(set->h_poses);
+  if (set->h_compact) (void)pinned_free(set->h_compact);
   set->d_descs = nullptr;
   set->d_blockmap = nullptr;
   set->d_partials = nullptr;
@@ -642,11 +642,11 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   GA_HIP(pool_malloc(&set->d_done, sizeof(int)));
   GA_HIP(hipMemsetAsync(set->d_done, 0, sizeof(int), set->stream));
   if (!set->h_flag) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&set->h_flag), 64, hipHostMallocMapped) == hipSuccess) {
+    if (pinned_malloc(&set->h_flag, 64) == hipSuccess) {
       *set->h_flag = 0;
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_flag_dev), set->h_flag, 0) != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipHostFree(set->h_flag);
+        (void)pinned_free(set->h_flag);
         set->h_flag = nullptr;
         set->h_flag_dev = nullptr;
       }
@@ -655,8 +655,8 @@ int factor_set_prepare(glim_amd_factor_set* set) {
       set->h_flag = nullptr;
     }
   }
-  GA_HIP(hipHostMalloc(&set->h_poses, nfa * 24 * sizeof(double), hipHostMallocDefault));
-  GA_HIP(hipHostMalloc(&set->h_compact, nfa * COMPACT * sizeof(double), hipHostMallocMapped));
+  GA_HIP(pinned_malloc(&set->h_poses, nfa * 24 * sizeof(double)));
+  GA_HIP(pinned_malloc(&set->h_compact, nfa * COMPACT * sizeof(double)));
   set->h_compact_dev = nullptr;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_compact_dev), set->h_compact, 0) != hipSuccess) {
     (void)hipGetLastError();
@@ -773,6 +773,7 @@ int glim_amd_factor_set_destroy(glim_amd_factor_set* set) {
   (void)hipSetDevice(set->ctx->device);
   (void)hipStreamSynchronize(set->stream);
   factor_set_release_plan(set);
+  if (set->h_flag) (void)pinned_free(set->h_flag);
   delete set;
   return GLIM_AMD_OK;
 }

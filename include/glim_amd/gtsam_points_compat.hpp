@@ -95,7 +95,19 @@ public:
     check(glim_amd_cloud_create_f32(c->ctx_->context(), n, xyz, cov33, normals3, &c->h_), "PointCloudGPU::clone");
     return c;
   }
+  // takes ownership of a cloud created by another C-ABI call (glim_amd_preprocess, glim_amd_cloud_deskew)
+  static Ptr adopt(glim_amd_cloud* h, Context ctx) {
+    auto c = Ptr(new PointCloudGPU(ctx ? ctx : StreamTempBufferRoundRobin::default_instance()));
+    c->h_ = h;
+    return c;
+  }
   ~PointCloudGPU() { glim_amd_cloud_destroy(h_); }
+  // parity / debug: FP32 coordinates back on the host (n x 3)
+  std::vector<float> download_points() const {
+    std::vector<float> xyz(size() * 3);
+    check(glim_amd_cloud_download(h_, xyz.data(), nullptr, nullptr, nullptr), "PointCloudGPU::download_points");
+    return xyz;
+  }
   std::size_t size() const {
     std::int64_t n = 0;
     glim_amd_cloud_size(h_, &n);

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/glim_amd/gtsam_points_compat.hpp"
+#include "../../include/glim_amd/glim_preprocess_compat.hpp"
 #include "../../oracle/vgicp_oracle.h"
 
 using namespace glim_amd;
@@ -151,6 +152,71 @@ int main() {
       REQUIRE(std::fabs(factors[0]->inlier_fraction() - ov) < 1e-12);
     }
     orc_voxelmap_destroy(om);
+  }
+  // ---- the per-scan front end: CloudPreprocessor::preprocess -> CloudDeskewing::deskew -> covariances (odometry_estimation_imu.cpp:300-325) ----
+  {
+    auto raw = std::make_shared<RawPoints>();
+    const int nr = 60000;
+    const std::vector<double> rp = make_scan(nr, 3.0, 2.0, 0.3, 99);
+    raw->stamp = 1234.5;
+    raw->points.resize(nr);
+    raw->times.resize(nr);
+    raw->intensities.resize(nr);
+    std::mt19937_64 rng(5);
+    std::uniform_real_distribution<double> U(0.0, 0.1);
+    for (int i = 0; i < nr; i++) {
+      raw->points[i] = {rp[4 * i], rp[4 * i + 1], rp[4 * i + 2], 1.0};
+      raw->times[i] = U(rng);
+      raw->intensities[i] = (double)(i % 255);
+    }
+    CloudPreprocessorParams params;
+    params.downsample_resolution = 0.25;
+    params.downsample_target = 8000;
+    params.distance_near_thresh = 1.0;
+    params.seed = 42;
+    CloudPreprocessor preprocessor(params);
+    auto frame = preprocessor.preprocess(raw);
+    // the oracle on the same scan with the same parameters
+    orc_preprocess_params op;
+    std::memset(&op, 0, sizeof(op));
+    const glim_amd_preprocess_params cp = params.c_params();
+    static_assert(sizeof(orc_preprocess_params) == sizeof(glim_amd_preprocess_params), "parameter blocks mirror each other");
+    std::memcpy(&op, &cp, sizeof(op));
+    op.seed = 42;
+    std::vector<double> ref_p(4 * (size_t)nr), ref_t(nr), ref_i(nr);
+    std::vector<int32_t> ref_nb((size_t)nr * 10);
+    const int m = orc_preprocess(rp.data(), raw->times.data(), raw->intensities.data(), nr, &op, ref_p.data(), ref_t.data(), ref_i.data(), ref_nb.data(), 0);
+    REQUIRE(frame->size() == m && m > 5000 && m <= 9600);
+    REQUIRE(frame->k_neighbors == 10 && (int)frame->neighbors.size() == 10 * m);
+    for (int i = 0; i < m; i++) {
+      for (int a = 0; a < 4; a++) REQUIRE(frame->points[i][a] == ref_p[4 * (size_t)i + a]);
+      REQUIRE(frame->times[i] == ref_t[i] && frame->intensities[i] == ref_i[i]);
+      if (i) REQUIRE(frame->times[i] >= frame->times[i - 1]);
+    }
+    for (size_t i = 0; i < frame->neighbors.size(); i++) REQUIRE(frame->neighbors[i] == ref_nb[i]);
+    REQUIRE(frame->scan_end_time == raw->stamp + frame->times[m - 1]);
+    // a second frame draws a different sample (the reference's mt19937 advances too)
+    auto frame2 = preprocessor.preprocess(raw);
+    REQUIRE(frame2->size() == m);
+    bool differs = false;
+    for (int i = 0; i < m && !differs; i++) differs = frame2->points[i] != frame->points[i];
+    REQUIRE(differs);
+    // deskew on the device, constant-velocity form, then covariances with the raw scan's neighbours
+    const Isometry3d T_imu_lidar = pose2d(0.1, -0.05, 0.02);
+    const Vector3d lv{{3.0, -1.0, 0.2}}, av{{0.05, -0.1, 0.8}};
+    CloudDeskewing deskewing;
+    auto deskewed = deskewing.deskew(*frame, T_imu_lidar, lv, av);
+    REQUIRE((int)deskewed->size() == m);
+    std::vector<double> ref_d(4 * (size_t)m);
+    orc_deskew_constvel(T_imu_lidar.m.data(), lv.data(), av.data(), ref_t.data(), ref_p.data(), m, ref_d.data());
+    const std::vector<float> got_d = deskewed->download_points();
+    for (int i = 0; i < m; i++)
+      for (int a = 0; a < 3; a++) REQUIRE(std::fabs((double)got_d[3 * (size_t)i + a] - ref_d[4 * (size_t)i + a]) <= 1e-6 * (1.0 + std::fabs(ref_d[4 * (size_t)i + a])));
+    deskewed->estimate_covariances(10);
+    auto vm = std::make_shared<GaussianVoxelMapGPU>(0.5);
+    vm->insert(*deskewed);
+    REQUIRE(vm->voxelmap_info().num_voxels > 100);
+    std::printf("front end OK: %d -> %d points\n", nr, m);
   }
   std::printf("test_compat OK: %d points, inliers level0 = %lld\n", n, (long long)factors[0]->linearized().num_inliers);
   return 0;
