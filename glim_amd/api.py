@@ -175,6 +175,13 @@ class PointCloudGPU:
         check(lib().glim_amd_cloud_download_frame(self._h, _dp(p4), _dp(t), _dp(it), _ip(nb)), "glim_amd_cloud_download_frame")
         return dict(points=p4[:, :3].copy(), times=t, intensities=it, neighbors=nb, k_neighbors=k)
 
+    def download_merged(self):
+        """The merged submap as PointCloudCPU holds it: (points N x 3, covs N x 3 x 3), exact FP64."""
+        n = self.size()
+        p4, c16 = np.zeros((n, 4)), np.zeros((n, 16))
+        check(lib().glim_amd_cloud_download_merged(self._h, _dp(p4), _dp(c16)), "glim_amd_cloud_download_merged")
+        return p4[:, :3].copy(), np.transpose(c16.reshape(n, 4, 4)[:, :3, :3], (0, 2, 1)).copy()
+
     def deskew(self, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None):
         """CloudDeskewing::deskew of a preprocessed cloud that is already on the device; the raw-scan neighbours are carried over."""
         Til = pose12(T_imu_lidar)
@@ -497,6 +504,42 @@ def preprocess_params(**kw):
         else:
             setattr(p, k, v)
     return p
+
+
+def _pack_frames(poses, frames_points, frames_covs):
+    """Host layouts of the reference for a list of frames: poses n x 12, Vector4d points, column-major Matrix4d covariances."""
+    nf = len(poses)
+    P12 = np.ascontiguousarray(np.stack([pose12(T) for T in poses])) if nf else np.zeros((1, 12))
+    p4s, c16s = [], []
+    for p, c in zip(frames_points, frames_covs):
+        p = np.asarray(p, dtype=np.float64).reshape(-1, np.shape(p)[-1] if np.ndim(p) == 2 else 3)
+        n = p.shape[0]
+        p4 = np.ones((n, 4))
+        p4[:, : p.shape[1]] = p
+        c = np.asarray(c, dtype=np.float64)
+        c16 = np.zeros((n, 4, 4))
+        if c.size == n * 9:
+            c16[:, :3, :3] = np.transpose(c.reshape(n, 3, 3), (0, 2, 1))
+        else:
+            c16[:] = c.reshape(n, 4, 4)
+        p4s.append(p4)
+        c16s.append(np.ascontiguousarray(c16.reshape(n, 16)))
+    sizes = np.array([len(p) for p in p4s], dtype=np.int64)
+    dp = C.POINTER(C.c_double)
+    pp = (dp * max(nf, 1))(*[_dp(p) for p in p4s])
+    cp = (dp * max(nf, 1))(*[_dp(c) for c in c16s])
+    return dict(nf=nf, P12=P12, p4s=p4s, c16s=c16s, sizes=sizes, pp=pp, cp=cp)
+
+
+def merge_frames(poses, frames_points, frames_covs, downsample_resolution, target_num_points=-1, seed=0, block_size=1024, ctx=None, packed=None):
+    """gtsam_points::merge_frames (sub_mapping.cpp:480-497) on the device.  poses[f]: T_origin_frame; frames_points[f]: N_f x 3 / x 4;
+    frames_covs[f]: N_f x 3 x 3 / 4 x 4.  Returns the merged PointCloudGPU (points + covariances)."""
+    ctx = ctx or default_context()
+    k = packed if packed is not None else _pack_frames(poses, frames_points, frames_covs)
+    h = C.c_void_p()
+    check(lib().glim_amd_merge_frames(ctx._h, k["nf"], _dp(k["P12"]), k["pp"], k["cp"], k["sizes"].ctypes.data_as(C.POINTER(C.c_int64)),
+                                      float(downsample_resolution), int(target_num_points), int(block_size), int(seed), C.byref(h)), "glim_amd_merge_frames")
+    return PointCloudGPU(h, ctx)
 
 
 def debug_sort_pairs(keys, vals=None, bits=64, ctx=None):

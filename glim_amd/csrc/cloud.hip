@@ -173,6 +173,7 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->pts64) (void)pool_free(c->pts64);
   if (c->times) (void)pool_free(c->times);
   if (c->intensities) (void)pool_free(c->intensities);
+  if (c->cov64) (void)pool_free(c->cov64);
   delete c;
   return GLIM_AMD_OK;
 }

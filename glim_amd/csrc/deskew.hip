@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "internal.hpp"
+#include "device_math.hpp"
 
 using namespace glim_amd;
 
@@ -130,9 +131,10 @@ __global__ __launch_bounds__(256) void deskew_pack_kernel(int64_t n, const doubl
   if (i >= n) return;
   const double4 p = reinterpret_cast<const double4*>(points4)[i];
   const double* T = table + 12 * (size_t)entry[i];
-  const double x = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3] * p.w;
-  const double y = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7] * p.w;
-  const double z = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11] * p.w;
+  // the oracle's expression with separate roundings (no FMA contraction): bit-identical FP64 result before the FP32 pack
+  const double x = dadd(dadd(dadd(dmul(T[0], p.x), dmul(T[1], p.y)), dmul(T[2], p.z)), dmul(T[3], p.w));
+  const double y = dadd(dadd(dadd(dmul(T[4], p.x), dmul(T[5], p.y)), dmul(T[6], p.z)), dmul(T[7], p.w));
+  const double z = dadd(dadd(dadd(dmul(T[8], p.x), dmul(T[9], p.y)), dmul(T[10], p.z)), dmul(T[11], p.w));
   pts[i] = make_float4((float)x, (float)y, (float)z, 1.0f);
 }
 

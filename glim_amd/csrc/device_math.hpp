@@ -7,6 +7,18 @@
 
 namespace glim_amd {
 
+// FP64 multiply / add that the compiler must NOT fuse into an FMA.  HIP compiles with -ffp-contract=fast-honor-pragmas and the
+// header's __dmul_rn / __dadd_rn are plain `x * y` / `x + y` (contractable), so the parity-critical expressions -- the ones the
+// CPU oracle evaluates with separate roundings (gcc -ffp-contract=off) -- are written with these two helpers.
+__device__ __forceinline__ double dmul(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double dadd(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 // fast_floor(x) = (int)x - (x < (int)x): the voxel-coordinate rule of the reference
 // (gtsam_points util/fast_floor.hpp; in-tree twin src/glim/viewer/editor/points_selector.cpp:177).
 __device__ __forceinline__ int fast_floor_d(double x) {

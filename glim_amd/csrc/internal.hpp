@@ -163,12 +163,14 @@ struct glim_amd_cloud {
   double4* pts64 = nullptr;
   double* times = nullptr;
   double* intensities = nullptr;
+  double* cov64 = nullptr;  // merged submaps (glim_amd_merge_frames): exact FP64 covariances, 6 per point (c00 c01 c02 c11 c12 c22)
   std::vector<double> h_times;  // host copy of `times` (the deskewing time table is built from it)
   size_t bytes() const {
     size_t b = (size_t)n * sizeof(float4);
     if (pts64) b += (size_t)n * sizeof(double4);
     if (times) b += (size_t)n * sizeof(double);
     if (intensities) b += (size_t)n * sizeof(double);
+    if (cov64) b += (size_t)n * 6 * sizeof(double);
     if (covA) b += (size_t)n * (sizeof(float4) + sizeof(float2));
     if (normals) b += (size_t)n * sizeof(float4);
     if (neighbors) b += (size_t)n * k * sizeof(int32_t);

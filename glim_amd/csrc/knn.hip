@@ -63,7 +63,7 @@ struct TopK {
 
 __device__ __forceinline__ double sqdist(double qx, double qy, double qz, double x, double y, double z) {
   const double dx = qx - x, dy = qy - y, dz = qz - z;
-  return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+  return dadd(dadd(dmul(dx, dx), dmul(dy, dy)), dmul(dz, dz));
 }
 
 // ---- exhaustive scan.  `queries` (optional): list of point indices to answer; otherwise every point. ----

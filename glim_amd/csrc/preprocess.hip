@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <vector>
 
 #include "internal.hpp"
 #include "device_math.hpp"
@@ -225,14 +226,14 @@ __global__ __launch_bounds__(256) void pp_filter_flag_kernel(int m, const double
   if (keep) {
     const double4 p = P[i];
     const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w);
-    const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(p.x, p.x), __dmul_rn(p.z, p.z)), __dmul_rn(p.y, p.y));
+    const double d2 = dadd(dadd(dmul(p.x, p.x), dmul(p.z, p.z)), dmul(p.y, p.y));
     keep = d2 > fp.near2 && d2 < fp.far2 && finite;
     if (keep && fp.crop) {
       double q[3] = {p.x, p.y, p.z};
       if (fp.crop_imu) {
 #pragma unroll
         for (int r = 0; r < 3; r++)
-          q[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(fp.T[4 * r], p.x), __dmul_rn(fp.T[4 * r + 1], p.y)), __dmul_rn(fp.T[4 * r + 2], p.z)),
+          q[r] = dadd(dadd(dadd(dmul(fp.T[4 * r], p.x), dmul(fp.T[4 * r + 1], p.y)), dmul(fp.T[4 * r + 2], p.z)),
                            fp.T[4 * r + 3]);
       }
       bool inside = true;
@@ -283,13 +284,13 @@ __global__ __launch_bounds__(256) void pp_mean_dist_kernel(int f, const double4*
     for (int j = 0; j < k; j++) {
       const double4 q = P[nb[(size_t)i * k + j]];
       const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-      s += __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+      s += __dsqrt_rn(dadd(dadd(dmul(dx, dx), dmul(dy, dy)), dmul(dz, dz)));
     }
     di = s / (double)k;
     d[i] = di;
   }
   // deterministic block sums of d and d^2 (fixed butterfly order), one partial pair per block
-  double a = di, b = __dmul_rn(di, di);
+  double a = di, b = dmul(di, di);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     a += __shfl_xor(a, off, 64);
@@ -313,8 +314,8 @@ __global__ void pp_outlier_thresh_kernel(int f, int blocks, const double* __rest
     sq += partial[2 * b + 1];
   }
   const double mean = sum / (double)f;
-  const double var = sq / (double)f - __dmul_rn(mean, mean);
-  *thresh = mean + std_mul * sqrt(var > 0.0 ? var : 0.0);
+  const double var = sq / (double)f - dmul(mean, mean);
+  *thresh = dadd(mean, dmul(std_mul, sqrt(var > 0.0 ? var : 0.0)));
 }
 
 __global__ __launch_bounds__(256) void pp_inlier_flag_kernel(int f, const double* __restrict__ d, const double* __restrict__ thresh,
@@ -327,6 +328,94 @@ __global__ __launch_bounds__(256) void pp_inlier_flag_kernel(int f, const double
 __global__ __launch_bounds__(256) void pp_compact_index_kernel(int m, const int* __restrict__ flags, const int* __restrict__ pos, u32* __restrict__ idx) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < m && flags[i]) idx[pos[i]] = (u32)i;
+}
+
+// ---- submap merge (gtsam_points::merge_frames, sub_mapping.cpp:480-497): p' = T p, C' = (R C) R^T upper triangle ----
+struct Pose12 {
+  double m[12];
+};
+
+__global__ __launch_bounds__(256) void mg_transform_kernel(int n, const double4* __restrict__ p4, const double* __restrict__ c16, Pose12 T,
+                                                           double4* __restrict__ P, double* __restrict__ C6) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = p4[i];
+  double q[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    q[r] = dadd(dadd(dadd(dmul(T.m[4 * r], p.x), dmul(T.m[4 * r + 1], p.y)), dmul(T.m[4 * r + 2], p.z)),
+                     dmul(T.m[4 * r + 3], p.w));
+  P[i] = make_double4(q[0], q[1], q[2], p.w);
+  const double* c = c16 + 16 * (size_t)i;  // column-major Matrix4d: (row, col) = c[4 * col + row]
+  double RC[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      RC[r][k] = dadd(dadd(dmul(T.m[4 * r], c[4 * k]), dmul(T.m[4 * r + 1], c[4 * k + 1])), dmul(T.m[4 * r + 2], c[4 * k + 2]));
+  int o = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int k = r; k < 3; k++)
+      C6[6 * (size_t)i + o++] =
+        dadd(dadd(dmul(RC[r][0], T.m[4 * k]), dmul(RC[r][1], T.m[4 * k + 1])), dmul(RC[r][2], T.m[4 * k + 2]));
+}
+
+__global__ __launch_bounds__(256) void mg_gather_sorted_kernel(int n, const u32* __restrict__ v, const double4* __restrict__ P, const double* __restrict__ C6,
+                                                               double4* __restrict__ sP, double* __restrict__ sC) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const u32 i = v[j];
+  sP[j] = P[i];
+#pragma unroll
+  for (int a = 0; a < 6; a++) sC[6 * (size_t)j + a] = C6[6 * (size_t)i + a];
+}
+
+__global__ __launch_bounds__(256) void mg_segment_mean_kernel(int m, const int* __restrict__ seg_start, const double4* __restrict__ sP,
+                                                              const double* __restrict__ sC, double4* __restrict__ outP, double* __restrict__ outC) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  const int begin = seg_start[s], end = seg_start[s + 1];
+  double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0, sc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = begin; j < end; j++) {  // sequential: the same additions in the same order as the CPU loop
+    const double4 p = sP[j];
+    sx += p.x;
+    sy += p.y;
+    sz += p.z;
+    sw += p.w;
+#pragma unroll
+    for (int a = 0; a < 6; a++) sc[a] += sC[6 * (size_t)j + a];
+  }
+  outP[s] = make_double4(sx / sw, sy / sw, sz / sw, sw / sw);
+#pragma unroll
+  for (int a = 0; a < 6; a++) outC[6 * (size_t)s + a] = sc[a] / sw;
+}
+
+__global__ __launch_bounds__(256) void mg_mark_kernel(int m, int keep, const u32* __restrict__ v, int* __restrict__ flags) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > m) return;
+  if (j == m) flags[m] = 0;
+  else flags[v[j]] = j < keep ? 1 : 0;
+}
+
+// final gather: exact FP64 values + the FP32 SoA image the factor path streams (idx == nullptr: identity)
+__global__ __launch_bounds__(256) void mg_output_kernel(int n, const u32* __restrict__ idx, const double4* __restrict__ P, const double* __restrict__ C6,
+                                                        double4* __restrict__ pts64, double* __restrict__ cov64, float4* __restrict__ pts,
+                                                        float4* __restrict__ covA, float2* __restrict__ covB) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const u32 i = idx ? idx[j] : (u32)j;
+  const double4 p = P[i];
+  double c[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) c[a] = C6[6 * (size_t)i + a];
+  pts64[j] = p;
+#pragma unroll
+  for (int a = 0; a < 6; a++) cov64[6 * (size_t)j + a] = c[a];
+  pts[j] = make_float4((float)p.x, (float)p.y, (float)p.z, 1.0f);
+  covA[j] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);  // c00 c01 c02 c11
+  covB[j] = make_float2((float)c[4], (float)c[5]);                            // c12 c22
 }
 
 inline int grid_for(int n) { return (n + 255) / 256; }
@@ -644,6 +733,172 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
     if (prm->k_correspondences > 0) GA_TRY(glim_amd_cloud_find_neighbors(c, prm->k_correspondences, nullptr));
   }
   *out = result.release();
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* poses12, const double* const* points4, const double* const* covs16,
+                          const int64_t* sizes, double resolution, int32_t target_num_points, int32_t block_size, uint64_t seed, glim_amd_cloud** out) {
+  if (!ctx || !out || num_frames < 0 || !(resolution > 0.0)) return GLIM_AMD_ERR_INVALID;
+  if (num_frames > 0 && (!poses12 || !points4 || !covs16 || !sizes)) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  int64_t total64 = 0, max_frame = 0;
+  for (int f = 0; f < num_frames; f++) {
+    if (sizes[f] < 0 || (sizes[f] > 0 && (!points4[f] || !covs16[f]))) return GLIM_AMD_ERR_INVALID;
+    total64 += sizes[f];
+    max_frame = std::max(max_frame, sizes[f]);
+  }
+  if (total64 > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
+  const int n = (int)total64;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream();
+  CloudGuard result;
+
+  // ---- upload frame by frame, transform into the submap origin, concatenate ----
+  DeviceTemp P, C6, stage_p, stage_c;
+  GA_HIP(pool_malloc(&P.p, (size_t)std::max(n, 1) * sizeof(double4)));
+  GA_HIP(pool_malloc(&C6.p, (size_t)std::max(n, 1) * 6 * sizeof(double)));
+  GA_HIP(pool_malloc(&stage_p.p, (size_t)std::max<int64_t>(max_frame, 1) * sizeof(double4)));
+  GA_HIP(pool_malloc(&stage_c.p, (size_t)std::max<int64_t>(max_frame, 1) * 16 * sizeof(double)));
+  int64_t at = 0;
+  for (int f = 0; f < num_frames; f++) {
+    const int nf = (int)sizes[f];
+    if (nf == 0) continue;
+    GA_HIP(hipMemcpyAsync(stage_p.p, points4[f], (size_t)nf * sizeof(double4), hipMemcpyHostToDevice, st));
+    GA_HIP(hipMemcpyAsync(stage_c.p, covs16[f], (size_t)nf * 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    Pose12 T;
+    memcpy(T.m, poses12 + 12 * (size_t)f, sizeof(T.m));
+    mg_transform_kernel<<<grid_for(nf), 256, 0, st>>>(nf, stage_p.as<double4>(), stage_c.as<double>(), T, P.as<double4>() + at, C6.as<double>() + 6 * at);
+    GA_HIP(hipGetLastError());
+    at += nf;
+  }
+
+  // ---- voxelgrid_sampling of the concatenation: keys, stable sort, runs, sequential means of points and covariances ----
+  int m = 0;
+  DeviceTemp avgP, avgC;
+  if (n > 0) {
+    DeviceTemp d_vkey, d_ckey, d_bb, d_nvalid, heads, seg, tiles, seg_start, sP, sC;
+    SortBuffers sb;
+    GA_TRY(sb.alloc(n));
+    GA_HIP(pool_malloc(&d_vkey.p, (size_t)n * sizeof(u64)));
+    GA_HIP(pool_malloc(&d_bb.p, 6 * sizeof(int)));
+    GA_HIP(pool_malloc(&d_nvalid.p, sizeof(int)));
+    const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    int h_bb[6];
+    GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+    pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, P.as<double4>(), 1.0 / resolution, d_vkey.as<u64>(), d_bb.as<int>());
+    GA_HIP(hipGetLastError());
+    GA_HIP(hipMemcpyAsync(h_bb, d_bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    int bx = 0, by = 0, bz = 0;
+    if (h_bb[0] <= h_bb[3]) {
+      bx = bits_for(h_bb[3] - h_bb[0]);
+      by = bits_for(h_bb[4] - h_bb[1]);
+      bz = bits_for(h_bb[5] - h_bb[2]);
+    } else {
+      h_bb[0] = h_bb[1] = h_bb[2] = 0;
+    }
+    const int vbits = bx + by + bz;
+    pp_compact_key_kernel<<<grid_for(n), 256, 0, st>>>(n, d_vkey.as<u64>(), h_bb[0], h_bb[1], h_bb[2], bx, by, vbits, sb.ka.as<u64>());
+    u64* ks = nullptr;
+    u32* vs = nullptr;
+    GA_HIP(radix_sort_pairs(st, n, vbits + 1, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), true, sb.hist.as<int>(), &ks, &vs));
+    GA_HIP(pool_malloc(&heads.p, (size_t)(n + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&seg.p, (size_t)(n + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)n + 1) * sizeof(int)));
+    GA_HIP(hipMemsetAsync(d_nvalid.p, 0, sizeof(int), st));
+    pp_head_flag_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, ks, 1ull << vbits, block_size, heads.as<int>(), d_nvalid.as<int>());
+    GA_HIP(exclusive_scan_int(st, heads.as<int>(), (unsigned int)n + 1, tiles.as<int>(), seg.as<int>()));
+    GA_HIP(hipMemcpyAsync(&m, seg.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(pool_malloc(&avgP.p, (size_t)std::max(m, 1) * sizeof(double4)));
+    GA_HIP(pool_malloc(&avgC.p, (size_t)std::max(m, 1) * 6 * sizeof(double)));
+    if (m > 0) {
+      GA_HIP(pool_malloc(&seg_start.p, (size_t)(m + 1) * sizeof(int)));
+      GA_HIP(pool_malloc(&sP.p, (size_t)n * sizeof(double4)));
+      GA_HIP(pool_malloc(&sC.p, (size_t)n * 6 * sizeof(double)));
+      pp_seg_start_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, heads.as<int>(), seg.as<int>(), d_nvalid.as<int>(), seg_start.as<int>());
+      mg_gather_sorted_kernel<<<grid_for(n), 256, 0, st>>>(n, vs, P.as<double4>(), C6.as<double>(), sP.as<double4>(), sC.as<double>());
+      mg_segment_mean_kernel<<<grid_for(m), 256, 0, st>>>(m, seg_start.as<int>(), sP.as<double4>(), sC.as<double>(), avgP.as<double4>(), avgC.as<double>());
+      GA_HIP(hipGetLastError());
+    }
+    GA_HIP(hipStreamSynchronize(st));  // scratch of this scope is released here
+  }
+
+  // ---- (target size) uniform random sample in the original order, then the output cloud ----
+  int out_n = m;
+  DeviceTemp idx;
+  if (target_num_points > 0 && m > target_num_points) {
+    const double rate = (double)target_num_points / (double)m;
+    out_n = (int)((double)m * rate);
+    SortBuffers sb;
+    GA_TRY(sb.alloc(m));
+    DeviceTemp flags, pos, tiles;
+    GA_HIP(pool_malloc(&flags.p, (size_t)(m + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&pos.p, (size_t)(m + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)m + 1) * sizeof(int)));
+    GA_HIP(pool_malloc(&idx.p, (size_t)std::max(out_n, 1) * sizeof(u32)));
+    u64* ks = nullptr;
+    u32* vs = nullptr;
+    pp_hash_key_kernel<<<grid_for(m), 256, 0, st>>>(m, seed, sb.ka.as<u64>());
+    GA_HIP(radix_sort_pairs(st, m, 32, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), true, sb.hist.as<int>(), &ks, &vs));
+    mg_mark_kernel<<<grid_for(m + 1), 256, 0, st>>>(m, out_n, vs, flags.as<int>());
+    GA_HIP(exclusive_scan_int(st, flags.as<int>(), (unsigned int)m + 1, tiles.as<int>(), pos.as<int>()));
+    pp_compact_index_kernel<<<grid_for(m), 256, 0, st>>>(m, flags.as<int>(), pos.as<int>(), idx.as<u32>());
+    GA_HIP(hipGetLastError());
+    GA_HIP(hipStreamSynchronize(st));
+  }
+  {
+    glim_amd_cloud* c = new glim_amd_cloud();
+    result.c = c;
+    c->ctx = ctx;
+    c->n = out_n;
+    const size_t nn = (size_t)std::max(out_n, 1);
+    hipError_t e = pool_malloc(&c->pts, nn * sizeof(float4));
+    if (e == hipSuccess) e = pool_malloc(&c->covA, nn * sizeof(float4));
+    if (e == hipSuccess) e = pool_malloc(&c->covB, nn * sizeof(float2));
+    if (e == hipSuccess) e = pool_malloc(&c->pts64, nn * sizeof(double4));
+    if (e == hipSuccess) e = pool_malloc(&c->cov64, nn * 6 * sizeof(double));
+    if (e != hipSuccess) {
+      set_hip_error(e, "pool_malloc(merged cloud)");
+      return e == hipErrorOutOfMemory ? GLIM_AMD_ERR_NOMEM : GLIM_AMD_ERR_HIP;
+    }
+    c->has_covs = true;
+    if (out_n > 0) {
+      mg_output_kernel<<<grid_for(out_n), 256, 0, st>>>(out_n, idx.p ? idx.as<u32>() : nullptr, avgP.as<double4>(), avgC.as<double>(), c->pts64, c->cov64,
+                                                        c->pts, c->covA, c->covB);
+      GA_HIP(hipGetLastError());
+    }
+    GA_HIP(hipStreamSynchronize(st));
+  }
+  *out = result.release();
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_cloud_download_merged(const glim_amd_cloud* c, double* points4, double* covs16) {
+  if (!c) return GLIM_AMD_ERR_INVALID;
+  if ((points4 && !c->pts64) || (covs16 && !c->cov64)) return GLIM_AMD_ERR_STATE;
+  if (c->n == 0) return GLIM_AMD_OK;
+  glim_amd_ctx* ctx = c->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream();
+  const size_t n = (size_t)c->n;
+  std::vector<double> c6;
+  if (points4) GA_HIP(hipMemcpyAsync(points4, c->pts64, n * sizeof(double4), hipMemcpyDeviceToHost, s));
+  if (covs16) {
+    c6.resize(n * 6);
+    GA_HIP(hipMemcpyAsync(c6.data(), c->cov64, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  GA_HIP(hipStreamSynchronize(s));
+  if (covs16) {
+    for (size_t i = 0; i < n; i++) {  // symmetric 3x3 -> column-major Matrix4d with a zero last row / column
+      const double* a = &c6[6 * i];
+      double* o = covs16 + 16 * i;
+      memset(o, 0, 16 * sizeof(double));
+      o[0] = a[0]; o[1] = o[4] = a[1]; o[2] = o[8] = a[2]; o[5] = a[3]; o[6] = o[9] = a[4]; o[10] = a[5];
+    }
+  }
   return GLIM_AMD_OK;
 }
 

@@ -137,6 +137,18 @@ int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, 
  * carried over, as the reference does (odometry_estimation_imu.cpp:313-320: deskew, then covariances from raw_frame->neighbors). */
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
                           const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out);
+/* ---- submap merge on device: gtsam_points::merge_frames(poses, frames, downsample_resolution, target_num_points)
+ * as called at src/glim/mapping/sub_mapping.cpp:480-497 (the reference's own GPU variant, merge_frames_gpu, is commented out at :491).
+ * Frame f (sizes[f] points: points4[f] n x Vector4d, covs16[f] n x column-major Matrix4d) is moved by poses12[f] (row-major 3x4
+ * T_origin_frame): p' = T p, C' = R C R^T; the concatenation is voxel-grid averaged (points and covariances) at
+ * `downsample_resolution`; when target_num_points > 0 and more points remain, a uniform random sample of that size is kept
+ * (same meaning as sub_mapping_passthrough.cpp:149-151).  The result is a device cloud with covariances, ready for
+ * GaussianVoxelMapGPU::insert / the factors (global_mapping.cpp:253-266); voxelgrid_block_size: see glim_amd_preprocess_params. */
+int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* poses12, const double* const* points4, const double* const* covs16,
+                          const int64_t* sizes, double downsample_resolution, int32_t target_num_points, int32_t voxelgrid_block_size, uint64_t seed,
+                          glim_amd_cloud** out);
+/* the merged submap back on the host as gtsam_points::PointCloudCPU holds it: points4 n x Vector4d, covs16 n x Matrix4d (exact FP64). */
+int glim_amd_cloud_download_merged(const glim_amd_cloud* cloud, double* points4, double* covs16);
 /* parity / debug only: the stable device radix sort behind the preprocessing (sorts by the low `bits` key bits; vals_in NULL = 0..n-1). */
 int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
                               uint32_t* vals_out);

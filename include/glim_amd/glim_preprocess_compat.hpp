@@ -171,4 +171,46 @@ public:
   }
 };
 
+// gtsam_points::merge_frames(poses, frames, downsample_resolution, target_num_points) as called at sub_mapping.cpp:480-497.
+// A frame is what gtsam_points::PointCloud exposes: raw pointers to Vector4d points and Matrix4d covariances.
+struct FrameView {
+  const double* points4 = nullptr;  // n x Vector4d
+  const double* covs16 = nullptr;   // n x Matrix4d, column-major
+  std::int64_t size = 0;
+};
+struct MergedFrame {  // gtsam_points::PointCloudCPU fields of the merged submap + the device-resident cloud
+  std::vector<Vector4d> points;
+  std::vector<std::array<double, 16>> covs;
+  PointCloudGPU::Ptr gpu;
+  std::size_t size() const { return points.size(); }
+};
+inline MergedFrame merge_frames(const std::vector<Isometry3d>& poses, const std::vector<FrameView>& frames, double downsample_resolution,
+                                int target_num_points = -1, std::uint64_t seed = 0, Context ctx = nullptr, bool download = true) {
+  if (poses.size() != frames.size()) throw std::runtime_error("merge_frames: poses / frames size mismatch");
+  ctx = ctx ? ctx : StreamTempBufferRoundRobin::default_instance();
+  const std::size_t nf = frames.size();
+  std::vector<double> poses12(12 * nf);
+  std::vector<const double*> pp(nf), cp(nf);
+  std::vector<std::int64_t> sizes(nf);
+  for (std::size_t f = 0; f < nf; f++) {
+    std::memcpy(&poses12[12 * f], poses[f].m.data(), 12 * sizeof(double));
+    pp[f] = frames[f].points4;
+    cp[f] = frames[f].covs16;
+    sizes[f] = frames[f].size;
+  }
+  glim_amd_cloud* h = nullptr;
+  check(glim_amd_merge_frames(ctx->context(), (std::int32_t)nf, poses12.data(), pp.data(), cp.data(), sizes.data(), downsample_resolution, target_num_points,
+                              1024, seed, &h),
+        "merge_frames");
+  MergedFrame out;
+  out.gpu = adopt_cloud(h, ctx);
+  if (download) {
+    const std::size_t m = out.gpu->size();
+    out.points.resize(m);
+    out.covs.resize(m);
+    check(glim_amd_cloud_download_merged(h, m ? out.points[0].data() : nullptr, m ? out.covs[0].data() : nullptr), "merge_frames download");
+  }
+  return out;
+}
+
 }  // namespace glim_amd

@@ -140,6 +140,8 @@ def lib():
         L.orc_preprocess_keep.argtypes = [dp, pp]
         L.orc_preprocess.restype = C.c_int
         L.orc_preprocess.argtypes = [dp, dp, dp, C.c_int, pp, dp, dp, dp, ip, C.c_int]
+        L.orc_merge_frames.restype = C.c_int
+        L.orc_merge_frames.argtypes = [C.c_int, dp, C.POINTER(dp), C.POINTER(dp), ip, C.c_double, C.c_int, C.c_int, C.c_uint64, dp, dp]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -434,3 +436,20 @@ def preprocess(points_xyz, times, intensities=None, params=None, neighbors=True,
                              _ip(nb) if nb is not None else None, int(num_threads))
     return dict(points=op[:m, :3].copy(), times=ot[:m].copy(), intensities=oi[:m].copy() if it is not None else None,
                 neighbors=nb[:m].copy() if nb is not None else None)
+
+
+def merge_frames(poses, frames_points, frames_covs, resolution, target_num_points=-1, seed=0, block_size=1024):
+    """gtsam_points::merge_frames (sub_mapping.cpp:480-497).  frames_points[f]: N_f x 3, frames_covs[f]: N_f x 3 x 3.
+    Returns (points M x 3, covs M x 3 x 3)."""
+    nf = len(poses)
+    P12 = np.ascontiguousarray(np.stack([pose12(T) for T in poses])) if nf else np.zeros((1, 12))
+    p4s = [points4(p) for p in frames_points]
+    c16s = [covs16(c) for c in frames_covs]
+    sizes = np.array([len(p) for p in p4s], dtype=np.int32)
+    dp = C.POINTER(C.c_double)
+    pp = (dp * nf)(*[_dp(p) for p in p4s])
+    cp = (dp * nf)(*[_dp(c) for c in c16s])
+    total = int(sizes.sum())
+    op, oc = np.zeros((max(total, 1), 4)), np.zeros((max(total, 1), 16))
+    m = lib().orc_merge_frames(nf, _dp(P12), pp, cp, _ip(sizes), float(resolution), int(block_size), int(target_num_points), int(seed), _dp(op), _dp(oc))
+    return op[:m, :3].copy(), covs33(oc[:m])

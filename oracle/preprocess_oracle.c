@@ -273,3 +273,90 @@ int orc_preprocess(const double* points4, const double* times, const double* int
   free(P); free(T); free(I); free(te); free(Q); free(QT); free(QI);
   return out_n;
 }
+
+/* ---- submap merge: gtsam_points::merge_frames as called at src/glim/mapping/sub_mapping.cpp:480-497 ----
+ * (!) restated from the upstream algorithm as recalled (src/gtsam_points/types/point_cloud_cpu_funcs.cpp): every frame is
+ *     moved into the submap origin -- p' = T p, C' = T C T^T with the 4x4 matrices (top-left block R C R^T) -- the frames are
+ *     concatenated in order and voxelgrid_sampling averages points AND covariances per voxel (the covariance of a voxel is the
+ *     plain mean of its members' covariances).
+ * (!) the 4th argument (submap_target_num_points, config_sub_mapping_gpu.json:54) is taken to mean what the in-tree sibling
+ *     sub_mapping_passthrough.cpp:149-151 does with the parameter of the same name: if the merged cloud is larger, a uniform
+ *     random sample of floor(size * (target / size)) points in their original order (gtsam_points::random_sampling).  Oracle
+ *     rule for the draw: the points with the smallest (orc_sample_hash(seed, index) >> 32, index).
+ * Oracle rules where upstream is implementation defined: R C R^T is evaluated as (R C) R^T, rows by columns, left to right,
+ * no contraction, and only its upper triangle is used (the product is symmetric up to rounding); order inside a voxel =
+ * (frame, index). */
+int orc_merge_frames(int num_frames, const double* poses12, const double* const* points4, const double* const* covs16, const int* sizes,
+                     double resolution, int block_size, int target_num_points, uint64_t seed, double* out_points4, double* out_covs16) {
+  int total = 0;
+  for (int f = 0; f < num_frames; f++) total += sizes[f];
+  double* P = (double*)malloc(sizeof(double) * 4 * (size_t)(total > 0 ? total : 1));
+  double* C = (double*)malloc(sizeof(double) * 6 * (size_t)(total > 0 ? total : 1)); /* c00 c01 c02 c11 c12 c22 */
+  int at = 0;
+  for (int f = 0; f < num_frames; f++) {
+    const double* T = poses12 + 12 * (size_t)f;
+    for (int i = 0; i < sizes[f]; i++, at++) {
+      const double* p = points4[f] + 4 * (size_t)i;
+      const double* c = covs16[f] + 16 * (size_t)i; /* column-major Matrix4d; symmetric: (r, c) = c[4 * c + r] */
+      for (int r = 0; r < 3; r++) P[4 * (size_t)at + r] = ((T[4 * r] * p[0] + T[4 * r + 1] * p[1]) + T[4 * r + 2] * p[2]) + T[4 * r + 3] * p[3];
+      P[4 * (size_t)at + 3] = p[3];
+      double RC[3][3];
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) RC[r][k] = (T[4 * r] * c[4 * k + 0] + T[4 * r + 1] * c[4 * k + 1]) + T[4 * r + 2] * c[4 * k + 2];
+      int o = 0;
+      for (int r = 0; r < 3; r++)
+        for (int k = r; k < 3; k++) C[6 * (size_t)at + o++] = (RC[r][0] * T[4 * k] + RC[r][1] * T[4 * k + 1]) + RC[r][2] * T[4 * k + 2];
+    }
+  }
+  int nv = 0, m = 0;
+  orc_sort_entry* e = sorted_by_key(P, total, resolution, 0, 0, &nv);
+  double* MP = (double*)malloc(sizeof(double) * 4 * (size_t)(nv > 0 ? nv : 1));
+  double* MC = (double*)malloc(sizeof(double) * 6 * (size_t)(nv > 0 ? nv : 1));
+  int pos = 0;
+  while (pos < nv) {
+    double s[4] = {0, 0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
+    int end = pos;
+    do {
+      for (int a = 0; a < 4; a++) s[a] += P[4 * (size_t)e[end].idx + a];
+      for (int a = 0; a < 6; a++) sc[a] += C[6 * (size_t)e[end].idx + a];
+      end++;
+    } while (end < nv && e[end].key == e[pos].key && !(block_size > 0 && end % block_size == 0));
+    for (int a = 0; a < 4; a++) MP[4 * (size_t)m + a] = s[a] / s[3];
+    for (int a = 0; a < 6; a++) MC[6 * (size_t)m + a] = sc[a] / s[3];
+    m++;
+    pos = end;
+  }
+  free(e);
+  /* (!) final random sampling to the target size, original (voxel) order kept */
+  int* keep = (int*)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+  int out_n = m;
+  if (target_num_points > 0 && m > target_num_points) {
+    const double rate = (double)target_num_points / (double)m;
+    out_n = (int)((double)m * rate);
+    orc_sort_entry* h = (orc_sort_entry*)malloc(sizeof(orc_sort_entry) * (size_t)m);
+    for (int i = 0; i < m; i++) {
+      h[i].key = orc_sample_hash(seed, (uint64_t)i) >> 32;
+      h[i].aux = 0;
+      h[i].idx = i;
+    }
+    qsort(h, (size_t)m, sizeof(orc_sort_entry), cmp_entry);
+    for (int i = 0; i < out_n; i++) {
+      h[i].key = 0;
+    }
+    qsort(h, (size_t)out_n, sizeof(orc_sort_entry), cmp_entry);
+    for (int i = 0; i < out_n; i++) keep[i] = h[i].idx;
+    free(h);
+  } else {
+    for (int i = 0; i < m; i++) keep[i] = i;
+  }
+  for (int i = 0; i < out_n; i++) {
+    const int j = keep[i];
+    memcpy(out_points4 + 4 * (size_t)i, MP + 4 * (size_t)j, 4 * sizeof(double));
+    const double* c = MC + 6 * (size_t)j;
+    double* o = out_covs16 + 16 * (size_t)i;
+    memset(o, 0, 16 * sizeof(double));
+    o[0] = c[0]; o[4] = o[1] = c[1]; o[8] = o[2] = c[2]; o[5] = c[3]; o[9] = o[6] = c[4]; o[10] = c[5];
+  }
+  free(keep); free(MP); free(MC); free(P); free(C);
+  return out_n;
+}

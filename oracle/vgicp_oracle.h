@@ -165,6 +165,12 @@ int orc_preprocess_keep(const double* p4, const orc_preprocess_params* prm);
 int orc_preprocess(const double* points4, const double* times, const double* intensities, int n, const orc_preprocess_params* prm,
                    double* out_points4, double* out_times, double* out_intensities, int32_t* out_neighbors, int num_threads);
 
+/* ---- submap merge  gtsam_points::merge_frames, src/glim/mapping/sub_mapping.cpp:480-497; see preprocess_oracle.c ----
+ * poses12: num_frames x 12 (T_origin_frame); points4[f] / covs16[f]: sizes[f] x Vector4d / column-major Matrix4d.
+ * out_*: sized for the total number of input points; returns the number of merged points. */
+int orc_merge_frames(int num_frames, const double* poses12, const double* const* points4, const double* const* covs16, const int* sizes,
+                     double resolution, int block_size, int target_num_points, uint64_t seed, double* out_points4, double* out_covs16);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

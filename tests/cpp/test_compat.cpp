@@ -217,6 +217,39 @@ int main() {
     vm->insert(*deskewed);
     REQUIRE(vm->voxelmap_info().num_voxels > 100);
     std::printf("front end OK: %d -> %d points\n", nr, m);
+    // submap merge of two keyframes (sub_mapping.cpp:480-497): device result == oracle, bit for bit
+    {
+      const int na = 20000, nb2 = 15000;
+      const std::vector<double> A = make_scan(na, 0.0, 0.0, 0.0, 7), B = make_scan(nb2, 0.4, 0.2, 0.05, 8);
+      std::vector<double> CA(16 * (size_t)na, 0.0), CB(16 * (size_t)nb2, 0.0);
+      std::mt19937_64 r2(3);
+      std::uniform_real_distribution<double> V(0.001, 0.02);
+      for (auto* CC : {&CA, &CB})
+        for (size_t i = 0; i < CC->size() / 16; i++) {
+          double* c = CC->data() + 16 * i;
+          const double a = V(r2), b = V(r2), d = V(r2), e = 0.3 * std::sqrt(a * b);
+          c[0] = (double)(float)a; c[5] = (double)(float)b; c[10] = (double)(float)d; c[1] = c[4] = (double)(float)e;
+        }
+      const std::vector<Isometry3d> Ts = {Isometry3d::Identity(), pose2d(0.4, 0.2, 0.05)};
+      const MergedFrame merged = merge_frames(Ts, {FrameView{A.data(), CA.data(), na}, FrameView{B.data(), CB.data(), nb2}}, 0.2, 9000, 11);
+      std::vector<double> poses12(24);
+      std::memcpy(&poses12[0], Ts[0].m.data(), 96);
+      std::memcpy(&poses12[12], Ts[1].m.data(), 96);
+      const double* pp[2] = {A.data(), B.data()};
+      const double* cp2[2] = {CA.data(), CB.data()};
+      const int sz[2] = {na, nb2};
+      std::vector<double> rp(4 * (size_t)(na + nb2)), rc(16 * (size_t)(na + nb2));
+      const int mm = orc_merge_frames(2, poses12.data(), pp, cp2, sz, 0.2, 1024, 9000, 11, rp.data(), rc.data());
+      REQUIRE((int)merged.size() == mm && mm > 8000 && mm <= 9000);
+      for (int i = 0; i < mm; i++) {
+        for (int a = 0; a < 4; a++) REQUIRE(merged.points[i][a] == rp[4 * (size_t)i + a]);
+        for (int a = 0; a < 16; a++) REQUIRE(merged.covs[i][a] == rc[16 * (size_t)i + a]);
+      }
+      auto vm2 = std::make_shared<GaussianVoxelMapGPU>(1.0);
+      vm2->insert(*merged.gpu);
+      REQUIRE(vm2->voxelmap_info().num_voxels > 20);
+      std::printf("merge OK: %d + %d -> %d points\n", na, nb2, mm);
+    }
   }
   std::printf("test_compat OK: %d points, inliers level0 = %lld\n", n, (long long)factors[0]->linearized().num_inliers);
   return 0;

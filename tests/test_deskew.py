@@ -110,7 +110,7 @@ def test_hip_deskew_matches_oracle(orc, form):
     ref32 = ref.astype(np.float32)
     ulp = np.spacing(np.abs(ref32))
     assert np.all(np.abs(xyz.astype(np.float64) - ref) <= ulp.astype(np.float64))
-    assert (xyz == ref32).mean() > 0.999
+    assert (xyz == ref32).mean() > 0.9999  # separate roundings on both sides (no FMA contraction): equal bar host-side table differences
     if form == "zero":
         np.testing.assert_array_equal(xyz, pts.astype(np.float32))
     # the deskewed cloud feeds the rest of the path: kNN + covariances + voxel map + factor run on it
