@@ -94,6 +94,11 @@ SYMBOLS = {
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
     "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_nn_index_create": (_i, [_vp, _d, _pp]),
+    "glim_amd_nn_index_destroy": (_i, [_vp]),
+    "glim_amd_gicp_linearize": (_i, [_vp, _vp, _dp, _d, _u32, C.POINTER(Linearized6)]),
+    "glim_amd_gicp_error": (_i, [_vp, _vp, _dp, _d, _dp, _lp]),
+    "glim_amd_gicp_correspondences": (_i, [_vp, _vp, _dp, _d, _ip]),
     "glim_amd_merge_frames": (_i, [_vp, _i32, _dp, C.POINTER(_dp), C.POINTER(_dp), _lp, _d, _i32, _i32, C.c_uint64, _pp]),
     "glim_amd_cloud_download_merged": (_i, [_vp, _dp, _dp]),
     "glim_amd_debug_sort_pairs": (_i, [_vp, _i64, _i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

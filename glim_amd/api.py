@@ -506,6 +506,73 @@ def preprocess_params(**kw):
     return p
 
 
+class IntegratedGICPFactor:
+    """gtsam_points::IntegratedGICPFactor on the device (sub_mapping.cpp:202, global_mapping.cpp:400, global_mapping_pose_graph.cpp:393).
+    Unary form: IntegratedGICPFactor(fixed_target_pose, source_key, target, source); binary: (target_key, source_key, target, source).
+    `target` / `source` are PointCloudGPU with covariances; the target's search index is built once here (or passed as `target_tree`)."""
+
+    def __init__(self, target, source_key, target_frame, source_frame, target_tree=None, max_correspondence_distance=1.0):
+        self.binary = np.isscalar(target)
+        self.target_key = int(target) if self.binary else None
+        self.fixed_target_pose = None if self.binary else np.asarray(target, dtype=np.float64)
+        self.source_key = int(source_key)
+        self.target_frame, self.source_frame = target_frame, source_frame
+        self.max_correspondence_distance = float(max_correspondence_distance)
+        self._inliers = 0
+        self._own_tree = target_tree is None
+        if target_tree is None:
+            h = C.c_void_p()
+            check(lib().glim_amd_nn_index_create(target_frame._h, self.max_correspondence_distance, C.byref(h)), "glim_amd_nn_index_create")
+            target_tree = h
+        self.target_tree = target_tree
+
+    def set_max_correspondence_distance(self, d):
+        self.max_correspondence_distance = float(d)
+
+    def calc_delta(self, values):
+        Ts = np.asarray(values[self.source_key], dtype=np.float64)
+        Tt = np.asarray(values[self.target_key], dtype=np.float64) if self.binary else self.fixed_target_pose
+        return np.linalg.inv(Tt) @ Ts
+
+    def linearize(self, values):
+        L = Linearized6()
+        T = pose12(self.calc_delta(values))
+        check(lib().glim_amd_gicp_linearize(self.target_tree, self.source_frame._h, _dp(T), self.max_correspondence_distance,
+                                            FACTOR_BINARY if self.binary else 0, C.byref(L)), "glim_amd_gicp_linearize")
+        out = _lin_to_dict(L)
+        self._inliers = out["num_inliers"]
+        return out
+
+    def error(self, values):
+        e, n = C.c_double(), C.c_int64()
+        T = pose12(self.calc_delta(values))
+        check(lib().glim_amd_gicp_error(self.target_tree, self.source_frame._h, _dp(T), self.max_correspondence_distance, C.byref(e), C.byref(n)),
+              "glim_amd_gicp_error")
+        self._inliers = n.value
+        return e.value
+
+    def inlier_fraction(self):
+        return self._inliers / max(1, self.source_frame.size())
+
+    def correspondences(self, values):
+        out = np.zeros(self.source_frame.size(), dtype=np.int32)
+        T = pose12(self.calc_delta(values))
+        check(lib().glim_amd_gicp_correspondences(self.target_tree, self.source_frame._h, _dp(T), self.max_correspondence_distance, _ip(out)),
+              "glim_amd_gicp_correspondences")
+        return out
+
+    def close(self):
+        if self._own_tree and self.target_tree:
+            lib().glim_amd_nn_index_destroy(self.target_tree)
+            self.target_tree = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _pack_frames(poses, frames_points, frames_covs):
     """Host layouts of the reference for a list of frames: poses n x 12, Vector4d points, column-major Matrix4d covariances."""
     nf = len(poses)

@@ -137,6 +137,25 @@ int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, 
  * carried over, as the reference does (odometry_estimation_imu.cpp:313-320: deskew, then covariances from raw_frame->neighbors). */
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
                           const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out);
+/* ---- GICP factor on device: gtsam_points::IntegratedGICPFactor -- nearest-neighbour correspondences instead
+ * of a voxel lookup -- as constructed at src/glim/mapping/sub_mapping.cpp:202 (between factors, one linearize, :203),
+ * src/glim/mapping/global_mapping.cpp:400-402 (set_max_correspondence_distance(0.5), 10 LM iterations) and
+ * src/glim/mapping/global_mapping_pose_graph.cpp:393-394 (loop validation; passes the target's pre-built tree). */
+typedef struct glim_amd_nn_index glim_amd_nn_index; /* the target's search structure (gtsam_points::KdTree at global_mapping_pose_graph.cpp:393) */
+/* Built once per target cloud (which needs covariances for the factor calls and must outlive the index), reused by every
+ * linearisation.  max_correspondence_distance_hint sizes the grid cells; any distance may be used in the calls below. */
+int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspondence_distance_hint, glim_amd_nn_index** out);
+int glim_amd_nn_index_destroy(glim_amd_nn_index* index);
+/* IntegratedGICPFactor::linearize at T_target_source (flags: GLIM_AMD_FACTOR_BINARY fills the target-side blocks). */
+int glim_amd_gicp_linearize(const glim_amd_nn_index* target, const glim_amd_cloud* source, const double* T_target_source12,
+                            double max_correspondence_distance, uint32_t flags, glim_amd_linearized6* out);
+/* IntegratedGICPFactor::error and ::inlier_fraction (num_inliers / source size) -- global_mapping_pose_graph.cpp:404-405. */
+int glim_amd_gicp_error(const glim_amd_nn_index* target, const glim_amd_cloud* source, const double* T_target_source12,
+                        double max_correspondence_distance, double* error, int64_t* num_inliers);
+/* parity / debug: matched target index per source point, or -1. */
+int glim_amd_gicp_correspondences(const glim_amd_nn_index* target, const glim_amd_cloud* source, const double* T_target_source12,
+                                  double max_correspondence_distance, int32_t* correspondences);
+
 /* ---- submap merge on device: gtsam_points::merge_frames(poses, frames, downsample_resolution, target_num_points)
  * as called at src/glim/mapping/sub_mapping.cpp:480-497 (the reference's own GPU variant, merge_frames_gpu, is commented out at :491).
  * Frame f (sizes[f] points: points4[f] n x Vector4d, covs16[f] n x column-major Matrix4d) is moved by poses12[f] (row-major 3x4

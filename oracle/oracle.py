@@ -140,6 +140,10 @@ def lib():
         L.orc_preprocess_keep.argtypes = [dp, pp]
         L.orc_preprocess.restype = C.c_int
         L.orc_preprocess.argtypes = [dp, dp, dp, C.c_int, pp, dp, dp, dp, ip, C.c_int]
+        L.orc_gicp_linearize.restype = C.c_int
+        L.orc_gicp_linearize.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, C.c_double, C.c_int, C.POINTER(Linearized6), ip]
+        L.orc_gicp_error.restype = C.c_double
+        L.orc_gicp_error.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, C.c_double, C.c_int, C.POINTER(C.c_int64)]
         L.orc_merge_frames.restype = C.c_int
         L.orc_merge_frames.argtypes = [C.c_int, dp, C.POINTER(dp), C.POINTER(dp), ip, C.c_double, C.c_int, C.c_int, C.c_uint64, dp, dp]
         L.orc_max_threads.restype = C.c_int
@@ -453,3 +457,26 @@ def merge_frames(poses, frames_points, frames_covs, resolution, target_num_point
     op, oc = np.zeros((max(total, 1), 4)), np.zeros((max(total, 1), 16))
     m = lib().orc_merge_frames(nf, _dp(P12), pp, cp, _ip(sizes), float(resolution), int(block_size), int(target_num_points), int(seed), _dp(op), _dp(oc))
     return op[:m, :3].copy(), covs33(oc[:m])
+
+
+def gicp_linearize(tgt_xyz, tgt_covs33, src_xyz, src_covs33, delta, max_correspondence_distance=1.0, num_threads=0, want_corr=False):
+    """gtsam_points::IntegratedGICPFactor::linearize (sub_mapping.cpp:202-203): exact nearest target point within the distance."""
+    tp, tc, sp, sc = points4(tgt_xyz), covs16(tgt_covs33), points4(src_xyz), covs16(src_covs33)
+    L = Linearized6()
+    corr = np.zeros(len(sp), dtype=np.int32) if want_corr else None
+    rc = lib().orc_gicp_linearize(_dp(tp), _dp(tc), len(tp), _dp(sp), _dp(sc), len(sp), _dp(pose12(delta)), float(max_correspondence_distance),
+                                  num_threads, C.byref(L), _ip(corr) if want_corr else None)
+    if rc != 0:
+        raise ValueError("orc_gicp_linearize failed")
+    out = _lin_to_dict(L)
+    if want_corr:
+        out["corr"] = corr
+    return out
+
+
+def gicp_error(tgt_xyz, tgt_covs33, src_xyz, src_covs33, delta, max_correspondence_distance=1.0, num_threads=0):
+    tp, tc, sp, sc = points4(tgt_xyz), covs16(tgt_covs33), points4(src_xyz), covs16(src_covs33)
+    ninl = C.c_int64()
+    e = lib().orc_gicp_error(_dp(tp), _dp(tc), len(tp), _dp(sp), _dp(sc), len(sp), _dp(pose12(delta)), float(max_correspondence_distance), num_threads,
+                             C.byref(ninl))
+    return float(e), int(ninl.value)

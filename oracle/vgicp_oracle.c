@@ -762,6 +762,79 @@ double orc_vgicp_error(const orc_voxelmap* target, const double* pts, const doub
   return ORC_ERROR_SCALE * total.err;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* GICP factor: gtsam_points::IntegratedGICPFactor as constructed at          */
+/* src/glim/mapping/sub_mapping.cpp:202, global_mapping.cpp:400, global_mapping_pose_graph.cpp:393  */
+/* ------------------------------------------------------------------------------------------------ */
+/* (!) upstream-recall (src/gtsam_points/factors/impl/integrated_gicp_factor_impl.hpp): update_correspondences() finds, for every
+ * source point, the nearest target point of q = delta p with a kd-tree (k = 1) and drops it when the squared distance exceeds
+ * max_correspondence_distance^2; the Mahalanobis matrix is (C_B + R C_A R^T)^-1 with the TARGET POINT's covariance; evaluate()
+ * is the VGICP expression with mu_B = the matched target point.  Oracle rules where upstream is implementation defined:
+ * exact nearest neighbour by FP64 (dx^2 + dy^2) + dz^2 without contraction, ties to the smaller target index; a match is kept
+ * when d^2 <= max^2.  corr (optional): n_s matched target indices or -1. */
+static void gicp_run(const double* tpts, const double* tcovs, int nt, const double* pts, const double* covs, int n, const double* T,
+                     double max_sq, int num_threads, int need_H, acc_t* total, int32_t* corr) {
+  num_threads = clamp_threads(num_threads);
+  acc_t* parts = (acc_t*)calloc((size_t)num_threads, sizeof(acc_t));
+#pragma omp parallel num_threads(num_threads)
+  {
+#ifdef _OPENMP
+    acc_t* A = &parts[omp_get_thread_num()];
+#else
+    acc_t* A = &parts[0];
+#endif
+#pragma omp for schedule(guided, 8)
+    for (int i = 0; i < n; i++) {
+      const double* p = pts + 4 * (size_t)i;
+      double q[3];
+      orc_transform_point(T, p, q);
+      int best = -1;
+      double best_d = INFINITY;
+      for (int j = 0; j < nt; j++) {
+        const double d = sqdist3(q, tpts + 4 * (size_t)j);
+        if (d < best_d) {
+          best_d = d;
+          best = j;
+        }
+      }
+      if (best >= 0 && !(best_d <= max_sq)) best = -1;
+      if (corr) corr[i] = best;
+      if (best < 0) continue;
+      double M[9];
+      fused_mahalanobis(tcovs + 16 * (size_t)best, covs + 16 * (size_t)i, T, M);
+      accumulate_point(A, T, p, q, tpts + 4 * (size_t)best, M, need_H);
+    }
+  }
+  memset(total, 0, sizeof(*total));
+  for (int t = 0; t < num_threads; t++) acc_add(total, &parts[t]);
+  free(parts);
+}
+
+int orc_gicp_linearize(const double* target_points4, const double* target_covs16, int nt, const double* src_points4, const double* src_covs16, int n,
+                       const double* delta, double max_correspondence_distance, int num_threads, orc_linearized6* out, int32_t* corr) {
+  if (!out) return -1;
+  acc_t total;
+  gicp_run(target_points4, target_covs16, nt, src_points4, src_covs16, n, delta, max_correspondence_distance * max_correspondence_distance, num_threads, 1,
+           &total, corr);
+  out->num_inliers = total.inliers;
+  out->error = ORC_ERROR_SCALE * total.err;
+  memcpy(out->H_tt, total.H_tt, sizeof(total.H_tt));
+  memcpy(out->H_ss, total.H_ss, sizeof(total.H_ss));
+  memcpy(out->H_ts, total.H_ts, sizeof(total.H_ts));
+  memcpy(out->b_t, total.b_t, sizeof(total.b_t));
+  memcpy(out->b_s, total.b_s, sizeof(total.b_s));
+  return 0;
+}
+
+double orc_gicp_error(const double* target_points4, const double* target_covs16, int nt, const double* src_points4, const double* src_covs16, int n,
+                      const double* delta, double max_correspondence_distance, int num_threads, int64_t* num_inliers) {
+  acc_t total;
+  gicp_run(target_points4, target_covs16, nt, src_points4, src_covs16, n, delta, max_correspondence_distance * max_correspondence_distance, num_threads, 0,
+           &total, NULL);
+  if (num_inliers) *num_inliers = total.inliers;
+  return ORC_ERROR_SCALE * total.err;
+}
+
 double orc_vgicp_error_frozen(const orc_voxelmap* target, const double* pts, const double* covs, int n, const double* delta_lin,
                               const double* delta_eval, int num_threads, int64_t* num_inliers) {
   acc_t total;

@@ -136,6 +136,15 @@ int orc_deskew_constvel(const double* T_imu_lidar12, const double* linear_vel3, 
 int orc_deskew_imu(const double* T_imu_lidar12, const double* imu_times, const double* imu_poses12, int n_imu, double stamp,
                    const double* times, const double* points4, int n, double* out4);
 
+/* ---- GICP factor  gtsam_points::IntegratedGICPFactor: sub_mapping.cpp:202, global_mapping.cpp:400,
+ * global_mapping_pose_graph.cpp:393.  Nearest target point within max_correspondence_distance (exact, ties to the smaller
+ * index), Mahalanobis matrix from the matched target point's covariance, same H / b / error expression as the VGICP factor.
+ * corr (optional): n matched target indices or -1. */
+int orc_gicp_linearize(const double* target_points4, const double* target_covs16, int nt, const double* src_points4, const double* src_covs16, int n,
+                       const double* delta, double max_correspondence_distance, int num_threads, orc_linearized6* out, int32_t* corr);
+double orc_gicp_error(const double* target_points4, const double* target_covs16, int nt, const double* src_points4, const double* src_covs16, int n,
+                      const double* delta, double max_correspondence_distance, int num_threads, int64_t* num_inliers);
+
 /* ---- scan preprocessing  src/glim/preprocess/cloud_preprocessor.cpp:92-188; see preprocess_oracle.c ---- */
 typedef struct orc_preprocess_params {
   double distance_near_thresh, distance_far_thresh; /* cloud_preprocessor.cpp:26-27 */
