@@ -16,6 +16,7 @@
 // inliers returns zero information (H = 0, b = 0, error = 0), never NaN.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -297,6 +298,78 @@ inline double IntegratedVGICPFactorGPU::error(const Values& values) {
 }
 
 // gtsam_points::overlap_gpu (single and multi-target forms) / overlap_auto
+// gtsam_points::KdTree of a target frame as GLIM's pose-graph module caches it (global_mapping_pose_graph.cpp:393,
+// `candidate.target->tree`): here the device grid index of glim_amd_nn_index_create.
+class NearestNeighborSearchGPU {
+public:
+  using Ptr = std::shared_ptr<NearestNeighborSearchGPU>;
+  using ConstPtr = std::shared_ptr<const NearestNeighborSearchGPU>;
+  explicit NearestNeighborSearchGPU(PointCloudGPU::ConstPtr target, double max_correspondence_distance_hint = 1.0) : target_(std::move(target)) {
+    check(glim_amd_nn_index_create(target_->handle(), max_correspondence_distance_hint, &h_), "NearestNeighborSearchGPU");
+  }
+  ~NearestNeighborSearchGPU() { glim_amd_nn_index_destroy(h_); }
+  NearestNeighborSearchGPU(const NearestNeighborSearchGPU&) = delete;
+  NearestNeighborSearchGPU& operator=(const NearestNeighborSearchGPU&) = delete;
+  glim_amd_nn_index* handle() const { return h_; }
+  const PointCloudGPU::ConstPtr& target() const { return target_; }
+
+private:
+  PointCloudGPU::ConstPtr target_;  // kept alive: the index refers to it
+  glim_amd_nn_index* h_ = nullptr;
+};
+
+// gtsam_points::IntegratedGICPFactor (sub_mapping.cpp:202, global_mapping.cpp:400-402, global_mapping_pose_graph.cpp:393-405)
+class IntegratedGICPFactor {
+public:
+  using shared_ptr = std::shared_ptr<IntegratedGICPFactor>;
+  // binary: (target_key, source_key, target frame, source frame[, target tree])
+  IntegratedGICPFactor(Key target_key, Key source_key, PointCloudGPU::ConstPtr target, PointCloudGPU::ConstPtr source,
+                       NearestNeighborSearchGPU::ConstPtr target_tree = nullptr)
+      : is_binary_(true), target_key_(target_key), source_key_(source_key), source_(std::move(source)),
+        tree_(target_tree ? std::move(target_tree) : std::make_shared<NearestNeighborSearchGPU>(std::move(target))) {}
+  // unary: (fixed_target_pose, source_key, target frame, source frame[, target tree])
+  IntegratedGICPFactor(const Isometry3d& fixed_target_pose, Key source_key, PointCloudGPU::ConstPtr target, PointCloudGPU::ConstPtr source,
+                       NearestNeighborSearchGPU::ConstPtr target_tree = nullptr)
+      : is_binary_(false), target_key_(0), source_key_(source_key), fixed_target_pose_(fixed_target_pose), source_(std::move(source)),
+        tree_(target_tree ? std::move(target_tree) : std::make_shared<NearestNeighborSearchGPU>(std::move(target))) {}
+
+  void set_max_correspondence_distance(double d) { max_correspondence_distance_ = d; }
+  void set_num_threads(int) {}  // accepted for source compatibility (global_mapping.cpp:402); the device has no thread knob
+  std::vector<Key> keys() const { return is_binary_ ? std::vector<Key>{target_key_, source_key_} : std::vector<Key>{source_key_}; }
+  std::size_t dim() const { return 6; }
+  bool is_binary() const { return is_binary_; }
+  Isometry3d calc_delta(const Values& values) const {
+    const Isometry3d& Ts = values.at(source_key_);
+    return (is_binary_ ? values.at(target_key_) : fixed_target_pose_).inverse() * Ts;
+  }
+  const LinearizedSystem6& linearize(const Values& values) {
+    const Isometry3d d = calc_delta(values);
+    check(glim_amd_gicp_linearize(tree_->handle(), source_->handle(), d.m.data(), max_correspondence_distance_, is_binary_ ? GLIM_AMD_FACTOR_BINARY : 0u,
+                                  &linearized_),
+          "IntegratedGICPFactor::linearize");
+    num_inliers_ = linearized_.num_inliers;
+    return linearized_;
+  }
+  double error(const Values& values) {
+    const Isometry3d d = calc_delta(values);
+    double e = 0.0;
+    check(glim_amd_gicp_error(tree_->handle(), source_->handle(), d.m.data(), max_correspondence_distance_, &e, &num_inliers_), "IntegratedGICPFactor::error");
+    return e;
+  }
+  double inlier_fraction() const { return (double)num_inliers_ / (double)std::max<std::size_t>(1, source_->size()); }
+  const LinearizedSystem6& linearized() const { return linearized_; }
+
+private:
+  bool is_binary_;
+  Key target_key_, source_key_;
+  Isometry3d fixed_target_pose_;
+  PointCloudGPU::ConstPtr source_;
+  NearestNeighborSearchGPU::ConstPtr tree_;
+  double max_correspondence_distance_ = 1.0;  // gtsam_points default: max_correspondence_distance_sq = 1.0
+  std::int64_t num_inliers_ = 0;
+  LinearizedSystem6 linearized_{};
+};
+
 inline double overlap_gpu(const GaussianVoxelMapGPU::ConstPtr& target, const PointCloudGPU::ConstPtr& source, const Isometry3d& delta) {
   const glim_amd_voxelmap* t = target->handle();
   double ov = 0.0;

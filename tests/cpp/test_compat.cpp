@@ -153,6 +153,39 @@ int main() {
     }
     orc_voxelmap_destroy(om);
   }
+  // ---- GICP factor (global_mapping.cpp:400-402): same frames, nearest-neighbour correspondences; step == oracle within 1e-4 ----
+  {
+    const Isometry3d gdelta = T_world_a.inverse() * T_world_b;
+    Values gvalues;
+    gvalues[0] = Isometry3d::Identity();
+    gvalues[1] = gdelta;
+    auto tree = std::make_shared<NearestNeighborSearchGPU>(fa, 0.5);
+    IntegratedGICPFactor gicp(0, 1, fa, fb, tree);
+    gicp.set_max_correspondence_distance(0.5);
+    gicp.set_num_threads(2);
+    const LinearizedSystem6& got = gicp.linearize(gvalues);
+    std::vector<float> c32a((size_t)n * 9), c32b((size_t)n * 9);
+    REQUIRE(glim_amd_cloud_download(fa->handle(), nullptr, c32a.data(), nullptr, nullptr) == GLIM_AMD_OK);
+    REQUIRE(glim_amd_cloud_download(fb->handle(), nullptr, c32b.data(), nullptr, nullptr) == GLIM_AMD_OK);
+    std::vector<double> ca16((size_t)n * 16, 0.0), cb16((size_t)n * 16, 0.0);
+    for (int i = 0; i < n; i++)
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+          ca16[16 * (size_t)i + 4 * c + r] = c32a[9 * (size_t)i + 3 * r + c];
+          cb16[16 * (size_t)i + 4 * c + r] = c32b[9 * (size_t)i + 3 * r + c];
+        }
+    orc_linearized6 ref;
+    REQUIRE(orc_gicp_linearize(pa.data(), ca16.data(), n, pb.data(), cb16.data(), n, gdelta.m.data(), 0.5, 0, &ref, nullptr) == 0);
+    REQUIRE(got.num_inliers == ref.num_inliers && ref.num_inliers > n / 2);
+    REQUIRE(std::fabs(got.error - ref.error) <= 2e-4 * ref.error);
+    REQUIRE(max_rel_diff(got.H_ss, ref.H_ss, 36) < 2e-4 && max_rel_diff(got.H_tt, ref.H_tt, 36) < 2e-4 && max_rel_diff(got.H_ts, ref.H_ts, 36) < 2e-4);
+    double dg[6], dr[6];
+    REQUIRE(orc_solve6(got.H_ss, got.b_s, 0.0, dg) == 0 && orc_solve6(ref.H_ss, ref.b_s, 0.0, dr) == 0);
+    for (int i = 0; i < 6; i++) REQUIRE(std::fabs(dg[i] - dr[i]) < 1e-4);
+    REQUIRE(std::fabs(gicp.error(gvalues) - got.error) <= 1e-9 * got.error);
+    REQUIRE(gicp.inlier_fraction() == (double)ref.num_inliers / n);
+    std::printf("gicp OK: %lld inliers\n", (long long)ref.num_inliers);
+  }
   // ---- the per-scan front end: CloudPreprocessor::preprocess -> CloudDeskewing::deskew -> covariances (odometry_estimation_imu.cpp:300-325) ----
   {
     auto raw = std::make_shared<RawPoints>();
