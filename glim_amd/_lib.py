@@ -94,6 +94,8 @@ SYMBOLS = {
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
     "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_cloud_save_compact": (_i, [_vp, C.c_char_p]),
+    "glim_amd_cloud_load_compact": (_i, [_vp, C.c_char_p, _pp]),
     "glim_amd_nn_index_create": (_i, [_vp, _d, _pp]),
     "glim_amd_nn_index_destroy": (_i, [_vp]),
     "glim_amd_gicp_linearize": (_i, [_vp, _vp, _dp, _d, _u32, C.POINTER(Linearized6)]),

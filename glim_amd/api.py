@@ -175,6 +175,18 @@ class PointCloudGPU:
         check(lib().glim_amd_cloud_download_frame(self._h, _dp(p4), _dp(t), _dp(it), _ip(nb)), "glim_amd_cloud_download_frame")
         return dict(points=p4[:, :3].copy(), times=t, intensities=it, neighbors=nb, k_neighbors=k)
 
+    def save_compact(self, directory):
+        """gtsam_points::PointCloud::save_compact (sub_map.cpp:62): *_compact.bin files inside `directory`."""
+        check(lib().glim_amd_cloud_save_compact(self._h, str(directory).encode()), "glim_amd_cloud_save_compact")
+
+    @staticmethod
+    def load_compact(directory, ctx=None):
+        """gtsam_points::PointCloudCPU::load (sub_map.cpp:142) + clone."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib().glim_amd_cloud_load_compact(ctx._h, str(directory).encode(), C.byref(h)), "glim_amd_cloud_load_compact")
+        return PointCloudGPU(h, ctx)
+
     def download_merged(self):
         """The merged submap as PointCloudCPU holds it: (points N x 3, covs N x 3 x 3), exact FP64."""
         n = self.size()

@@ -1,6 +1,8 @@
 // cloud.hip -- PointCloudGPU equivalent: upload + FP64-AoS -> FP32-SoA pack on the device (kernel K7).
 // Replaces gtsam_points::PointCloudGPU::clone as called at src/glim/odometry/odometry_estimation_gpu.cpp:96,
 // src/glim/mapping/sub_mapping.cpp:168,393 and src/glim/mapping/global_mapping.cpp:253,260,743.
+#include <string>
+
 #include "internal.hpp"
 
 using namespace glim_amd;
@@ -215,6 +217,96 @@ int glim_amd_cloud_download(const glim_amd_cloud* c, float* xyz, float* cov33, f
   if (neighbors) GA_HIP(hipMemcpyAsync(neighbors, c->neighbors, (size_t)n * c->k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GA_HIP(hipStreamSynchronize(s));
   return GLIM_AMD_OK;
+}
+
+// gtsam_points::PointCloud::save_compact (sub_map.cpp:62): FP32 files next to data.txt -- points_compact.bin (x y z), covs_compact.bin
+// (c00 c01 c02 c11 c12 c22), normals_compact.bin (x y z), times_compact.bin, intensities_compact.bin.  The device SoA already
+// holds exactly these values, so saving is a download plus a repack of the covariance halves.
+static int write_file(const std::string& path, const void* data, size_t bytes) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return GLIM_AMD_ERR_INVALID;
+  const size_t w = bytes ? fwrite(data, 1, bytes, f) : 0;
+  fclose(f);
+  return w == bytes ? GLIM_AMD_OK : GLIM_AMD_ERR_INVALID;
+}
+static bool read_file(const std::string& path, std::vector<char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(sz > 0 ? (size_t)sz : 0);
+  const size_t r = sz > 0 ? fread(out.data(), 1, (size_t)sz, f) : 0;
+  fclose(f);
+  return r == out.size();
+}
+
+int glim_amd_cloud_save_compact(const glim_amd_cloud* c, const char* dir) {
+  if (!c || !dir) return GLIM_AMD_ERR_INVALID;
+  const size_t n = (size_t)c->n;
+  const std::string d(dir);
+  std::vector<float> xyz(n * 3), cov9(c->has_covs ? n * 9 : 0), nrm(c->has_normals ? n * 3 : 0);
+  GA_TRY(glim_amd_cloud_download(c, xyz.data(), c->has_covs ? cov9.data() : nullptr, c->has_normals ? nrm.data() : nullptr, nullptr));
+  GA_TRY(write_file(d + "/points_compact.bin", xyz.data(), xyz.size() * sizeof(float)));
+  if (c->has_covs) {
+    std::vector<float> cov6(n * 6);
+    for (size_t i = 0; i < n; i++) {
+      const float* a = &cov9[9 * i];
+      float* o = &cov6[6 * i];
+      o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[4]; o[4] = a[5]; o[5] = a[8];
+    }
+    GA_TRY(write_file(d + "/covs_compact.bin", cov6.data(), cov6.size() * sizeof(float)));
+  }
+  if (c->has_normals) GA_TRY(write_file(d + "/normals_compact.bin", nrm.data(), nrm.size() * sizeof(float)));
+  if (c->times || c->intensities) {
+    std::vector<double> t(c->times ? n : 0), it(c->intensities ? n : 0);
+    GA_TRY(glim_amd_cloud_download_frame(c, nullptr, c->times ? t.data() : nullptr, c->intensities ? it.data() : nullptr, nullptr));
+    std::vector<float> f(n);
+    if (c->times) {
+      for (size_t i = 0; i < n; i++) f[i] = (float)t[i];
+      GA_TRY(write_file(d + "/times_compact.bin", f.data(), n * sizeof(float)));
+    }
+    if (c->intensities) {
+      for (size_t i = 0; i < n; i++) f[i] = (float)it[i];
+      GA_TRY(write_file(d + "/intensities_compact.bin", f.data(), n * sizeof(float)));
+    }
+  }
+  return GLIM_AMD_OK;
+}
+
+// gtsam_points::PointCloudCPU::load (sub_map.cpp:142) followed by PointCloudGPU::clone: compact FP32 files, or the full-precision
+// points.bin (Vector4d) / covs.bin (Matrix4d) / normals.bin (Vector4d) pair when the compact ones are absent.
+int glim_amd_cloud_load_compact(glim_amd_ctx* ctx, const char* dir, glim_amd_cloud** out) {
+  if (!ctx || !dir || !out) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  const std::string d(dir);
+  std::vector<char> pb, cb, nb;
+  if (read_file(d + "/points_compact.bin", pb)) {
+    if (pb.size() % (3 * sizeof(float))) return GLIM_AMD_ERR_INVALID;
+    const size_t n = pb.size() / (3 * sizeof(float));
+    const bool has_c = read_file(d + "/covs_compact.bin", cb), has_n = read_file(d + "/normals_compact.bin", nb);
+    if ((has_c && cb.size() != n * 6 * sizeof(float)) || (has_n && nb.size() != n * 3 * sizeof(float))) return GLIM_AMD_ERR_INVALID;
+    std::vector<float> cov9(has_c ? n * 9 : 0);
+    if (has_c) {
+      const float* c6 = reinterpret_cast<const float*>(cb.data());
+      for (size_t i = 0; i < n; i++) {
+        const float* a = c6 + 6 * i;
+        float* o = &cov9[9 * i];
+        o[0] = a[0]; o[1] = o[3] = a[1]; o[2] = o[6] = a[2]; o[4] = a[3]; o[5] = o[7] = a[4]; o[8] = a[5];
+      }
+    }
+    return glim_amd_cloud_create_f32(ctx, (int64_t)n, reinterpret_cast<const float*>(pb.data()), has_c ? cov9.data() : nullptr,
+                                     has_n ? reinterpret_cast<const float*>(nb.data()) : nullptr, out);
+  }
+  if (read_file(d + "/points.bin", pb)) {
+    if (pb.size() % (4 * sizeof(double))) return GLIM_AMD_ERR_INVALID;
+    const size_t n = pb.size() / (4 * sizeof(double));
+    const bool has_c = read_file(d + "/covs.bin", cb), has_n = read_file(d + "/normals.bin", nb);
+    if ((has_c && cb.size() != n * 16 * sizeof(double)) || (has_n && nb.size() != n * 4 * sizeof(double))) return GLIM_AMD_ERR_INVALID;
+    return glim_amd_cloud_create(ctx, (int64_t)n, reinterpret_cast<const double*>(pb.data()), has_c ? reinterpret_cast<const double*>(cb.data()) : nullptr,
+                                 has_n ? reinterpret_cast<const double*>(nb.data()) : nullptr, out);
+  }
+  return GLIM_AMD_ERR_INVALID;
 }
 
 int glim_amd_cloud_set_neighbors(glim_amd_cloud* c, int k, const int32_t* neighbors) {

@@ -93,6 +93,13 @@ int glim_amd_cloud_memory_usage(const glim_amd_cloud* cloud, size_t* bytes);
 /* copy back (parity / debug): any pointer may be NULL.  xyz n x 3, cov33 n x 9, normals3 n x 3, neighbors n x k. */
 int glim_amd_cloud_download(const glim_amd_cloud* cloud, float* xyz, float* cov33, float* normals3, int32_t* neighbors);
 
+/* gtsam_points::PointCloud::save_compact(dir) / PointCloudCPU::load(dir) + clone, as SubMap::save / SubMap::load use them for a
+ * submap's merged cloud (src/glim/mapping/sub_map.cpp:62, :142): FP32 files points_compact.bin (n x xyz), covs_compact.bin
+ * (n x c00 c01 c02 c11 c12 c22), normals_compact.bin, times_compact.bin, intensities_compact.bin inside `dir` (which must exist).
+ * load also accepts the full-precision points.bin / covs.bin / normals.bin (Vector4d / Matrix4d) when no compact files exist. */
+int glim_amd_cloud_save_compact(const glim_amd_cloud* cloud, const char* dir);
+int glim_amd_cloud_load_compact(glim_amd_ctx* ctx, const char* dir, glim_amd_cloud** out);
+
 /* CloudDeskewing::deskew fused with the upload: src/glim/common/cloud_deskewing.cpp:11-53 (constant
  * velocity: n_imu == 0, linear_vel3 / angular_vel3, NULL = zero) and :55-133 (IMU poses: imu_times[n_imu], imu_poses12[n_imu x 12]
  * = T_world_imu row-major 3x4, `stamp` = scan start time), as called at src/glim/odometry/odometry_estimation_imu.cpp:313-316.
