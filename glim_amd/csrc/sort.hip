@@ -12,13 +12,17 @@
 //               order == the output order of a stable sort: all pairs with a smaller digit first, then the same digit in
 //               earlier blocks) -- the table has <= 256 columns and sits in L2, so re-deriving it per block is cheaper than
 //               a separate single-block scan launch; above 256 blocks a separate rs_offsets launch does it once.
-//               The block then re-reads its tile in ROUNDS rounds of 256 threads; inside a round the rank of a pair among
-//               the equal digits is  (equal digits in earlier rounds)  +  (equal digits in earlier waves of this round)  +
-//               (equal digits in lower lanes of this wave); the last term comes from 8 ballots (one per digit bit), so the
-//               order inside a tile is exactly the index order
-// ROUNDS (1, 2, 4, 8) is the smallest tile that keeps the grid at <= 256 blocks: small inputs still spread over the chip.
+//               Every wavefront of the block then ranks its own chunk of the tile (ROUNDS rounds of 64 pairs): rank among
+//               the equal digits =  (equal digits in earlier wavefronts)  +  (equal digits in this wavefront's earlier
+//               rounds)  +  (equal digits in lower lanes of this round); the last term comes from 8 ballots (one per digit
+//               bit), so the order inside a tile is exactly the index order.  Two block barriers per pass.
+// ROUNDS (1, 2, 4, 8) is the smallest tile that keeps the grid at <= 128 blocks (GLIM_AMD_RS_BLOCKS): small inputs still spread
+// over the chip, while the per-block re-derivation of the offsets (the whole table is read by every block) stays cheap.
 // Only the key bits the caller declares significant are sorted (`bits`): voxel keys are compacted to the bounding box of the
 // scan first (~20 bits instead of 63), so a 131 072-point scan needs 3 passes, not 8.
+#include <algorithm>
+#include <cstdlib>
+
 #include "internal.hpp"
 
 using namespace glim_amd;
@@ -71,14 +75,57 @@ __global__ __launch_bounds__(1024) void rs_offsets_kernel(int* __restrict__ hist
   }
 }
 
+// Tile layout: wavefront w of a block owns the ROUNDS * 64 consecutive pairs [w * ROUNDS * 64, (w + 1) * ROUNDS * 64) of the tile and
+// walks them in ROUNDS rounds of 64, so the stable order inside a tile is (wavefront, round, lane) == the index order.  Phase 1 needs
+// no block barrier: a wavefront ranks its own pairs against its own LDS counters (lock-step execution orders the counter read of
+// round r + 1 after the leader's update of round r).  Two barriers per pass in total.
 template <int ROUNDS, bool FUSED>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in,
                                                                 unsigned long long* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int n,
                                                                 int shift, int mask, const int* __restrict__ table, int stride) {
-  __shared__ int wave_cnt[RS_THREADS / 64][256];
-  __shared__ int running[256];
-  __shared__ int s_wave[RS_THREADS / 64];
+  constexpr int WAVES = RS_THREADS / 64;
+  __shared__ int wave_cnt[WAVES][256];   // phase 1: digit counts of each wavefront's chunk; phase 2: its base offset per digit
+  __shared__ int s_wave[WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int w = 0; w < WAVES; w++) wave_cnt[w][tid] = 0;
+  __syncthreads();
+
+  // ---- phase 1: load, digit, rank inside the wavefront's chunk ----
+  const int base = blockIdx.x * (RS_THREADS * ROUNDS) + wave * (ROUNDS * 64) + lane;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  unsigned long long key[ROUNDS];
+  unsigned int val[ROUNDS];
+  int rank[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const int i = base + r * 64;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : 0ull;
+    val[r] = valid ? (vals_in ? vals_in[i] : (unsigned int)i) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    const bool valid = base + r * 64 < n;
+    const int d = (int)(key[r] >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const int below = __popcll(peers & lt_mask);
+    const int prior = wave_cnt[wave][d];  // equal digits in this wavefront's earlier rounds
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) wave_cnt[wave][d] = prior + __popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = prior + below;
+  }
+  __syncthreads();
+
+  // ---- phase 2: thread d turns the per-wavefront counts of digit d into base offsets ----
+  int offset;
   if (FUSED) {
     // row `tid` of the histogram table (stride is a multiple of 4, padding columns are zero): digit total and the part in earlier blocks
     const int4* row = reinterpret_cast<const int4*>(table + (size_t)tid * stride);
@@ -101,49 +148,26 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned l
     __syncthreads();
     int wave_off = 0;
     for (int w = 0; w < wave; w++) wave_off += s_wave[w];
-    running[tid] = wave_off + inc - total + before;
+    offset = wave_off + inc - total + before;
   } else {
-    running[tid] = table[(size_t)tid * stride + blockIdx.x];
+    offset = table[(size_t)tid * stride + blockIdx.x];
   }
 #pragma unroll
-  for (int w = 0; w < RS_THREADS / 64; w++) wave_cnt[w][tid] = 0;
+  for (int w = 0; w < WAVES; w++) {
+    const int c = wave_cnt[w][tid];
+    wave_cnt[w][tid] = offset;
+    offset += c;
+  }
   __syncthreads();
-  const int base = blockIdx.x * (RS_THREADS * ROUNDS);
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  // ---- phase 3: scatter ----
 #pragma unroll
   for (int r = 0; r < ROUNDS; r++) {
-    const int i = base + r * RS_THREADS + tid;
-    const bool valid = i < n;
-    const unsigned long long key = valid ? keys_in[i] : 0ull;
-    const unsigned int val = valid ? (vals_in ? vals_in[i] : (unsigned int)i) : 0u;
-    const int d = (int)(key >> shift) & mask;
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const bool bit = (d >> b) & 1;
-      const unsigned long long bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    const int rank_in_wave = __popcll(peers & lt_mask);
-    if (valid && rank_in_wave == 0) wave_cnt[wave][d] = __popcll(peers);
-    __syncthreads();
-    if (valid) {
-      int off = running[d];
-      for (int w = 0; w < wave; w++) off += wave_cnt[w][d];
-      const int dst = off + rank_in_wave;
-      keys_out[dst] = key;
-      vals_out[dst] = val;
-    }
-    if (r + 1 < ROUNDS) {
-      __syncthreads();
-      int add = 0;
-#pragma unroll
-      for (int w = 0; w < RS_THREADS / 64; w++) {
-        add += wave_cnt[w][tid];
-        wave_cnt[w][tid] = 0;
-      }
-      running[tid] += add;
-      __syncthreads();
+    if (base + r * 64 < n) {
+      const int d = (int)(key[r] >> shift) & mask;
+      const int dst = wave_cnt[wave][d] + rank[r];
+      keys_out[dst] = key[r];
+      vals_out[dst] = val[r];
     }
   }
 }
@@ -160,9 +184,17 @@ void launch_pass(hipStream_t st, int B, int stride, const unsigned long long* ki
   }
 }
 
+inline int block_target() {
+  static const int t = [] {
+    const char* e = getenv("GLIM_AMD_RS_BLOCKS");  // tuning knob: largest grid the tile choice aims for (<= RS_FUSED_MAX_BLOCKS)
+    const int v = e ? atoi(e) : 128;  // measured on MI355X, 131 072 pairs: 64 blocks 16.5 us / pass, 128: 14.8, 256: 18.9 (every block reads the whole table)
+    return std::max(1, std::min(v, RS_FUSED_MAX_BLOCKS));
+  }();
+  return t;
+}
 inline int pick_rounds(int n) {
   for (int r = 1; r < 8; r <<= 1)
-    if ((n + RS_THREADS * r - 1) / (RS_THREADS * r) <= RS_FUSED_MAX_BLOCKS) return r;
+    if ((n + RS_THREADS * r - 1) / (RS_THREADS * r) <= block_target()) return r;
   return 8;
 }
 inline int table_stride(int n) {

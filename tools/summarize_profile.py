@@ -1,0 +1,85 @@
+"""Turn the raw rocprofv3 output of tools/profile.sh (gpurun_out/prof_<tag>/) into the committed summaries under profiles/<tag>/:
+summary.json (per kernel x grid: calls, avg / min / max duration from the kernel trace; FETCH_SIZE / WRITE_SIZE averages from
+the separate PMC passes), kernel_stats.csv (rocprofv3's own --stats table) and traffic.json (HBM bytes per launch of the dominant
+kernel, corrected as MI355X_MICROARCH.md prescribes with the calibration measured by tools/fetch_calib.sh).
+
+usage: python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01 [factors_per_launch]"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+F = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    m = glob.glob(os.path.join(src, pattern), recursive=True)
+    return m[0] if m else None
+
+
+def by_kernel_grid(path, value_col, scale=1.0):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+        acc[(r["Kernel_Name"], grid)].append(float(r[value_col]) * scale)
+    return acc
+
+
+summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   "
+                      "(tools/profile.sh; PMC passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE)"}
+trace = one("stats/**/*kernel_trace.csv")
+rows = []
+if trace:
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        acc[(r["Kernel_Name"], int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        rows.append({"kernel": k, "grid": g, "calls": len(v), "avg_us": round(sum(v) / len(v), 3), "min_us": round(min(v), 3), "max_us": round(max(v), 3)})
+summary["kernel_trace_by_grid"] = rows
+for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    path = one(f"{tag}/**/*counter_collection.csv")
+    out = []
+    if path:
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+        for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            out.append({"kernel": k, "grid": g, "counter": counter, "calls": len(v), "avg": sum(v) / len(v)})
+    summary[tag] = out
+json.dump(summary, open(os.path.join(dst, "summary.json"), "w"), indent=1)
+stats = one("stats/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
+bench = os.path.join(src, "bench_stats.json")
+if os.path.exists(bench) and os.path.getsize(bench):
+    shutil.copy(bench, os.path.join(dst, "bench_under_rocprof.json"))
+
+# traffic of the dominant kernel (largest total time among vgicp_kernel instantiations)
+tj = os.path.join(dst, "traffic.json")
+old = json.load(open(tj)) if os.path.exists(tj) else {}
+dom = next((r for r in rows if "vgicp_kernel" in r["kernel"]), None)
+if dom and summary["pmc_fetch"]:
+    f = next((x for x in summary["pmc_fetch"] if x["kernel"] == dom["kernel"] and x["grid"] == dom["grid"]), None)
+    w = next((x for x in summary["pmc_write"] if x["kernel"] == dom["kernel"] and x["grid"] == dom["grid"]), None)
+    cal = old.get("calibration", {})
+    factor = cal.get("factor_coalesced", 1.926)
+    n_pts = F * 131072
+    stream_bytes = 24 * n_pts  # plane-form stream: the part of the reads FETCH_SIZE under-reports by `factor`
+    stream_raw_kb = stream_bytes / 1024.0 / factor
+    if f:
+        gather_raw_kb = max(0.0, f["avg"] - stream_raw_kb)
+        read = stream_bytes + gather_raw_kb * 1024.0
+        wr = (w["avg"] * 1024.0) if w else 0.0
+        old.update({
+            "workload": f"odometry128k (bench.py default, F={F}), plane-form source clouds",
+            "kernel": dom["kernel"][dom["kernel"].find("vgicp_kernel"):].split("(")[0],
+            "kernel_avg_us_rocprof": dom["avg_us"],
+            "fetch_size_kb_raw": f["avg"], "write_size_kb_raw": w["avg"] if w else None,
+            "read_bytes_per_launch": read, "read_bytes_per_launch_upper": stream_bytes + 2 * gather_raw_kb * 1024.0,
+            "write_bytes_per_launch": wr, "traffic_bytes_per_launch": read + wr,
+            "factors_per_launch_when_measured": F, "traffic_bytes_per_factor": (read + wr) / F,
+        })
+        json.dump(old, open(tj, "w"), indent=1)
+print(json.dumps({"kernels": len(rows), "dominant": dom and {k: dom[k] for k in ("grid", "calls", "avg_us")}, "traffic_per_factor": old.get("traffic_bytes_per_factor")}))
