@@ -615,6 +615,11 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   // finished exhaustively.  Measured alternatives on MI355X (131 072-pt LiDAR scan / 307 104-pt depth frame, ms): starting 8x finer
   // with 2 rings per level 2.8 / 2.2, 4x finer 2.1 / 2.0, this schedule 0.97 / 1.22 -- every extra level costs a grid rebuild and a
   // latency-bound pass (~0.5 ms), which outweighs the shorter candidate lists of the dense cells next to the sensor.
+  DeviceTemp dbg_buf;  // GLIM_AMD_KNN_DEBUG=<file>: per-query work counters of level 0 (candidates, probes, last ring, 10 ns ticks), int32[n][4]
+  if (getenv("GLIM_AMD_KNN_DEBUG")) {
+    GA_HIP(pool_malloc(&dbg_buf.p, (size_t)n * 4 * sizeof(int)));
+    GA_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n * 4 * sizeof(int), st));
+  }
   double fine = 1.0;
   if (const char* env = getenv("GLIM_AMD_KNN_FINE")) fine = std::max(1.0, atof(env));
   int level_ring = MAX_RING;
