@@ -136,13 +136,21 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float4* 
 }
 
 // ---- grid query: one lane per point, in cell order ----
+// What bounds this kernel on MI355X (per-query counters, GLIM_AMD_KNN_DEBUG): a wavefront lasts as long as its slowest lane, and a
+// scan is far from uniformly dense -- the mean query of a 131 072-point LiDAR scan sees 278 candidates, the cells next to the sensor
+// 4000 (p99), so the few wavefronts that hold those queries set the kernel time (0.8 of the 0.95 ms).  Tried and measured slower:
+// G = 2 / 4 / 8 lanes per query with a shuffle merge of their top-K lists (1.2 / 1.4-1.8 / 2.4 ms: the walk is not latency-bound,
+// the extra lanes only add merge work); queries in arrival order instead of cell order (0.94 / 1.44 vs 0.97 / 1.18 ms on the LiDAR
+// scan / depth frame); a directly addressed grid with contiguous row runs instead of hash probes (1.42 ms); starting on a 4-8x
+// finer grid with 2 rings per level (2.1-2.8 ms: every extra level costs a grid rebuild and another pass).  What helped: four
+// candidate loads in flight per lane (1.3 -> 0.95 ms).
 template <int K>
 __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __restrict__ sorted, double h, double inv_h,
                                                        const unsigned long long* __restrict__ keys, unsigned int mask, const int* __restrict__ starts,
                                                        const int* __restrict__ counts, int k, int32_t* __restrict__ out, int* __restrict__ unresolved,
                                                        int* __restrict__ stats, const float4* __restrict__ pts, const int* __restrict__ queries,
                                                        int num_queries, int max_ring, int* __restrict__ dbg) {
-  // first pass: one lane per point in cell order (queries == nullptr); retry passes on a coarser grid: the listed points only
+  // first pass: every point in cell order (queries == nullptr); retry passes on a coarser grid: the listed points only
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= (queries ? num_queries : n)) return;
   float4 q4;
@@ -195,8 +203,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
           if (found < 0) continue;
           const int b = starts[found], e = b + counts[found];
           dbg_cand += e - b;
-          // four candidates per trip, loads issued back to back: the walk is a chain of dependent L2 round trips, and with one
-          // wavefront or two per SIMD (131 072 queries on 1024 SIMDs) nothing else hides them
+          // four candidates per trip, loads issued back to back
           int j = b;
           for (; j + 4 <= e; j += 4) {
             const float4 c0 = sorted[j], c1 = sorted[j + 1], c2 = sorted[j + 2], c3 = sorted[j + 3];
@@ -230,132 +237,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
 #pragma unroll
   for (int j = 0; j < K; j++)
     if (j < k) out[(size_t)self * k + j] = best.idx[j];  // fewer than k points in the whole cloud never reaches here (n > k enforced)
-}
-
-// ---- dense grid (default whenever the bounding box holds <= DENSE_MAX_CELLS cells): cells are addressed directly, x fastest,
-// and the points are counting-sorted by linear cell id, so the cells dx = -r .. r of one (dy, dz) row are ONE contiguous run of
-// the sorted array: a ring costs 8 r full rows + 2 end cells of the interior rows -- 45 range lookups (two loads each, no hashing,
-// no collisions) for rings 0..2 instead of 125 hash probes. ----
-constexpr long long DENSE_MAX_CELLS = 32ll << 20;
-
-struct DenseGrid {
-  int cmin[3];  // cell coordinate of the grid origin (floor(bbox_min / h))
-  int dim[3];
-};
-
-// stats: [0] occupied cells, [1] points without a cell (non-finite), [2] unresolved queries
-__global__ __launch_bounds__(256) void dense_count_kernel(int n, const float4* __restrict__ pts, double inv_h, DenseGrid g, int* __restrict__ counts,
-                                                          int* __restrict__ cell_of, int* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  const double t[3] = {(double)p.x * inv_h, (double)p.y * inv_h, (double)p.z * inv_h};
-  int c[3];
-  bool ok = true;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    ok = ok && (t[a] >= -1048576.0 && t[a] < 1048576.0);
-    c[a] = ok ? fast_floor_d(t[a]) - g.cmin[a] : 0;
-    ok = ok && c[a] >= 0 && c[a] < g.dim[a];
-  }
-  if (!ok) {
-    atomicAdd(&stats[1], 1);
-    cell_of[i] = -1;
-    return;
-  }
-  const int cell = (c[2] * g.dim[1] + c[1]) * g.dim[0] + c[0];
-  if (atomicAdd(&counts[cell], 1) == 0) atomicAdd(&stats[0], 1);
-  cell_of[i] = cell;
-}
-
-__global__ __launch_bounds__(256) void dense_scatter_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ cell_of,
-                                                            const int* __restrict__ starts, int* __restrict__ cursor, float4* __restrict__ sorted) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int c = cell_of[i];
-  if (c < 0) return;
-  const int pos = starts[c] + atomicAdd(&cursor[c], 1);
-  const float4 p = pts[i];
-  sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
-}
-
-template <int K>
-__global__ void knn_dense_kernel(int n, const float4* __restrict__ sorted, double h, double inv_h, DenseGrid g, const int* __restrict__ starts, int k,
-                                 int32_t* __restrict__ out, int* __restrict__ unresolved, int* __restrict__ stats, const float4* __restrict__ pts,
-                                 const int* __restrict__ queries, int num_queries) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= (queries ? num_queries : n)) return;
-  float4 q4;
-  if (queries) {
-    const int qi = queries[s];
-    const float4 p = pts[qi];
-    q4 = make_float4(p.x, p.y, p.z, __int_as_float(qi));
-  } else {
-    q4 = sorted[s];
-  }
-  const int self = __float_as_int(q4.w);
-  const double qx = q4.x, qy = q4.y, qz = q4.z;
-  const double tx = qx * inv_h, ty = qy * inv_h, tz = qz * inv_h;
-  const int ax = fast_floor_d(tx), ay = fast_floor_d(ty), az = fast_floor_d(tz);
-  double margin = fmin(fmin(tx - (double)ax, (double)(ax + 1) - tx), fmin(fmin(ty - (double)ay, (double)(ay + 1) - ty), fmin(tz - (double)az, (double)(az + 1) - tz)));
-  margin = fmax(0.0, margin * h * 0.999999);
-  const int cx = ax - g.cmin[0], cy = ay - g.cmin[1], cz = az - g.cmin[2];  // grid-relative cell of the query
-  TopK<K> best;
-  best.init(self);
-  bool done = false;
-  for (int ring = 0; ring <= MAX_RING; ring++) {
-    if (ring >= 1) {
-      const double reach = (double)(ring - 1) * h * 0.999999 + margin;
-      if (best.d[K - 1] < reach * reach) {
-        done = true;
-        break;
-      }
-    }
-    const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dim[0] - 1);
-    for (int dz = -ring; dz <= ring; dz++) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.dim[2]) continue;
-      for (int dy = -ring; dy <= ring; dy++) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.dim[1]) continue;
-        const int row = (z * g.dim[1] + y) * g.dim[0];
-        const bool shell_yz = (abs(dz) == ring) || (abs(dy) == ring);
-        if (shell_yz) {
-          // the whole row segment x0 .. x1 is new: one contiguous run of the sorted array
-          if (x0 <= x1) {
-            const int b = starts[row + x0], e = starts[row + x1 + 1];
-            for (int j = b; j < e; j++) {
-              const float4 c = sorted[j];
-              best.push(sqdist(qx, qy, qz, (double)c.x, (double)c.y, (double)c.z), __float_as_int(c.w));
-            }
-          }
-        } else {
-          // interior row: only the two end cells dx = -ring and dx = +ring are new
-#pragma unroll
-          for (int side = 0; side < 2; side++) {
-            const int x = side ? cx + ring : cx - ring;
-            if (x < 0 || x >= g.dim[0]) continue;
-            const int b = starts[row + x], e = starts[row + x + 1];
-            for (int j = b; j < e; j++) {
-              const float4 c = sorted[j];
-              best.push(sqdist(qx, qy, qz, (double)c.x, (double)c.y, (double)c.z), __float_as_int(c.w));
-            }
-          }
-        }
-      }
-    }
-  }
-  if (!done) {
-    const double reach = (double)MAX_RING * h * 0.999999 + margin;
-    done = best.d[K - 1] < reach * reach;
-  }
-  if (!done) {
-    unresolved[atomicAdd(&stats[2], 1)] = self;
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < K; j++)
-    if (j < k) out[(size_t)self * k + j] = best.idx[j];
 }
 
 // bounding box by ordered-int atomics: bb[0..2] = min, bb[3..5] = max (as order-preserving ints)
@@ -445,128 +326,6 @@ int sort_into_grid(hipStream_t st, int n, const float4* pts, GridBuffers& g) {
   return GLIM_AMD_OK;
 }
 
-template <int K>
-void launch_dense(hipStream_t st, int n, const float4* sorted, double h, const DenseGrid& g, const int* starts, int k, int32_t* out, int* unresolved,
-                  int* stats, const float4* pts, const int* queries, int nq) {
-  const int work = queries ? nq : n;
-  if (work <= 0) return;
-  const int block = work < 65536 ? 64 : 256;  // small clouds: one wavefront per block spreads the latency-bound walks over more CUs
-  knn_dense_kernel<K><<<(work + block - 1) / block, block, 0, st>>>(n, sorted, h, 1.0 / h, g, starts, k, out, unresolved, stats, pts, queries, nq);
-}
-
-struct DenseBuffers {
-  DeviceTemp starts, cursor, cell_of, sorted, stats, tile_sums;
-  size_t cap_cells = 0;
-};
-
-// cells of the bounding box at cell edge h; false if that exceeds DENSE_MAX_CELLS
-bool dense_dims(const float* bb_min, const float* bb_max, double h, DenseGrid& g, long long& cells) {
-  cells = 1;
-  for (int a = 0; a < 3; a++) {
-    // the device's own expression (coordinate * (1 / h)), plus one spare cell on either side
-    const double inv_h = 1.0 / h;
-    const double lo = std::floor((double)bb_min[a] * inv_h) - 1.0, hi = std::floor((double)bb_max[a] * inv_h) + 1.0;
-    if (!(lo >= -1048576.0 && hi < 1048576.0)) return false;
-    g.cmin[a] = (int)lo;
-    g.dim[a] = (int)(hi - lo) + 1;
-    cells *= g.dim[a];
-    if (cells > DENSE_MAX_CELLS) return false;
-  }
-  return true;
-}
-
-int build_dense(hipStream_t st, int n, const float4* pts, double h, const DenseGrid& g, long long cells, DenseBuffers& d, int* h_stats) {
-  if ((size_t)cells + 1 > d.cap_cells) {
-    if (d.starts.p) (void)pool_free(d.starts.p);
-    if (d.cursor.p) (void)pool_free(d.cursor.p);
-    if (d.tile_sums.p) (void)pool_free(d.tile_sums.p);
-    d.starts.p = d.cursor.p = d.tile_sums.p = nullptr;
-    GA_HIP(pool_malloc(&d.starts.p, ((size_t)cells + 1) * sizeof(int)));
-    GA_HIP(pool_malloc(&d.cursor.p, ((size_t)cells + 1) * sizeof(int)));
-    GA_HIP(pool_malloc(&d.tile_sums.p, scan_scratch_ints((unsigned int)cells + 1) * sizeof(int)));
-    d.cap_cells = (size_t)cells + 1;
-  }
-  GA_HIP(hipMemsetAsync(d.cursor.p, 0, ((size_t)cells + 1) * sizeof(int), st));  // counts first, cursors later
-  GA_HIP(hipMemsetAsync(d.stats.p, 0, 4 * sizeof(int), st));
-  dense_count_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, 1.0 / h, g, d.cursor.as<int>(), d.cell_of.as<int>(), d.stats.as<int>());
-  GA_HIP(hipGetLastError());
-  GA_HIP(hipMemcpyAsync(h_stats, d.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
-  return GLIM_AMD_OK;
-}
-
-int sort_into_dense(hipStream_t st, int n, const float4* pts, long long cells, DenseBuffers& d) {
-  GA_HIP(exclusive_scan_int(st, d.cursor.as<int>(), (unsigned int)cells + 1, d.tile_sums.as<int>(), d.starts.as<int>()));
-  GA_HIP(hipMemsetAsync(d.cursor.p, 0, ((size_t)cells + 1) * sizeof(int), st));
-  dense_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, d.cell_of.as<int>(), d.starts.as<int>(), d.cursor.as<int>(), d.sorted.as<float4>());
-  GA_HIP(hipGetLastError());
-  return GLIM_AMD_OK;
-}
-
-// Dense-grid kNN.  *handled = false when the bounding box does not fit a dense grid (or holds points without a cell): the caller
-// falls back to the hashed grid.
-int knn_dense(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out, const float* bb_min, const float* bb_max, double h,
-              double h_min, double diag, double ppc, bool* handled) {
-  *handled = false;
-  DenseGrid g;
-  long long cells = 0;
-  while (!dense_dims(bb_min, bb_max, h, g, cells)) {
-    h *= 1.26;  // coarsen until the box fits (x2 cells per step)
-    if (h > 1e6) return GLIM_AMD_OK;
-  }
-  DenseBuffers d;
-  DeviceTemp unresolved_a, unresolved_b;
-  GA_HIP(pool_malloc(&d.cell_of.p, (size_t)n * sizeof(int)));
-  GA_HIP(pool_malloc(&d.sorted.p, (size_t)n * sizeof(float4)));
-  GA_HIP(pool_malloc(&d.stats.p, 4 * sizeof(int)));
-  GA_HIP(pool_malloc(&unresolved_a.p, (size_t)n * sizeof(int)));
-  GA_HIP(pool_malloc(&unresolved_b.p, (size_t)n * sizeof(int)));
-  int h_stats[4] = {0, 0, 0, 0};
-  for (int attempt = 0; attempt < 4; attempt++) {
-    GA_TRY(build_dense(st, n, pts, h, g, cells, d, h_stats));
-    if (h_stats[1] != 0) return GLIM_AMD_OK;  // non-finite points: let the hashed path report them
-    const double per_cell = (double)n / std::max(1, h_stats[0]);
-    double h_try = h;
-    if (per_cell > 2.7 * ppc && attempt < 3 && h * 0.5 >= h_min) h_try = h * 0.5;
-    else if (per_cell < 0.5 * ppc && attempt < 3) h_try = h * 2.0;
-    DenseGrid g_try;
-    long long cells_try = 0;
-    if (h_try == h || !dense_dims(bb_min, bb_max, h_try, g_try, cells_try)) break;
-    h = h_try;
-    g = g_try;
-    cells = cells_try;
-  }
-  int* todo = unresolved_a.as<int>();
-  int* next = unresolved_b.as<int>();
-  int num_todo = 0;
-  for (int level = 0; level < 12; level++) {
-    if (level > 0) {
-      h *= 4.0;
-      if (!dense_dims(bb_min, bb_max, h, g, cells)) return GLIM_AMD_ERR_RANGE;  // cannot happen: coarser grids are smaller
-      GA_TRY(build_dense(st, n, pts, h, g, cells, d, h_stats));
-    }
-    GA_TRY(sort_into_dense(st, n, pts, cells, d));
-    GA_HIP(hipMemsetAsync(d.stats.as<int>() + 2, 0, sizeof(int), st));
-    DISPATCH_K(launch_dense, st, n, d.sorted.as<float4>(), h, g, d.starts.as<int>(), k, out, next, d.stats.as<int>(), pts, level > 0 ? todo : (const int*)nullptr,
-               num_todo);
-    GA_HIP(hipGetLastError());
-    GA_HIP(hipMemcpyAsync(h_stats, d.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
-    num_todo = h_stats[2];
-    if (num_todo == 0) {
-      *handled = true;
-      return GLIM_AMD_OK;
-    }
-    std::swap(todo, next);
-    if ((double)MAX_RING * h > diag) break;
-  }
-  DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)todo, num_todo);
-  GA_HIP(hipGetLastError());
-  GA_HIP(hipStreamSynchronize(st));
-  *handled = true;
-  return GLIM_AMD_OK;
-}
-
 int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out) {
   // ---- cell edge from the data: a surface-like cloud of n points in its bounding box, ~3 points per occupied cell ----
   DeviceTemp bb, unresolved_a, unresolved_b;
@@ -590,13 +349,6 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   const double h_min = max_abs / 1.0e6 + 1e-9;  // keep cell coordinates inside the 21-bit key range
   h = std::max(h, h_min);
   const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
-
-  if (getenv("GLIM_AMD_KNN_DENSE") != nullptr) {  // experiment: directly addressed grid with row runs (no faster than the hashed one, see below)
-    const float bb_min[3] = {unordered(h_bb[0]), unordered(h_bb[1]), unordered(h_bb[2])}, bb_max[3] = {unordered(h_bb[3]), unordered(h_bb[4]), unordered(h_bb[5])};
-    bool handled = false;
-    GA_TRY(knn_dense(ctx, st, n, pts, k, out, bb_min, bb_max, h, h_min, diag, ppc, &handled));
-    if (handled) return GLIM_AMD_OK;
-  }
 
   g.T = next_pow2((unsigned long long)n * 2);
   GA_HIP(pool_malloc(&g.keys.p, (size_t)g.T * sizeof(unsigned long long)));
