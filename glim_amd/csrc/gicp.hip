@@ -180,6 +180,17 @@ __device__ __forceinline__ int nearest(const GicpArgs& a, double qx, double qy, 
       for (int dy = -ring; dy <= ring; dy++) {
         const bool shell_yz = (abs(dz) == ring) || (abs(dy) == ring);
         for (int dx = -ring; dx <= ring; dx += (shell_yz || ring == 0) ? 1 : 2 * ring) {
+          if (ring >= 1) {
+            // prune: no point of this cell is closer than the gap between q and the cell's box (shrunk so that rounding in the cell
+            // assignment cannot make it optimistic); strictly greater than the current best / the radius, so ties are still seen
+            const double gx = dx > 0 ? (double)(cx + dx) - tx : (dx < 0 ? tx - (double)(cx + dx + 1) : 0.0);
+            const double gy = dy > 0 ? (double)(cy + dy) - ty : (dy < 0 ? ty - (double)(cy + dy + 1) : 0.0);
+            const double gz = dz > 0 ? (double)(cz + dz) - tz : (dz < 0 ? tz - (double)(cz + dz + 1) : 0.0);
+            const double gap = a.h * 0.999999;
+            const double ex = fmax(0.0, gx) * gap, ey = fmax(0.0, gy) * gap, ez = fmax(0.0, gz) * gap;
+            const double g2 = ex * ex + ey * ey + ez * ez;
+            if (g2 > best_d || g2 > a.max_sq) continue;
+          }
           const u32 ux = (u32)(cx + dx + KEY_OFFSET), uy = (u32)(cy + dy + KEY_OFFSET), uz = (u32)(cz + dz + KEY_OFFSET);
           if ((ux | uy | uz) >> KEY_BITS) continue;
           const u64 key = (u64)ux | ((u64)uy << 21) | ((u64)uz << 42);
