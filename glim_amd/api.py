@@ -585,6 +585,23 @@ class IntegratedGICPFactor:
             pass
 
 
+def median_distance(points, max_scan_count=256):
+    """gtsam_points::median_distance (odometry_estimation_gpu.cpp:91, global_mapping.cpp:239): host side, as in the reference."""
+    p = np.asarray(points, dtype=np.float64)[:, :3]
+    n = len(p)
+    if n == 0:
+        return 0.0
+    step = 1 if n < max_scan_count else n // max_scan_count
+    d = np.sort(np.sqrt((p[::step] ** 2).sum(1)))
+    return float(d[len(d) // 2])
+
+
+def adaptive_voxel_resolution(dist_median, voxel_resolution, voxel_resolution_max, voxel_resolution_dmin, voxel_resolution_dmax):
+    """base_resolution of odometry_estimation_gpu.cpp:92-93 / global_mapping.cpp:240-241."""
+    p = max(0.0, min(1.0, (dist_median - voxel_resolution_dmin) / (voxel_resolution_dmax - voxel_resolution_dmin)))
+    return voxel_resolution + p * (voxel_resolution_max - voxel_resolution)
+
+
 def _pack_frames(poses, frames_points, frames_covs):
     """Host layouts of the reference for a list of frames: poses n x 12, Vector4d points, column-major Matrix4d covariances."""
     nf = len(poses)

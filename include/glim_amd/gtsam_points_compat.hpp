@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -369,6 +370,26 @@ private:
   std::int64_t num_inliers_ = 0;
   LinearizedSystem6 linearized_{};
 };
+
+// gtsam_points::median_distance(frame, max_scan_count) and the resolution blend GLIM applies to it
+// (odometry_estimation_gpu.cpp:90-93, global_mapping.cpp:238-241): host-side, as in the reference.
+inline double median_distance(const double* points4, std::int64_t n, std::size_t max_scan_count = 256) {
+  if (n <= 0) return 0.0;
+  const std::size_t step = (std::size_t)n < max_scan_count ? 1 : (std::size_t)n / max_scan_count;
+  std::vector<double> dists;
+  dists.reserve((std::size_t)n / step + 1);
+  for (std::size_t i = 0; i < (std::size_t)n; i += step) {
+    const double* p = points4 + 4 * i;
+    dists.push_back(std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+  }
+  std::nth_element(dists.begin(), dists.begin() + dists.size() / 2, dists.end());
+  return dists[dists.size() / 2];
+}
+inline double adaptive_voxel_resolution(double dist_median, double voxel_resolution, double voxel_resolution_max, double voxel_resolution_dmin,
+                                        double voxel_resolution_dmax) {
+  const double p = std::max(0.0, std::min(1.0, (dist_median - voxel_resolution_dmin) / (voxel_resolution_dmax - voxel_resolution_dmin)));
+  return voxel_resolution + p * (voxel_resolution_max - voxel_resolution);
+}
 
 inline double overlap_gpu(const GaussianVoxelMapGPU::ConstPtr& target, const PointCloudGPU::ConstPtr& source, const Isometry3d& delta) {
   const glim_amd_voxelmap* t = target->handle();

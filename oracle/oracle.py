@@ -144,6 +144,10 @@ def lib():
         L.orc_gicp_linearize.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, C.c_double, C.c_int, C.POINTER(Linearized6), ip]
         L.orc_gicp_error.restype = C.c_double
         L.orc_gicp_error.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, C.c_double, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_median_distance.restype = C.c_double
+        L.orc_median_distance.argtypes = [dp, C.c_int, C.c_int]
+        L.orc_adaptive_resolution.restype = C.c_double
+        L.orc_adaptive_resolution.argtypes = [C.c_double] * 5
         L.orc_merge_frames.restype = C.c_int
         L.orc_merge_frames.argtypes = [C.c_int, dp, C.POINTER(dp), C.POINTER(dp), ip, C.c_double, C.c_int, C.c_int, C.c_uint64, dp, dp]
         L.orc_max_threads.restype = C.c_int
@@ -480,3 +484,12 @@ def gicp_error(tgt_xyz, tgt_covs33, src_xyz, src_covs33, delta, max_corresponden
     e = lib().orc_gicp_error(_dp(tp), _dp(tc), len(tp), _dp(sp), _dp(sc), len(sp), _dp(pose12(delta)), float(max_correspondence_distance), num_threads,
                              C.byref(ninl))
     return float(e), int(ninl.value)
+
+
+def median_distance(points_xyz, max_scan_count=256):
+    p4 = points4(points_xyz)
+    return float(lib().orc_median_distance(_dp(p4), len(p4), int(max_scan_count)))
+
+
+def adaptive_resolution(dist_median, r0, rmax, dmin, dmax):
+    return float(lib().orc_adaptive_resolution(float(dist_median), float(r0), float(rmax), float(dmin), float(dmax)))

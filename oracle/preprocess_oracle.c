@@ -360,3 +360,32 @@ int orc_merge_frames(int num_frames, const double* poses12, const double* const*
   free(keep); free(MP); free(MC); free(P); free(C);
   return out_n;
 }
+
+/* ---- adaptive voxel resolution: gtsam_points::median_distance(frame, 256) as called at
+ * src/glim/odometry/odometry_estimation_gpu.cpp:90-93 and src/glim/mapping/global_mapping.cpp:238-241 ----
+ * (!) upstream-recall: every step-th point (step = n / max_scan_count, at least 1), Euclidean norm of xyz, the element at
+ * index size / 2 of the sorted list (std::nth_element).  The call sites then blend the base resolution:
+ * p = clamp((d - dmin) / (dmax - dmin), 0, 1), resolution = r0 + p (rmax - r0). */
+static int cmp_double(const void* a, const void* b) {
+  const double x = *(const double*)a, y = *(const double*)b;
+  return (x > y) - (x < y);
+}
+double orc_median_distance(const double* points4, int n, int max_scan_count) {
+  if (n <= 0) return 0.0;
+  const int step = n < max_scan_count ? 1 : n / max_scan_count;
+  double* d = (double*)malloc(sizeof(double) * (size_t)(n / step + 1));
+  int m = 0;
+  for (int i = 0; i < n; i += step) {
+    const double* p = points4 + 4 * (size_t)i;
+    d[m++] = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  }
+  qsort(d, (size_t)m, sizeof(double), cmp_double);
+  const double med = d[m / 2];
+  free(d);
+  return med;
+}
+double orc_adaptive_resolution(double dist_median, double r0, double rmax, double dmin, double dmax) {
+  double p = (dist_median - dmin) / (dmax - dmin);
+  p = p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
+  return r0 + p * (rmax - r0);
+}

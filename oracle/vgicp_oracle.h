@@ -180,6 +180,10 @@ int orc_preprocess(const double* points4, const double* times, const double* int
 int orc_merge_frames(int num_frames, const double* poses12, const double* const* points4, const double* const* covs16, const int* sizes,
                      double resolution, int block_size, int target_num_points, uint64_t seed, double* out_points4, double* out_covs16);
 
+/* ---- adaptive voxel resolution (row a9): gtsam_points::median_distance + the blend at odometry_estimation_gpu.cpp:90-93 ---- */
+double orc_median_distance(const double* points4, int n, int max_scan_count);
+double orc_adaptive_resolution(double dist_median, double r0, double rmax, double dmin, double dmax);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -97,6 +97,19 @@ int main(int argc, char** argv) {
   REQUIRE(std::get<0>(h.matching_cost_factors[2]) == "gicp" && std::get<1>(h.matching_cost_factors[2]) == 1 && std::get<2>(h.matching_cost_factors[2]) == 2);
   REQUIRE(submap_dir("/tmp/dump", 12) == "/tmp/dump/000012");
   REQUIRE(!GraphTxt().load(dir + "/missing"));
+  // row a9 host helpers: median range of <= max_scan_count strided samples and the resolution blend
+  {
+    std::vector<double> pts;
+    for (int i = 0; i < 1000; i++) {
+      const double r = 1.0 + 0.01 * i;
+      pts.insert(pts.end(), {r, 0.0, 0.0, 1.0});
+    }
+    REQUIRE(std::fabs(median_distance(pts.data(), 1000, 256) - (1.0 + 0.01 * 501)) < 1e-12);  // step 3 -> 334 samples, element 167 -> i = 501
+    REQUIRE(std::fabs(median_distance(pts.data(), 100, 256) - (1.0 + 0.01 * 50)) < 1e-12);
+    REQUIRE(median_distance(pts.data(), 0) == 0.0);
+    REQUIRE(std::fabs(adaptive_voxel_resolution(8.0, 0.25, 0.5, 4.0, 12.0) - 0.375) < 1e-15);
+    REQUIRE(adaptive_voxel_resolution(1.0, 0.25, 0.5, 4.0, 12.0) == 0.25 && adaptive_voxel_resolution(99.0, 0.25, 0.5, 4.0, 12.0) == 0.5);
+  }
   std::printf("test_io OK\n");
   return 0;
 }

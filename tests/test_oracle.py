@@ -412,3 +412,21 @@ def test_overlap_single_and_multi_target(orc, small_pair):
     assert orc.overlap(vm, s["points"], far) == 0.0
     # any-hit semantics (odometry_estimation_gpu.cpp:224-231)
     assert orc.overlap([vm, vm], s["points"], [far, small_pair["delta"]]) == pytest.approx(ov, abs=1e-15)
+
+
+def test_median_distance_and_adaptive_resolution(orc, small_pair):
+    """SURVEY 8a row a9 (host side in the reference too): oracle == numpy == the product's host helper."""
+    from glim_amd import api
+
+    pts = np.asarray(small_pair["source"]["points"], dtype=np.float64)
+    for cap in (256, 100, 10**6):
+        step = 1 if len(pts) < cap else len(pts) // cap
+        d = np.sort(np.linalg.norm(pts[::step], axis=1))
+        ref = d[len(d) // 2]
+        assert orc.median_distance(pts, cap) == pytest.approx(ref, rel=1e-15)
+        assert api.median_distance(pts, cap) == pytest.approx(ref, rel=1e-15)
+    # config_odometry_gpu.json: voxel_resolution 0.25, max 0.5, dmin 4.0, dmax 12.0
+    for dm, want in ((1.0, 0.25), (4.0, 0.25), (8.0, 0.375), (12.0, 0.5), (50.0, 0.5)):
+        assert orc.adaptive_resolution(dm, 0.25, 0.5, 4.0, 12.0) == pytest.approx(want)
+        assert api.adaptive_voxel_resolution(dm, 0.25, 0.5, 4.0, 12.0) == pytest.approx(want)
+    assert orc.median_distance(np.zeros((0, 3))) == 0.0 and api.median_distance(np.zeros((0, 3))) == 0.0
