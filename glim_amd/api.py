@@ -66,8 +66,9 @@ class Context:
         return {"name": name.value.decode(), "free_bytes": free.value, "total_bytes": total.value, "num_cus": cus.value}
 
     def close(self):
+        """Destroys the context.  Refused (GlimAmdError, the context stays usable) while clouds / maps / factor sets made from it are alive."""
         if self._h:
-            lib().glim_amd_ctx_destroy(self._h)
+            check(lib().glim_amd_ctx_destroy(self._h), "glim_amd_ctx_destroy")
             self._h = None
 
     def __del__(self):

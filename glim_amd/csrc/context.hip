@@ -83,6 +83,7 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
 
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx) {
   if (!ctx) return GLIM_AMD_OK;
+  if (ctx->live_children.load() != 0) return GLIM_AMD_ERR_STATE;  // children must be destroyed first; the context stays valid
   (void)hipSetDevice(ctx->device);
   for (auto s : ctx->streams) (void)hipStreamSynchronize(s);
   if (ctx->owns_streams)

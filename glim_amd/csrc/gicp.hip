@@ -28,7 +28,7 @@
 using namespace glim_amd;
 
 struct glim_amd_nn_index {
-  glim_amd_ctx* ctx = nullptr;
+  CtxRef ctx;
   const glim_amd_cloud* cloud = nullptr;  // not owned; must outlive the index
   int n = 0;
   double h = 0.0;                         // cell edge

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -131,6 +132,7 @@ constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
 // C-ABI object definitions (opaque to callers)
 // ---------------------------------------------------------------------------------------------------------------
 struct glim_amd_ctx {
+  std::atomic<int> live_children{0};  // clouds, voxel maps, factor sets and search indices created from this context and not yet destroyed
   int device = 0;
   int num_cus = 0;
   bool owns_streams = true;
@@ -145,8 +147,28 @@ struct glim_amd_ctx {
   }
 };
 
+// Back-pointer of a child object to its context that also keeps the context's live-children count: destroying a context that still
+// has children is refused (GLIM_AMD_ERR_STATE) instead of leaving them dangling (SURVEY.md 8b "Ownership").
+struct CtxRef {
+  glim_amd_ctx* c = nullptr;
+  CtxRef() = default;
+  CtxRef(const CtxRef&) = delete;
+  CtxRef& operator=(const CtxRef&) = delete;
+  CtxRef& operator=(glim_amd_ctx* p) {
+    if (c) c->live_children--;
+    c = p;
+    if (c) c->live_children++;
+    return *this;
+  }
+  ~CtxRef() {
+    if (c) c->live_children--;
+  }
+  operator glim_amd_ctx*() const { return c; }
+  glim_amd_ctx* operator->() const { return c; }
+};
+
 struct glim_amd_cloud {
-  glim_amd_ctx* ctx = nullptr;
+  CtxRef ctx;
   int64_t n = 0;
   float4* pts = nullptr;
   float4* covA = nullptr;
@@ -180,7 +202,7 @@ struct glim_amd_cloud {
 };
 
 struct glim_amd_voxelmap {
-  glim_amd_ctx* ctx = nullptr;
+  CtxRef ctx;
   double resolution = 0.0;
   double inv_resolution = 0.0;
   int32_t num_voxels = 0;
@@ -189,7 +211,7 @@ struct glim_amd_voxelmap {
 };
 
 struct glim_amd_factor_set {
-  glim_amd_ctx* ctx = nullptr;
+  CtxRef ctx;
   hipStream_t stream = nullptr;
   struct Entry {
     const glim_amd_voxelmap* target;

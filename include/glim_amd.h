@@ -15,7 +15,8 @@
  *     covariances (16 doubles, column-major, zero last row/col)   include/glim/preprocess/preprocessed_frame.hpp:31,
  *     src/glim/common/cloud_covariance_estimation.cpp:96.  Host arrays are borrowed only for the duration of a call.
  *   - all device work of a context runs on its HIP stream(s); calls are synchronous unless named *_async.
- *   - handles are owned by the caller; destroy children (clouds, voxel maps, factor sets) before their context.
+ *   - handles are owned by the caller; destroy children (clouds, voxel maps, factor sets, search indices) before their context:
+ *     glim_amd_ctx_destroy refuses (GLIM_AMD_ERR_STATE) while any child is alive.
  */
 #ifndef GLIM_AMD_H
 #define GLIM_AMD_H
@@ -73,6 +74,7 @@ int glim_amd_device_count(void);
  * (src/glim/odometry/odometry_estimation_gpu.cpp:76-77, src/glim/mapping/sub_mapping.cpp:86-87, global_mapping.cpp:110).
  * external_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create `num_streams` streams. */
 int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim_amd_ctx** out);
+/* GLIM_AMD_ERR_STATE (and the context stays valid) while clouds, voxel maps, factor sets or search indices created from it are alive. */
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
 int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* gtsam_points::cuda_device_names / cuda_mem_get_info (src/glim/util/debug.cpp:84, viewer/memory_monitor.cpp:39). */

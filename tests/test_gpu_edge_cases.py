@@ -169,3 +169,23 @@ def test_device_memory_pool_can_be_disabled(api, monkeypatch):
             vm.close()
             g.close()
     c2.close()
+
+
+@pytest.mark.gpu
+def test_context_refuses_to_die_before_its_children(small_pair):
+    """SURVEY 8b ownership: destroying a context with live handles is an error code, not undefined behaviour."""
+    from glim_amd import api
+
+    ctx = api.Context(0, 1)
+    g = api.PointCloudGPU.clone(small_pair["source"]["points"], small_pair["source"]["covs"], ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g)
+    fs = api.NonlinearFactorSetGPU(ctx)
+    with pytest.raises(api.GlimAmdError):
+        ctx.close()
+    assert g.size() == len(small_pair["source"]["points"])  # still usable
+    fs.close()
+    vm.close()
+    with pytest.raises(api.GlimAmdError):
+        ctx.close()
+    g.close()
+    ctx.close()  # now fine
