@@ -448,3 +448,29 @@ def test_plane_form_kernel_matches_general_kernel_and_oracle(api, ctx, orc, monk
     # surface validation reads the normals from the plane-form stream in one kernel and from the normal array in the other
     assert results[("plane", True)]["num_inliers"] == results[("general", True)]["num_inliers"] <= ref["num_inliers"]
     assert np.abs(gn_step(results[("plane", True)]) - gn_step(results[("general", True)])).max() < 1e-5
+
+
+def test_knn_chunk_and_grid_paths_agree(api, ctx, orc, monkeypatch):
+    """The two device kNN implementations (Hilbert-ordered chunks, hashed grid) and the oracle give identical lists, also on a cloud
+    with a strongly non-uniform density, exact duplicates and a size that is not a multiple of the chunk length."""
+    rng = np.random.default_rng(11)
+    dense = rng.normal(size=(20000, 3)) * [0.05, 0.05, 0.02]
+    sparse = rng.uniform(-30, 30, size=(9000, 3)) * [1, 1, 0.1]
+    line = np.c_[np.linspace(0, 40, 2937), np.zeros(2937), np.zeros(2937)]
+    pts = np.vstack([dense, sparse, line, dense[:500]]).astype(np.float32)  # the last 500 duplicate earlier points exactly
+    ref = orc.knn(pts.astype(np.float64), 10)
+    g = api.PointCloudGPU.clone(pts, ctx=ctx)
+    got_chunk = g.find_neighbors(10)
+    monkeypatch.setenv("GLIM_AMD_KNN_GRID", "1")
+    got_grid = g.find_neighbors(10)
+    monkeypatch.delenv("GLIM_AMD_KNN_GRID")
+    np.testing.assert_array_equal(got_chunk, ref)
+    np.testing.assert_array_equal(got_grid, ref)
+    for k in (1, 5, 16, 32):
+        np.testing.assert_array_equal(g.find_neighbors(k), orc.knn(pts.astype(np.float64), k))
+    # small clouds default to the grid path; the chunk path must agree there too (last chunk partially filled)
+    small = api.PointCloudGPU.clone(pts[::7], ctx=ctx)
+    ref_small = orc.knn(pts[::7].astype(np.float64), 10)
+    np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
+    monkeypatch.setenv("GLIM_AMD_KNN_CHUNKS", "1")
+    np.testing.assert_array_equal(small.find_neighbors(10), ref_small)

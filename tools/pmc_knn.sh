@@ -12,7 +12,7 @@ for sub in ('a','b'):
     for f in glob.glob('$OUT/'+sub+'/*/*counter_collection.csv'):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'knn_grid_kernel' in r['Kernel_Name'] and int(r['Grid_Size']) > 100000:
+            if ('knn_grid_kernel' in r['Kernel_Name'] or 'knn_chunk_kernel' in r['Kernel_Name']) and int(r['Grid_Size']) > 100000:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in sorted(agg.items()): print(k, len(v), sum(v)/len(v))
 PY
