@@ -8,8 +8,8 @@
 //
 // Three implementations, same result:
 //   * curve-ordered chunks (default, knn_curve): Hilbert sort, 64-point chunks with boxes, one wavefront per chunk streaming the
-//     candidate chunks through LDS; adapts to the local density by construction.  0.50 ms for a 131 072-point LiDAR scan,
-//     0.79 ms for a 307 104-point depth frame on MI355X.
+//     candidate chunks through LDS; adapts to the local density by construction.  0.48 ms for a 131 072-point LiDAR scan,
+//     0.76 ms for a 307 104-point depth frame on MI355X.
 //   * hashed uniform grid (GLIM_AMD_KNN_GRID=1, knn_grid): counting sort into cells, ring walk per query with exactness bound and
 //     coarser retry levels: 0.85 / 1.11 ms; kept for cross-checking.
 //   * exhaustive: LDS-tiled scan of every point (tiny clouds, and the grid path's last resort).
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   // records which ones pass its k-th best of the moment in a 64-bit mask (inclusive test, so ties are kept); (2) the lanes pop
   // their masks together -- the K-step insertion then runs max-popcount times per chunk instead of once per candidate, and for
   // most chunks after the first three nobody has anything to insert.
-  auto scan_chunk = [&](int cc, bool need) {
+  auto scan_chunk = [&](int cc, bool need, bool seed) {
     const float4 p = sorted[cc * CHUNK + lane];
     dbg_tiles++;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -565,6 +565,20 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
     s_idx[w][lane] = __float_as_int(p.w);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    unsigned long long seeded = 0ull;
+    if (seed) {
+      // own chunk: every lane first inserts its K + 2 nearest points ALONG THE CURVE (itself, then +-1, +-2, ...), which are mostly
+      // its nearest in space too, so that the threshold of the mask pass below is already tight (otherwise all 64 candidates of
+      // the first chunk pass an infinite threshold and cost one insertion round each)
+#pragma unroll
+      for (int t = 0; t < K + 2; t++) {
+        const int off = (t & 1) ? ((t + 1) >> 1) : -(t >> 1);
+        const int j = (lane + off) & (CHUNK - 1);
+        seeded |= 1ull << j;
+        const int idx = s_idx[w][j];
+        if (idx >= 0) best.push(sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]), idx);
+      }
+    }
     const double thr = need ? best.d[K - 1] : -1.0;  // lanes that do not need this chunk accept nothing
     unsigned int mlo = 0u, mhi = 0u;
 #pragma unroll
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       const double d = sqdist(qx, qy, qz, s_xyz[w][32 + j][0], s_xyz[w][32 + j][1], s_xyz[w][32 + j][2]);
       mhi |= (d <= thr ? 1u : 0u) << j;
     }
-    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+    unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
     while (__any(m != 0ull)) {
       dbg_pops++;
       if (m != 0ull) {
@@ -589,9 +603,9 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
     }
   };
 
-  scan_chunk(c, true);
-  if (c > 0) scan_chunk(c - 1, true);
-  if (c + 1 < C) scan_chunk(c + 1, true);
+  scan_chunk(c, true, true);
+  if (c > 0) scan_chunk(c - 1, true, false);
+  if (c + 1 < C) scan_chunk(c + 1, true, false);
 
   const float qlo[3] = {box[6 * c], box[6 * c + 1], box[6 * c + 2]}, qhi[3] = {box[6 * c + 3], box[6 * c + 4], box[6 * c + 5]};
   // Groups of 64 chunks are visited from the query chunk's own group outwards (alternating sides): chunks that are close on the
@@ -627,7 +641,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       const double gz = fmax(0.0, fmax((double)b[2] - qz, qz - (double)b[5]));
       const bool need = (gx * gx + gy * gy + gz * gz) * (1.0 - 1e-12) <= best.d[K - 1];
       if (__ballot(need) == 0ull) continue;
-      scan_chunk(cc, need);
+      scan_chunk(cc, need, false);
     }
   }
   if (dbg && lane == 0) {
