@@ -172,6 +172,7 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->neighbors) (void)pool_free(c->neighbors);
   if (c->pn4) (void)pool_free(c->pn4);
   if (c->n2) (void)pool_free(c->n2);
+  if (c->curve_rank) (void)pool_free(c->curve_rank);
   if (c->pts64) (void)pool_free(c->pts64);
   if (c->times) (void)pool_free(c->times);
   if (c->intensities) (void)pool_free(c->intensities);

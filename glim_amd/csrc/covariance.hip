@@ -88,7 +88,8 @@ __device__ V3 smallest_eigenvector(double m00, double m01, double m02, double m1
 
 __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __restrict__ pts, const int32_t* __restrict__ nbrs, int k_corr,
                                                          int k_nbr, float4* __restrict__ covA, float2* __restrict__ covB,
-                                                         float4* __restrict__ normals, float4* __restrict__ pn4, float2* __restrict__ n2) {
+                                                         float4* __restrict__ normals, float4* __restrict__ pn4, float2* __restrict__ n2,
+                                                         const unsigned int* __restrict__ rank) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
@@ -116,8 +117,11 @@ __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __
   }
   normals[i] = make_float4((float)e.x, (float)e.y, (float)e.z, 0.0f);
   // plane-form stream for the factor kernel (24 B per point): xyz + the unit normal the covariance is a function of
-  pn4[i] = make_float4(p.x, p.y, p.z, (float)e.x);
-  n2[i] = make_float2((float)e.y, (float)e.z);
+  // plane-form stream of the factor kernel: in Hilbert order when the cloud has one, so that the 64 lanes of a wavefront look up a
+  // handful of neighbouring voxels instead of voxels spread along a scan line (the factor sums over all points: order is free)
+  const unsigned int o = rank ? rank[i] : (unsigned int)i;
+  pn4[o] = make_float4(p.x, p.y, p.z, (float)e.x);
+  n2[o] = make_float2((float)e.y, (float)e.z);
 }
 
 }  // namespace
@@ -139,7 +143,8 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->n2) GA_HIP(pool_malloc(&c->n2, nn * sizeof(float2)));
   if (c->n > 0) {
     const int n = (int)c->n;
-    covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals, c->pn4, c->n2);
+    GA_TRY(cloud_curve_rank(c, ctx->stream()));
+    covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals, c->pn4, c->n2, c->curve_rank);
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(ctx->stream()));
   }

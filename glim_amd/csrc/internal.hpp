@@ -51,6 +51,9 @@ struct DeviceTemp {
   }
 };
 
+// Hilbert rank of a cloud's points (knn.hip); no-op when present, tiny, or disabled
+int cloud_curve_rank(::glim_amd_cloud* c, hipStream_t st);
+
 // stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
 size_t radix_sort_scratch_bytes(int n);
 hipError_t radix_sort_pairs(hipStream_t st, int n, int bits, unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
@@ -176,6 +179,7 @@ struct glim_amd_cloud {
   float4* normals = nullptr;
   float4* pn4 = nullptr;  // plane-form stream (x y z nx), see load_point<PLANE> in vgicp.hip
   float2* n2 = nullptr;   //                   (ny nz)
+  unsigned int* curve_rank = nullptr;  // position of point i on the Hilbert curve through the cloud (knn.hip); orders the plane-form stream
   bool plane_form = false;
   int32_t* neighbors = nullptr;
   int k = 0;

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void curve_key_kernel(int n, const float4* __r
 
 // one wavefront per chunk: points in curve order (xyz + original index, index -1 and +inf coordinates past the end) and the chunk boxes
 __global__ __launch_bounds__(256) void curve_gather_kernel(int n, int C, const float4* __restrict__ pts, const unsigned int* __restrict__ order,
-                                                           float4* __restrict__ sorted, float* __restrict__ box /* [C][6] */) {
+                                                           float4* __restrict__ sorted, float* __restrict__ box /* [C][6] */,
+                                                           unsigned int* __restrict__ rank) {
   const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
   const int s = c * CHUNK + lane;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void curve_gather_kernel(int n, int C, const f
     const unsigned int i = order[s];
     const float4 p = pts[i];
     q = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
+    if (rank) rank[i] = (unsigned int)s;
   }
   sorted[s] = q;
   float lo[3] = {q.x, q.y, q.z}, hi[3] = {s < n ? q.x : -inf, s < n ? q.y : -inf, s < n ? q.z : -inf};
@@ -662,7 +664,7 @@ void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const flo
   knn_chunk_kernel<K><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
 }
 
-int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out) {
+int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out, unsigned int* rank) {
   DeviceTemp bb, ka, kb, va, vb, hist, sorted, box, stats;
   const int C = (n + CHUNK - 1) / CHUNK;
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
@@ -696,10 +698,10 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   unsigned int* order = nullptr;
   GA_HIP(radix_sort_pairs(st, n, 3 * bits, ka.as<unsigned long long>(), va.as<unsigned int>(), kb.as<unsigned long long>(), vb.as<unsigned int>(), true,
                           hist.as<int>(), &ks, &order));
-  curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>());
+  curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), rank);
   DeviceTemp dbg;
   if (getenv("GLIM_AMD_KNN_DEBUG")) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
-  DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>());
+  if (k > 0) DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>());  // k == 0: ordering only
   GA_HIP(hipGetLastError());
   if (dbg.p) {
     std::vector<int> hd((size_t)C * 4);
@@ -716,6 +718,23 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
 }
 
 }  // namespace
+
+namespace glim_amd {
+
+// Hilbert rank of every point of a cloud that has none yet (clouds whose neighbours came from the host or from the grid path).
+// Caller holds ctx->mu.  Tiny clouds and clouds with non-finite points simply stay in arrival order.
+int cloud_curve_rank(glim_amd_cloud* c, hipStream_t st) {
+  if (c->curve_rank || c->n < 4096 || c->n > (int64_t)(1 << 28) || getenv("GLIM_AMD_NO_CURVE_ORDER") != nullptr) return GLIM_AMD_OK;
+  GA_HIP(pool_malloc(&c->curve_rank, (size_t)c->n * sizeof(unsigned int)));
+  const int rc = knn_curve(c->ctx, st, (int)c->n, c->pts, 0, nullptr, c->curve_rank);
+  if (rc != GLIM_AMD_OK) {
+    (void)pool_free(c->curve_rank);
+    c->curve_rank = nullptr;
+  }
+  return rc == GLIM_AMD_ERR_RANGE ? GLIM_AMD_OK : rc;
+}
+
+}  // namespace glim_amd
 
 extern "C" {
 
@@ -744,7 +763,11 @@ int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_o
     // path is 0.09 ms faster on a 12 000-point preprocessed scan, level at 42k-58k points, 1.4-1.7x slower from 131k points up
     const bool grid = getenv("GLIM_AMD_KNN_GRID") != nullptr || (n < 24576 && getenv("GLIM_AMD_KNN_CHUNKS") == nullptr);
     if (grid) GA_TRY(knn_grid(ctx, st, n, c->pts, k, c->neighbors));
-    else GA_TRY(knn_curve(ctx, st, n, c->pts, k, c->neighbors));
+    else {
+      // the Hilbert rank of every point is kept: estimate_covariances writes the factor's plane-form stream in that order
+      if (!c->curve_rank && getenv("GLIM_AMD_NO_CURVE_ORDER") == nullptr) GA_HIP(pool_malloc(&c->curve_rank, (size_t)n * sizeof(unsigned int)));
+      GA_TRY(knn_curve(ctx, st, n, c->pts, k, c->neighbors, c->curve_rank));
+    }
   }
   if (neighbors_out) GA_HIP(hipMemcpyAsync(neighbors_out, c->neighbors, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GA_HIP(hipStreamSynchronize(st));
