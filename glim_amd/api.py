@@ -302,14 +302,16 @@ class GaussianVoxelMapGPU:
 
 
 def _lin_to_dict(L):
+    # one buffer view of the 976-byte struct (int64 + 121 doubles) instead of five element-wise ctypes -> numpy conversions
+    a = np.frombuffer(L, dtype=np.float64, count=122).copy()
     return {
         "num_inliers": int(L.num_inliers),
-        "error": float(L.error),
-        "H_tt": np.array(L.H_tt).reshape(6, 6),
-        "H_ss": np.array(L.H_ss).reshape(6, 6),
-        "H_ts": np.array(L.H_ts).reshape(6, 6),
-        "b_t": np.array(L.b_t),
-        "b_s": np.array(L.b_s),
+        "error": float(a[1]),
+        "H_tt": a[2:38].reshape(6, 6),
+        "H_ss": a[38:74].reshape(6, 6),
+        "H_ts": a[74:110].reshape(6, 6),
+        "b_t": a[110:116],
+        "b_s": a[116:122],
     }
 
 
