@@ -12,8 +12,10 @@
 //   H_ss += J_s^T M J_s,  b_s += J_s^T M r,   J_s = [R hat(p) | -R]
 //
 // Two algebraic restructurings keep the kernel HBM-bound (DESIGN.md "K4"):
-//   (1) everything is evaluated in the SOURCE frame: A = R^T M R = (R^T C_B R + C_A)^-1, rs = R^T r, J' = [hat(p) | -I];
-//       then H_ss = J'^T A J' has the block form [[-P A P, P A], [(P A)^T, A]] with P = hat(p) -- 21 + 6 + 1 sums per point.
+//   (1) the rotation is factored out of the Jacobian: J_s = [R hat(p) | -R] = [hat(q') | -I] diag(R, R) with q' = R p = q - t, so the
+//       kernel accumulates H' = sum J'^T M J' = [[-Q M Q, Q M], [(Q M)^T, M]] (Q = hat(q')) and b' = [u x q'; -u], u = M r, in the
+//       target frame -- 21 + 6 + 1 sums per point -- and the finalise step applies diag(R, R) once per factor in FP64.  For
+//       plane-form clouds R C_A R^T = I - (1 - 1e-3) m m^T with m = R n, so M needs no 3x3 sandwich at all.
 //   (2) the target-side blocks of a BINARY factor are never accumulated per point: J_t = -J_s Ad(delta^-1) exactly, hence
 //       H_tt = Ad^T H_ss Ad, H_ts = -Ad^T H_ss, b_t = -Ad^T b_s are recovered in FP64 from the 6x6 source block
 //       (glim_amd_expand_compact).  A binary factor costs the same 28 accumulators as a unary one instead of 122.
@@ -114,7 +116,7 @@ struct FinalizeArgs {
 // g = tid / 32, j = tid % 32, sums rows g, g + 8, g + 16, ... of value j; the 8 group sums are then added in group order.  The
 // order depends only on the plan, so results are bit-reproducible whichever block happens to run this.
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
-                                                double (*s_part)[PARTIAL_STRIDE], double* s_sum) {
+                                                double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
   const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int first = d.first_block, nb = d.num_blocks;
   double s = 0.0;
@@ -133,9 +135,55 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   if (t == 0) o[0] = s_sum[28];
   if (t == 1) o[1] = s_sum[27];
   if (mode == MODE_LINEARIZE) {
-    if (t < 21) o[2 + t] = s_sum[c_acc_of_upper[t]];
-    if (t >= 21 && t < 24) o[2 + t] = s_sum[t];          // b_w = sum u x p
-    if (t >= 24 && t < 27) o[2 + t] = -s_sum[t];         // b_v = -sum u
+    // The kernel accumulated H' = sum J'^T M J' and b' = sum J'^T M r for J' = [hat(R p) | -I] in the target frame; with
+    // J_s = J' diag(R, R):  H_ss = diag(R, R)^T H' diag(R, R), b_s = diag(R, R)^T b', i.e. every 3x3 block B' becomes R^T B' R and
+    // every 3-vector R^T v.  Thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors; the results land in s_sum.
+    __shared__ double s_rot[32];
+    if (t < 4) {
+      double R[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
+      if (t < 3) {
+        double B[9];
+        if (t == 0) {
+          B[0] = s_sum[0]; B[1] = s_sum[1]; B[2] = s_sum[2]; B[3] = s_sum[1]; B[4] = s_sum[3]; B[5] = s_sum[4]; B[6] = s_sum[2]; B[7] = s_sum[4]; B[8] = s_sum[5];
+        } else if (t == 1) {
+#pragma unroll
+          for (int i = 0; i < 9; i++) B[i] = s_sum[6 + i];
+        } else {
+          B[0] = s_sum[15]; B[1] = s_sum[16]; B[2] = s_sum[17]; B[3] = s_sum[16]; B[4] = s_sum[18]; B[5] = s_sum[19]; B[6] = s_sum[17]; B[7] = s_sum[19]; B[8] = s_sum[20];
+        }
+        double BR[9], O[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) BR[3 * r + c] = B[3 * r] * R[c] + B[3 * r + 1] * R[3 + c] + B[3 * r + 2] * R[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) O[3 * r + c] = R[r] * BR[c] + R[3 + r] * BR[3 + c] + R[6 + r] * BR[6 + c];  // (R^T BR)[r][c]
+        if (t == 0) {
+          s_rot[0] = O[0]; s_rot[1] = O[1]; s_rot[2] = O[2]; s_rot[3] = O[4]; s_rot[4] = O[5]; s_rot[5] = O[8];
+        } else if (t == 1) {
+#pragma unroll
+          for (int i = 0; i < 9; i++) s_rot[6 + i] = O[i];
+        } else {
+          s_rot[15] = O[0]; s_rot[16] = O[1]; s_rot[17] = O[2]; s_rot[18] = O[4]; s_rot[19] = O[5]; s_rot[20] = O[8];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          s_rot[21 + c] = R[c] * s_sum[21] + R[3 + c] * s_sum[22] + R[6 + c] * s_sum[23];   // R^T (sum u x q')
+          s_rot[24 + c] = R[c] * s_sum[24] + R[3 + c] * s_sum[25] + R[6 + c] * s_sum[26];   // R^T (sum u)
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 21) o[2 + t] = s_rot[c_acc_of_upper[t]];
+    if (t >= 21 && t < 24) o[2 + t] = s_rot[t];          // b_w = R^T sum u x q'
+    if (t >= 24 && t < 27) o[2 + t] = -s_rot[t];         // b_v = -R^T sum u
   } else if (t >= 2 && t < COMPACT) {
     o[t] = 0.0;
   }
@@ -205,6 +253,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
       PointIn cur[U];
       float4 head[U];
       float qr[U][3];  // q relative to the centre of its voxel (|.| <= res/2): FP32 without cancellation
+      float qp[U][3];  // q' = R p = q - t: the rotated source point, the lever arm of the target-frame Jacobian
       unsigned long long key[U];
       unsigned int bkt[U];
 
@@ -227,6 +276,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         transform_point_d(Tl, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, qx, qy, qz);
         const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
 #endif
+        qp[u][0] = (float)(qx - Tl[3]);
+        qp[u][1] = (float)(qy - Tl[7]);
+        qp[u][2] = (float)(qz - Tl[11]);
         // floor(t) == fast_floor(t) for every in-range coordinate (same integer, bit-exact); v_floor_f64 + one subtraction also
         // gives the in-voxel fraction for free
 #if GLIM_AMD_ABLATE == 2
@@ -309,13 +361,25 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
         const float4 r2 = gld4(rp + 32);   // c22 count - -
 #endif
-        float4 ca = cur[u].ca;
-        float2 cb = cur[u].cb;
-        if (PLANE) {  // C_A = I - (1 - 1e-3) n n^T rebuilt from the streamed unit normal
-          const float w = 0.999f, nx = cur[u].p.w, ny = cur[u].cb.x, nz = cur[u].cb.y;
-          const float wx = w * nx, wy = w * ny;
-          ca = make_float4(1.f - wx * nx, -wx * ny, -wx * nz, 1.f - wy * ny);
-          cb = make_float2(-wy * nz, 1.f - w * nz * nz);
+        // C_t = R C_A R^T, the source covariance in the TARGET frame (symmetric: t00 t01 t02 t11 t12 t22)
+        float t00, t01, t02, t11, t12, t22;
+        if (PLANE) {
+          // C_A = I - (1 - 1e-3) n n^T  =>  C_t = I - (1 - 1e-3) m m^T with m = R n: 9 + 9 operations instead of a 45-operation sandwich
+          const float nx = cur[u].p.w, ny = cur[u].cb.x, nz = cur[u].cb.y;
+          const float mx = R00 * nx + R01 * ny + R02 * nz;
+          const float my = R10 * nx + R11 * ny + R12 * nz;
+          const float mz = R20 * nx + R21 * ny + R22 * nz;
+          const float w = 0.999f, wx = w * mx, wy = w * my;
+          t00 = 1.f - wx * mx; t01 = -wx * my; t02 = -wx * mz;
+          t11 = 1.f - wy * my; t12 = -wy * mz; t22 = 1.f - w * mz * mz;
+        } else {
+          const float4 ca = cur[u].ca;  // c00 c01 c02 c11
+          const float2 cb = cur[u].cb;  // c12 c22
+          const float a00 = R00 * ca.x + R01 * ca.y + R02 * ca.z, a01 = R00 * ca.y + R01 * ca.w + R02 * cb.x, a02 = R00 * ca.z + R01 * cb.x + R02 * cb.y;
+          const float a10 = R10 * ca.x + R11 * ca.y + R12 * ca.z, a11 = R10 * ca.y + R11 * ca.w + R12 * cb.x, a12 = R10 * ca.z + R11 * cb.x + R12 * cb.y;
+          const float a20 = R20 * ca.x + R21 * ca.y + R22 * ca.z, a21 = R20 * ca.y + R21 * ca.w + R22 * cb.x, a22 = R20 * ca.z + R21 * cb.x + R22 * cb.y;
+          t00 = a00 * R00 + a01 * R01 + a02 * R02; t01 = a00 * R10 + a01 * R11 + a02 * R12; t02 = a00 * R20 + a01 * R21 + a02 * R22;
+          t11 = a10 * R10 + a11 * R11 + a12 * R12; t12 = a10 * R20 + a11 * R21 + a12 * R22; t22 = a20 * R20 + a21 * R21 + a22 * R22;
         }
 
         // residual mu - q, both relative to the voxel centre
@@ -324,23 +388,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         const float rz = r0.z - qr[u][2];
 
 #if GLIM_AMD_ABLATE == 3
-        acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2.x + ca.x + ca.y + ca.z + ca.w + cb.x + cb.y + cur[u].p.x;
+        acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2.x + t00 + t01 + t02 + t11 + t12 + t22 + cur[u].p.x;
         continue;
 #endif
-        // S = R^T C_B R + C_A   (source frame, symmetric).  Non-hit lanes get S = I so the algebra stays finite.
-        const float b00 = hit ? r0.w : 1.f, b01 = hit ? r1.x : 0.f, b02 = hit ? r1.y : 0.f;
-        const float b11 = hit ? r1.z : 1.f, b12 = hit ? r1.w : 0.f, b22 = hit ? r2.x : 1.f;
-        const float w00 = b00 * R00 + b01 * R10 + b02 * R20, w01 = b00 * R01 + b01 * R11 + b02 * R21, w02 = b00 * R02 + b01 * R12 + b02 * R22;
-        const float w10 = b01 * R00 + b11 * R10 + b12 * R20, w11 = b01 * R01 + b11 * R11 + b12 * R21, w12 = b01 * R02 + b11 * R12 + b12 * R22;
-        const float w20 = b02 * R00 + b12 * R10 + b22 * R20, w21 = b02 * R01 + b12 * R11 + b22 * R21, w22 = b02 * R02 + b12 * R12 + b22 * R22;
-        const float S00 = ca.x + R00 * w00 + R10 * w10 + R20 * w20;
-        const float S01 = ca.y + R00 * w01 + R10 * w11 + R20 * w21;
-        const float S02 = ca.z + R00 * w02 + R10 * w12 + R20 * w22;
-        const float S11 = ca.w + R01 * w01 + R11 * w11 + R21 * w21;
-        const float S12 = cb.x + R01 * w02 + R11 * w12 + R21 * w22;
-        const float S22 = cb.y + R02 * w02 + R12 * w12 + R22 * w22;
+        // S = C_B + R C_A R^T   (TARGET frame, symmetric).  Non-hit lanes get C_B = I so the algebra stays finite.
+        const float S00 = (hit ? r0.w : 1.f) + t00, S01 = (hit ? r1.x : 0.f) + t01, S02 = (hit ? r1.y : 0.f) + t02;
+        const float S11 = (hit ? r1.z : 1.f) + t11, S12 = (hit ? r1.w : 0.f) + t12, S22 = (hit ? r2.x : 1.f) + t22;
 
-        // A = S^-1 by cofactors (symmetric); idet = 0 on non-hit lanes zeroes every contribution below
+        // M = S^-1 by cofactors (symmetric, called A below); idet = 0 on non-hit lanes zeroes every contribution below
         const float k00 = S11 * S22 - S12 * S12;
         const float k01 = S02 * S12 - S01 * S22;
         const float k02 = S01 * S12 - S02 * S11;
@@ -353,18 +408,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
         const float A12 = (S01 * S02 - S00 * S12) * idet;
         const float A22 = (S00 * S11 - S01 * S01) * idet;
 
-        // rs = R^T r,  u = A rs,  e = rs . u
-        const float rsx = R00 * rx + R10 * ry + R20 * rz;
-        const float rsy = R01 * rx + R11 * ry + R21 * rz;
-        const float rsz = R02 * rx + R12 * ry + R22 * rz;
-        const float ux = A00 * rsx + A01 * rsy + A02 * rsz;
-        const float uy = A01 * rsx + A11 * rsy + A12 * rsz;
-        const float uz = A02 * rsx + A12 * rsy + A22 * rsz;
-        acc[27] += rsx * ux + rsy * uy + rsz * uz;
+        // u = M r,  e = r . u   (r = mu - q is already a target-frame vector)
+        const float ux = A00 * rx + A01 * ry + A02 * rz;
+        const float uy = A01 * rx + A11 * ry + A12 * rz;
+        const float uz = A02 * rx + A12 * ry + A22 * rz;
+        acc[27] += rx * ux + ry * uy + rz * uz;
 
         if (MODE == MODE_LINEARIZE) {
-          const float x = cur[u].p.x, y = cur[u].p.y, z = cur[u].p.z;
-          // G = hat(p) A : column j = p x A[:,j]
+          // J_s = [R hat(p) | -R] = [hat(q') | -I] diag(R, R) with q' = R p: everything below is accumulated for J' = [hat(q') | -I] and M in
+          // the target frame; the constant diag(R, R) is applied once per factor, in FP64, by finalize_factor
+          const float x = qp[u][0], y = qp[u][1], z = qp[u][2];
+          // G = hat(q') M : column j = q' x M[:,j]
           const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
           const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
           const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
@@ -434,17 +488,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
     s_last = last_one;
   }
   __syncthreads();
-  if (s_last) finalize_factor(d, f, partials, fa, MODE, s_part, s_sum);
+  if (s_last) finalize_factor(d, f, partials, fa, MODE, s_part, s_sum, Tl);
 }
 
 // Stand-alone finalisation (default): one block of 256 threads per factor.
 __global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
-                                                       int mode) {
+                                                       int mode, const double* __restrict__ poses_lin, const InlinePose ip) {
   __shared__ double s_part[8][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int f = blockIdx.x;
   const FactorDesc d = descs[f];
-  finalize_factor(d, f, partials, fa, mode, s_part, s_sum);
+  finalize_factor(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
 }
 
 __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
@@ -733,7 +787,7 @@ int launch_linearize(glim_amd_factor_set* set, double* out, long long row_offset
   if (nf == 0) return GLIM_AMD_OK;
   const FinalizeArgs fa = finalize_args(set, out, row_offset, set->poll);
   launch_vgicp_linearize(set, fa);
-  if (!fa.fused) finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_LINEARIZE);
+  if (!fa.fused) finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_LINEARIZE, set->d_poses, set->inline_pose);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
@@ -949,7 +1003,7 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
       vgicp_kernel<MODE_ERROR, false, 1, 3, false, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(
         set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, InlinePose{}, fa);
   }
-  if (!fa.fused) finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_ERROR);
+  if (!fa.fused) finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_ERROR, set->d_poses, InlinePose{});
   GA_HIP(hipGetLastError());
   GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
   GA_HIP(hipStreamSynchronize(set->stream));

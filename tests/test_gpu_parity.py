@@ -397,7 +397,8 @@ def test_full_size_scan_properties(api, ctx, orc):
     assert got2["num_inliers"] == 2 * got["num_inliers"]
     # (the duplicate was uploaded with explicit FP32 covariances -> general kernel; the original is plane-form -> 24 B/pt kernel:
     #  the two evaluate C_A from differently rounded images of the same matrix, hence the 1e-5-level tolerance)
-    np.testing.assert_allclose(got2["H_ss"], 2 * got["H_ss"], rtol=0, atol=2e-5 * np.abs(got["H_ss"]).max())
+    # (FP32 block partials over a different partition of twice the points: ~sqrt(N) eps = 2-3e-5 of the largest entry)
+    np.testing.assert_allclose(got2["H_ss"], 2 * got["H_ss"], rtol=0, atol=5e-5 * np.abs(got["H_ss"]).max())
     np.testing.assert_allclose(got2["b_s"], 2 * got["b_s"], rtol=0, atol=2e-4 * np.abs(got["b_s"]).max() + 1e-3)
     assert np.abs(gn_step(got2) - gn_step(got)).max() < 1e-6
     # voxel means against their own map at identity: zero residual
