@@ -475,3 +475,25 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc, monkeypatch):
     np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
     monkeypatch.setenv("GLIM_AMD_KNN_CHUNKS", "1")
     np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
+
+
+@pytest.mark.parametrize("name", ["lattice", "identical", "offset", "two_scales"])
+def test_knn_exact_on_degenerate_distributions(api, ctx, orc, monkeypatch, name):
+    """Exact ties everywhere (lattice), all points identical, a cloud far from the origin, 1000x density contrast: both device paths."""
+    rng = np.random.default_rng(5)
+    if name == "lattice":
+        pts = np.stack(np.meshgrid(np.arange(20), np.arange(20), np.arange(15), indexing="ij"), -1).reshape(-1, 3) * 0.25
+    elif name == "identical":
+        pts = np.tile([[1.0, 2.0, 3.0]], (3000, 1))
+    elif name == "offset":
+        pts = rng.uniform(-1, 1, (6000, 3)) + [1e5, -2e5, 3e4]
+    else:
+        pts = np.vstack([rng.normal(size=(4000, 3)) * 0.01, rng.uniform(-50, 50, (3000, 3))])
+    pts = pts.astype(np.float32)
+    ref = orc.knn(pts.astype(np.float64), 10, method="brute")
+    g = api.PointCloudGPU.clone(pts, ctx=ctx)
+    monkeypatch.setenv("GLIM_AMD_KNN_CHUNKS", "1")
+    np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    monkeypatch.delenv("GLIM_AMD_KNN_CHUNKS")
+    monkeypatch.setenv("GLIM_AMD_KNN_GRID", "1")
+    np.testing.assert_array_equal(g.find_neighbors(10), ref)
