@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __
 }
 
 int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_cloud** out) {
+  if (n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;  // kernels index points with 32-bit ints
   glim_amd_cloud* c = new glim_amd_cloud();
   c->ctx = ctx;
   c->n = n;
@@ -312,6 +313,14 @@ int glim_amd_cloud_load_compact(glim_amd_ctx* ctx, const char* dir, glim_amd_clo
 
 int glim_amd_cloud_set_neighbors(glim_amd_cloud* c, int k, const int32_t* neighbors) {
   if (!c || k <= 0 || (c->n > 0 && !neighbors)) return GLIM_AMD_ERR_INVALID;
+  {
+    // the covariance kernel gathers pts[neighbors[..]]: an index outside [0, n) would be an out-of-bounds device read
+    const uint32_t un = (uint32_t)c->n;
+    uint32_t bad = 0;
+    const size_t total = (size_t)c->n * (size_t)k;
+    for (size_t i = 0; i < total; i++) bad |= (uint32_t)((uint32_t)neighbors[i] >= un);
+    if (bad) return GLIM_AMD_ERR_INVALID;
+  }
   glim_amd_ctx* ctx = c->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));

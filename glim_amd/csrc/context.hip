@@ -233,7 +233,7 @@ hipError_t pinned_malloc_impl(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
-  hipError_t e = hipHostMalloc(p, want, hipHostMallocMapped);
+  hipError_t e = hipHostMalloc(p, want, hipHostMallocMapped | hipHostMallocPortable);  // cached blocks may be handed to a context on another device
   if (e == hipSuccess && !pool_disabled()) {
     std::lock_guard<std::mutex> lock(P.mu);
     P.live[*p] = want;

@@ -116,8 +116,7 @@ __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __
     e.x = -e.x; e.y = -e.y; e.z = -e.z;
   }
   normals[i] = make_float4((float)e.x, (float)e.y, (float)e.z, 0.0f);
-  // plane-form stream for the factor kernel (24 B per point): xyz + the unit normal the covariance is a function of
-  // plane-form stream of the factor kernel: in Hilbert order when the cloud has one, so that the 64 lanes of a wavefront look up a
+  // plane-form stream of the factor kernel (24 B per point: xyz + the unit normal the covariance is a function of), in Hilbert order when the cloud has one, so that the 64 lanes of a wavefront look up a
   // handful of neighbouring voxels instead of voxels spread along a scan line (the factor sums over all points: order is free)
   const unsigned int o = rank ? rank[i] : (unsigned int)i;
   pn4[o] = make_float4(p.x, p.y, p.z, (float)e.x);

@@ -392,7 +392,11 @@ int run_gicp(const glim_amd_nn_index* ix, const glim_amd_cloud* source, const do
   a.n = n;
   memcpy(a.T, T12, sizeof(a.T));
   a.max_sq = max_dist * max_dist;
-  a.max_ring = std::min(GICP_MAX_RING, (int)std::ceil(max_dist / ix->h) + 1);
+  // rings after which the scanned cube covers the correspondence radius; the walk is bounded, so a radius far beyond what the index was
+  // sized for (cells are hint/3 .. hint wide) is refused rather than searched incompletely
+  const double rings = std::ceil(max_dist / ix->h) + 1.0;
+  if (!(rings <= (double)GICP_MAX_RING)) return GLIM_AMD_ERR_UNSUPPORTED;
+  a.max_ring = (int)rings;
   // the search is latency-bound: spread the points over >= 4 blocks per CU when there are enough of them
   const int target_blocks = std::max(1, ctx->num_cus * 4);
   a.ppt = std::max(1, std::min(64, (n + BLOCK * target_blocks - 1) / (BLOCK * target_blocks)));

@@ -200,7 +200,9 @@ inline int pick_rounds(int n) {
 inline int table_stride(int n) {
   const int r = pick_rounds(n);
   const int B = (n + RS_THREADS * r - 1) / (RS_THREADS * r);
-  return (B + 3) & ~3;
+  // fused offsets read the rows as int4 (padding columns stay zero); the separate rs_offsets launch scans the table in place, so it
+  // must not have padding columns (they would carry prefix values into the next pass)
+  return B <= RS_FUSED_MAX_BLOCKS ? ((B + 3) & ~3) : B;
 }
 
 }  // namespace

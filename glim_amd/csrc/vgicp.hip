@@ -1083,6 +1083,7 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
     if (!targets[t] || targets[t]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
     if (!targets[t]->buckets) return GLIM_AMD_ERR_STATE;
   }
+  if (source->ctx != ctx) return GLIM_AMD_ERR_INVALID;
   if (source->n == 0) {
     *overlap = 0.0;
     return GLIM_AMD_OK;

@@ -152,7 +152,8 @@ int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12
  * src/glim/mapping/global_mapping_pose_graph.cpp:393-394 (loop validation; passes the target's pre-built tree). */
 typedef struct glim_amd_nn_index glim_amd_nn_index; /* the target's search structure (gtsam_points::KdTree at global_mapping_pose_graph.cpp:393) */
 /* Built once per target cloud (which needs covariances for the factor calls and must outlive the index), reused by every
- * linearisation.  max_correspondence_distance_hint sizes the grid cells; any distance may be used in the calls below. */
+ * linearisation.  max_correspondence_distance_hint sizes the grid cells (hint/3 .. hint wide); the calls below accept any distance up
+ * to 21 x hint and return GLIM_AMD_ERR_UNSUPPORTED beyond that (the ring walk is bounded at 64 cells: rebuild with a larger hint). */
 int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspondence_distance_hint, glim_amd_nn_index** out);
 int glim_amd_nn_index_destroy(glim_amd_nn_index* index);
 /* IntegratedGICPFactor::linearize at T_target_source (flags: GLIM_AMD_FACTOR_BINARY fills the target-side blocks). */
@@ -185,7 +186,7 @@ int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const 
  * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> padded with i.
  * Result stays on the device inside the cloud (and is copied to neighbors_out, n x k, when not NULL). */
 int glim_amd_cloud_find_neighbors(glim_amd_cloud* cloud, int k, int32_t* neighbors_out);
-/* upload caller-provided neighbours (n x k) instead. */
+/* upload caller-provided neighbours (n x k) instead; GLIM_AMD_ERR_INVALID if any index is outside [0, n). */
 int glim_amd_cloud_set_neighbors(glim_amd_cloud* cloud, int k, const int32_t* neighbors);
 /* CloudCovarianceEstimation::estimate (src/glim/common/cloud_covariance_estimation.cpp:43-122, PLANE regularisation :181-196):
  * fills the cloud's covariances and sensor-facing normals from the first k_neighbors stored neighbours. */

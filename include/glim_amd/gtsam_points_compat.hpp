@@ -104,6 +104,8 @@ public:
     return c;
   }
   ~PointCloudGPU() { glim_amd_cloud_destroy(h_); }
+  PointCloudGPU(const PointCloudGPU&) = delete;  // owns a device handle
+  PointCloudGPU& operator=(const PointCloudGPU&) = delete;
   // parity / debug: FP32 coordinates back on the host (n x 3)
   std::vector<float> download_points() const {
     std::vector<float> xyz(size() * 3);
@@ -149,6 +151,7 @@ public:
   }
   ~GaussianVoxelMapGPU() { glim_amd_voxelmap_destroy(h_); }
   GaussianVoxelMapGPU(const GaussianVoxelMapGPU&) = delete;
+  GaussianVoxelMapGPU& operator=(const GaussianVoxelMapGPU&) = delete;
   double voxel_resolution() const {
     double r = 0;
     glim_amd_voxelmap_info(h_, nullptr, nullptr, &r, nullptr);
@@ -239,6 +242,7 @@ public:
   }
   ~NonlinearFactorSetGPU() { glim_amd_factor_set_destroy(h_); }
   NonlinearFactorSetGPU(const NonlinearFactorSetGPU&) = delete;
+  NonlinearFactorSetGPU& operator=(const NonlinearFactorSetGPU&) = delete;
   bool add(const IntegratedVGICPFactorGPU::shared_ptr& factor) {
     if (!factor) return false;
     check(glim_amd_factor_set_add(h_, factor->target()->handle(), factor->source()->handle(), factor->flags(), nullptr), "NonlinearFactorSetGPU::add");
@@ -298,7 +302,6 @@ inline double IntegratedVGICPFactorGPU::error(const Values& values) {
   return e;
 }
 
-// gtsam_points::overlap_gpu (single and multi-target forms) / overlap_auto
 // gtsam_points::KdTree of a target frame as GLIM's pose-graph module caches it (global_mapping_pose_graph.cpp:393,
 // `candidate.target->tree`): here the device grid index of glim_amd_nn_index_create.
 class NearestNeighborSearchGPU {
@@ -391,6 +394,7 @@ inline double adaptive_voxel_resolution(double dist_median, double voxel_resolut
   return voxel_resolution + p * (voxel_resolution_max - voxel_resolution);
 }
 
+// gtsam_points::overlap_gpu (single and multi-target forms) / overlap_auto   (odometry_estimation_gpu.cpp:231-326)
 inline double overlap_gpu(const GaussianVoxelMapGPU::ConstPtr& target, const PointCloudGPU::ConstPtr& source, const Isometry3d& delta) {
   const glim_amd_voxelmap* t = target->handle();
   double ov = 0.0;

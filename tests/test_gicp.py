@@ -182,3 +182,9 @@ def test_hip_gicp_edge_cases(orc):
     bare = api.PointCloudGPU.clone(sp, ctx=ctx)
     with pytest.raises(api.GlimAmdError):
         api.IntegratedGICPFactor(np.eye(4), 1, tg, bare).linearize({1: delta})
+    # a radius far beyond what the index was sized for is refused (bounded ring walk), not searched incompletely
+    g.set_max_correspondence_distance(100.0)
+    with pytest.raises(api.GlimAmdError):
+        g.linearize({1: delta})
+    g.set_max_correspondence_distance(5.0)  # 5 x the hint the shared index was built with: fine, and still exact
+    np.testing.assert_array_equal(g.correspondences({1: delta}), orc.gicp_linearize(tp, tc, sp, sc, delta, 5.0, want_corr=True)["corr"])

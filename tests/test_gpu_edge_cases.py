@@ -189,3 +189,26 @@ def test_context_refuses_to_die_before_its_children(small_pair):
         ctx.close()
     g.close()
     ctx.close()  # now fine
+
+
+def test_invalid_caller_input_is_an_error_code_not_a_fault(api, ctx, small_pair):
+    """Host-supplied neighbour indices outside [0, n) and handles of another context are refused (GLIM_AMD_ERR_INVALID)."""
+    pts = small_pair["source"]["points"][:500]
+    g = api.PointCloudGPU.clone(pts, ctx=ctx)
+    nb = np.tile(np.arange(5, dtype=np.int32), (500, 1))
+    g.set_neighbors(nb)  # valid
+    for bad in (500, -1, 2**31 - 1):
+        nb2 = nb.copy()
+        nb2[123, 2] = bad
+        with pytest.raises(api.GlimAmdError):
+            g.set_neighbors(nb2)
+    g.estimate_covariances(5)  # the valid lists are still in place
+    other = api.Context(0, 1)
+    g2 = api.PointCloudGPU.clone(pts, small_pair["source"]["covs"][:500], ctx=other)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g)
+    with pytest.raises(api.GlimAmdError):
+        api.overlap_gpu(vm, g2, np.eye(4), ctx=ctx)
+    with pytest.raises(api.GlimAmdError):
+        api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g2)
+    g2.close()
+    other.close()

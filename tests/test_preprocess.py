@@ -203,7 +203,7 @@ def test_oracle_preprocess_empty_and_tiny(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,bits", [(0, 64), (1, 64), (777, 13), (2048, 8), (2049, 21), (200000, 64), (200000, 37), (50000, 0)])
+@pytest.mark.parametrize("n,bits", [(0, 64), (1, 64), (777, 13), (2048, 8), (2049, 21), (200000, 64), (200000, 37), (50000, 0), (600001, 24)])  # last: > 256 blocks, the separate-offsets path
 def test_hip_radix_sort_is_stable_and_exact(n, bits):
     from glim_amd import api
 
