@@ -213,7 +213,9 @@ public:
 
   // slow path (own upload / launch / download), used when no NonlinearFactorSetGPU pre-linearised this factor
   inline const LinearizedSystem6& linearize(const Values& values);
-  inline double error(const Values& values);
+  // `linearization_values` != nullptr: correspondences and Mahalanobis matrices frozen at that point (the GPU factor's behaviour after a
+  // linearisation); nullptr: recomputed at `values` (the CPU factor's behaviour)
+  inline double error(const Values& values, const Values* linearization_values = nullptr);
 
   const GaussianVoxelMapGPU::ConstPtr& target() const { return target_; }
   const PointCloudGPU::ConstPtr& source() const { return source_; }
@@ -262,14 +264,18 @@ public:
     check(glim_amd_factor_set_linearize(h_, poses.data(), out.data()), "NonlinearFactorSetGPU::linearize");
     for (std::size_t i = 0; i < factors_.size(); i++) factors_[i]->store_linearized(out[i]);
   }
-  std::vector<double> error(const Values& values) {
+  std::vector<double> error(const Values& values, const Values* linearization_values = nullptr) {
     std::vector<double> err(factors_.size());
     if (factors_.empty()) return err;
-    std::vector<double> poses(12 * factors_.size());
-    for (std::size_t i = 0; i < factors_.size(); i++) std::memcpy(&poses[12 * i], factors_[i]->calc_delta(values).m.data(), 12 * sizeof(double));
-    check(glim_amd_factor_set_error(h_, nullptr, poses.data(), err.data(), nullptr), "NonlinearFactorSetGPU::error");
+    std::vector<double> poses(12 * factors_.size()), lin(linearization_values ? 12 * factors_.size() : 0);
+    for (std::size_t i = 0; i < factors_.size(); i++) {
+      std::memcpy(&poses[12 * i], factors_[i]->calc_delta(values).m.data(), 12 * sizeof(double));
+      if (linearization_values) std::memcpy(&lin[12 * i], factors_[i]->calc_delta(*linearization_values).m.data(), 12 * sizeof(double));
+    }
+    check(glim_amd_factor_set_error(h_, linearization_values ? lin.data() : nullptr, poses.data(), err.data(), nullptr), "NonlinearFactorSetGPU::error");
     return err;
   }
+  const std::vector<IntegratedVGICPFactorGPU::shared_ptr>& factors() const { return factors_; }
 
 private:
   Context ctx_;
@@ -290,13 +296,15 @@ inline const LinearizedSystem6& IntegratedVGICPFactorGPU::linearize(const Values
   return linearized_;
 }
 
-inline double IntegratedVGICPFactorGPU::error(const Values& values) {
+inline double IntegratedVGICPFactorGPU::error(const Values& values, const Values* linearization_values) {
   glim_amd_factor_set* set = nullptr;
   check(glim_amd_factor_set_create(source_->context()->context(), &set), "factor_set_create");
   int rc = glim_amd_factor_set_add(set, target_->handle(), source_->handle(), flags(), nullptr);
   const Isometry3d d = calc_delta(values);
+  Isometry3d dl;
+  if (linearization_values) dl = calc_delta(*linearization_values);
   double e = 0.0;
-  if (rc == GLIM_AMD_OK) rc = glim_amd_factor_set_error(set, nullptr, d.m.data(), &e, nullptr);
+  if (rc == GLIM_AMD_OK) rc = glim_amd_factor_set_error(set, linearization_values ? dl.m.data() : nullptr, d.m.data(), &e, nullptr);
   glim_amd_factor_set_destroy(set);
   check(rc, "IntegratedVGICPFactorGPU::error");
   return e;
