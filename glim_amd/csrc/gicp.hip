@@ -323,7 +323,16 @@ __global__ __launch_bounds__(256) void gicp_finalize_kernel(const float* __restr
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
   double s = 0.0;
-  for (int c = g; c < nb; c += 8) s += (double)partials[(size_t)c * PARTIAL_STRIDE + j];
+  int c = g;
+  constexpr int INFLIGHT = 16;  // loads of 16 trips in flight, additions in the same order (see vgicp.hip finalize_factor)
+  for (; c + 8 * (INFLIGHT - 1) < nb; c += 8 * INFLIGHT) {
+    float v[INFLIGHT];
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)(c + 8 * u) * PARTIAL_STRIDE + j];
+#pragma unroll
+    for (int u = 0; u < INFLIGHT; u++) s += (double)v[u];
+  }
+  for (; c < nb; c += 8) s += (double)partials[(size_t)c * PARTIAL_STRIDE + j];
   s_part[g][j] = s;
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
