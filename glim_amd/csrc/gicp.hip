@@ -323,16 +323,15 @@ __global__ __launch_bounds__(256) void gicp_finalize_kernel(const float* __restr
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
   double s = 0.0;
-  int c = g;
   constexpr int INFLIGHT = 16;  // loads of 16 trips in flight, additions in the same order (see vgicp.hip finalize_factor)
-  for (; c + 8 * (INFLIGHT - 1) < nb; c += 8 * INFLIGHT) {
+  for (int c = g; c < nb; c += 8 * INFLIGHT) {
     float v[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)(c + 8 * u) * PARTIAL_STRIDE + j];
+    for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)min(c + 8 * u, nb - 1) * PARTIAL_STRIDE + j];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) s += (double)v[u];
+    for (int u = 0; u < INFLIGHT; u++)
+      if (c + 8 * u < nb) s += (double)v[u];
   }
-  for (; c < nb; c += 8) s += (double)partials[(size_t)c * PARTIAL_STRIDE + j];
   s_part[g][j] = s;
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {

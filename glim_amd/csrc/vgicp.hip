@@ -123,19 +123,18 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   // load pair per trip the 64 trips of a thread are 64 memory round trips (~23 us, most of a synchronous single-factor call).  The
   // loads of 16 trips are therefore issued together; the additions keep their order, so the sums are bit-identical.
   double s = 0.0;
-  int c = g;
   constexpr int INFLIGHT = 16;
-  for (; c + 8 * (INFLIGHT - 1) < nb; c += 8 * INFLIGHT) {
+  for (int c = g; c < nb; c += 8 * INFLIGHT) {
     int r[INFLIGHT];
     float v[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) r[u] = fa.rows[first + c + 8 * u];
+    for (int u = 0; u < INFLIGHT; u++) r[u] = fa.rows[first + min(c + 8 * u, nb - 1)];  // past the end: a valid row, value unused
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)r[u] * PARTIAL_STRIDE + j];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) s += (double)v[u];
+    for (int u = 0; u < INFLIGHT; u++)
+      if (c + 8 * u < nb) s += (double)v[u];
   }
-  for (; c < nb; c += 8) s += (double)partials[(size_t)fa.rows[first + c] * PARTIAL_STRIDE + j];
   s_part[g][j] = s;
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
