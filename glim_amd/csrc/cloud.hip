@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __
 }
 
 int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_cloud** out) {
-  if (n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;  // kernels index points with 32-bit ints
+  if (n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;  // kernels address points with 32-bit byte offsets (16 B per point)
   glim_amd_cloud* c = new glim_amd_cloud();
   c->ctx = ctx;
   c->n = n;

@@ -851,7 +851,7 @@ int glim_amd_factor_set_add(glim_amd_factor_set* set, const glim_amd_voxelmap* t
   if (!set || !target || !source) return GLIM_AMD_ERR_INVALID;
   if (target->ctx != set->ctx || source->ctx != set->ctx) return GLIM_AMD_ERR_INVALID;
   if (!target->buckets || !source->has_covs) return GLIM_AMD_ERR_STATE;
-  if (source->n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;
+  if (source->n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;  // 32-bit byte offsets into the point streams
   set->entries.push_back({target, source, flags});
   set->dirty = true;
   if (factor_index) *factor_index = (int32_t)set->entries.size() - 1;

@@ -219,7 +219,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (!m || !cloud || cloud->ctx != m->ctx) return GLIM_AMD_ERR_INVALID;
   if (!cloud->has_covs) return GLIM_AMD_ERR_STATE;
   if (m->buckets) return GLIM_AMD_ERR_UNSUPPORTED;  // GLIM's GPU path builds each map with a single insert()
-  if (cloud->n > (int64_t)(1u << 30)) return GLIM_AMD_ERR_INVALID;
+  if (cloud->n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;
   glim_amd_ctx* ctx = m->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
