@@ -98,3 +98,21 @@ def test_expand_compact_matches_oracle_binary_blocks(orc, small_pair):
     np.testing.assert_allclose(got["b_s"], ref["b_s"], rtol=0, atol=0)
     un = api.expand_compact(compact, T, 0)
     assert not np.any(un["H_tt"]) and not np.any(un["H_ts"]) and not np.any(un["b_t"])
+
+
+def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
+    """include/glim_amd.h must be consumable from C (the FFI of any host language binds it): the pure-C per-frame example compiles with
+    -std=c99 -pedantic -Werror, links against the shared library and runs its no-device branch here."""
+    import subprocess
+
+    from glim_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    exe = str(tmp_path / "c_abi_frame")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_frame.c"), "-o", exe, "-L" + os.path.join(ROOT, "glim_amd"), "-lglim_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "glim_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "glim_amd ABI version" in out.stdout
