@@ -27,14 +27,18 @@ case "${1:-}" in
     [ -f "$EXP" ] || { echo "missing $EXP: run 'tools/ab_exp.sh build' first"; exit 1; }
     GLIM_AMD_LIB=$EXP timeout 150 python -m pytest tests -m gpu -x -q -p no:cacheprovider < /dev/null > $OUT/parity_exp.log 2>&1
     tail -3 $OUT/parity_exp.log
+    GLIM_AMD_LIB=$EXP GLIM_AMD_FUSED_FINALIZE=1 timeout 100 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_edge_cases.py -m gpu -x -q -p no:cacheprovider < /dev/null > $OUT/parity_expfused.log 2>&1
+    tail -3 $OUT/parity_expfused.log
     for rep in 1 2; do
-      for v in main exp; do
-        if [ $v = exp ]; then export GLIM_AMD_LIB=$EXP; else unset GLIM_AMD_LIB; fi
+      for v in main exp expfused; do   # expfused: the branch's single-dispatch finalisation (GLIM_AMD_FUSED_FINALIZE=1)
+        unset GLIM_AMD_LIB GLIM_AMD_FUSED_FINALIZE
+        if [ $v != main ]; then export GLIM_AMD_LIB=$EXP; fi
+        if [ $v = expfused ]; then export GLIM_AMD_FUSED_FINALIZE=1; fi
         timeout 40 python tools/batch_sweep.py < /dev/null > $OUT/sweep_${v}_$rep.json 2> $OUT/sweep_${v}_$rep.err
         timeout 120 python bench.py --no-cpu-baseline < /dev/null > $OUT/bench_${v}_$rep.json 2> $OUT/bench_${v}_$rep.err
       done
     done
-    unset GLIM_AMD_LIB
+    unset GLIM_AMD_LIB GLIM_AMD_FUSED_FINALIZE
     python - <<'PY'
 import glob, json, os
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out", "ab_exp")
