@@ -305,6 +305,10 @@ def run_odometry128k(args, D, api, ctx):
                 "collective": "rccl_all_reduce[world*F x 29] f64" if world > 1 else "none", "device": ctx.device_info()["name"],
             },
             "roofline": roofline, "sync_single_factor_calls_per_s": 1e3 / sync_ms_c, "sync_single_factor_calls_per_s_via_python": sync_rate,
+            # BASELINE.json configs[1] also names the single-factor loop {set pose, linearize, read the record back}:
+            # it is latency, not throughput -- reported here next to `value`, which is the batched form GLIM's NonlinearFactorSetGPU uses
+            "single_factor_loop": {"calls_per_s": 1e3 / sync_ms_c, "us_per_call": sync_ms_c * 1e3, "calls": 500,
+                                   "what": "one 131072-pt factor per call: pose in, fused kernel + FP64 finalise, 232-B record on the host, host sync"},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline_and_parity(api, clouds[0], clouds[1], deltas[0], args.resolution, got)
