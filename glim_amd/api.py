@@ -21,6 +21,8 @@ from . import _lib
 from ._lib import FACTOR_BINARY, FACTOR_SURFACE_VALIDATION, GlimAmdError, Linearized6, PreprocessParams, check, lib  # noqa: F401
 
 _default_ctx = None
+STREAM_LEGACY = 1  # hipStreamLegacy ((hipStream_t)1): the null stream, as an explicit handle
+STREAM_PER_THREAD = 2  # hipStreamPerThread
 
 
 def _dp(a):
@@ -51,8 +53,12 @@ class Context:
 
     def __init__(self, device=0, num_streams=1, external_stream=None):
         h = C.c_void_p()
-        check(lib().glim_amd_ctx_create(int(device), int(num_streams), C.c_void_p(external_stream) if external_stream else None,
-                                        C.byref(h)), "glim_amd_ctx_create")
+        ext = None
+        if external_stream is not None:
+            # 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns for torch's default stream): the C ABI
+            # takes the HIP handle for it, hipStreamLegacy, because NULL means "create private streams"
+            ext = C.c_void_p(int(external_stream) if int(external_stream) != 0 else STREAM_LEGACY)
+        check(lib().glim_amd_ctx_create(int(device), int(num_streams), ext, C.byref(h)), "glim_amd_ctx_create")
         self._h = h
         self.device = device
 

@@ -70,6 +70,52 @@ __global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __
   }
 }
 
+// Plane-form test: does every stored covariance equal I - (1 - 1e-3) n n^T for the stored unit normal, within FP32 rounding of the two
+// uploads?  (GLIM's CloudCovarianceEstimation only emits this form, cloud_covariance_estimation.cpp:20,:181-196, together with the
+// eigenvector it is built from as the normal, :98-101; a frame that keeps the CPU estimator and is uploaded with
+// PointCloudGPU::clone(frame) therefore qualifies for the 24 B/pt factor kernel.)  Tolerance: C and n are each rounded to FP32
+// independently (<= 6e-8 per coefficient), n n^T then differs by <= 1.3e-7 per entry; 4e-7 leaves margin and is far below any covariance a
+// merged / averaged cloud would show (those differ from the form by 1e-3 or more).
+__global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4* __restrict__ covA, const float2* __restrict__ covB,
+                                                         const float4* __restrict__ nrm, unsigned int* __restrict__ violations) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const float4 a = covA[i];
+    const float2 b = covB[i];
+    const float4 v = nrm[i];
+    const float w = 0.999f, tol = 4e-7f;
+    bad = !(fabsf(a.x - (1.f - w * v.x * v.x)) <= tol && fabsf(a.y + w * v.x * v.y) <= tol && fabsf(a.z + w * v.x * v.z) <= tol &&
+            fabsf(a.w - (1.f - w * v.y * v.y)) <= tol && fabsf(b.x + w * v.y * v.z) <= tol && fabsf(b.y - (1.f - w * v.z * v.z)) <= tol);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(violations, 1u);
+}
+
+// factor streams in the Hilbert order of the cloud (rank == null: arrival order)
+__global__ __launch_bounds__(256) void plane_stream_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ nrm,
+                                                           const unsigned int* __restrict__ rank, float4* __restrict__ pn4, float2* __restrict__ n2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int o = rank ? rank[i] : (unsigned int)i;
+  const float4 p = pts[i], v = nrm[i];
+  pn4[o] = make_float4(p.x, p.y, p.z, v.x);
+  n2[o] = make_float2(v.y, v.z);
+}
+__global__ __launch_bounds__(256) void general_stream_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
+                                                             const float2* __restrict__ covB, const float4* __restrict__ nrm,
+                                                             const unsigned int* __restrict__ rank, float4* __restrict__ gs0, float4* __restrict__ gs1,
+                                                             float* __restrict__ gs2, float4* __restrict__ gsn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int o = rank ? rank[i] : (unsigned int)i;
+  const float4 p = pts[i], a = covA[i];
+  const float2 b = covB[i];
+  gs0[o] = make_float4(p.x, p.y, p.z, a.x);
+  gs1[o] = make_float4(a.y, a.z, a.w, b.x);
+  gs2[o] = b.y;
+  if (gsn) gsn[o] = nrm[i];
+}
+
 int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_cloud** out) {
   if (n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;  // kernels address points with 32-bit byte offsets (16 B per point)
   glim_amd_cloud* c = new glim_amd_cloud();
@@ -92,6 +138,53 @@ int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_
 }
 
 }  // namespace
+
+namespace glim_amd {
+
+int detect_plane_form(glim_amd_cloud* c, hipStream_t st) {
+  c->plane_form = false;
+  if (c->n <= 0 || !c->covA || !c->covB || !c->normals || !c->has_covs || !c->has_normals) return GLIM_AMD_OK;
+  unsigned int* d_bad = nullptr;
+  GA_HIP(pool_malloc(&d_bad, sizeof(unsigned int)));
+  unsigned int bad = 1;
+  hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned int), st);
+  if (e == hipSuccess) {
+    plane_form_kernel<<<(int)((c->n + 255) / 256), 256, 0, st>>>(c->n, c->covA, c->covB, c->normals, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)pool_free(d_bad);
+  if (e != hipSuccess) {
+    set_hip_error(e, "detect_plane_form");
+    return GLIM_AMD_ERR_HIP;
+  }
+  c->plane_form = (bad == 0);
+  return GLIM_AMD_OK;
+}
+
+int ensure_factor_streams(glim_amd_cloud* c, hipStream_t st) {
+  if (!c->has_covs || c->n <= 0) return GLIM_AMD_OK;
+  const bool want_plane = c->plane_form && c->normals;
+  if (want_plane ? (c->pn4 && c->n2) : (c->gs0 != nullptr)) return GLIM_AMD_OK;
+  const int n = (int)c->n;
+  GA_TRY(cloud_curve_rank(c, st));
+  if (want_plane) {
+    if (!c->pn4) GA_HIP(pool_malloc(&c->pn4, (size_t)n * sizeof(float4)));
+    if (!c->n2) GA_HIP(pool_malloc(&c->n2, (size_t)n * sizeof(float2)));
+    plane_stream_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, c->pts, c->normals, c->curve_rank, c->pn4, c->n2);
+  } else {
+    GA_HIP(pool_malloc(&c->gs0, (size_t)n * sizeof(float4)));
+    GA_HIP(pool_malloc(&c->gs1, (size_t)n * sizeof(float4)));
+    GA_HIP(pool_malloc(&c->gs2, (size_t)n * sizeof(float)));
+    if (c->has_normals && c->normals) GA_HIP(pool_malloc(&c->gsn, (size_t)n * sizeof(float4)));
+    general_stream_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, c->pts, c->covA, c->covB, c->normals, c->curve_rank, c->gs0, c->gs1, c->gs2, c->gsn);
+  }
+  GA_HIP(hipGetLastError());
+  return GLIM_AMD_OK;  // stream-ordered: the factor kernels that read the streams are enqueued behind this on streams of the same context
+}
+
+}  // namespace glim_amd
 
 extern "C" {
 
@@ -123,6 +216,13 @@ int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       set_hip_error(e, "cloud_create upload/pack");
       glim_amd_cloud_destroy(c);
       return GLIM_AMD_ERR_HIP;
+    }
+    if (covs16 && normals4) {
+      const int rc = detect_plane_form(c, s);
+      if (rc != GLIM_AMD_OK) {
+        glim_amd_cloud_destroy(c);
+        return rc;
+      }
     }
   }
   *out = c;
@@ -158,6 +258,13 @@ int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, co
       glim_amd_cloud_destroy(c);
       return GLIM_AMD_ERR_HIP;
     }
+    if (cov33 && normals3) {
+      const int rc = detect_plane_form(c, s);
+      if (rc != GLIM_AMD_OK) {
+        glim_amd_cloud_destroy(c);
+        return rc;
+      }
+    }
   }
   *out = c;
   return GLIM_AMD_OK;
@@ -165,7 +272,14 @@ int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, co
 
 int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (!c) return GLIM_AMD_OK;
-  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->ctx) {
+    (void)hipSetDevice(c->ctx->device);
+    c->ctx->quiesce();  // asynchronous factor launches may still be reading this cloud: its memory goes back to the pool below
+  }
+  if (c->gs0) (void)pool_free(c->gs0);
+  if (c->gs1) (void)pool_free(c->gs1);
+  if (c->gs2) (void)pool_free(c->gs2);
+  if (c->gsn) (void)pool_free(c->gsn);
   if (c->pts) (void)pool_free(c->pts);
   if (c->covA) (void)pool_free(c->covA);
   if (c->covB) (void)pool_free(c->covB);

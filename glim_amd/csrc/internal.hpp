@@ -53,6 +53,16 @@ struct DeviceTemp {
 
 // Hilbert rank of a cloud's points (knn.hip); no-op when present, tiny, or disabled
 int cloud_curve_rank(::glim_amd_cloud* c, hipStream_t st);
+// factor streams of a cloud that has covariances (cloud.hip); no-op when present.  Caller holds the context mutex.
+int ensure_factor_streams(::glim_amd_cloud* c, hipStream_t st);
+// plane-form test of a freshly uploaded cloud with covariances and normals (cloud.hip): sets c->plane_form
+int detect_plane_form(::glim_amd_cloud* c, hipStream_t st);
+// diagnostic switches of the per-call path, read from the environment ONCE per process (vgicp.hip); the plan-time switches
+// (GLIM_AMD_NO_PLANE, GLIM_AMD_PPT, ...) are read when a factor set builds its plan
+struct CallSwitches {
+  bool no_poll, no_inline_pose;
+};
+const CallSwitches& call_switches();
 
 // stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
 size_t radix_sort_scratch_bytes(int n);
@@ -101,12 +111,18 @@ constexpr int KEY_OFFSET = 1 << 20;
 
 // Per-factor descriptor consumed by the fused VGICP kernel (device array, rebuilt when the set changes).
 struct FactorDesc {
-  const float4* pts;        // source xyz1
-  const float4* covA;       // c00 c01 c02 c11
-  const float2* covB;       // c12 c22
-  const float4* normals;    // may be null
-  const float4* pn4;        // plane-form stream: x y z nx   (null unless the cloud is plane-form)
-  const float2* n2;         //                    ny nz
+  const float4* pts;        // source xyz1, arrival order (correspondence / debug kernels)
+  const float4* normals;    // arrival order, may be null
+  // factor stream of the source cloud, in the Hilbert order of the cloud (glim_amd_cloud, "factor streams"):
+  //   plane-form (plane != 0): s0 = float4 (x y z nx), s1 = float2 (ny nz)                                    24 B per point
+  //   general                : s0 = float4 (x y z c00), s1 = float4 (c01 c02 c11 c12), s2 = float c22,        36 B per point
+  //                            sn = float4 normals in stream order (null without normals; surface validation only)
+  const void* s0;
+  const void* s1;
+  const void* s2;
+  const float4* sn;
+  int plane;
+  int pad0;
   const VoxelBucket* buckets;  // target table
   unsigned int num_buckets;    // any size >= 1 (range reduction by multiply-shift)
   int n;                    // source points
@@ -142,6 +158,13 @@ struct glim_amd_ctx {
   std::vector<hipStream_t> streams;
   int next_stream = 0;
   std::mutex mu;
+  // set by the *_async entry points: device work may still be reading buffers when the call returns, so the next call that recycles
+  // device memory of this context (destroy / re-plan) synchronises the streams first (quiesce)
+  std::atomic<bool> async_pending{false};
+  void quiesce() {
+    if (async_pending.exchange(false))
+      for (auto s : streams) (void)hipStreamSynchronize(s);
+  }
   hipStream_t stream() const { return streams[0]; }
   hipStream_t round_robin() {
     hipStream_t s = streams[next_stream];
@@ -177,9 +200,18 @@ struct glim_amd_cloud {
   float4* covA = nullptr;
   float2* covB = nullptr;
   float4* normals = nullptr;
-  float4* pn4 = nullptr;  // plane-form stream (x y z nx), see load_point<PLANE> in vgicp.hip
-  float2* n2 = nullptr;   //                   (ny nz)
-  unsigned int* curve_rank = nullptr;  // position of point i on the Hilbert curve through the cloud (knn.hip); orders the plane-form stream
+  // Factor streams: what the VGICP kernel reads per source point, written in the Hilbert order of the cloud so that the 64 lanes of a
+  // wavefront look up a handful of neighbouring voxels (the factor sums over all points: their order is free).
+  //   plane-form clouds (C = I - (1 - 1e-3) n n^T, the only form GLIM's covariance estimator emits): pn4 + n2, 24 B per point;
+  //   written by the covariance kernel, or lazily by ensure_factor_streams for clouds uploaded with matching covariances + normals
+  //   any other cloud: gs0 + gs1 + gs2 (+ gsn), 36 B per point, built lazily by ensure_factor_streams (cloud.hip)
+  float4* pn4 = nullptr;  // x y z nx
+  float2* n2 = nullptr;   // ny nz
+  float4* gs0 = nullptr;  // x y z c00
+  float4* gs1 = nullptr;  // c01 c02 c11 c12
+  float* gs2 = nullptr;   // c22
+  float4* gsn = nullptr;  // normals in stream order
+  unsigned int* curve_rank = nullptr;  // position of point i on the Hilbert curve through the cloud (knn.hip); orders the factor streams
   bool plane_form = false;
   int32_t* neighbors = nullptr;
   int k = 0;
@@ -201,6 +233,8 @@ struct glim_amd_cloud {
     if (normals) b += (size_t)n * sizeof(float4);
     if (neighbors) b += (size_t)n * k * sizeof(int32_t);
     if (pn4) b += (size_t)n * (sizeof(float4) + sizeof(float2));
+    if (gs0) b += (size_t)n * (2 * sizeof(float4) + sizeof(float));
+    if (gsn) b += (size_t)n * sizeof(float4);
     return b;
   }
 };
@@ -224,25 +258,26 @@ struct glim_amd_factor_set {
   };
   std::vector<Entry> entries;
   bool dirty = true;  // device plan needs a rebuild
-  // device plan
+  // device plan: rows [0, plane_rows) = blocks of factors whose source cloud is plane-form (24 B/pt kernel), rows [plane_rows,
+  // total_rows) = blocks of the other factors (36 B/pt kernel); each segment is its own launch
   int points_per_thread = 1;
-  bool plane_form = false;  // every source cloud of the set is plane-form -> 24 B/pt kernel
-  int variant_u = 2, variant_minw = 3;  // kernel variant: points in flight per lane, occupancy hint
-  int total_blocks = 0;
+  int plane_rows = 0, total_rows = 0;
   glim_amd::FactorDesc* d_descs = nullptr;
   int2* d_blockmap = nullptr;
   float* d_partials = nullptr;
   double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
   double* d_compact = nullptr;    // n x COMPACT
-  double* h_poses = nullptr;      // pinned
+  // pinned pose staging: a ring, because an asynchronous call returns while its host-to-device copy may still be reading the slot
+  static constexpr int POSE_RING = 4;
+  double* h_poses = nullptr;      // POSE_RING x (2 x n x 12)
+  hipEvent_t pose_events[POSE_RING] = {nullptr, nullptr, nullptr, nullptr};
+  bool pose_pending[POSE_RING] = {false, false, false, false};
+  int pose_slot = 0;
   double* h_compact = nullptr;    // pinned, host-mapped
-  int* d_tickets = nullptr;          // per-factor block arrival counters (fused finalisation)
-  bool fused_finalize = true;
   int* d_done = nullptr;             // finalise-block arrival counter (polling fast path)
   unsigned int* h_flag = nullptr;    // host-mapped completion word, written by the last finalise block
   unsigned int* h_flag_dev = nullptr;
   unsigned int poll_seq = 0;
-  bool poll = false;
   glim_amd::InlinePose inline_pose{};  // single-factor sets: the pose rides in the kernel arguments
   double* h_compact_dev = nullptr;  // device view of h_compact (small sets: results land in host memory, no D2H copy)
   size_t cap_factors = 0, cap_blocks = 0;

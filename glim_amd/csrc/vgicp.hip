@@ -74,42 +74,45 @@ __device__ __forceinline__ float2 gld2(const void* p) {
   const v2f_t v = *reinterpret_cast<gf2_t>(reinterpret_cast<uintptr_t>(p));
   return make_float2(v.x, v.y);
 }
+__device__ __forceinline__ float gld1(const void* p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(p));
+}
 
 struct PointIn {
-  float4 p;   // xyz1            (PLANE: x y z nx)
-  float4 ca;  // c00 c01 c02 c11 (PLANE: unused)
-  float2 cb;  // c12 c22         (PLANE: ny nz)
+  float4 p;   // PLANE: x y z nx        general: x y z c00
+  float4 ca;  // PLANE: unused          general: c01 c02 c11 c12
+  float2 cb;  // PLANE: ny nz           general: c22 -
 };
 
-// PLANE = the source cloud's covariances are the PLANE-regularised form C = I - (1 - 1e-3) n n^T produced by
-// glim_amd_cloud_estimate_covariances (the only form GLIM's CloudCovarianceEstimation emits, cloud_covariance_estimation.cpp:20,
-// :181-196): the factor then streams 24 B per point (xyz + unit normal) instead of 40 B and rebuilds C in registers.
+// Factor streams (glim_amd_cloud, internal.hpp), both written in the Hilbert order of the cloud.
+// PLANE = the source cloud's covariances are the PLANE-regularised form C = I - (1 - 1e-3) n n^T (the only form GLIM's
+// CloudCovarianceEstimation emits, cloud_covariance_estimation.cpp:20, :181-196): the factor streams 24 B per point (xyz + unit normal)
+// and rebuilds C in registers; any other cloud streams 36 B per point (xyz + the six covariance coefficients).
 template <bool PLANE>
 __device__ __forceinline__ PointIn load_point(const FactorDesc& d, unsigned int i) {
   PointIn r;
+  r.p = gld4(reinterpret_cast<const char*>(d.s0) + i * 16u);  // uniform base + 32-bit lane offset (n <= 2^28)
   if (PLANE) {
-    r.p = gld4(reinterpret_cast<const char*>(d.pn4) + i * 16u);  // uniform base + 32-bit lane offset (n <= 2^28)
-    r.cb = gld2(reinterpret_cast<const char*>(d.n2) + i * 8u);
+    r.cb = gld2(reinterpret_cast<const char*>(d.s1) + i * 8u);
     r.ca = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    r.p = gld3(reinterpret_cast<const char*>(d.pts) + i * 16u);
-    r.ca = gld4(reinterpret_cast<const char*>(d.covA) + i * 16u);
-    r.cb = gld2(reinterpret_cast<const char*>(d.covB) + i * 8u);
+    r.ca = gld4(reinterpret_cast<const char*>(d.s1) + i * 16u);
+    r.cb = make_float2(gld1(reinterpret_cast<const char*>(d.s2) + i * 4u), 0.f);
   }
   return r;
 }
 
-// Arguments of the per-factor finalisation (shared by the fused tail of vgicp_kernel and the stand-alone finalize_kernel).
+// Arguments of the per-factor finalisation (finalize_kernel).  In-kernel finalisation by the last block of a factor was measured slower
+// twice (per-block agent-scope release: 122 vs 80 us per 64 factors; write-through row stores: 149 vs 143 us per 128 factors, 22.9 vs
+// 18.8 us per synchronous single-factor call) and is gone: the second dispatch costs less than any in-kernel hand-off.
 struct FinalizeArgs {
-  const int* rows;           // per factor: the grid block ids that hold its partial rows, in chunk order
-  int* tickets;              // per factor: arrival counter of its blocks (fused path; zero between launches)
+  const int* rows;           // per factor: the plan rows (blocks) that hold its partial sums, in chunk order
   double* out;               // compact records
   long long out_row_offset;
   int* done_counter;         // finished factors of this launch (polling fast path)
   unsigned int* host_flag;   // host-mapped completion word or null
   unsigned int seq;
   int num_factors;
-  int fused;                 // 1: the last block of a factor finalises it inside vgicp_kernel; 0: finalize_kernel does
 };
 
 // Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 256 threads of ONE block.  Thread (g, j),
@@ -224,15 +227,14 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 // 48-byte voxel-slot gathers of trip t are issued back to back BEFORE the algebra of trip t, every lane runs the algebra
 // and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
 // the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
-template <int MODE, bool FROZEN, int U, int MINW, bool PLANE, bool INLINE>
-__global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
-                                                             const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
-                                                             float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa) {
+template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
+__global__ __launch_bounds__(BLOCK, 3) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+                                                          const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
+                                                          float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa, int block_offset) {
+  constexpr int U = 1;  // points per loop trip (2 and 4 were measured slower: more registers, fewer resident waves)
   __shared__ float s_red[4][PARTIAL_STRIDE];
-  __shared__ double s_part[8][PARTIAL_STRIDE];
-  __shared__ double s_sum[PARTIAL_STRIDE];
-  __shared__ int s_last;
-  const int2 bm = blockmap[blockIdx.x];
+  const int gblock = block_offset + (int)blockIdx.x;  // row of this block in the plan (the plane-form and the general segment are separate launches)
+  const int2 bm = blockmap[gblock];
   const int f = bm.x;
   if (f < 0) return;  // padding block of the XCD-aware map
   const FactorDesc d = descs[f];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
   const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
   const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
-  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.normals != nullptr);
+  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.sn != nullptr);
   const float resf = (float)d.res;
   const int last = d.n - 1;
 
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
           // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
           // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
           const float4 nn = PLANE ? make_float4(cur[u].p.w, cur[u].cb.x, cur[u].cb.y, 0.f)
-                                  : gld4(reinterpret_cast<const char*>(d.normals) + (unsigned int)min(i, last) * 16u);
+                                  : gld4(reinterpret_cast<const char*>(d.sn) + (unsigned int)min(i, last) * 16u);
           const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
           const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
           const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
@@ -387,11 +389,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
           t00 = 1.f - wx * mx; t01 = -wx * my; t02 = -wx * mz;
           t11 = 1.f - wy * my; t12 = -wy * mz; t22 = 1.f - w * mz * mz;
         } else {
-          const float4 ca = cur[u].ca;  // c00 c01 c02 c11
-          const float2 cb = cur[u].cb;  // c12 c22
-          const float a00 = R00 * ca.x + R01 * ca.y + R02 * ca.z, a01 = R00 * ca.y + R01 * ca.w + R02 * cb.x, a02 = R00 * ca.z + R01 * cb.x + R02 * cb.y;
-          const float a10 = R10 * ca.x + R11 * ca.y + R12 * ca.z, a11 = R10 * ca.y + R11 * ca.w + R12 * cb.x, a12 = R10 * ca.z + R11 * cb.x + R12 * cb.y;
-          const float a20 = R20 * ca.x + R21 * ca.y + R22 * ca.z, a21 = R20 * ca.y + R21 * ca.w + R22 * cb.x, a22 = R20 * ca.z + R21 * cb.x + R22 * cb.y;
+          const float c00 = cur[u].p.w, c01 = cur[u].ca.x, c02 = cur[u].ca.y, c11 = cur[u].ca.z, c12 = cur[u].ca.w, c22 = cur[u].cb.x;
+          const float a00 = R00 * c00 + R01 * c01 + R02 * c02, a01 = R00 * c01 + R01 * c11 + R02 * c12, a02 = R00 * c02 + R01 * c12 + R02 * c22;
+          const float a10 = R10 * c00 + R11 * c01 + R12 * c02, a11 = R10 * c01 + R11 * c11 + R12 * c12, a12 = R10 * c02 + R11 * c12 + R12 * c22;
+          const float a20 = R20 * c00 + R21 * c01 + R22 * c02, a21 = R20 * c01 + R21 * c11 + R22 * c12, a22 = R20 * c02 + R21 * c12 + R22 * c22;
           t00 = a00 * R00 + a01 * R01 + a02 * R02; t01 = a00 * R10 + a01 * R11 + a02 * R12; t02 = a00 * R20 + a01 * R21 + a02 * R22;
           t11 = a10 * R10 + a11 * R11 + a12 * R12; t12 = a10 * R20 + a11 * R21 + a12 * R22; t22 = a20 * R20 + a21 * R21 + a22 * R22;
         }
@@ -479,33 +480,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void vgicp_kernel(const FactorDesc* __
     float v = 0.f;
     const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
     if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
-    partials[(size_t)blockIdx.x * PARTIAL_STRIDE + j] = v;
+    partials[(size_t)gblock * PARTIAL_STRIDE + j] = v;
   }
-  if (!fa.fused) return;
-
-  // ---- fused finalisation: the LAST block of this factor to arrive sums the factor's partial rows (fixed order) ----
-  // Placement-independent hand-off (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", cdna_hip_programming.md G16): the
-  // storing wave drains its stores, one lane issues an agent-scope release (L2 write-back) and takes a ticket with a relaxed
-  // agent-scope atomic; the block that draws the last ticket issues one agent-scope acquire (drops its stale L1 lines) before
-  // any lane reads the other blocks' rows with plain loads.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(fa.tickets + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last_one = (ticket == d.num_blocks - 1);
-    if (last_one) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(fa.tickets + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    }
-    s_last = last_one;
-  }
-  __syncthreads();
-  if (s_last) finalize_factor(d, f, partials, fa, MODE, s_part, s_sum, Tl);
 }
 
-// Stand-alone finalisation (default): one block of 256 threads per factor.
+// Finalisation: one block of 256 threads per factor.
 __global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
                                                        int mode, const double* __restrict__ poses_lin, const InlinePose ip) {
   __shared__ double s_part[8][PARTIAL_STRIDE];
@@ -571,21 +550,26 @@ void hat3(const double* a, double* H) {
 
 }  // namespace
 
+
 // -----------------------------------------------------------------------------------------------------------------
 // plan management
 // -----------------------------------------------------------------------------------------------------------------
 namespace glim_amd {
 
+const CallSwitches& call_switches() {
+  static const CallSwitches s = {getenv("GLIM_AMD_NO_POLL") != nullptr, getenv("GLIM_AMD_NO_INLINE_POSE") != nullptr};
+  return s;
+}
+
 void factor_set_release_plan(glim_amd_factor_set* set) {
+  // the plan's buffers go back to the pool: nothing enqueued earlier (asynchronous entry points included) may still be using them
+  if (set->d_descs && set->stream) (void)hipStreamSynchronize(set->stream);
   if (set->d_descs) (void)pool_free(set->d_descs);
   if (set->d_blockmap) (void)pool_free(set->d_blockmap);
   if (set->d_partials) (void)pool_free(set->d_partials);
   if (set->d_poses) (void)pool_free(set->d_poses);
   if (set->d_compact) (void)pool_free(set->d_compact);
   if (set->d_done) (void)pool_free(set->d_done);
-  set->d_done = nullptr;
-  if (set->d_tickets) (void)pool_free(set->d_tickets);
-  set->d_tickets = nullptr;
   if (set->h_poses) (void)pinned_free(set->h_poses);
   if (set->h_compact) (void)pinned_free(set->h_compact);
   set->d_descs = nullptr;
@@ -593,51 +577,69 @@ void factor_set_release_plan(glim_amd_factor_set* set) {
   set->d_partials = nullptr;
   set->d_poses = nullptr;
   set->d_compact = nullptr;
+  set->d_done = nullptr;
   set->h_poses = nullptr;
   set->h_compact = nullptr;
   set->h_compact_dev = nullptr;
+  for (int i = 0; i < glim_amd_factor_set::POSE_RING; i++) set->pose_pending[i] = false;
   set->cap_factors = set->cap_blocks = 0;
 }
 
-// Build the device plan: factor descriptors, chunking, and the XCD-aware block -> (factor, chunk) map.
-// Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"); when the set holds enough
-// factors, all chunks of one factor are given block ids of one residue class so that the factor's voxel table stays in a
-// single XCD's 4 MiB L2.  This is a speed-only choice: any placement is correct.
+// Build the device plan: factor descriptors, chunking, and the block -> (factor, chunk) map.
+// Factors whose source cloud is plane-form take the 24 B/pt kernel, the others the general 36 B/pt kernel -- decided per factor, so one
+// cloud with averaged covariances (a merged submap) does not demote the rest of the set; the two groups occupy separate row segments of
+// the plan and are launched separately.
+// Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"); when a segment holds enough factors,
+// all chunks of one factor are given rows of one residue class so that the factor's voxel table stays in a single XCD's 4 MiB L2.
+// This is a speed-only choice: any placement is correct.
 int factor_set_prepare(glim_amd_factor_set* set) {
   if (!set->dirty) return GLIM_AMD_OK;
   const int nf = (int)set->entries.size();
   glim_amd_ctx* ctx = set->ctx;
   long long total_points = 0;
   for (auto& e : set->entries) total_points += e.source->n;
-  // Grid sizing: aim for ONE resident set of blocks (num_cus x blocks_per_cu) with equal work each, so every lane reduces
-  // its 28 accumulators exactly once and there is no tail wave; each factor gets blocks in proportion to its points.
+  // Grid sizing: aim for ONE resident set of blocks (num_cus x blocks_per_cu) with equal work each, so every lane reduces its 28
+  // accumulators exactly once; each factor gets blocks in proportion to its points.  (Finer grids were measured level: 1280 blocks
+  // 142.7 us, 2560 142.6, 5120 138.6, 10240 142.9 per 128 factors.)
   const int blocks_per_cu = 5;  // 96 VGPRs -> 5 waves/SIMD -> 5 blocks of 4 waves per CU
   long long target_blocks = (long long)std::max(1, ctx->num_cus) * blocks_per_cu;
   if (const char* env = getenv("GLIM_AMD_TARGET_BLOCKS")) target_blocks = std::max(1, atoi(env));
   int forced_ppt = 0;
   if (const char* env = getenv("GLIM_AMD_PPT")) forced_ppt = std::max(1, std::min(256, atoi(env)));
-  set->variant_u = 1;
-  set->variant_minw = 3;
-  if (const char* env = getenv("GLIM_AMD_U")) set->variant_u = atoi(env);
-  if (const char* env = getenv("GLIM_AMD_MINW")) set->variant_minw = atoi(env);
+  const bool allow_plane = getenv("GLIM_AMD_NO_PLANE") == nullptr;
 
   set->h_descs.assign(nf, FactorDesc());
-  bool all_plane = nf > 0 && getenv("GLIM_AMD_NO_PLANE") == nullptr;
   std::vector<int> nblocks(nf);
-  long long total_blocks = 0;
   for (int f = 0; f < nf; f++) {
     const auto& e = set->entries[f];
+    glim_amd_cloud* src = const_cast<glim_amd_cloud*>(e.source);  // lazily built stream copies are a cache, not a change of the cloud
+    if (!allow_plane && src->plane_form && !src->gs0) {
+      // diagnostic switch: run a plane-form cloud through the general kernel (its covariance arrays hold the same matrix)
+      src->plane_form = false;
+      const int rc = ensure_factor_streams(src, set->stream);
+      src->plane_form = true;
+      GA_TRY(rc);
+    } else {
+      GA_TRY(ensure_factor_streams(src, set->stream));
+    }
     FactorDesc& d = set->h_descs[f];
-    d.pts = e.source->pts;
-    d.covA = e.source->covA;
-    d.covB = e.source->covB;
-    d.normals = e.source->has_normals ? e.source->normals : nullptr;
-    d.pn4 = e.source->pn4;
-    d.n2 = e.source->n2;
-    all_plane = all_plane && e.source->plane_form && e.source->pn4 && e.source->n2;
+    d.pts = src->pts;
+    d.normals = src->has_normals ? src->normals : nullptr;
+    d.plane = (allow_plane && src->plane_form && src->pn4 && src->n2) ? 1 : 0;
+    if (d.plane) {
+      d.s0 = src->pn4;
+      d.s1 = src->n2;
+      d.s2 = nullptr;
+      d.sn = nullptr;
+    } else {
+      d.s0 = src->gs0;
+      d.s1 = src->gs1;
+      d.s2 = src->gs2;
+      d.sn = src->gsn;
+    }
     d.buckets = e.target->buckets;
     d.num_buckets = e.target->num_buckets;
-    d.n = (int)e.source->n;
+    d.n = (int)src->n;
     d.inv_res = e.target->inv_resolution;
     d.res = e.target->resolution;
     d.flags = e.flags;
@@ -649,64 +651,60 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     d.ppt = ppt;
     nblocks[f] = std::max(1, (d.n + BLOCK * ppt - 1) / (BLOCK * ppt));
     d.num_blocks = nblocks[f];
-    total_blocks += nblocks[f];
   }
   set->points_per_thread = nf ? set->h_descs[0].ppt : 1;
-  set->plane_form = all_plane;
 
-  // block map
+  // block map: the plane-form segment first, then the general one
   std::vector<int2> blockmap;
-  const bool xcd_group = nf >= 16 && getenv("GLIM_AMD_NO_XCD_MAP") == nullptr;
-  if (!xcd_group) {
-    blockmap.reserve((size_t)total_blocks);
+  const bool want_xcd = getenv("GLIM_AMD_NO_XCD_MAP") == nullptr;
+  int seg_rows[2] = {0, 0};
+  for (int seg = 0; seg < 2; seg++) {  // seg 0: plane-form factors, seg 1: the others
+    std::vector<int> fs;
     for (int f = 0; f < nf; f++)
-      for (int c = 0; c < nblocks[f]; c++) blockmap.push_back(make_int2(f, c));
-  } else {
-    std::vector<std::vector<int2>> per_xcd(8);
-    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int f = 0; f < nf; f++) {
-      int x = 0;
-      for (int k = 1; k < 8; k++)
-        if (load[k] < load[x]) x = k;
-      load[x] += nblocks[f];
-      for (int c = 0; c < nblocks[f]; c++) per_xcd[x].push_back(make_int2(f, c));
+      if ((set->h_descs[f].plane != 0) == (seg == 0)) fs.push_back(f);
+    const size_t base = blockmap.size();
+    if (fs.size() < 16 || !want_xcd) {
+      for (int f : fs)
+        for (int c = 0; c < nblocks[f]; c++) blockmap.push_back(make_int2(f, c));
+    } else {
+      std::vector<std::vector<int2>> per_xcd(8);
+      long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f : fs) {
+        int x = 0;
+        for (int k = 1; k < 8; k++)
+          if (load[k] < load[x]) x = k;
+        load[x] += nblocks[f];
+        for (int c = 0; c < nblocks[f]; c++) per_xcd[x].push_back(make_int2(f, c));
+      }
+      size_t longest = 0;
+      for (auto& v : per_xcd) longest = std::max(longest, v.size());
+      blockmap.resize(base + longest * 8, make_int2(-1, 0));
+      for (int x = 0; x < 8; x++)
+        for (size_t j = 0; j < per_xcd[x].size(); j++) blockmap[base + j * 8 + x] = per_xcd[x][j];
     }
-    size_t longest = 0;
-    for (auto& v : per_xcd) longest = std::max(longest, v.size());
-    blockmap.assign(longest * 8, make_int2(-1, 0));
-    for (int x = 0; x < 8; x++)
-      for (size_t j = 0; j < per_xcd[x].size(); j++) blockmap[j * 8 + x] = per_xcd[x][j];
+    seg_rows[seg] = (int)(blockmap.size() - base);
   }
-  // rows[]: for each factor the list of grid block ids that hold its partials, in chunk order
+  // rows[]: for each factor the plan rows that hold its partial sums, in chunk order
+  long long total_blocks = 0;
+  for (int f = 0; f < nf; f++) {
+    set->h_descs[f].first_block = (int)total_blocks;
+    total_blocks += nblocks[f];
+  }
   std::vector<int> rows((size_t)total_blocks);
-  {
-    std::vector<int> first(nf);
-    int acc = 0;
-    for (int f = 0; f < nf; f++) {
-      first[f] = acc;
-      set->h_descs[f].first_block = acc;
-      acc += nblocks[f];
-    }
-    for (size_t b = 0; b < blockmap.size(); b++) {
-      if (blockmap[b].x < 0) continue;
-      rows[(size_t)first[blockmap[b].x] + blockmap[b].y] = (int)b;
-    }
+  for (size_t b = 0; b < blockmap.size(); b++) {
+    if (blockmap[b].x < 0) continue;
+    rows[(size_t)set->h_descs[blockmap[b].x].first_block + blockmap[b].y] = (int)b;
   }
-  set->total_blocks = (int)blockmap.size();
 
   factor_set_release_plan(set);
+  set->plane_rows = seg_rows[0];
+  set->total_rows = (int)blockmap.size();
   const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
   GA_HIP(pool_malloc(&set->d_descs, nfa * sizeof(FactorDesc)));
   GA_HIP(pool_malloc(&set->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
   GA_HIP(pool_malloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
   GA_HIP(pool_malloc(&set->d_poses, nfa * 24 * sizeof(double)));
   GA_HIP(pool_malloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
-  GA_HIP(pool_malloc(&set->d_tickets, nfa * sizeof(int)));
-  GA_HIP(hipMemsetAsync(set->d_tickets, 0, nfa * sizeof(int), set->stream));
-  // Fused in-kernel finalisation was measured SLOWER on MI355X (64 x 131k-pt factors: 122 us vs 77 us + 3 us finalise kernel;
-  // single factor: 39 us vs 34.5 us per synchronous call): one agent-scope release per block (L2 write-back) costs more than the
-  // kernel boundary it removes.  Kept as an opt-in experiment.
-  set->fused_finalize = getenv("GLIM_AMD_FUSED_FINALIZE") != nullptr;
   GA_HIP(pool_malloc(&set->d_done, sizeof(int)));
   GA_HIP(hipMemsetAsync(set->d_done, 0, sizeof(int), set->stream));
   if (!set->h_flag) {
@@ -723,7 +721,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
       set->h_flag = nullptr;
     }
   }
-  GA_HIP(pinned_malloc(&set->h_poses, nfa * 24 * sizeof(double)));
+  GA_HIP(pinned_malloc(&set->h_poses, (size_t)glim_amd_factor_set::POSE_RING * nfa * 24 * sizeof(double)));
   GA_HIP(pinned_malloc(&set->h_compact, nfa * COMPACT * sizeof(double)));
   set->h_compact_dev = nullptr;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_compact_dev), set->h_compact, 0) != hipSuccess) {
@@ -737,7 +735,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     GA_HIP(hipMemcpyAsync(set->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
     GA_HIP(hipMemcpyAsync(reinterpret_cast<char*>(set->d_blockmap) + nba * sizeof(int2), rows.data(), rows.size() * sizeof(int),
                           hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipStreamSynchronize(set->stream));
+    GA_HIP(hipStreamSynchronize(set->stream));  // the staging vectors above die with this scope
   }
   set->dirty = false;
   return GLIM_AMD_OK;
@@ -747,34 +745,6 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 
 namespace {
 
-// kernel-variant dispatch: (U, MINW) chosen per plan (GLIM_AMD_U / GLIM_AMD_MINW override the tuned default)
-template <int U, int W, bool PLANE, bool INLINE>
-void launch_lin2(glim_amd_factor_set* set, const FinalizeArgs& fa) {
-  vgicp_kernel<MODE_LINEARIZE, false, U, W, PLANE, INLINE><<<set->total_blocks, BLOCK, 0, set->stream>>>(
-    set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, set->inline_pose, fa);
-}
-template <int U, int W>
-void launch_lin(glim_amd_factor_set* set, const FinalizeArgs& fa) {
-  const bool inl = set->inline_pose.valid != 0;
-  if (set->plane_form) {
-    if (inl) launch_lin2<U, W, true, true>(set, fa);
-    else launch_lin2<U, W, true, false>(set, fa);
-  } else {
-    if (inl) launch_lin2<U, W, false, true>(set, fa);
-    else launch_lin2<U, W, false, false>(set, fa);
-  }
-}
-
-struct FinalizeArgs;
-void launch_vgicp_linearize(glim_amd_factor_set* set, const FinalizeArgs& fa) {
-  const int u = set->variant_u, w = set->variant_minw;
-#define GA_CASE(UU, WW) \
-  if (u == UU && w == WW) return launch_lin<UU, WW>(set, fa);
-  GA_CASE(1, 3) GA_CASE(1, 4) GA_CASE(2, 3) GA_CASE(2, 4)
-#undef GA_CASE
-  return launch_lin<1, 3>(set, fa);
-}
-
 const int* rows_ptr(const glim_amd_factor_set* set) {
   return reinterpret_cast<const int*>(reinterpret_cast<const char*>(set->d_blockmap) + set->cap_blocks * sizeof(int2));
 }
@@ -782,41 +752,125 @@ const int* rows_ptr(const glim_amd_factor_set* set) {
 FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long long row_offset, bool poll) {
   FinalizeArgs fa;
   fa.rows = rows_ptr(set);
-  fa.tickets = set->d_tickets;
   fa.out = out;
   fa.out_row_offset = row_offset;
   fa.done_counter = set->d_done;
   fa.host_flag = poll ? set->h_flag_dev : nullptr;
   fa.seq = set->poll_seq;
   fa.num_factors = (int)set->entries.size();
-  fa.fused = set->fused_finalize ? 1 : 0;
   return fa;
 }
 
+template <int MODE, bool FROZEN, bool INLINE>
+void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa) {
+  const double* lin = set->d_poses;
+  const double* ev = set->d_poses + set->entries.size() * 12;
+  if (set->plane_rows > 0)
+    vgicp_kernel<MODE, FROZEN, true, INLINE><<<set->plane_rows, BLOCK, 0, set->stream>>>(set->d_descs, lin, ev, set->d_blockmap, set->d_partials,
+                                                                                       set->inline_pose, fa, 0);
+  if (set->total_rows > set->plane_rows)
+    vgicp_kernel<MODE, FROZEN, false, INLINE><<<set->total_rows - set->plane_rows, BLOCK, 0, set->stream>>>(
+      set->d_descs, lin, ev, set->d_blockmap, set->d_partials, set->inline_pose, fa, set->plane_rows);
+}
+
+// the fused kernel(s) alone (no finalisation): used by the profiling entry point
+void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const FinalizeArgs& fa) {
+  const bool inl = set->inline_pose.valid != 0;
+  if (mode == MODE_LINEARIZE) {
+    if (inl) launch_segments<MODE_LINEARIZE, false, true>(set, fa);
+    else launch_segments<MODE_LINEARIZE, false, false>(set, fa);
+  } else if (frozen) {
+    launch_segments<MODE_ERROR, true, false>(set, fa);
+  } else {
+    if (inl) launch_segments<MODE_ERROR, false, true>(set, fa);
+    else launch_segments<MODE_ERROR, false, false>(set, fa);
+  }
+}
+
 // enqueue (no sync): poses already in d_poses / the inline pose; writes compact records to `out` rows [row_offset, row_offset + n).
-// Two launches by default (main kernel + FP64 finalise); GLIM_AMD_FUSED_FINALIZE=1 lets the last block of every factor finalise
-// it in-kernel instead (measured slower, see factor_set_prepare).
-int launch_linearize(glim_amd_factor_set* set, double* out, long long row_offset) {
+// Two or three launches: the fused kernel per plan segment + the FP64 finalise.
+int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll) {
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
-  const FinalizeArgs fa = finalize_args(set, out, row_offset, set->poll);
-  launch_vgicp_linearize(set, fa);
-  if (!fa.fused) finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_LINEARIZE, set->d_poses, set->inline_pose);
+  const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
+  launch_vgicp(set, mode, frozen, fa);
+  finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
 
-int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_eval) {
+// Poses to the device.  Single-factor sets without an evaluation pose pass the pose in the kernel arguments (no copy at all).  Otherwise
+// the poses are staged in one slot of a pinned ring and copied asynchronously; a slot is reused only after the copy that read it has
+// completed (event), so back-to-back asynchronous calls never see each other's poses.
+int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, bool async_call) {
   const size_t nf = set->entries.size();
   set->inline_pose.valid = 0;
-  if (nf == 1 && !T_eval && getenv("GLIM_AMD_NO_INLINE_POSE") == nullptr) {  // single factor: the pose rides in the kernel arguments
+  if (nf == 1 && !T_eval && !call_switches().no_inline_pose) {
     memcpy(set->inline_pose.m, T_lin, 12 * sizeof(double));
     set->inline_pose.valid = 1;
     return GLIM_AMD_OK;
   }
-  memcpy(set->h_poses, T_lin, nf * 12 * sizeof(double));
-  if (T_eval) memcpy(set->h_poses + nf * 12, T_eval, nf * 12 * sizeof(double));
-  GA_HIP(hipMemcpyAsync(set->d_poses, set->h_poses, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
+  const int slot = set->pose_slot;
+  set->pose_slot = (slot + 1) % glim_amd_factor_set::POSE_RING;
+  if (set->pose_pending[slot]) {
+    GA_HIP(hipEventSynchronize(set->pose_events[slot]));
+    set->pose_pending[slot] = false;
+  }
+  double* h = set->h_poses + (size_t)slot * set->cap_factors * 24;
+  memcpy(h, T_lin, nf * 12 * sizeof(double));
+  if (T_eval) memcpy(h + nf * 12, T_eval, nf * 12 * sizeof(double));
+  GA_HIP(hipMemcpyAsync(set->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
+  if (async_call) {
+    if (!set->pose_events[slot]) GA_HIP(hipEventCreateWithFlags(&set->pose_events[slot], hipEventDisableTiming));
+    GA_HIP(hipEventRecord(set->pose_events[slot], set->stream));
+    set->pose_pending[slot] = true;
+  }
+  return GLIM_AMD_OK;
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#endif
+}
+
+// One synchronous evaluation (linearise or error) of the whole set: results in set->h_compact when this returns.
+// Small sets (the per-frame odometry case): the finalise kernel writes the 232-byte records straight into host-mapped pinned memory and
+// then publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of paying a stream-synchronise
+// round trip -- no device-to-host copy, and for a single factor no host-to-device copy either.  The context mutex is held only while
+// the work is enqueued, so factor sets of one context (different streams of its pool) overlap on the device when driven from
+// different host threads, like the reference's StreamTempBufferRoundRobin factors.
+int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval) {
+  const size_t nf = set->entries.size();
+  bool poll = false;
+  {
+    std::lock_guard<std::mutex> lock(set->ctx->mu);
+    GA_HIP(hipSetDevice(set->ctx->device));
+    GA_TRY(factor_set_prepare(set));
+    GA_TRY(upload_poses(set, T_lin, T_eval, false));
+    const bool mapped = set->h_compact_dev && nf <= 1024;
+    poll = mapped && set->h_flag && !call_switches().no_poll;
+    if (poll) set->poll_seq++;
+    GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? set->h_compact_dev : set->d_compact, 0, poll));
+    if (!mapped) GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  }
+  bool done = false;
+  if (poll) {
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile unsigned int* flag = set->h_flag;
+    for (unsigned long spins = 0;; spins++) {
+      if (*flag == set->poll_seq) {
+        done = true;
+        break;
+      }
+      cpu_relax();
+      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // fall back
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!done) GA_HIP(hipStreamSynchronize(set->stream));
   return GLIM_AMD_OK;
 }
 
@@ -841,6 +895,8 @@ int glim_amd_factor_set_destroy(glim_amd_factor_set* set) {
   (void)hipSetDevice(set->ctx->device);
   (void)hipStreamSynchronize(set->stream);
   factor_set_release_plan(set);
+  for (int i = 0; i < glim_amd_factor_set::POSE_RING; i++)
+    if (set->pose_events[i]) (void)hipEventDestroy(set->pose_events[i]);
   if (set->h_flag) (void)pinned_free(set->h_flag);
   delete set;
   return GLIM_AMD_OK;
@@ -933,40 +989,7 @@ int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T, gli
   const size_t nf = set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
   if (!T || !out) return GLIM_AMD_ERR_INVALID;
-  std::lock_guard<std::mutex> lock(set->ctx->mu);
-  GA_HIP(hipSetDevice(set->ctx->device));
-  GA_TRY(factor_set_prepare(set));
-  GA_TRY(upload_poses(set, T, nullptr));
-  if (set->h_compact_dev && nf <= 1024) {
-    // small sets (the per-frame odometry case): the finalise kernel writes the 232-B records straight into host-mapped pinned
-    // memory and then publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of paying a
-    // stream-synchronise round trip.  No device-to-host copy, and for a single factor no host-to-device copy either.
-    const bool poll = set->h_flag && getenv("GLIM_AMD_NO_POLL") == nullptr;
-    set->poll = poll;
-    set->poll_seq++;
-    const int rc = launch_linearize(set, set->h_compact_dev, 0);
-    set->poll = false;
-    GA_TRY(rc);
-    bool done = false;
-    if (poll) {
-      const auto t0 = std::chrono::steady_clock::now();
-      volatile unsigned int* flag = set->h_flag;
-      for (unsigned long spins = 0;; spins++) {
-        if (*flag == set->poll_seq) {
-          done = true;
-          break;
-        }
-        __builtin_ia32_pause();
-        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // fall back
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    if (!done) GA_HIP(hipStreamSynchronize(set->stream));
-  } else {
-    GA_TRY(launch_linearize(set, set->d_compact, 0));
-    GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
-    GA_HIP(hipStreamSynchronize(set->stream));
-  }
+  GA_TRY(run_sync(set, MODE_LINEARIZE, T, nullptr));
   for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(set->h_compact + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
   return GLIM_AMD_OK;
 }
@@ -991,8 +1014,9 @@ int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const d
   std::lock_guard<std::mutex> lock(set->ctx->mu);
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
-  GA_TRY(upload_poses(set, T, nullptr));
-  return launch_linearize(set, out_device, out_row_offset);
+  GA_TRY(upload_poses(set, T, nullptr, true));
+  set->ctx->async_pending.store(true);  // clouds / maps destroyed later must wait for this work (glim_amd_ctx::quiesce)
+  return enqueue(set, MODE_LINEARIZE, false, out_device, out_row_offset, false);
 }
 
 int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, double* errors, int64_t* inliers) {
@@ -1000,27 +1024,9 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
   const size_t nf = set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
   if (!T_eval || !errors) return GLIM_AMD_ERR_INVALID;
-  std::lock_guard<std::mutex> lock(set->ctx->mu);
-  GA_HIP(hipSetDevice(set->ctx->device));
-  GA_TRY(factor_set_prepare(set));
-  const FinalizeArgs fa = finalize_args(set, set->d_compact, 0, false);
-  if (T_lin) {
-    GA_TRY(upload_poses(set, T_lin, T_eval));
-    vgicp_kernel<MODE_ERROR, true, 1, 3, false, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(
-      set->d_descs, set->d_poses, set->d_poses + nf * 12, set->d_blockmap, set->d_partials, InlinePose{}, fa);
-  } else {
-    GA_TRY(upload_poses(set, T_eval, nullptr));
-    if (set->inline_pose.valid)
-      vgicp_kernel<MODE_ERROR, false, 1, 3, false, true><<<set->total_blocks, BLOCK, 0, set->stream>>>(
-        set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, set->inline_pose, fa);
-    else
-      vgicp_kernel<MODE_ERROR, false, 1, 3, false, false><<<set->total_blocks, BLOCK, 0, set->stream>>>(
-        set->d_descs, set->d_poses, set->d_poses, set->d_blockmap, set->d_partials, InlinePose{}, fa);
-  }
-  if (!fa.fused) finalize_kernel<<<(int)nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, MODE_ERROR, set->d_poses, InlinePose{});
-  GA_HIP(hipGetLastError());
-  GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
-  GA_HIP(hipStreamSynchronize(set->stream));
+  // T_lin == NULL: correspondences at the evaluation pose (one pose per factor); otherwise frozen at T_lin and evaluated at T_eval
+  if (T_lin) GA_TRY(run_sync(set, MODE_ERROR, T_lin, T_eval));
+  else GA_TRY(run_sync(set, MODE_ERROR, T_eval, nullptr));
   for (size_t f = 0; f < nf; f++) {
     errors[f] = set->h_compact[f * COMPACT + 1];
     if (inliers) inliers[f] = (int64_t)llround(set->h_compact[f * COMPACT]);
@@ -1063,24 +1069,23 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   std::lock_guard<std::mutex> lock(set->ctx->mu);
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
-  GA_TRY(upload_poses(set, T, nullptr));
+  GA_TRY(upload_poses(set, T, nullptr, false));
   hipEvent_t e0, e1;
   GA_HIP(hipEventCreate(&e0));
   GA_HIP(hipEventCreate(&e1));
   // warm-up (clocks, caches, TLBs)
-  for (int i = 0; i < 10; i++) GA_TRY(launch_linearize(set, set->d_compact, 0));
+  for (int i = 0; i < 10; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, set->d_compact, 0, false));
   GA_HIP(hipStreamSynchronize(set->stream));
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));
   const FinalizeArgs fa_prof = finalize_args(set, set->d_compact, 0, false);
-  for (int i = 0; i < iters; i++)
-    launch_vgicp_linearize(set, fa_prof);
+  for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof);
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (ms_kernel) *ms_kernel = ms / (float)iters;
   GA_HIP(hipEventRecord(e0, set->stream));
-  for (int i = 0; i < iters; i++) GA_TRY(launch_linearize(set, set->d_compact, 0));
+  for (int i = 0; i < iters; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, set->d_compact, 0, false));
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -209,7 +209,10 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int /*init_nu
 
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (!m) return GLIM_AMD_OK;
-  if (m->ctx) (void)hipSetDevice(m->ctx->device);
+  if (m->ctx) {
+    (void)hipSetDevice(m->ctx->device);
+    m->ctx->quiesce();  // asynchronous factor launches may still be reading this table
+  }
   if (m->buckets) (void)pool_free(m->buckets);
   delete m;
   return GLIM_AMD_OK;

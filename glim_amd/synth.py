@@ -8,6 +8,7 @@ the FP64 CPU oracle and the HIP kernels consume bit-identical inputs.
 This is host-side workload generation for tests and bench.py (numpy only); it is not on the hot path.
 """
 import math
+import os
 
 import numpy as np
 
@@ -126,6 +127,25 @@ def pose(x, y, z, yaw=0.0, pitch=0.0, roll=0.0):
 def scan(scene, T_world_sensor, dirs, frame_id=0, sigma=0.01, seed=SCENE_SEED, max_range=np.inf, min_range=0.0):
     """One scan in the SENSOR frame: N x 3 float32 (rays without a return inside [min_range, max_range] are dropped)."""
     T = np.asarray(T_world_sensor, dtype=np.float64)
+    cache = os.environ.get("GLIM_AMD_SCAN_CACHE")  # workload-generation cache for back-to-back A/B runs of bench.py (never on the hot path)
+    if cache:
+        import hashlib
+
+        h = hashlib.sha1()
+        for a in (T, np.ascontiguousarray(dirs), scene.boxes, scene.cylinders, np.array([scene.half_x, scene.half_y, scene.height, frame_id, sigma, seed, max_range, min_range], dtype=np.float64)):
+            h.update(np.ascontiguousarray(a).tobytes())
+        path = os.path.join(cache, h.hexdigest() + ".npy")
+        if os.path.exists(path):
+            return np.load(path)
+        pts = _scan(scene, T, dirs, frame_id, sigma, seed, max_range, min_range)
+        os.makedirs(cache, exist_ok=True)
+        np.save(path + ".tmp.npy", pts)
+        os.replace(path + ".tmp.npy", path)
+        return pts
+    return _scan(scene, T, dirs, frame_id, sigma, seed, max_range, min_range)
+
+
+def _scan(scene, T, dirs, frame_id, sigma, seed, max_range, min_range):
     dw = dirs @ T[:3, :3].T
     t = scene.raycast(T[:3, 3], dw)
     rng = np.random.default_rng(seed + int(frame_id))

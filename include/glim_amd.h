@@ -72,7 +72,8 @@ int glim_amd_device_count(void);
 
 /* Replaces gtsam_points::CUDAStream + StreamTempBufferRoundRobin(num_streams)
  * (src/glim/odometry/odometry_estimation_gpu.cpp:76-77, src/glim/mapping/sub_mapping.cpp:86-87, global_mapping.cpp:110).
- * external_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create `num_streams` streams. */
+ * external_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create `num_streams` streams.  The null stream is
+ * named explicitly: pass hipStreamLegacy ((hipStream_t)1) or hipStreamPerThread ((hipStream_t)2), never 0. */
 int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim_amd_ctx** out);
 /* GLIM_AMD_ERR_STATE (and the context stays valid) while clouds, voxel maps, factor sets or search indices created from it are alive. */
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
