@@ -128,6 +128,7 @@ SYMBOLS = {
     "glim_amd_expand_compact": (_i, [_dp, _dp, _u32, C.POINTER(Linearized6)]),
     "glim_amd_factor_set_profile": (_i, [_vp, _dp, _i, _fp, _fp]),
     "glim_amd_factor_set_profile_sync": (_i, [_vp, _dp, _i, _fp]),
+    "glim_amd_factor_set_profile_lm": (_i, [_vp, _dp, _i, _fp, _fp]),
     "glim_amd_overlap": (_i, [_vp, _i32, _pp, _dp, _vp, _dp]),
 }
 

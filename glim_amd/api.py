@@ -501,6 +501,13 @@ class NonlinearFactorSetGPU:
         check(lib().glim_amd_factor_set_profile_sync(self._h, _dp(T), int(iters), C.byref(a)), "glim_amd_factor_set_profile_sync")
         return a.value
 
+    def profile_lm(self, T_target_source, iters=20):
+        """(ms per synchronous linearize(), ms per synchronous error()) of the whole set, timed inside the library."""
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
+        a, b = C.c_float(), C.c_float()
+        check(lib().glim_amd_factor_set_profile_lm(self._h, _dp(T), int(iters), C.byref(a), C.byref(b)), "glim_amd_factor_set_profile_lm")
+        return a.value, b.value
+
     def close(self):
         if self._h:
             lib().glim_amd_factor_set_destroy(self._h)

@@ -1007,6 +1007,26 @@ int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T, 
   return GLIM_AMD_OK;
 }
 
+int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T, int iters, float* ms_linearize, float* ms_error) {
+  if (!set || !T || iters <= 0) return GLIM_AMD_ERR_INVALID;
+  const size_t nf = set->entries.size();
+  if (nf == 0) return GLIM_AMD_ERR_STATE;
+  std::vector<glim_amd_linearized6> out(nf);
+  std::vector<double> err(nf);
+  for (int i = 0; i < 3; i++) {
+    GA_TRY(glim_amd_factor_set_linearize(set, T, out.data()));
+    GA_TRY(glim_amd_factor_set_error(set, nullptr, T, err.data(), nullptr));
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_factor_set_linearize(set, T, out.data()));
+  auto t1 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_factor_set_error(set, nullptr, T, err.data(), nullptr));
+  auto t2 = std::chrono::steady_clock::now();
+  if (ms_linearize) *ms_linearize = (float)(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
+  if (ms_error) *ms_error = (float)(std::chrono::duration<double, std::milli>(t2 - t1).count() / iters);
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const double* T, double* out_device, int64_t out_row_offset) {
   if (!set || !out_device || out_row_offset < 0) return GLIM_AMD_ERR_INVALID;
   if (set->entries.empty()) return GLIM_AMD_OK;

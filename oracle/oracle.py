@@ -1,6 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/vgicp_oracle.{h,c}).
 
-TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see vgicp_oracle.h).  Only tests/, __graft_entry__.smoke()
+TEST INFRASTRUCTURE ONLY -- parity partly pinned: covariance + deskewing against the reference's own compiled code (oracle/_ref), the
+gtsam_points rows unpinned (see vgicp_oracle.h).  Only tests/, __graft_entry__.smoke()
 and bench.py's cpu_baseline leg may import this module; the product package `glim_amd` must never do so.
 """
 import ctypes as C
@@ -20,6 +21,39 @@ def build(force=False):
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+# ---- oracle/_ref: the reference's own translation units (cloud_covariance_estimation.cpp, cloud_deskewing.cpp) compiled from
+# /root/reference against stand-in headers (oracle/Makefile target `ref`).  Present in this container and -- as a prebuilt, git-ignored
+# .so that travels with the snapshot -- on the GPU box; /root/reference itself is never read at run time.
+_REF_PATH = os.path.join(_HERE, "_ref", "libglim_ref.so")
+_REFERENCE_ROOT = "/root/reference"
+_ref = None
+
+
+def build_ref(force=False):
+    """Compile oracle/_ref/libglim_ref.so when the reference tree is present; returns the path or None."""
+    if not os.path.isdir(os.path.join(_REFERENCE_ROOT, "src", "glim", "common")):
+        return _REF_PATH if os.path.exists(_REF_PATH) else None
+    subprocess.check_call(["make", "-C", _HERE, "ref"] + (["-B"] if force else ["-s"]), stdout=subprocess.DEVNULL)
+    return _REF_PATH
+
+
+def ref_lib():
+    """The compiled reference translation units, or None when neither the prebuilt .so nor /root/reference exists."""
+    global _ref
+    if _ref is None:
+        path = build_ref()
+        if path is None or not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.ref_covariance_estimate.restype = C.c_int
+        L.ref_covariance_estimate.argtypes = [dp, C.c_int, ip, C.c_int, C.c_int, dp, dp, C.c_int]
+        L.ref_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
+        L.ref_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
+        _ref = L
+    return _ref
 
 
 class Linearized6(C.Structure):
@@ -241,8 +275,9 @@ def knn(points_xyz, k, num_threads=0, method="auto", cell=0.0):
     return out
 
 
-def covariances(points_xyz, neighbors, k_neighbors=None, num_threads=0):
-    """returns (normals N x 3, covs N x 3 x 3) per cloud_covariance_estimation.cpp:43-122."""
+def covariances(points_xyz, neighbors, k_neighbors=None, num_threads=0, ref=False):
+    """returns (normals N x 3, covs N x 3 x 3) per cloud_covariance_estimation.cpp:43-122.  ref=True: run the reference's own compiled
+    CloudCovarianceEstimation::estimate (oracle/_ref) instead of the restatement."""
     p4 = points4(points_xyz)
     n = p4.shape[0]
     nb = np.ascontiguousarray(neighbors, dtype=np.int32).reshape(n, -1)
@@ -250,9 +285,10 @@ def covariances(points_xyz, neighbors, k_neighbors=None, num_threads=0):
     k_nbr = k_corr if k_neighbors is None else int(k_neighbors)
     normals = np.zeros((n, 4))
     covs = np.zeros((n, 16))
-    rc = lib().orc_covariance_estimate(_dp(p4), n, _ip(nb), k_corr, k_nbr, _dp(normals), _dp(covs), num_threads)
+    fn = ref_lib().ref_covariance_estimate if ref else lib().orc_covariance_estimate
+    rc = fn(_dp(p4), n, _ip(nb), k_corr, k_nbr, _dp(normals), _dp(covs), num_threads)
     if rc != 0:
-        raise ValueError("orc_covariance_estimate failed")
+        raise ValueError("covariance_estimate failed")
     return normals[:, :3].copy(), covs33(covs)
 
 
@@ -384,9 +420,12 @@ def gn_align(vmap, src_xyz, src_covs33, T_init, max_iters=8, lam=0.0, num_thread
     return pose44(T), deltas[:it].copy()
 
 
-def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=(0, 0, 0), angular_vel=(0, 0, 0)):
+def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=(0, 0, 0), angular_vel=(0, 0, 0), ref=False):
     """CloudDeskewing::deskew (cloud_deskewing.cpp): IMU-pose form when imu_times/imu_poses are given, else constant velocity.
-    Returns N x 3 float64."""
+    Returns N x 3 float64.  ref=True: the reference's own compiled CloudDeskewing (oracle/_ref)."""
+    L = ref_lib() if ref else lib()
+    f_imu = L.ref_deskew_imu if ref else L.orc_deskew_imu
+    f_cv = L.ref_deskew_constvel if ref else L.orc_deskew_constvel
     p4 = points4(points_xyz)
     n = p4.shape[0]
     t = _f64(times, (n,))
@@ -395,10 +434,10 @@ def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp
     if imu_times is not None and len(imu_times) > 0:
         it = _f64(imu_times, (-1,))
         ip = np.ascontiguousarray(np.stack([pose12(P) for P in imu_poses]))
-        lib().orc_deskew_imu(_dp(Til), _dp(it), _dp(ip), len(it), float(stamp), _dp(t), _dp(p4), n, _dp(out))
+        f_imu(_dp(Til), _dp(it), _dp(ip), len(it), float(stamp), _dp(t), _dp(p4), n, _dp(out))
     else:
         lv, av = _f64(linear_vel, (3,)), _f64(angular_vel, (3,))
-        lib().orc_deskew_constvel(_dp(Til), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _dp(out))
+        f_cv(_dp(Til), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _dp(out))
     return out[:, :3].copy()
 
 

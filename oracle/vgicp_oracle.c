@@ -1001,6 +1001,47 @@ static void apply_pose(const double* T, const double* p4, double* out4) {
   out4[3] = p4[3];
 }
 
+/* gtsam::Pose3::Expmap as GTSAM 4.2 evaluates it (cloud_deskewing.cpp:43 calls it): R = so3::ExpmapFunctor(omega).expmap() = I + sin(theta) K +
+ * (1 - cos(theta)) K^2 with K = hat(omega) / theta and 1 - cos(theta) = 2 sin^2(theta / 2) (first order I + hat(omega) when theta^2 <= eps);
+ * t = (omega x v - R (omega x v) + omega (omega . v)) / theta^2, or v when theta^2 <= eps.  Same operation order as the stand-in
+ * oracle/ref_standin/gtsam/geometry/Pose3.h, so that orc_deskew_constvel == the compiled reference (oracle/_ref) bit for bit. */
+static void pose3_expmap_gtsam(const double* xi, double* T) {
+  const double eps = 2.220446049250313e-16;
+  const double w[3] = {xi[0], xi[1], xi[2]}, v[3] = {xi[3], xi[4], xi[5]};
+  const double theta2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  double W[9], R[9];
+  hat3(w, W);
+  if (theta2 <= eps) {
+    for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
+  } else {
+    const double theta = sqrt(theta2);
+    const double sin_theta = sin(theta);
+    const double s2 = sin(theta / 2.0);
+    const double one_minus_cos = 2.0 * s2 * s2;
+    double K[9], KK[9];
+    for (int i = 0; i < 9; i++) K[i] = W[i] / theta;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = (K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c]) + K[3 * r + 2] * K[6 + c];
+    for (int i = 0; i < 9; i++) R[i] = (((i % 4 == 0) ? 1.0 : 0.0) + K[i] * sin_theta) + KK[i] * one_minus_cos;
+  }
+  double t[3];
+  if (theta2 > eps) {
+    const double wv = (w[0] * v[0] + w[1] * v[1]) + w[2] * v[2];
+    double c[3], Rc[3];
+    cross3(w, v, c);
+    for (int r = 0; r < 3; r++) Rc[r] = (R[3 * r] * c[0] + R[3 * r + 1] * c[1]) + R[3 * r + 2] * c[2];
+    for (int r = 0; r < 3; r++) t[r] = ((c[r] - Rc[r]) + w[r] * wv) / theta2;
+  } else {
+    t[0] = v[0]; t[1] = v[1]; t[2] = v[2];
+  }
+  for (int r = 0; r < 3; r++) {
+    T[4 * r + 0] = R[3 * r + 0];
+    T[4 * r + 1] = R[3 * r + 1];
+    T[4 * r + 2] = R[3 * r + 2];
+    T[4 * r + 3] = t[r];
+  }
+}
+
 int orc_deskew_constvel(const double* T_imu_lidar, const double* linear_vel, const double* angular_vel, const double* times,
                         const double* points4, int n, double* out4) {
   if (n <= 0) return 0;
@@ -1014,7 +1055,7 @@ int orc_deskew_constvel(const double* T_imu_lidar, const double* linear_vel, con
     const double dt = table[i];
     const double xi[6] = {dt * angular_vel[0], dt * angular_vel[1], dt * angular_vel[2], dt * linear_vel[0], dt * linear_vel[1], dt * linear_vel[2]};
     double T_imu1_imu0[12], inv[12], tmp[12];
-    orc_se3_exp(xi, T_imu1_imu0);                 /* :43 */
+    pose3_expmap_gtsam(xi, T_imu1_imu0);          /* :43 */
     orc_pose_inverse(T_imu1_imu0, inv);
     orc_pose_compose(T_lidar_imu, inv, tmp);      /* :44  T_lidar_imu * T_imu1_imu0^-1 * T_imu_lidar */
     orc_pose_compose(tmp, T_imu_lidar, TT + 12 * (size_t)i);

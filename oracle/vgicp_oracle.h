@@ -5,13 +5,15 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it -- as the checker /
  * the timed CPU baseline, never as the thing shipped.
  *
- * PARITY UNPINNED: the reference (koide3/glim v1.2.2) ships no tests, golden vectors or fixtures for
- * this path, and the arithmetic of rows a4/a6 lives in the un-vendored dependency koide3/gtsam_points
- * (required >= 1.2.2 by /root/reference/CMakeLists.txt:28), which is absent from this container.  The
- * in-tree pieces (kNN contract, covariance estimation) are restated line-by-line from the files cited
- * at each function; the gtsam_points pieces are restated from its published algorithm (VGICP, Koide et
- * al. ICRA 2021) and from GLIM's call sites, and are pinned only by analytic known-answer tests
- * (tests/test_oracle_*.py).  See DESIGN.md "Oracle".
+ * PARITY: PARTLY PINNED.  The reference (koide3/glim v1.2.2) ships no tests, golden vectors or fixtures for this path.
+ *   - Pinned by the reference's own code: orc_covariance_estimate (row a2) and orc_deskew_* (8f rank 2) are checked BIT FOR BIT
+ *     against oracle/_ref/libglim_ref.so = /root/reference/src/glim/common/cloud_covariance_estimation.cpp and cloud_deskewing.cpp
+ *     compiled unmodified (oracle/Makefile target `ref`; stand-in Eigen/GTSAM headers in oracle/ref_standin/) and against the vectors
+ *     that library generated (tests/golden/ref_small.npz, tests/test_ref.py).
+ *   - UNPINNED: the arithmetic of rows a4/a6/a8 (voxel map, VGICP factor, overlap) and the samplers / merge_frames / GICP of 8f live in the
+ *     un-vendored dependency koide3/gtsam_points (required >= 1.2.2 by /root/reference/CMakeLists.txt:28), absent from this
+ *     container: restated from its published algorithm (VGICP, Koide et al. ICRA 2021) and from GLIM's call sites, pinned only by
+ *     analytic known-answer tests (tests/test_oracle.py).  See DESIGN.md "Oracle".
  *
  * Layout conventions follow the reference: points are homogeneous Vector4d (x,y,z,1), covariances are
  * Matrix4d (column-major 4x4, zero last row/col)  -- include/glim/preprocess/preprocessed_frame.hpp:31,

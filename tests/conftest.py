@@ -13,6 +13,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_available():
+    try:
+        from glim_amd import _lib
+
+        return os.path.exists(_lib.LIB_PATH) and _lib.lib().glim_amd_device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a machine without a HIP device skips the gpu-marked tests instead of failing them.  An explicit
+    `-m gpu` run is left alone: there a missing device or library must FAIL loudly (the driver's GPU tier relies on that)."""
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (gpu-marked test)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import oracle
