@@ -130,6 +130,18 @@ SYMBOLS = {
     "glim_amd_factor_set_profile_sync": (_i, [_vp, _dp, _i, _fp]),
     "glim_amd_factor_set_profile_lm": (_i, [_vp, _dp, _i, _fp, _fp]),
     "glim_amd_overlap": (_i, [_vp, _i32, _pp, _dp, _vp, _dp]),
+    "glim_amd_multi_create": (_i, [_ip, _i32, _pp]),
+    "glim_amd_multi_destroy": (_i, [_vp]),
+    "glim_amd_multi_info": (_i, [_vp, _ip, _ip, _lp]),
+    "glim_amd_multi_add_cloud": (_i, [_vp, _i64, _dp, _dp, _dp, _ip]),
+    "glim_amd_multi_add_cloud_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _ip]),
+    "glim_amd_multi_cloud_estimate_covariances": (_i, [_vp, _i32, _i]),
+    "glim_amd_multi_add_voxelmap": (_i, [_vp, _i32, _d, _ip]),
+    "glim_amd_multi_set_factors": (_i, [_vp, _i64, _ip, _ip, C.POINTER(C.c_uint32)]),
+    "glim_amd_multi_shard": (_i, [_vp, _lp]),
+    "glim_amd_multi_linearize": (_i, [_vp, _dp, C.POINTER(Linearized6), _dp]),
+    "glim_amd_multi_profile": (_i, [_vp, _dp, _i, _fp]),
+    "glim_amd_shard_bounds": (_i, [_dp, _i64, _i32, _lp]),
 }
 
 _lib = None

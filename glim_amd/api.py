@@ -520,6 +520,86 @@ class NonlinearFactorSetGPU:
             pass
 
 
+class MultiDeviceCost:
+    """Single-process, multi-device evaluation of a multi-scan VGICP cost (glim_amd_multi_*, include/glim_amd.h): clouds and voxel maps
+    replicated on every device, the factor list sharded, one RCCL all-gather of the compact records per evaluation."""
+
+    def __init__(self, devices=(0,)):
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().glim_amd_multi_create(_ip(dev), len(dev), C.byref(h)), "glim_amd_multi_create")
+        self._h = h
+        self.factors = []
+
+    def info(self):
+        nd, rc, nf = C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().glim_amd_multi_info(self._h, C.byref(nd), C.byref(rc), C.byref(nf)), "glim_amd_multi_info")
+        return {"num_devices": nd.value, "uses_rccl": bool(rc.value), "num_factors": nf.value}
+
+    def add_cloud(self, points, covs=None, normals=None):
+        points = np.asarray(points)
+        n = points.shape[0]
+        cid = C.c_int32()
+        xyz = np.ascontiguousarray(points[:, :3], dtype=np.float32)
+        c = None if covs is None else np.ascontiguousarray(np.asarray(covs, dtype=np.float32)[:, :3, :3]).reshape(n, 9)
+        nr = None if normals is None else np.ascontiguousarray(np.asarray(normals, dtype=np.float32)[:, :3])
+        check(lib().glim_amd_multi_add_cloud_f32(self._h, n, _fp(xyz), _fp(c), _fp(nr), C.byref(cid)), "glim_amd_multi_add_cloud_f32")
+        return cid.value
+
+    def estimate_covariances(self, cloud_id, k=10):
+        check(lib().glim_amd_multi_cloud_estimate_covariances(self._h, int(cloud_id), int(k)), "glim_amd_multi_cloud_estimate_covariances")
+
+    def add_voxelmap(self, cloud_id, resolution):
+        mid = C.c_int32()
+        check(lib().glim_amd_multi_add_voxelmap(self._h, int(cloud_id), float(resolution), C.byref(mid)), "glim_amd_multi_add_voxelmap")
+        return mid.value
+
+    def set_factors(self, target_map_ids, source_cloud_ids, flags=None):
+        t = np.ascontiguousarray(target_map_ids, dtype=np.int32)
+        s = np.ascontiguousarray(source_cloud_ids, dtype=np.int32)
+        f = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint32)
+        check(lib().glim_amd_multi_set_factors(self._h, len(t), _ip(t), _ip(s), None if f is None else f.ctypes.data_as(C.POINTER(C.c_uint32))),
+              "glim_amd_multi_set_factors")
+        self._n = len(t)
+
+    def shard(self):
+        b = np.zeros(self.info()["num_devices"] + 1, dtype=np.int64)
+        check(lib().glim_amd_multi_shard(self._h, b.ctypes.data_as(C.POINTER(C.c_int64))), "glim_amd_multi_shard")
+        return b
+
+    def linearize(self, T_target_source):
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(self._n, 12))
+        out = (Linearized6 * self._n)()
+        tot = C.c_double()
+        check(lib().glim_amd_multi_linearize(self._h, _dp(T), out, C.byref(tot)), "glim_amd_multi_linearize")
+        return [_lin_to_dict(L) for L in out], tot.value
+
+    def profile(self, T_target_source, iters=10):
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(self._n, 12))
+        ms = C.c_float()
+        check(lib().glim_amd_multi_profile(self._h, _dp(T), int(iters), C.byref(ms)), "glim_amd_multi_profile")
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().glim_amd_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_bounds(costs, world):
+    """glim_amd_shard_bounds: the C implementation of the sharding rule (host only; works without a device)."""
+    c = np.ascontiguousarray(costs, dtype=np.float64)
+    b = np.zeros(int(world) + 1, dtype=np.int64)
+    check(lib().glim_amd_shard_bounds(_dp(c) if len(c) else None, len(c), int(world), b.ctypes.data_as(C.POINTER(C.c_int64))), "glim_amd_shard_bounds")
+    return [int(x) for x in b]
+
+
 def preprocess_params(**kw):
     """glim_amd_preprocess_params with the shipped defaults (config/config_preprocess.json), fields overridden by keyword."""
     p = PreprocessParams()

@@ -249,6 +249,38 @@ int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_t
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
 int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
 
+/* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
+ *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
+ * One process, N devices: a context + a host worker thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per
+ * device.  Clouds and voxel maps are replicated on every device, the factor list is sharded into contiguous cost-balanced chunks, every
+ * device linearises its chunk and ONE ncclAllGather of the 29-double compact records over xGMI completes the result; records are
+ * expanded on the host in the original factor order.  All calls are synchronous and must come from one host thread at a time. */
+typedef struct glim_amd_multi glim_amd_multi;
+/* devices: distinct HIP device ordinals.  A multi-device handle without a working RCCL is refused (GLIM_AMD_ERR_HIP) rather than
+ * silently gathering over PCIe; a single device works either way (GLIM_AMD_MULTI_NO_RCCL=1 skips the collective there). */
+int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out);
+int glim_amd_multi_destroy(glim_amd_multi* multi);
+int glim_amd_multi_info(const glim_amd_multi* multi, int32_t* num_devices, int32_t* uses_rccl, int64_t* num_factors);
+/* replicated PointCloudGPU::clone (same arguments as glim_amd_cloud_create / _f32); cloud_id indexes the replicas */
+int glim_amd_multi_add_cloud(glim_amd_multi* multi, int64_t n, const double* points4, const double* covs16, const double* normals4, int32_t* cloud_id);
+int glim_amd_multi_add_cloud_f32(glim_amd_multi* multi, int64_t n, const float* xyz, const float* cov33, const float* normals3, int32_t* cloud_id);
+/* kNN (k) + CloudCovarianceEstimation on every replica (deterministic kernels: the replicas stay bit-identical) */
+int glim_amd_multi_cloud_estimate_covariances(glim_amd_multi* multi, int32_t cloud_id, int k);
+/* replicated GaussianVoxelMapGPU(resolution).insert(cloud) */
+int glim_amd_multi_add_voxelmap(glim_amd_multi* multi, int32_t cloud_id, double resolution, int32_t* map_id);
+/* the factor list: factor f = IntegratedVGICPFactorGPU(maps[target_map_ids[f]], clouds[source_cloud_ids[f]]), flags[f] (NULL = unary);
+ * replaces the previous list and shards it over the devices (cost of a factor = its source points). */
+int glim_amd_multi_set_factors(glim_amd_multi* multi, int64_t num_factors, const int32_t* target_map_ids, const int32_t* source_cloud_ids,
+                               const uint32_t* flags);
+/* device d owns factors [bounds[d], bounds[d + 1]); bounds has num_devices + 1 entries */
+int glim_amd_multi_shard(const glim_amd_multi* multi, int64_t* bounds);
+/* H / b / error of every factor at T_target_source (n x 12); out (n records) and total_error may be NULL */
+int glim_amd_multi_linearize(glim_amd_multi* multi, const double* T_target_source, glim_amd_linearized6* out, double* total_error);
+/* wall-clock milliseconds per whole-cost evaluation (all devices + collective + host expansion skipped), over `iters` evaluations */
+int glim_amd_multi_profile(glim_amd_multi* multi, const double* T_target_source, int iters, float* ms_per_evaluation);
+/* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
+int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
+
 /* ---- overlap: overlap_gpu / overlap_auto (odometry_estimation_gpu.cpp:231,248,265,279,326; sub_mapping.cpp:252-253;
  *      global_mapping.cpp:322,448).  Fraction of source points that hit an occupied voxel of ANY target under its delta. */
 int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T_target_source,

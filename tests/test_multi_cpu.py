@@ -29,6 +29,23 @@ def test_shard_bounds_are_contiguous_and_balanced():
     assert multi.shard_bounds([1] * 8, 8) == list(range(9))
 
 
+def test_c_abi_shard_bounds_equals_python_rule():
+    """The single-process multi-device entry (glim_amd_multi_set_factors) shards with glim_amd_shard_bounds; the one-process-per-GPU harness
+    (glim_amd/multi.py) with shard_bounds: same rule, same boundaries."""
+    from glim_amd import _lib, api, multi
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    rng = np.random.default_rng(3)
+    for n, w in [(0, 1), (0, 4), (1, 1), (1, 8), (3, 8), (5, 2), (64, 8), (1000, 7), (32640, 8), (32640, 3)]:
+        costs = rng.integers(1, 70000, size=n)
+        assert api.shard_bounds(costs, w) == list(multi.shard_bounds(costs, w)), (n, w)
+    assert api.shard_bounds([5, 5, 5, 5], 2) == [0, 2, 4]
+    assert api.shard_bounds([100, 1, 1, 1], 2) == [0, 1, 4]
+    with pytest.raises(api.GlimAmdError):
+        api.shard_bounds([1.0], 0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
