@@ -59,11 +59,14 @@ __device__ __forceinline__ unsigned long long voxel_key(double qx, double qy, do
 // (hash * num_buckets) >> 32, so any table size works and no power-of-two rounding wastes memory).  The three 21-bit axis
 // fields are combined with full-rate 24-bit multiply-adds, then one xor-shift-multiply round.  Any hash is valid because
 // lookups compare the full key.
-// GLIM_AMD_PAIR_SHIFT = 1 would make the two x-adjacent voxels 2m and 2m+1 share a two-way bucket (one 128-byte line for both).
-// Measured SLOWER on MI355X (87-90 us vs 80 us per 64 factors): more keys then sit in way 1, whose record lies in the second
-// 64-byte sector of the line, and HBM is fetched per 64-byte sector -- so the default keeps voxels unpaired (way 0 first).
+// GLIM_AMD_PAIR_SHIFT = 1: the two x-adjacent voxels 2m and 2m+1 hash to the same bucket and share its two ways, i.e. one 128-byte
+// line.  The L2 fetches whole 128-byte lines from HBM (TCC_EA0_RDREQ_128B = all read requests of the factor kernel, none 32/64-byte), so
+// a lookup costs a line per touched BUCKET; with the source stream in Hilbert order the two voxels of a pair are looked up close in
+// time and the pair costs one line instead of two.  Measured on MI355X (128 x 131 072-pt factors, 0.5 m maps): 143 -> 131 us per
+// launch, provided the table is large enough (6 buckets per voxel) that a bucket rarely receives two different pairs -- at 3 buckets
+// per voxel the extra spills to the next bucket eat the gain (145 us), which is what the first trial of this idea measured.
 #ifndef GLIM_AMD_PAIR_SHIFT
-#define GLIM_AMD_PAIR_SHIFT 0
+#define GLIM_AMD_PAIR_SHIFT 1
 #endif
 __device__ __forceinline__ unsigned int hash_fields(unsigned int ux, unsigned int uy, unsigned int uz) {
   unsigned int h = __umul24((ux & 0x1fffffu) >> GLIM_AMD_PAIR_SHIFT, 0x9E3779u) + __umul24(uy & 0x1fffffu, 0x85EBCBu) + __umul24(uz & 0x1fffffu, 0xC2B2AFu);

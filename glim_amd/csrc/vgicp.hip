@@ -228,7 +228,7 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 // and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
 // the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
 template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
-__global__ __launch_bounds__(BLOCK, 3) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+__global__ __launch_bounds__(BLOCK, 5) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
                                                           float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa, int block_offset) {
   constexpr int U = 1;  // points per loop trip (2 and 4 were measured slower: more registers, fewer resident waves)
@@ -407,8 +407,13 @@ __global__ __launch_bounds__(BLOCK, 3) void vgicp_kernel(const FactorDesc* __res
         continue;
 #endif
         // S = C_B + R C_A R^T   (TARGET frame, symmetric).  Non-hit lanes get C_B = I so the algebra stays finite.
+#if GLIM_AMD_ABLATE == 8  // no selects on the voxel covariance: a lane without a match reads some finite record (another voxel's or zeros)
+        const float S00 = r0.w + t00, S01 = r1.x + t01, S02 = r1.y + t02;
+        const float S11 = r1.z + t11, S12 = r1.w + t12, S22 = r2.x + t22;
+#else
         const float S00 = (hit ? r0.w : 1.f) + t00, S01 = (hit ? r1.x : 0.f) + t01, S02 = (hit ? r1.y : 0.f) + t02;
         const float S11 = (hit ? r1.z : 1.f) + t11, S12 = (hit ? r1.w : 0.f) + t12, S22 = (hit ? r2.x : 1.f) + t22;
+#endif
 
         // M = S^-1 by cofactors (symmetric, called A below); idet = 0 on non-hit lanes zeroes every contribution below
         const float k00 = S11 * S22 - S12 * S12;

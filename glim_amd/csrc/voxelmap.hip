@@ -248,8 +248,9 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
 
   const int num_voxels = h_stats[0];
-  // keys per bucket = 1 / bucket_factor (default 1/3: a key misses its home bucket with probability ~0.5 %)
-  unsigned long long bucket_factor = 3;
+  // buckets per voxel (default 6: x-adjacent voxel pairs share a bucket -- device_math.hpp GLIM_AMD_PAIR_SHIFT -- so about 0.1 pairs per
+  // bucket, and a pair finds its home bucket taken by another pair about 1 % of the time)
+  unsigned long long bucket_factor = 6;
   if (const char* env = getenv("GLIM_AMD_BUCKET_FACTOR")) bucket_factor = (unsigned long long)std::max(1, atoi(env));
   const unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
   if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;  // 32-bit byte offsets into the bucket table (4 GiB, ~11 M voxels)
