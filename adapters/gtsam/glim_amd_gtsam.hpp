@@ -121,6 +121,7 @@ public:
       lin_delta_ = delta;
       lin_valid_ = true;
       lin_values_ = to_values(values);
+      err_valid_ = false;  // a cached error was evaluated with the correspondences of the PREVIOUS linearisation point
     }
     return make_hessian_factor(keys(), impl_->is_binary(), impl_->linearized());
   }
@@ -145,6 +146,7 @@ public:
     lin_values_ = to_values(values);
     lin_delta_ = impl_->calc_delta(lin_values_);
     lin_valid_ = true;
+    err_valid_ = false;  // see linearize()
   }
   void store_error(const gtsam::Values& values, double e) const {
     err_delta_ = impl_->calc_delta(to_values(values));

@@ -1,0 +1,83 @@
+// gtsam_points/types/gaussian_voxelmap_gpu.hpp, MI355X edition: GaussianVoxelMapGPU(resolution, init_num_buckets, max_bucket_scan_count,
+// target_points_drop_rate, stream) + insert(frame) (odometry_estimation_gpu.cpp:103-104; sub_mapping.cpp:398-399; global_mapping.cpp:265-266,
+// 747-748), VoxelMapInfo (viewer/standard_viewer_mem.cpp:76-77) and overlap_gpu / overlap_auto (odometry_estimation_gpu.cpp:231,248,265,279,326;
+// sub_mapping.cpp:252-253; global_mapping.cpp:322,448).
+#pragma once
+
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <gtsam_points/types/gaussian_voxelmap.hpp>
+#include <gtsam_points/types/point_cloud_gpu.hpp>
+
+struct CUstream_st;
+
+namespace gtsam_points {
+
+struct VoxelMapInfo {
+  int num_voxels;
+  int num_buckets;
+  int max_bucket_scan_count;
+  float voxel_resolution;
+};
+
+class GaussianVoxelMapGPU : public GaussianVoxelMap {
+public:
+  using Ptr = std::shared_ptr<GaussianVoxelMapGPU>;
+  using ConstPtr = std::shared_ptr<const GaussianVoxelMapGPU>;
+
+  // init_num_buckets / max_bucket_scan_count / target_points_drop_rate are accepted and ignored: the table is sized from the cloud and no
+  // point is ever dropped (include/glim_amd.h)
+  GaussianVoxelMapGPU(float resolution, int init_num_buckets = 8192 * 2, int max_bucket_scan_count = 10, double target_points_drop_rate = 1e-3,
+                      CUstream_st* /*stream*/ = nullptr)
+  : impl_(std::make_shared<glim_amd::GaussianVoxelMapGPU>(resolution, init_num_buckets, max_bucket_scan_count, target_points_drop_rate)) {
+    voxelmap_info.num_voxels = 0;
+    voxelmap_info.num_buckets = 0;
+    voxelmap_info.max_bucket_scan_count = max_bucket_scan_count;
+    voxelmap_info.voxel_resolution = resolution;
+  }
+  ~GaussianVoxelMapGPU() override {}
+
+  double voxel_resolution() const override { return impl_->voxel_resolution(); }
+  void insert(const PointCloud& frame) override {
+    const auto* gpu = dynamic_cast<const PointCloudGPU*>(&frame);
+    if (gpu) impl_->insert(*gpu->device());
+    else impl_->insert(*glim_amd::clone(frame));
+    const auto info = impl_->voxelmap_info();
+    voxelmap_info.num_voxels = info.num_voxels;
+    voxelmap_info.num_buckets = info.num_buckets;
+  }
+  void save_compact(const std::string& /*path*/) const { throw std::runtime_error("GaussianVoxelMapGPU::save_compact: not supported (upstream neither)"); }
+  size_t memory_usage_gpu() const { return impl_->voxelmap_info().bytes; }
+  const glim_amd::GaussianVoxelMapGPU::ConstPtr device() const { return impl_; }
+
+  VoxelMapInfo voxelmap_info;  // standard_viewer_mem.cpp:77 reads num_voxels / num_buckets
+
+private:
+  std::shared_ptr<glim_amd::GaussianVoxelMapGPU> impl_;
+};
+
+inline glim_amd::GaussianVoxelMapGPU::ConstPtr device_map(const GaussianVoxelMap::ConstPtr& voxelmap) {
+  auto gpu = std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(voxelmap);
+  if (!gpu) throw std::runtime_error("a GPU factor / overlap_gpu needs a GaussianVoxelMapGPU target (upstream aborts here too)");
+  return gpu->device();
+}
+
+inline double overlap_gpu(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta, CUstream_st* /*stream*/ = nullptr) {
+  return glim_amd::overlap_gpu(device_map(target), device_cloud(source), delta);
+}
+inline double overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets, const PointCloud::ConstPtr& source, const std::vector<Eigen::Isometry3d>& deltas,
+                          CUstream_st* /*stream*/ = nullptr) {
+  std::vector<glim_amd::GaussianVoxelMapGPU::ConstPtr> t;
+  for (const auto& m : targets) t.push_back(device_map(m));
+  return glim_amd::overlap_gpu(t, device_cloud(source), deltas);
+}
+// overlap_auto dispatches on the map type upstream; GLIM's GPU configurations only ever pass GPU maps to it (global_mapping.cpp:448)
+inline double overlap_auto(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta) {
+  return overlap_gpu(target, source, delta);
+}
+
+}  // namespace gtsam_points

@@ -1,0 +1,60 @@
+"""The outer plugin ABI: GLIM's own GPU odometry module source compiled UNMODIFIED against the drop-in include tree
+adapters/gtsam_points_hip, and that tree driven on the GPU the way the module drives gtsam_points.
+
+  * compile test (only where /root/reference exists): /root/reference/src/glim/odometry/odometry_estimation_gpu.cpp + adapters/glim/
+    odometry_estimation_hip_create.cpp -> object files that reference this library's symbols and export create_odometry_estimation_module.
+    Third-party headers are stand-ins (tests/cpp/glim_standin: Eigen / GTSAM / spdlog / OpenCV / the CPU half of gtsam_points are not
+    installed here); GLIM's headers are the real ones.  Linking needs libglim + GTSAM and is out of reach in this image.
+  * run test (GPU): tests/cpp/test_shim.cpp -- PointCloudGPU::clone, GaussianVoxelMapGPU(res, 8192 * 2, 10, 1e-3, *stream), the six-argument
+    IntegratedVGICPFactorGPU constructors, NonlinearFactorSetGPU, overlap_gpu -- against the plain C ABI on the same data.
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+INCLUDES = ["-I" + os.path.join(ROOT, "adapters", "gtsam_points_hip"), "-I" + os.path.join(ROOT, "adapters", "gtsam"), "-I" + os.path.join(ROOT, "include"),
+            "-I" + os.path.join(ROOT, "tests", "cpp", "glim_standin")]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "glim", "odometry")), reason="the reference tree is not present on this machine")
+def test_reference_odometry_module_source_compiles_unmodified_against_the_hip_headers(tmp_path):
+    src = os.path.join(REF, "src", "glim", "odometry", "odometry_estimation_gpu.cpp")
+    obj = str(tmp_path / "odometry_estimation_gpu.o")
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c"] + INCLUDES + ["-I" + os.path.join(REF, "include"), src, "-o", obj])
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
+    # the module's GPU call sites resolved to this library: six-argument factor constructors, overlap_gpu, the C ABI underneath
+    assert "gtsam_points::IntegratedVGICPFactorGPU::IntegratedVGICPFactorGPU(unsigned long, unsigned long, std::shared_ptr<gtsam_points::GaussianVoxelMap const> const&" in syms
+    assert "gtsam_points::IntegratedVGICPFactorGPU::IntegratedVGICPFactorGPU(gtsam::Pose3 const&" in syms
+    assert "U glim_amd_factor_set_linearize" in syms and "U glim_amd_overlap" in syms and "U glim_amd_voxelmap_insert" in syms and "U glim_amd_cloud_create" in syms
+    assert "glim::OdometryEstimationGPU::create_factors" in syms and "glim::OdometryEstimationGPU::update_keyframes_overlap" in syms
+    create = str(tmp_path / "create.o")
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c"] + INCLUDES + ["-I" + os.path.join(REF, "include"),
+                                                                                os.path.join(ROOT, "adapters", "glim", "odometry_estimation_hip_create.cpp"), "-o", create])
+    assert " T create_odometry_estimation_module" in subprocess.run(["nm", create], capture_output=True, text=True, check=True).stdout
+
+
+def _build_shim_test(tmp_path):
+    from glim_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    exe = str(tmp_path / "test_shim")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w"] + INCLUDES + [os.path.join(ROOT, "tests", "cpp", "test_shim.cpp"), "-o", exe,
+                                                                           "-L" + os.path.join(ROOT, "glim_amd"), "-lglim_amd", "-Wl,-rpath," + os.path.join(ROOT, "glim_amd"),
+                                                                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_shim_tree_compiles_and_links(tmp_path):
+    _build_shim_test(tmp_path)
+
+
+@pytest.mark.gpu
+def test_shim_tree_runs_like_the_reference_call_sites(tmp_path):
+    exe = _build_shim_test(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "test_shim OK" in out.stdout
