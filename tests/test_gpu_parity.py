@@ -461,7 +461,10 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc, monkeypatch):
     pts = np.vstack([dense, sparse, line, dense[:500]]).astype(np.float32)  # the last 500 duplicate earlier points exactly
     ref = orc.knn(pts.astype(np.float64), 10)
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
-    got_chunk = g.find_neighbors(10)
+    got_chunk = g.find_neighbors(10)  # 32 437 points: the pair-lane chunk kernel
+    monkeypatch.setenv("GLIM_AMD_KNN_WAVE64", "1")
+    np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    monkeypatch.delenv("GLIM_AMD_KNN_WAVE64")
     monkeypatch.setenv("GLIM_AMD_KNN_GRID", "1")
     got_grid = g.find_neighbors(10)
     monkeypatch.delenv("GLIM_AMD_KNN_GRID")
@@ -493,7 +496,12 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, monkeypatch, name)
     ref = orc.knn(pts.astype(np.float64), 10, method="brute")
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
     monkeypatch.setenv("GLIM_AMD_KNN_CHUNKS", "1")
-    np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    for variant in ("GLIM_AMD_KNN_WAVE64", "GLIM_AMD_KNN_PAIR"):  # 64 queries per wavefront / 32 queries with two lanes each
+        monkeypatch.setenv(variant, "1")
+        np.testing.assert_array_equal(g.find_neighbors(10), ref)
+        for k in (3, 16, 32):
+            np.testing.assert_array_equal(g.find_neighbors(k), orc.knn(pts.astype(np.float64), k, method="brute"))
+        monkeypatch.delenv(variant)
     monkeypatch.delenv("GLIM_AMD_KNN_CHUNKS")
     monkeypatch.setenv("GLIM_AMD_KNN_GRID", "1")
     np.testing.assert_array_equal(g.find_neighbors(10), ref)
