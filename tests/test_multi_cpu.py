@@ -84,6 +84,21 @@ def _worker(rank, world, port, q):
         rows = [multi.compact_from_linearized(orc.vgicp_linearize(maps[pairs[f][0]], scans[pairs[f][1]], covs[pairs[f][1]], deltas[f]))
                 for f in ev.owned()]
         blocks = ev.evaluate_host(np.array(rows).reshape(-1, multi.COMPACT)).numpy()
+        # the same exchange on rows the HIP kernels really produced (tests/golden/hip_rows.npz, captured on an MI355X by
+        # tests/golden/make_golden_hip_rows.py for this very problem): shard, all-reduce, expand; the expansion must reproduce the
+        # records the GPU run expanded itself, bit for bit, and agree with the oracle within the factor tolerance
+        hip = dict(np.load(os.path.join(ROOT, "tests", "golden", "hip_rows.npz")))
+        hip_blocks = ev.evaluate_host(hip["rows"][ev.lo:ev.hi]).numpy()
+        assert np.array_equal(hip_blocks, hip["rows"])
+        hip_maps = [orc.VoxelMap(1.0).insert(p, c.astype(np.float64)) for p, c in zip(scans, hip["covs"])]
+        for f, (i, j) in enumerate(pairs):
+            got = api.expand_compact(hip_blocks[f], hip["deltas"][f], api.FACTOR_BINARY)
+            assert np.array_equal(got["H_tt"], hip["H_tt"][f]) and np.array_equal(got["H_ts"], hip["H_ts"][f]) and np.array_equal(got["b_t"], hip["b_t"][f])
+            D = np.eye(4)
+            D[:3, :4] = hip["deltas"][f].reshape(3, 4)
+            ref = orc.vgicp_linearize(hip_maps[i], scans[j], hip["covs"][j].astype(np.float64), D)
+            assert got["num_inliers"] == ref["num_inliers"]
+            assert np.abs(got["H_tt"] - ref["H_tt"]).max() <= 2e-4 * np.abs(ref["H_tt"]).max()
         # every rank must now hold every factor; compare with the unsharded evaluation
         worst = 0.0
         for f, (i, j) in enumerate(pairs):

@@ -25,8 +25,8 @@ def by_kernel_grid(path, value_col, scale=1.0):
     return acc
 
 
-summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   "
-                      "(tools/profile.sh; PMC passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE)"}
+summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --inner 16 --no-cpu-baseline --no-m2   "
+                      "(tools/profile.sh; PMC passes, each its own run: --pmc FETCH_SIZE; --pmc WRITE_SIZE; --pmc TCC_EA0_RDREQ_{32,64,128}B_sum)"}
 trace = one("stats/**/*kernel_trace.csv")
 rows = []
 if trace:
@@ -56,30 +56,43 @@ bench = os.path.join(src, "bench_stats.json")
 if os.path.exists(bench) and os.path.getsize(bench):
     shutil.copy(bench, os.path.join(dst, "bench_under_rocprof.json"))
 
-# traffic of the dominant kernel (largest total time among vgicp_kernel instantiations)
+# traffic of the dominant kernel (largest total time among vgicp_kernel instantiations), per launch.
+# MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B although the requests of a wide stream are 128 B -- double it.  The
+# request-size counters give the same correction directly: bytes = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B (separate PMC pass); both are
+# recorded, the request counters are the figure used (they need no assumption about which part of the reads is "wide").
 tj = os.path.join(dst, "traffic.json")
-old = json.load(open(tj)) if os.path.exists(tj) else {}
 dom = next((r for r in rows if "vgicp_kernel" in r["kernel"]), None)
-if dom and summary["pmc_fetch"]:
-    f = next((x for x in summary["pmc_fetch"] if x["kernel"] == dom["kernel"] and x["grid"] == dom["grid"]), None)
-    w = next((x for x in summary["pmc_write"] if x["kernel"] == dom["kernel"] and x["grid"] == dom["grid"]), None)
-    cal = old.get("calibration", {})
-    factor = cal.get("factor_coalesced", 1.926)
-    n_pts = F * 131072
-    stream_bytes = 24 * n_pts  # plane-form stream: the part of the reads FETCH_SIZE under-reports by `factor`
-    stream_raw_kb = stream_bytes / 1024.0 / factor
-    if f:
-        gather_raw_kb = max(0.0, f["avg"] - stream_raw_kb)
-        read = stream_bytes + gather_raw_kb * 1024.0
-        wr = (w["avg"] * 1024.0) if w else 0.0
-        old.update({
+out = {}
+if dom:
+    def avg_of(tag, counter):
+        path = one(f"{tag}/**/*counter_collection.csv")
+        if not path:
+            return None
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+             if r["Counter_Name"] == counter and r["Kernel_Name"] == dom["kernel"] and int(r["Grid_Size"]) == dom["grid"]]
+        return sum(v) / len(v) if v else None
+
+    fetch_kb, write_kb = avg_of("pmc_fetch", "FETCH_SIZE"), avg_of("pmc_write", "WRITE_SIZE")
+    r32, r64, r128 = (avg_of("pmc_rdreq", f"TCC_EA0_RDREQ_{b}B_sum") for b in (32, 64, 128))
+    read = None
+    if r128 is not None:
+        read = 32.0 * (r32 or 0.0) + 64.0 * (r64 or 0.0) + 128.0 * r128
+    elif fetch_kb is not None:
+        read = 2.0 * fetch_kb * 1024.0
+    wr = (write_kb or 0.0) * 1024.0
+    if read is not None:
+        out = {
             "workload": f"odometry128k (bench.py default, F={F}), plane-form source clouds",
             "kernel": dom["kernel"][dom["kernel"].find("vgicp_kernel"):].split("(")[0],
             "kernel_avg_us_rocprof": dom["avg_us"],
-            "fetch_size_kb_raw": f["avg"], "write_size_kb_raw": w["avg"] if w else None,
-            "read_bytes_per_launch": read, "read_bytes_per_launch_upper": stream_bytes + 2 * gather_raw_kb * 1024.0,
+            "source": "rocprofv3 --pmc passes of tools/profile.sh (FETCH_SIZE; WRITE_SIZE; TCC_EA0_RDREQ_{32,64,128}B_sum), averages over the launches of the dominant kernel",
+            "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
+            "rdreq_32B": r32, "rdreq_64B": r64, "rdreq_128B": r128,
+            "read_bytes_per_launch": read,
+            "read_bytes_per_launch_from_2x_fetch_size": None if fetch_kb is None else 2.0 * fetch_kb * 1024.0,
             "write_bytes_per_launch": wr, "traffic_bytes_per_launch": read + wr,
             "factors_per_launch_when_measured": F, "traffic_bytes_per_factor": (read + wr) / F,
-        })
-        json.dump(old, open(tj, "w"), indent=1)
-print(json.dumps({"kernels": len(rows), "dominant": dom and {k: dom[k] for k in ("grid", "calls", "avg_us")}, "traffic_per_factor": old.get("traffic_bytes_per_factor")}))
+            "stream_bytes_per_launch": 24.0 * F * 131072, "gather_bytes_per_launch": read - 24.0 * F * 131072,
+        }
+        json.dump(out, open(tj, "w"), indent=1)
+print(json.dumps({"kernels": len(rows), "dominant": dom and {k: dom[k] for k in ("grid", "calls", "avg_us")}, "traffic_per_factor": out.get("traffic_bytes_per_factor")}))
