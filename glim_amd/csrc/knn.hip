@@ -300,6 +300,9 @@ void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const un
                                                            max_ring, dbg);
 }
 
+#ifdef GLIM_AMD_DEV_K10  // development builds only (tools/isa_stats.py turn-around): instantiate the k = 10 kernels alone
+#define DISPATCH_K(FN, ...) FN<10>(__VA_ARGS__)
+#else
 #define DISPATCH_K(FN, ...)                      \
   do {                                           \
     if (k <= 8) FN<8>(__VA_ARGS__);              \
@@ -308,6 +311,8 @@ void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const un
     else if (k <= 24) FN<24>(__VA_ARGS__);       \
     else FN<32>(__VA_ARGS__);                    \
   } while (0)
+
+#endif
 
 unsigned int next_pow2(unsigned long long v) {
   unsigned long long p = 1;
@@ -898,6 +903,10 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // for ~20-34 % more instructions (the lock-step insertion loop costs max-over-lanes rounds either way).  It wins where the 64-query kernel
   // leaves SIMDs empty (65 536 points: 204 -> 165 us kernel, 0.44 -> 0.33 ms per call), ties at 131 072 and loses at 307 200 (517 -> 785 us).
   // GLIM_AMD_KNN_WAVE64=1 / GLIM_AMD_KNN_PAIR=1 force one or the other.
+  // Also measured and removed: 2 / 4 wavefronts per query chunk, each owning every 2nd / 4th candidate chunk with its own top-k list, the query's
+  // bound shared through LDS (ds_min_u64) and the lists merged by rank at the end -- bit-identical lists, but 0.73 / 0.62 ms against 0.50 ms
+  // at 131 072 points and 1.06 / 1.19 against 0.77 ms at 307 104: every list has to be filled and pruned on its own, so the total work grows
+  // faster than the longest wavefront shrinks.
   const bool pair_lanes = !dbg.p && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
   if (k > 0 && pair_lanes) {
     DeviceTemp box32;

@@ -37,7 +37,7 @@ using namespace glim_amd;
 namespace {
 
 #ifndef GLIM_AMD_ABLATE
-#define GLIM_AMD_ABLATE 0  // profiling-only variants (tools/ablate.sh): 1 no gathers, 2 FP32 transform, 3 no algebra, 4 key gather only, 6 linear (coalesced) bucket index
+#define GLIM_AMD_ABLATE 0  // profiling-only variants (tools/ablate.sh): 1 no gathers, 3 no algebra, 4 key gather only
 #endif
 
 constexpr int BLOCK = 256;
@@ -220,6 +220,242 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   }
 }
 
+#ifndef GLIM_AMD_K4_TIMING
+#define GLIM_AMD_K4_TIMING 0  // diagnostic build: per-block start / end time stamps and placement (tools/k4_timing.py)
+#endif
+
+// resident waves per SIMD the register allocation aims for: the plane-form kernel fits 96 VGPRs (5 waves), the general one needs 99 (4 waves)
+#ifndef GLIM_AMD_MINW_PLANE
+#define GLIM_AMD_MINW_PLANE 5
+#endif
+#ifndef GLIM_AMD_MINW_GENERAL
+#define GLIM_AMD_MINW_GENERAL 4
+#endif
+
+struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: lives in SGPRs)
+  float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+
+// What a point carries from the probe stage (trip t-1) to the algebra stage (trip t) of the pipelined loop.
+template <bool PLANE>
+struct Probe {
+  unsigned long long key;  // packed voxel coordinate of q, EMPTY_KEY when the lane has no point / out of range / failed validation
+  unsigned int bkt;        // home bucket
+  float4 head;             // both keys of the home bucket (in flight until the next trip)
+  float qr0, qr1, qr2;     // q relative to the centre of its voxel (|.| <= res/2): FP32 without cancellation
+  float qp0, qp1, qp2;     // q' = R p = q - t: the rotated source point, the lever arm of the target-frame Jacobian
+  float c0, c1, c2, c3, c4, c5;  // PLANE: m = R n in c0..c2; general: C_t = R C_A R^T (t00 t01 t02 t11 t12 t22)
+};
+
+template <bool FROZEN, bool PLANE>
+__device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const PointIn& pt, int i, bool in_trip, const double* __restrict__ Tl,
+                                                    const double* __restrict__ Te, const Rot32& R, bool validate, int last) {
+  Probe<PLANE> o;
+  const bool ok = in_trip && (i < d.n);
+  double qx, qy, qz;
+  transform_point_d(Tl, (double)pt.p.x, (double)pt.p.y, (double)pt.p.z, qx, qy, qz);
+  const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
+  o.qp0 = (float)(qx - Tl[3]);
+  o.qp1 = (float)(qy - Tl[7]);
+  o.qp2 = (float)(qz - Tl[11]);
+  // floor(t) == fast_floor(t) for every in-range coordinate (same integer, bit-exact); v_floor_f64 + one subtraction also gives the
+  // in-voxel fraction for free
+  const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+  const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
+  // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
+  const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
+  const bool valid = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
+  o.key = valid ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
+  const unsigned int hsh = hash_fields(ux, uy, uz);
+  if (FROZEN) {
+    double ex, ey, ez;
+    transform_point_d(Te, (double)pt.p.x, (double)pt.p.y, (double)pt.p.z, ex, ey, ez);
+    o.qr0 = (float)(ex - ((double)cx + 0.5) * d.res);
+    o.qr1 = (float)(ey - ((double)cy + 0.5) * d.res);
+    o.qr2 = (float)(ez - ((double)cz + 0.5) * d.res);
+  } else {
+    const float resf = (float)d.res;
+    o.qr0 = ((float)(tx - fx) - 0.5f) * resf;
+    o.qr1 = ((float)(ty - fy) - 0.5f) * resf;
+    o.qr2 = ((float)(tz - fz) - 0.5f) * resf;
+  }
+  if (PLANE) {
+    // C_A = I - (1 - 1e-3) n n^T  =>  R C_A R^T = I - (1 - 1e-3) m m^T with m = R n
+    const float nx = pt.p.w, ny = pt.cb.x, nz = pt.cb.y;
+    o.c0 = R.r00 * nx + R.r01 * ny + R.r02 * nz;
+    o.c1 = R.r10 * nx + R.r11 * ny + R.r12 * nz;
+    o.c2 = R.r20 * nx + R.r21 * ny + R.r22 * nz;
+    o.c3 = o.c4 = o.c5 = 0.f;
+  } else {
+    // C_t = R C_A R^T (symmetric: t00 t01 t02 t11 t12 t22), computed here rather than in the algebra stage: its 9 temporaries are dead
+    // before the algebra's own peak of live values
+    const float c00 = pt.p.w, c01 = pt.ca.x, c02 = pt.ca.y, c11 = pt.ca.z, c12 = pt.ca.w, c22 = pt.cb.x;
+    const float a00 = R.r00 * c00 + R.r01 * c01 + R.r02 * c02, a01 = R.r00 * c01 + R.r01 * c11 + R.r02 * c12, a02 = R.r00 * c02 + R.r01 * c12 + R.r02 * c22;
+    const float a10 = R.r10 * c00 + R.r11 * c01 + R.r12 * c02, a11 = R.r10 * c01 + R.r11 * c11 + R.r12 * c12, a12 = R.r10 * c02 + R.r11 * c12 + R.r12 * c22;
+    const float a20 = R.r20 * c00 + R.r21 * c01 + R.r22 * c02, a21 = R.r20 * c01 + R.r21 * c11 + R.r22 * c12, a22 = R.r20 * c02 + R.r21 * c12 + R.r22 * c22;
+    o.c0 = a00 * R.r00 + a01 * R.r01 + a02 * R.r02; o.c1 = a00 * R.r10 + a01 * R.r11 + a02 * R.r12; o.c2 = a00 * R.r20 + a01 * R.r21 + a02 * R.r22;
+    o.c3 = a10 * R.r10 + a11 * R.r11 + a12 * R.r12; o.c4 = a10 * R.r20 + a11 * R.r21 + a12 * R.r22; o.c5 = a20 * R.r20 + a21 * R.r21 + a22 * R.r22;
+  }
+  if (validate) {
+    // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
+    // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
+    float rnx, rny, rnz;
+    if (PLANE) {
+      rnx = o.c0; rny = o.c1; rnz = o.c2;
+    } else {
+      const float4 nn = gld4(reinterpret_cast<const char*>(d.sn) + (unsigned int)min(i, last) * 16u);
+      rnx = R.r00 * nn.x + R.r01 * nn.y + R.r02 * nn.z;
+      rny = R.r10 * nn.x + R.r11 * nn.y + R.r12 * nn.z;
+      rnz = R.r20 * nn.x + R.r21 * nn.y + R.r22 * nn.z;
+    }
+    if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) o.key = EMPTY_KEY;
+    asm volatile("" : "+v"(o.qp0));  // keeps this block a (wave-uniform) branch: flattened into selects it costs every factor 12 instructions
+  }
+  o.bkt = __umulhi(hsh, d.num_buckets);
+#if GLIM_AMD_ABLATE == 1
+  o.head = make_float4(__uint_as_float((unsigned int)o.key), __uint_as_float((unsigned int)(o.key >> 32)), 0.f, 0.f);
+#else
+  o.head = gld4(reinterpret_cast<const char*>(d.buckets) + o.bkt * 128u);  // both keys of the home bucket (32-bit offset: <= 2^25 buckets)
+#endif
+  return o;
+}
+
+// Per-point algebra in the TARGET frame (all lanes run it; `hit` predicates the contributions through idet = 0).
+template <int MODE, bool PLANE>
+__device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, const float4& r0, const float4& r1, float r2c22, const Probe<PLANE>& s,
+                                                 const Rot32& R) {
+  // C_t = R C_A R^T, the source covariance in the target frame (symmetric: t00 t01 t02 t11 t12 t22)
+  float t00, t01, t02, t11, t12, t22;
+  if (PLANE) {
+    // C_A = I - (1 - 1e-3) n n^T  =>  C_t = I - (1 - 1e-3) m m^T with m = R n (probe stage): 9 + 9 operations instead of the 45-operation sandwich
+    const float mx = s.c0, my = s.c1, mz = s.c2;
+    const float w = 0.999f, wx = w * mx, wy = w * my;
+    t00 = 1.f - wx * mx; t01 = -wx * my; t02 = -wx * mz;
+    t11 = 1.f - wy * my; t12 = -wy * mz; t22 = 1.f - w * mz * mz;
+  } else {
+    t00 = s.c0; t01 = s.c1; t02 = s.c2; t11 = s.c3; t12 = s.c4; t22 = s.c5;
+  }
+  // residual mu - q, both relative to the voxel centre
+  const float rx = r0.x - s.qr0, ry = r0.y - s.qr1, rz = r0.z - s.qr2;
+#if GLIM_AMD_ABLATE == 3
+  acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2c22 + t00 + t01 + t02 + t11 + t12 + t22 + s.qp0;
+  return;
+#endif
+  // S = C_B + R C_A R^T (symmetric).  Non-hit lanes get C_B = I so the algebra stays finite.
+  const float S00 = (hit ? r0.w : 1.f) + t00, S01 = (hit ? r1.x : 0.f) + t01, S02 = (hit ? r1.y : 0.f) + t02;
+  const float S11 = (hit ? r1.z : 1.f) + t11, S12 = (hit ? r1.w : 0.f) + t12, S22 = (hit ? r2c22 : 1.f) + t22;
+  // M = S^-1 by cofactors (symmetric, called A below); idet = 0 on non-hit lanes zeroes every contribution below
+  const float k00 = S11 * S22 - S12 * S12;
+  const float k01 = S02 * S12 - S01 * S22;
+  const float k02 = S01 * S12 - S02 * S11;
+  const float det = S00 * k00 + S01 * k01 + S02 * k02;
+  float idet = __builtin_amdgcn_rcpf(det);         // 1 ulp hardware reciprocal ...
+  idet = fmaf(fmaf(-det, idet, 1.0f), idet, idet);  // ... + one Newton step (full FP32 accuracy, no division sequence)
+  idet = hit ? idet : 0.f;
+  const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
+  const float A11 = (S00 * S22 - S02 * S02) * idet;
+  const float A12 = (S01 * S02 - S00 * S12) * idet;
+  const float A22 = (S00 * S11 - S01 * S01) * idet;
+  // u = M r,  e = r . u   (r = mu - q is already a target-frame vector)
+  const float ux = A00 * rx + A01 * ry + A02 * rz;
+  const float uy = A01 * rx + A11 * ry + A12 * rz;
+  const float uz = A02 * rx + A12 * ry + A22 * rz;
+  acc[27] += rx * ux + ry * uy + rz * uz;
+  if (MODE == MODE_LINEARIZE) {
+    // J_s = [R hat(p) | -R] = [hat(q') | -I] diag(R, R) with q' = R p: everything below is accumulated for J' = [hat(q') | -I] and M in the
+    // target frame; the constant diag(R, R) is applied once per factor, in FP64, by finalize_factor
+    const float x = s.qp0, y = s.qp1, z = s.qp2;
+    // G = hat(q') M : column j = q' x M[:,j]
+    const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
+    const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
+    const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
+    // Hww = -G hat(q') : row i = q' x G[i,:]
+    acc[0] += y * g02 - z * g01;
+    acc[1] += z * g00 - x * g02;
+    acc[2] += x * g01 - y * g00;
+    acc[3] += z * g10 - x * g12;
+    acc[4] += x * g11 - y * g10;
+    acc[5] += x * g21 - y * g20;
+    acc[6] += g00; acc[7] += g01; acc[8] += g02;
+    acc[9] += g10; acc[10] += g11; acc[11] += g12;
+    acc[12] += g20; acc[13] += g21; acc[14] += g22;
+    acc[15] += A00; acc[16] += A01; acc[17] += A02; acc[18] += A11; acc[19] += A12; acc[20] += A22;
+    // b_w = u x q',  b_v = -u
+    acc[21] += uy * z - uz * y;
+    acc[22] += uz * x - ux * z;
+    acc[23] += ux * y - uy * x;
+    acc[24] += ux; acc[25] += uy; acc[26] += uz;
+  }
+}
+
+template <bool PLANE>
+struct PipeCtx {  // wave-uniform context of the pipelined loop
+  const FactorDesc& d;
+  const double* Tl;
+  const double* Te;
+  const Rot32& R;
+  int base, stride, ppt, last;
+  bool validate;
+};
+
+// One trip of the software-pipelined point loop.  `pr` holds the probe of point `it` on entry (its 16-byte key gather was issued in the
+// previous trip) and the probe of point it+1 on exit; `nxt` holds the stream data of point it+1 on entry and of it+2 on exit (AHEAD = 1).
+//   (1) resolve the probe of point `it` and issue the dependent 36-byte record gather (an on-chip hit: the key load fetched the line),
+//   (2) transform point it+AHEAD (FP64), derive its key and issue ITS key gather -- the only load that normally goes to HBM at random,
+//       so it gets a whole trip of algebra (this wave's and the other resident waves') to come back,
+//   (3) issue the coalesced stream loads of point it+AHEAD+1,
+//   (4) wait for the records of point `it` only (the OLDEST loads in flight: counted vmcnt) and run the algebra.
+// The first version of the loop issued key gather t, stream t+1, then waited for the key, then for the record, inside one trip: two
+// dependent memory round trips (one of them HBM) exposed per trip per wave, which 5 waves per SIMD could not cover (waves parked on
+// memory 67 % of their cycles, VALU 60 % busy).
+template <int MODE, bool FROZEN, bool PLANE>
+__device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers) {
+  constexpr int AHEAD = 1;
+  const FactorDesc& d = pc.d;
+  // (1) resolve point `it`
+  const Probe<PLANE> cur = pr;
+  unsigned long long k0 = (unsigned long long)__float_as_uint(cur.head.x) | ((unsigned long long)__float_as_uint(cur.head.y) << 32);
+  unsigned long long k1 = (unsigned long long)__float_as_uint(cur.head.z) | ((unsigned long long)__float_as_uint(cur.head.w) << 32);
+  unsigned int b = cur.bkt;
+  if (cur.key != EMPTY_KEY) {
+    // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
+    while (k0 != cur.key && k1 != cur.key && k1 != EMPTY_KEY) {
+      b = (b + 1 == d.num_buckets) ? 0u : b + 1;
+      const float4 h = gld4(reinterpret_cast<const char*>(d.buckets) + b * 128u);
+      k0 = (unsigned long long)__float_as_uint(h.x) | ((unsigned long long)__float_as_uint(h.y) << 32);
+      k1 = (unsigned long long)__float_as_uint(h.z) | ((unsigned long long)__float_as_uint(h.w) << 32);
+    }
+  }
+  const bool in1 = (k1 == cur.key);
+  const bool hit = (cur.key != EMPTY_KEY) && (k0 == cur.key || in1);
+  wave_inliers += __popcll(__ballot(hit));  // wave-uniform count: scalar registers, no per-lane counter
+  // every lane reads a record (way 0 of the last bucket when there is no hit) so the wavefront does not diverge
+  const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
+#if GLIM_AMD_ABLATE == 1 || GLIM_AMD_ABLATE == 4
+  (void)rp;
+  const float4 r0 = make_float4(0.01f * cur.qp0, 0.01f, -0.02f, 1.0f);
+  const float4 r1 = make_float4(0.01f, 0.02f, 0.9f, 0.03f);
+  const float r2 = 0.8f + 0.001f * cur.qp1;
+#else
+  const float4 r0 = gld4(rp);        // mx my mz c00
+  const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
+  const float r2 = gld1(rp + 32);    // c22
+#endif
+  // (2) probe of point it+AHEAD (a lane past its last point probes with EMPTY_KEY at a clamped, valid address)
+  pr = probe_point<FROZEN, PLANE>(d, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
+  // (3) stream loads of point it+AHEAD+1
+  nxt = load_point<PLANE>(d, (unsigned int)min(pc.base + (it + AHEAD + 1) * pc.stride, pc.last));
+  // (4) algebra of point `it`
+  accumulate_point<MODE, PLANE>(acc, hit, r0, r1, r2, cur, pc.R);
+  // The key gather the NEXT trip resolves is consumed HERE, at the very end of this trip, and nowhere earlier: without this pin the
+  // register allocator recycles two of its destination registers as algebra temporaries and copies them out mid-trip, which puts the
+  // s_waitcnt for the HBM gather 85 instructions after its issue instead of a whole trip.
+  asm volatile("" : "+v"(pr.head.x), "+v"(pr.head.y), "+v"(pr.head.z), "+v"(pr.head.w));
+  // Likewise the six FP32 offsets of the point probed in this trip must EXIST here: left alone, the scheduler sinks the FP64 -> FP32
+  // conversions into the next trip and carries the six FP64 values (12 VGPRs instead of 6) around the loop.
+  asm volatile("" : "+v"(pr.qr0), "+v"(pr.qr1), "+v"(pr.qr2), "+v"(pr.qp0), "+v"(pr.qp1), "+v"(pr.qp2));
+}
+
 // MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
 // Mahalanobis matrices frozen at the linearisation pose.  U: points per loop trip.  MINW: occupancy hint (waves per SIMD).
 //
@@ -228,11 +464,14 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 // and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
 // the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
 template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
-__global__ __launch_bounds__(BLOCK, 5) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+__global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
-                                                          float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa, int block_offset) {
-  constexpr int U = 1;  // points per loop trip (2 and 4 were measured slower: more registers, fewer resident waves)
+                                                          float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa, int block_offset,
+                                                          int blocks_per_round) {
   __shared__ float s_red[4][PARTIAL_STRIDE];
+#if GLIM_AMD_K4_TIMING
+  const unsigned long long timing_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+#endif
   const int gblock = block_offset + (int)blockIdx.x;  // row of this block in the plan (the plane-form and the general segment are separate launches)
   const int2 bm = blockmap[gblock];
   const int f = bm.x;
@@ -247,219 +486,43 @@ __global__ __launch_bounds__(BLOCK, 5) void vgicp_kernel(const FactorDesc* __res
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
   const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
   const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
+  const Rot32 R = {R00, R01, R02, R10, R11, R12, R20, R21, R22};
   const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.sn != nullptr);
-  const float resf = (float)d.res;
   const int last = d.n - 1;
 
   float acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; j++) acc[j] = 0.f;
-  int inliers = 0;
+  int wave_inliers = 0;  // wave-uniform count (scalar registers)
 
   const int ppt = d.ppt;
-  const int base = bm.y * (BLOCK * ppt) + threadIdx.x;
+  // Points of a factor are dealt to its blocks in 256-point hands, round robin: trip t of block (chunk) c covers points
+  // [(t * num_blocks + c) * 256, +256).  Contiguous chunks (block c = points [c * ppt * 256, +ppt * 256)) left the launch TAIL-bound: in
+  // Hilbert order a chunk is one region of the scan, and a region of sparse far-range points touches several times more bucket lines per
+  // point than a dense near-range one -- per-block time stamps (tools/k4_timing.py) showed equal-sized blocks of ONE resident set taking
+  // 75 ... 159 us (median 114), the kernel lasting as long as the slowest.  Dealt round robin every block sees the same mix.
+  const int stride = d.num_blocks * BLOCK;
+  const int base = bm.y * BLOCK + threadIdx.x;
   if (d.n > 0) {
-    // prologue: points of trip 0 (indices clamped so every load is in bounds; validity is tracked separately)
-    PointIn nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      nxt[u] = load_point<PLANE>(d, (unsigned int)min(base + u * BLOCK, last));
-    }
-    for (int it0 = 0; it0 < ppt; it0 += U) {
-      PointIn cur[U];
-      float4 head[U];
-      float qr[U][3];  // q relative to the centre of its voxel (|.| <= res/2): FP32 without cancellation
-      float qp[U][3];  // q' = R p = q - t: the rotated source point, the lever arm of the target-frame Jacobian
-      unsigned long long key[U];
-      unsigned int bkt[U];
-
-      // ---- FP64 transform -> voxel key -> 16-byte gather of the home bucket's two keys ----
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        cur[u] = nxt[u];
-        const int i = base + (it0 + u) * BLOCK;
-        const bool ok = (it0 + u < ppt) && (i < d.n);
-#if GLIM_AMD_ABLATE == 2
-        const float qxf = R00 * cur[u].p.x + R01 * cur[u].p.y + R02 * cur[u].p.z + (float)Tl[3];
-        const float qyf = R10 * cur[u].p.x + R11 * cur[u].p.y + R12 * cur[u].p.z + (float)Tl[7];
-        const float qzf = R20 * cur[u].p.x + R21 * cur[u].p.y + R22 * cur[u].p.z + (float)Tl[11];
-        const float ir = (float)d.inv_res;
-        const float tx = qxf * ir, ty = qyf * ir, tz = qzf * ir;
-        const double qx = qxf, qy = qyf, qz = qzf;
-        (void)qx; (void)qy; (void)qz;
-#else
-        double qx, qy, qz;
-        transform_point_d(Tl, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, qx, qy, qz);
-        const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
-#endif
-        qp[u][0] = (float)(qx - Tl[3]);
-        qp[u][1] = (float)(qy - Tl[7]);
-        qp[u][2] = (float)(qz - Tl[11]);
-        // floor(t) == fast_floor(t) for every in-range coordinate (same integer, bit-exact); v_floor_f64 + one subtraction also
-        // gives the in-voxel fraction for free
-#if GLIM_AMD_ABLATE == 2
-        const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
-        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-#else
-        const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
-        const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
-#endif
-        // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
-        const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
-        const bool valid = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
-        key[u] = valid ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
-        unsigned int hsh = hash_fields(ux, uy, uz);
-        if (FROZEN) {
-          double ex, ey, ez;
-          transform_point_d(Te, (double)cur[u].p.x, (double)cur[u].p.y, (double)cur[u].p.z, ex, ey, ez);
-          qr[u][0] = (float)(ex - ((double)cx + 0.5) * d.res);
-          qr[u][1] = (float)(ey - ((double)cy + 0.5) * d.res);
-          qr[u][2] = (float)(ez - ((double)cz + 0.5) * d.res);
-        } else {
-          qr[u][0] = ((float)(tx - fx) - 0.5f) * resf;
-          qr[u][1] = ((float)(ty - fy) - 0.5f) * resf;
-          qr[u][2] = ((float)(tz - fz) - 0.5f) * resf;
-        }
-        if (validate) {
-          // surface validation (upstream predicate unverified -- SURVEY.md App. B.5): the source normal faces the source sensor
-          // (p . n <= 0, cloud_covariance_estimation.cpp:98-101); reject when the transformed surface faces away from the target origin.
-          const float4 nn = PLANE ? make_float4(cur[u].p.w, cur[u].cb.x, cur[u].cb.y, 0.f)
-                                  : gld4(reinterpret_cast<const char*>(d.sn) + (unsigned int)min(i, last) * 16u);
-          const float rnx = R00 * nn.x + R01 * nn.y + R02 * nn.z;
-          const float rny = R10 * nn.x + R11 * nn.y + R12 * nn.z;
-          const float rnz = R20 * nn.x + R21 * nn.y + R22 * nn.z;
-          if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) key[u] = EMPTY_KEY;
-        }
-        bkt[u] = __umulhi(hsh, d.num_buckets);
-#if GLIM_AMD_ABLATE == 6
-        bkt[u] = (unsigned int)(base + (it0 + u) * BLOCK) % d.num_buckets;  // coalesced stand-in for the hashed bucket
-        key[u] = EMPTY_KEY - 1;
-#endif
-#if GLIM_AMD_ABLATE == 1
-        head[u] = make_float4(__uint_as_float((unsigned int)key[u]), __uint_as_float((unsigned int)(key[u] >> 32)), 0.f, 0.f);
-#else
-        head[u] = gld4(reinterpret_cast<const char*>(d.buckets) + bkt[u] * 128u);  // both keys of the home bucket (32-bit offset: <= 2^25 buckets)
-#endif
+    // Software pipeline over the points of this lane (pipe_trip above): the key gather of a point is issued one trip before its algebra.
+    // (Issuing it two trips ahead buys little: loads return in order, so the record gather of the trip in between would wait for it.)
+    PipeCtx<PLANE> pc = {d, Tl, Te, R, base, stride, ppt, last, validate};
+    PointIn nxt = load_point<PLANE>(d, (unsigned int)min(base, last));
+    Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base, ppt > 0, Tl, Te, R, validate, last);
+    nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
+    const int prio_phase = gblock / blocks_per_round;  // which of the CU's resident blocks this one is (dispatch is round robin over the CUs)
+    for (int it = 0; it < ppt; it++) {
+      // The SIMD's issue arbiter serves the highest user priority first and, among equals, the OLDEST wave: with every wave at priority 0 the
+      // blocks dispatched first ran ahead (block time rose with the block index, 105 -> 138 us, whatever the data) and left their CUs
+      // half empty for the last quarter of the launch.  Rotating the user priority trip by trip, phase-shifted per resident block, gives
+      // every wave the same share of the issue slots, so the resident set finishes together.
+      switch ((it + prio_phase) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
       }
-      // ---- coalesced loads of the NEXT trip, issued behind the gathers (counted vmcnt lets the gathers be consumed first) ----
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        nxt[u] = load_point<PLANE>(d, (unsigned int)min(base + (it0 + U + u) * BLOCK, last));
-      }
-      // ---- resolve the probe, then the per-point algebra (all lanes; accumulation predicated by hit) ----
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        unsigned long long k0 = (unsigned long long)__float_as_uint(head[u].x) | ((unsigned long long)__float_as_uint(head[u].y) << 32);
-        unsigned long long k1 = (unsigned long long)__float_as_uint(head[u].z) | ((unsigned long long)__float_as_uint(head[u].w) << 32);
-        unsigned int b = bkt[u];
-        if (key[u] != EMPTY_KEY) {
-          // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
-          while (k0 != key[u] && k1 != key[u] && k1 != EMPTY_KEY) {
-            b = (b + 1 == d.num_buckets) ? 0u : b + 1;
-            const float4 h = gld4(reinterpret_cast<const char*>(d.buckets) + b * 128u);
-            k0 = (unsigned long long)__float_as_uint(h.x) | ((unsigned long long)__float_as_uint(h.y) << 32);
-            k1 = (unsigned long long)__float_as_uint(h.z) | ((unsigned long long)__float_as_uint(h.w) << 32);
-          }
-        }
-        const bool in1 = (k1 == key[u]);
-        const bool hit = (key[u] != EMPTY_KEY) && (k0 == key[u] || in1);
-        inliers += hit ? 1 : 0;
-        // 48-byte record of the matching way: the line was just fetched by the key load, so this dependent read stays on chip;
-        // every lane reads (way 0 when there is no hit) so the wavefront does not diverge
-        const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
-#if GLIM_AMD_ABLATE == 1 || GLIM_AMD_ABLATE == 4
-        (void)rp;
-        const float4 r0 = make_float4(0.01f * cur[u].p.x, 0.01f, -0.02f, 1.0f);
-        const float4 r1 = make_float4(0.01f, 0.02f, 0.9f, 0.03f);
-        const float4 r2 = make_float4(0.8f + 0.001f * cur[u].p.y, 0.f, 0.f, 0.f);
-#else
-        const float4 r0 = gld4(rp);        // mx my mz c00
-        const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
-        const float4 r2 = gld4(rp + 32);   // c22 count - -
-#endif
-        // C_t = R C_A R^T, the source covariance in the TARGET frame (symmetric: t00 t01 t02 t11 t12 t22)
-        float t00, t01, t02, t11, t12, t22;
-        if (PLANE) {
-          // C_A = I - (1 - 1e-3) n n^T  =>  C_t = I - (1 - 1e-3) m m^T with m = R n: 9 + 9 operations instead of a 45-operation sandwich
-          const float nx = cur[u].p.w, ny = cur[u].cb.x, nz = cur[u].cb.y;
-          const float mx = R00 * nx + R01 * ny + R02 * nz;
-          const float my = R10 * nx + R11 * ny + R12 * nz;
-          const float mz = R20 * nx + R21 * ny + R22 * nz;
-          const float w = 0.999f, wx = w * mx, wy = w * my;
-          t00 = 1.f - wx * mx; t01 = -wx * my; t02 = -wx * mz;
-          t11 = 1.f - wy * my; t12 = -wy * mz; t22 = 1.f - w * mz * mz;
-        } else {
-          const float c00 = cur[u].p.w, c01 = cur[u].ca.x, c02 = cur[u].ca.y, c11 = cur[u].ca.z, c12 = cur[u].ca.w, c22 = cur[u].cb.x;
-          const float a00 = R00 * c00 + R01 * c01 + R02 * c02, a01 = R00 * c01 + R01 * c11 + R02 * c12, a02 = R00 * c02 + R01 * c12 + R02 * c22;
-          const float a10 = R10 * c00 + R11 * c01 + R12 * c02, a11 = R10 * c01 + R11 * c11 + R12 * c12, a12 = R10 * c02 + R11 * c12 + R12 * c22;
-          const float a20 = R20 * c00 + R21 * c01 + R22 * c02, a21 = R20 * c01 + R21 * c11 + R22 * c12, a22 = R20 * c02 + R21 * c12 + R22 * c22;
-          t00 = a00 * R00 + a01 * R01 + a02 * R02; t01 = a00 * R10 + a01 * R11 + a02 * R12; t02 = a00 * R20 + a01 * R21 + a02 * R22;
-          t11 = a10 * R10 + a11 * R11 + a12 * R12; t12 = a10 * R20 + a11 * R21 + a12 * R22; t22 = a20 * R20 + a21 * R21 + a22 * R22;
-        }
-
-        // residual mu - q, both relative to the voxel centre
-        const float rx = r0.x - qr[u][0];
-        const float ry = r0.y - qr[u][1];
-        const float rz = r0.z - qr[u][2];
-
-#if GLIM_AMD_ABLATE == 3
-        acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2.x + t00 + t01 + t02 + t11 + t12 + t22 + cur[u].p.x;
-        continue;
-#endif
-        // S = C_B + R C_A R^T   (TARGET frame, symmetric).  Non-hit lanes get C_B = I so the algebra stays finite.
-#if GLIM_AMD_ABLATE == 8  // no selects on the voxel covariance: a lane without a match reads some finite record (another voxel's or zeros)
-        const float S00 = r0.w + t00, S01 = r1.x + t01, S02 = r1.y + t02;
-        const float S11 = r1.z + t11, S12 = r1.w + t12, S22 = r2.x + t22;
-#else
-        const float S00 = (hit ? r0.w : 1.f) + t00, S01 = (hit ? r1.x : 0.f) + t01, S02 = (hit ? r1.y : 0.f) + t02;
-        const float S11 = (hit ? r1.z : 1.f) + t11, S12 = (hit ? r1.w : 0.f) + t12, S22 = (hit ? r2.x : 1.f) + t22;
-#endif
-
-        // M = S^-1 by cofactors (symmetric, called A below); idet = 0 on non-hit lanes zeroes every contribution below
-        const float k00 = S11 * S22 - S12 * S12;
-        const float k01 = S02 * S12 - S01 * S22;
-        const float k02 = S01 * S12 - S02 * S11;
-        const float det = S00 * k00 + S01 * k01 + S02 * k02;
-        float idet = __builtin_amdgcn_rcpf(det);         // 1 ulp hardware reciprocal ...
-        idet = fmaf(fmaf(-det, idet, 1.0f), idet, idet);  // ... + one Newton step (full FP32 accuracy, no division sequence)
-        idet = hit ? idet : 0.f;
-        const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
-        const float A11 = (S00 * S22 - S02 * S02) * idet;
-        const float A12 = (S01 * S02 - S00 * S12) * idet;
-        const float A22 = (S00 * S11 - S01 * S01) * idet;
-
-        // u = M r,  e = r . u   (r = mu - q is already a target-frame vector)
-        const float ux = A00 * rx + A01 * ry + A02 * rz;
-        const float uy = A01 * rx + A11 * ry + A12 * rz;
-        const float uz = A02 * rx + A12 * ry + A22 * rz;
-        acc[27] += rx * ux + ry * uy + rz * uz;
-
-        if (MODE == MODE_LINEARIZE) {
-          // J_s = [R hat(p) | -R] = [hat(q') | -I] diag(R, R) with q' = R p: everything below is accumulated for J' = [hat(q') | -I] and M in
-          // the target frame; the constant diag(R, R) is applied once per factor, in FP64, by finalize_factor
-          const float x = qp[u][0], y = qp[u][1], z = qp[u][2];
-          // G = hat(q') M : column j = q' x M[:,j]
-          const float g00 = y * A02 - z * A01, g01 = y * A12 - z * A11, g02 = y * A22 - z * A12;
-          const float g10 = z * A00 - x * A02, g11 = z * A01 - x * A12, g12 = z * A02 - x * A22;
-          const float g20 = x * A01 - y * A00, g21 = x * A11 - y * A01, g22 = x * A12 - y * A02;
-          // Hww = -G hat(p) : row i = p x G[i,:]
-          acc[0] += y * g02 - z * g01;
-          acc[1] += z * g00 - x * g02;
-          acc[2] += x * g01 - y * g00;
-          acc[3] += z * g10 - x * g12;
-          acc[4] += x * g11 - y * g10;
-          acc[5] += x * g21 - y * g20;
-          acc[6] += g00; acc[7] += g01; acc[8] += g02;
-          acc[9] += g10; acc[10] += g11; acc[11] += g12;
-          acc[12] += g20; acc[13] += g21; acc[14] += g22;
-          acc[15] += A00; acc[16] += A01; acc[17] += A02; acc[18] += A11; acc[19] += A12; acc[20] += A22;
-          // b_w = u x p,  b_v = -u
-          acc[21] += uy * z - uz * y;
-          acc[22] += uz * x - ux * z;
-          acc[23] += ux * y - uy * x;
-          acc[24] += ux; acc[25] += uy; acc[26] += uz;
-        }
-      }
+      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers);
     }
   }
 
@@ -476,8 +539,7 @@ __global__ __launch_bounds__(BLOCK, 5) void vgicp_kernel(const FactorDesc* __res
     if (lane == 63) s_red[wave][27] = v;
   }
   {
-    const float v = wave_sum_to_lane63((float)inliers);  // <= 64 * ppt: exact in FP32
-    if (lane == 63) s_red[wave][28] = v;
+    if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
   }
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
@@ -485,6 +547,17 @@ __global__ __launch_bounds__(BLOCK, 5) void vgicp_kernel(const FactorDesc* __res
     float v = 0.f;
     const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
     if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
+#if GLIM_AMD_K4_TIMING
+    // diagnostic build (tools/k4_timing.py): when and where this block ran, in the three spare slots of its partial row
+    if (j >= 29) {
+      unsigned int xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned int w = j == 29 ? (unsigned int)timing_t0 : (j == 30 ? (unsigned int)t1 : ((xcc & 0xfu) << 16) | (hwid & 0xffffu));
+      v = __uint_as_float(w);
+    }
+#endif
     partials[(size_t)gblock * PARTIAL_STRIDE + j] = v;
   }
 }
@@ -601,17 +674,16 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   if (!set->dirty) return GLIM_AMD_OK;
   const int nf = (int)set->entries.size();
   glim_amd_ctx* ctx = set->ctx;
-  long long total_points = 0;
-  for (auto& e : set->entries) total_points += e.source->n;
-  // Grid sizing: aim for ONE resident set of blocks (num_cus x blocks_per_cu) with equal work each, so every lane reduces its 28
-  // accumulators exactly once; each factor gets blocks in proportion to its points.  (Finer grids were measured level: 1280 blocks
-  // 142.7 us, 2560 142.6, 5120 138.6, 10240 142.9 per 128 factors.)
-  const int blocks_per_cu = 5;  // 96 VGPRs -> 5 waves/SIMD -> 5 blocks of 4 waves per CU
-  long long target_blocks = (long long)std::max(1, ctx->num_cus) * blocks_per_cu;
-  if (const char* env = getenv("GLIM_AMD_TARGET_BLOCKS")) target_blocks = std::max(1, atoi(env));
+  const bool allow_plane = getenv("GLIM_AMD_NO_PLANE") == nullptr;
+  // Grid sizing: the plane-form and the general factors are separate launches (segments); each aims for ONE resident set of blocks
+  // (num_cus x waves per SIMD of that kernel variant) with equal work each, so every lane reduces its 28 accumulators exactly once; each
+  // factor gets blocks in proportion to its points.  (Finer grids were measured level: 1280 blocks 142.7 us, 2560 142.6, 5120 138.6,
+  // 10240 142.9 per 128 factors.)
+  long long seg_points[2] = {0, 0};
+  long long seg_target[2] = {(long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_PLANE, (long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_GENERAL};
+  if (const char* env = getenv("GLIM_AMD_TARGET_BLOCKS")) seg_target[0] = seg_target[1] = std::max(1, atoi(env));
   int forced_ppt = 0;
   if (const char* env = getenv("GLIM_AMD_PPT")) forced_ppt = std::max(1, std::min(256, atoi(env)));
-  const bool allow_plane = getenv("GLIM_AMD_NO_PLANE") == nullptr;
 
   set->h_descs.assign(nf, FactorDesc());
   std::vector<int> nblocks(nf);
@@ -648,8 +720,13 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     d.inv_res = e.target->inv_resolution;
     d.res = e.target->resolution;
     d.flags = e.flags;
+    seg_points[d.plane ? 0 : 1] += d.n;
+  }
+  for (int f = 0; f < nf; f++) {
+    FactorDesc& d = set->h_descs[f];
     int ppt = forced_ppt;
     if (!ppt) {
+      const long long target_blocks = seg_target[d.plane ? 0 : 1], total_points = seg_points[d.plane ? 0 : 1];
       const long long share = std::max(1ll, (target_blocks * (long long)d.n + total_points / 2) / std::max(1ll, total_points));
       ppt = (int)std::max(1ll, std::min(256ll, ((long long)d.n + share * BLOCK - 1) / (share * BLOCK)));
     }
@@ -772,10 +849,10 @@ void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa) {
   const double* ev = set->d_poses + set->entries.size() * 12;
   if (set->plane_rows > 0)
     vgicp_kernel<MODE, FROZEN, true, INLINE><<<set->plane_rows, BLOCK, 0, set->stream>>>(set->d_descs, lin, ev, set->d_blockmap, set->d_partials,
-                                                                                       set->inline_pose, fa, 0);
+                                                                                       set->inline_pose, fa, 0, std::max(1, set->ctx->num_cus));
   if (set->total_rows > set->plane_rows)
     vgicp_kernel<MODE, FROZEN, false, INLINE><<<set->total_rows - set->plane_rows, BLOCK, 0, set->stream>>>(
-      set->d_descs, lin, ev, set->d_blockmap, set->d_partials, set->inline_pose, fa, set->plane_rows);
+      set->d_descs, lin, ev, set->d_blockmap, set->d_partials, set->inline_pose, fa, set->plane_rows, std::max(1, set->ctx->num_cus));
 }
 
 // the fused kernel(s) alone (no finalisation): used by the profiling entry point
@@ -1109,6 +1186,23 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (ms_kernel) *ms_kernel = ms / (float)iters;
+#if GLIM_AMD_K4_TIMING
+  if (const char* path = getenv("GLIM_AMD_K4_TIMING_DUMP")) {
+    // rows of (factor, chunk, start, end [10 ns ticks], xcc << 16 | HW_ID) of the LAST launch above
+    std::vector<float> hp((size_t)set->total_rows * PARTIAL_STRIDE);
+    std::vector<int2> hb((size_t)set->total_rows);
+    GA_HIP(hipMemcpy(hp.data(), set->d_partials, hp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    GA_HIP(hipMemcpy(hb.data(), set->d_blockmap, hb.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    if (FILE* fp = fopen(path, "wb")) {
+      for (int r = 0; r < set->total_rows; r++) {
+        unsigned int rec[5] = {(unsigned int)hb[r].x, (unsigned int)hb[r].y, 0, 0, 0};
+        memcpy(&rec[2], &hp[(size_t)r * PARTIAL_STRIDE + 29], 3 * sizeof(unsigned int));
+        fwrite(rec, sizeof(rec), 1, fp);
+      }
+      fclose(fp);
+    }
+  }
+#endif
   GA_HIP(hipEventRecord(e0, set->stream));
   for (int i = 0; i < iters; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, set->d_compact, 0, false));
   GA_HIP(hipEventRecord(e1, set->stream));

@@ -1,17 +1,10 @@
 #!/bin/bash
-# Profiling-only: builds ablated variants of the VGICP kernel (glim_amd/csrc/vgicp.hip, GLIM_AMD_ABLATE) and times them.
-# Run on the GPU box.  The results of ablated kernels are wrong by construction; only their timing is meaningful.
+# Profiling-only: ablated builds of the fused VGICP kernel (glim_amd/csrc/vgicp.hip, GLIM_AMD_ABLATE) for tools/kexp.sh.
+#   1  no gathers (keys and records synthesised in registers: stream + algebra only)      3  no algebra (loads only)
+#   4  key gather only (records synthesised)
+# The results of ablated kernels are wrong by construction; only their timing is meaningful.
+#   here:        tools/ablate.sh            (builds build/ab/abl{1,3,4})
+#   on the GPU:  LIBS="main abl1 abl3 abl4" bash tools/kexp.sh      (main = tools/ab_variant.sh main)
 set -e
 cd "$(dirname "$0")/.."
-SRC=glim_amd/csrc
-for a in ${ABLATIONS:-1 2 3}; do
-  mkdir -p /tmp/abl$a
-  for f in context cloud voxelmap vgicp covariance knn; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -DGLIM_AMD_ABLATE=$a -c $SRC/$f.hip -o /tmp/abl$a/$f.o &
-  done
-  wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abl$a/*.o -o /tmp/abl$a/libglim_amd.so
-done
-S='[{"GLIM_AMD_U":1}]'
-echo "baseline"; SWEEP=$S python tools/sweep.py 2>&1 | grep kernel_us
-for a in ${ABLATIONS:-1 2 3}; do echo "ablate $a"; GLIM_AMD_LIB=/tmp/abl$a/libglim_amd.so SWEEP=$S python tools/sweep.py 2>&1 | grep kernel_us; done
+for a in ${ABLATIONS:-1 3 4}; do tools/ab_variant.sh abl$a -DGLIM_AMD_ABLATE=$a; done

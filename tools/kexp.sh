@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/kexp; mkdir -p $OUT
 export GLIM_AMD_SCAN_CACHE=/tmp/glim_amd_scan_cache
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for name in ${LIBS:-main}; do
   GLIM_AMD_LIB=$PWD/build/ab/$name/libglim_amd.so KEXP_TAG=$name timeout 300 python tools/kexp.py < /dev/null 2> $OUT/$name.err | tee -a $OUT/results.jsonl
 done

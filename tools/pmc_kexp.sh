@@ -13,7 +13,7 @@ while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $group --output-format csv -d $OUT/g$i -- python $REPO/tools/kexp.py > $OUT/g$i.out 2> $OUT/g$i.err
-done <<'GROUPS'
+done < <(if [ -n "$PMC_GROUPS_FILE" ]; then cat "$PMC_GROUPS_FILE"; else cat <<'GROUPS'
 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
 TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum
@@ -25,6 +25,7 @@ SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_SALU S
 TD_TD_BUSY_sum TD_TC_STALL_sum TCP_RFIFO_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum
 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_READ_SECTORS_sum
 GROUPS
+fi)
 python3 - <<PY
 import csv, glob, collections, json
 agg = collections.OrderedDict()

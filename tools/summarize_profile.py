@@ -1,7 +1,7 @@
 """Turn the raw rocprofv3 output of tools/profile.sh (gpurun_out/prof_<tag>/) into the committed summaries under profiles/<tag>/:
 summary.json (per kernel x grid: calls, avg / min / max duration from the kernel trace; FETCH_SIZE / WRITE_SIZE averages from
 the separate PMC passes), kernel_stats.csv (rocprofv3's own --stats table) and traffic.json (HBM bytes per launch of the dominant
-kernel, corrected as MI355X_MICROARCH.md prescribes with the calibration measured by tools/fetch_calib.sh).
+kernel: bytes from the L2 read-request size counters, which need no correction; the doubled FETCH_SIZE of MI355X_MICROARCH.md is recorded next to it).
 
 usage: python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01 [factors_per_launch]"""
 import csv, glob, json, os, shutil, sys
