@@ -68,15 +68,18 @@ __device__ __forceinline__ unsigned long long voxel_key(double qx, double qy, do
 #ifndef GLIM_AMD_PAIR_SHIFT
 #define GLIM_AMD_PAIR_SHIFT 1
 #endif
+// ux, uy, uz: the three 21-bit fields, already confined to 21 bits (a lane whose coordinate is out of range carries EMPTY_KEY and only
+// needs SOME in-range bucket)
 __device__ __forceinline__ unsigned int hash_fields(unsigned int ux, unsigned int uy, unsigned int uz) {
-  unsigned int h = __umul24((ux & 0x1fffffu) >> GLIM_AMD_PAIR_SHIFT, 0x9E3779u) + __umul24(uy & 0x1fffffu, 0x85EBCBu) + __umul24(uz & 0x1fffffu, 0xC2B2AFu);
+  unsigned int h = __umul24(ux >> GLIM_AMD_PAIR_SHIFT, 0x9E3779u) + __umul24(uy, 0x85EBCBu) + __umul24(uz, 0xC2B2AFu);
   h ^= h >> 15;
   h *= 0x2C1B3C6Du;
   h ^= h >> 13;
   return h;
 }
 __device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
-  return hash_fields((unsigned int)(k >> (2 * KEY_BITS)), (unsigned int)(k >> KEY_BITS), (unsigned int)k);
+  const unsigned int m = (1u << KEY_BITS) - 1u;
+  return hash_fields((unsigned int)(k >> (2 * KEY_BITS)) & m, (unsigned int)(k >> KEY_BITS) & m, (unsigned int)k & m);
 }
 __device__ __forceinline__ unsigned int bucket_of(unsigned long long key, unsigned int num_buckets) {
   return __umulhi(hash_key(key), num_buckets);

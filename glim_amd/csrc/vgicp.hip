@@ -264,8 +264,7 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
   const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
   // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
   const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
-  const bool valid = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
-  o.key = valid ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
+  bool keep = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
   const unsigned int hsh = hash_fields(ux, uy, uz);
   if (FROZEN) {
     double ex, ey, ez;
@@ -308,9 +307,10 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
       rny = R.r10 * nn.x + R.r11 * nn.y + R.r12 * nn.z;
       rnz = R.r20 * nn.x + R.r21 * nn.y + R.r22 * nn.z;
     }
-    if (rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f) o.key = EMPTY_KEY;
+    keep = keep && !(rnx * (float)qx + rny * (float)qy + rnz * (float)qz > 0.f);
     asm volatile("" : "+v"(o.qp0));  // keeps this block a (wave-uniform) branch: flattened into selects it costs every factor 12 instructions
   }
+  o.key = keep ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
   o.bkt = __umulhi(hsh, d.num_buckets);
 #if GLIM_AMD_ABLATE == 1
   o.head = make_float4(__uint_as_float((unsigned int)o.key), __uint_as_float((unsigned int)(o.key >> 32)), 0.f, 0.f);
@@ -341,10 +341,12 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
   acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2c22 + t00 + t01 + t02 + t11 + t12 + t22 + s.qp0;
   return;
 #endif
-  // S = C_B + R C_A R^T (symmetric).  Non-hit lanes get C_B = I so the algebra stays finite.
-  const float S00 = (hit ? r0.w : 1.f) + t00, S01 = (hit ? r1.x : 0.f) + t01, S02 = (hit ? r1.y : 0.f) + t02;
-  const float S11 = (hit ? r1.z : 1.f) + t11, S12 = (hit ? r1.w : 0.f) + t12, S22 = (hit ? r2c22 : 1.f) + t22;
-  // M = S^-1 by cofactors (symmetric, called A below); idet = 0 on non-hit lanes zeroes every contribution below
+  // S = C_B + R C_A R^T (symmetric).  A lane without a match has read SOME record of the table -- another voxel's, or the zeros of an empty
+  // way (voxelmap.hip initialises every record) -- so everything up to the determinant is finite for it too; idet = 0 (a select, not a
+  // product) then zeroes its contributions exactly.  No per-coefficient selects.
+  const float S00 = r0.w + t00, S01 = r1.x + t01, S02 = r1.y + t02;
+  const float S11 = r1.z + t11, S12 = r1.w + t12, S22 = r2c22 + t22;
+  // M = S^-1 by cofactors (symmetric, called A below)
   const float k00 = S11 * S22 - S12 * S12;
   const float k01 = S02 * S12 - S01 * S22;
   const float k02 = S01 * S12 - S02 * S11;
@@ -407,7 +409,7 @@ struct PipeCtx {  // wave-uniform context of the pipelined loop
 //   (4) wait for the records of point `it` only (the OLDEST loads in flight: counted vmcnt) and run the algebra.
 // The first version of the loop issued key gather t, stream t+1, then waited for the key, then for the record, inside one trip: two
 // dependent memory round trips (one of them HBM) exposed per trip per wave, which 5 waves per SIMD could not cover (waves parked on
-// memory 67 % of their cycles, VALU 60 % busy).
+// memory 71 % of their cycles; 50 % with this form -- tools/pmc_kexp.sh, profiles/r02/probe/).
 template <int MODE, bool FROZEN, bool PLANE>
 __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers) {
   constexpr int AHEAD = 1;
@@ -454,6 +456,19 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   // Likewise the six FP32 offsets of the point probed in this trip must EXIST here: left alone, the scheduler sinks the FP64 -> FP32
   // conversions into the next trip and carries the six FP64 values (12 VGPRs instead of 6) around the loop.
   asm volatile("" : "+v"(pr.qr0), "+v"(pr.qr1), "+v"(pr.qr2), "+v"(pr.qp0), "+v"(pr.qp1), "+v"(pr.qp2));
+}
+
+// The SIMD's issue arbiter serves the highest user priority first and, among equals, the OLDEST wave: with every wave at priority 0 the
+// blocks dispatched first ran ahead (block time rose with the block index, 105 -> 138 us, whatever the data: tools/k4_timing.py) and left
+// their CUs half empty for the last quarter of the launch.  Rotating the user priority trip by trip, phase-shifted per resident block,
+// gives every wave the same share of the issue slots, so the resident set finishes together (125 -> 119.5 us per 128 factors).
+__device__ __forceinline__ void rotate_priority(int step) {
+  switch (step & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
 }
 
 // MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
@@ -512,16 +527,7 @@ __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_
     nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
     const int prio_phase = gblock / blocks_per_round;  // which of the CU's resident blocks this one is (dispatch is round robin over the CUs)
     for (int it = 0; it < ppt; it++) {
-      // The SIMD's issue arbiter serves the highest user priority first and, among equals, the OLDEST wave: with every wave at priority 0 the
-      // blocks dispatched first ran ahead (block time rose with the block index, 105 -> 138 us, whatever the data) and left their CUs
-      // half empty for the last quarter of the launch.  Rotating the user priority trip by trip, phase-shifted per resident block, gives
-      // every wave the same share of the issue slots, so the resident set finishes together.
-      switch ((it + prio_phase) & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-      }
+      rotate_priority(it + prio_phase);
       pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers);
     }
   }
