@@ -461,7 +461,9 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
 // The SIMD's issue arbiter serves the highest user priority first and, among equals, the OLDEST wave: with every wave at priority 0 the
 // blocks dispatched first ran ahead (block time rose with the block index, 105 -> 138 us, whatever the data: tools/k4_timing.py) and left
 // their CUs half empty for the last quarter of the launch.  Rotating the user priority trip by trip, phase-shifted per resident block,
-// gives every wave the same share of the issue slots, so the resident set finishes together (125 -> 119.5 us per 128 factors).
+// gives every wave the same share of the issue slots, so the resident set finishes together (125 -> 119.5 us per 128 factors).  Measured
+// level with it: five phases for five resident blocks, four trips per level; worse: a static priority that favours the younger blocks
+// (profiles/r02/probe/kexp_ab_priority_schemes.jsonl).
 __device__ __forceinline__ void rotate_priority(int step) {
   switch (step & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
