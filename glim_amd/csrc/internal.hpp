@@ -261,6 +261,7 @@ struct glim_amd_factor_set {
   // device plan: rows [0, plane_rows) = blocks of factors whose source cloud is plane-form (24 B/pt kernel), rows [plane_rows,
   // total_rows) = blocks of the other factors (36 B/pt kernel); each segment is its own launch
   int points_per_thread = 1;
+  int max_rows_per_factor = 0;    // most blocks (partial rows) any factor of the plan owns: picks the finalise kernel's width
   int plane_rows = 0, total_rows = 0;
   glim_amd::FactorDesc* d_descs = nullptr;
   int2* d_blockmap = nullptr;

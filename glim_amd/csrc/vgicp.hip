@@ -115,35 +115,37 @@ struct FinalizeArgs {
   int num_factors;
 };
 
-// Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 256 threads of ONE block.  Thread (g, j),
-// g = tid / 32, j = tid % 32, sums rows g, g + 8, g + 16, ... of value j; the 8 group sums are then added in group order.  The
+// Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 32 * G threads of ONE block.  Thread (g, j),
+// g = tid / 32, j = tid % 32, sums rows g, g + G, g + 2 G, ... of value j; the G group sums are then added in group order.  The
 // order depends only on the plan, so results are bit-reproducible whichever block happens to run this.
+// G = 8 (256 threads) for factor sets, whose factors own a handful of rows each; G = 32 (1024 threads) when one factor is spread over
+// the whole chip (the synchronous single-factor call of the odometry: ~500 rows, now one batch of loads per thread instead of four).
+template <int G>
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
                                                 double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
   const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int first = d.first_block, nb = d.num_blocks;
-  // A single factor spread over the whole chip has ~500 partial rows and ONE finalising block: with one dependent (row id -> value)
-  // load pair per trip the 64 trips of a thread are 64 memory round trips (~23 us, most of a synchronous single-factor call).  The
-  // loads of 16 trips are therefore issued together; the additions keep their order, so the sums are bit-identical.
+  // With one dependent (row id -> value) load pair per trip the trips of a thread are as many memory round trips (~23 us for a chip-wide
+  // factor: most of a synchronous single-factor call).  The loads of 16 trips are therefore issued together; the additions keep their order.
   double s = 0.0;
   constexpr int INFLIGHT = 16;
-  for (int c = g; c < nb; c += 8 * INFLIGHT) {
+  for (int c = g; c < nb; c += G * INFLIGHT) {
     int r[INFLIGHT];
     float v[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) r[u] = fa.rows[first + min(c + 8 * u, nb - 1)];  // past the end: a valid row, value unused
+    for (int u = 0; u < INFLIGHT; u++) r[u] = fa.rows[first + min(c + G * u, nb - 1)];  // past the end: a valid row, value unused
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)r[u] * PARTIAL_STRIDE + j];
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++)
-      if (c + 8 * u < nb) s += (double)v[u];
+      if (c + G * u < nb) s += (double)v[u];
   }
   s_part[g][j] = s;
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) t += s_part[k][threadIdx.x];
+    for (int k = 0; k < G; k++) t += s_part[k][threadIdx.x];
     s_sum[threadIdx.x] = t;
   }
   __syncthreads();
@@ -570,14 +572,15 @@ __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_
   }
 }
 
-// Finalisation: one block of 256 threads per factor.
-__global__ __launch_bounds__(256) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
-                                                       int mode, const double* __restrict__ poses_lin, const InlinePose ip) {
-  __shared__ double s_part[8][PARTIAL_STRIDE];
+// Finalisation: one block of 32 * G threads per factor.
+template <int G>
+__global__ __launch_bounds__(32 * G) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
+                                                          int mode, const double* __restrict__ poses_lin, const InlinePose ip) {
+  __shared__ double s_part[G][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int f = blockIdx.x;
   const FactorDesc d = descs[f];
-  finalize_factor(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
+  finalize_factor<G>(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
 }
 
 __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
@@ -743,6 +746,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     d.num_blocks = nblocks[f];
   }
   set->points_per_thread = nf ? set->h_descs[0].ppt : 1;
+  set->max_rows_per_factor = nf ? *std::max_element(nblocks.begin(), nblocks.end()) : 0;
 
   // block map: the plane-form segment first, then the general one
   std::vector<int2> blockmap;
@@ -884,7 +888,10 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   if (nf == 0) return GLIM_AMD_OK;
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   launch_vgicp(set, mode, frozen, fa);
-  finalize_kernel<<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
+  if (set->max_rows_per_factor > 128)
+    finalize_kernel<32><<<nf, 1024, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
+  else
+    finalize_kernel<8><<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
