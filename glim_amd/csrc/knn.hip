@@ -302,7 +302,15 @@ void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const un
 
 #ifdef GLIM_AMD_DEV_K10  // development builds only (tools/isa_stats.py turn-around): instantiate the k = 10 kernels alone
 #define DISPATCH_K(FN, ...) FN<10>(__VA_ARGS__)
+#define DISPATCH_K16(FN, ...) FN<10>(__VA_ARGS__)
 #else
+// k <= 16 only (the pair-lane kernel keeps two top-k lists per query in registers: beyond 16 entries it spills)
+#define DISPATCH_K16(FN, ...)                    \
+  do {                                           \
+    if (k <= 8) FN<8>(__VA_ARGS__);              \
+    else if (k <= 10) FN<10>(__VA_ARGS__);       \
+    else FN<16>(__VA_ARGS__);                    \
+  } while (0)
 #define DISPATCH_K(FN, ...)                      \
   do {                                           \
     if (k <= 8) FN<8>(__VA_ARGS__);              \
@@ -907,12 +915,12 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // bound shared through LDS (ds_min_u64) and the lists merged by rank at the end -- bit-identical lists, but 0.73 / 0.62 ms against 0.50 ms
   // at 131 072 points and 1.06 / 1.19 against 0.77 ms at 307 104: every list has to be filled and pruned on its own, so the total work grows
   // faster than the longest wavefront shrinks.
-  const bool pair_lanes = !dbg.p && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
+  const bool pair_lanes = !dbg.p && k <= 16 && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
   if (k > 0 && pair_lanes) {
     DeviceTemp box32;
     GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
     half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
-    DISPATCH_K(launch_pairs, st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out);
+    DISPATCH_K16(launch_pairs, st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out);
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
