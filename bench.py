@@ -262,9 +262,11 @@ def run_odometry128k(args, D, api, ctx):
         pose_sets.append(P)
     out = torch.zeros(world * F, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
 
-    # collective mode: two block arrays so that the all-reduce of evaluation i (RCCL's stream) overlaps the kernels of evaluation
-    # i+1 (our stream); work.wait() only orders the streams, the host never blocks inside the timed loop
-    bufs = [out, torch.zeros_like(out)]
+    # collective mode: every rank owns F rows, so the exchange is an all-gather of equal shards; two send / receive pairs so that the
+    # all-gather of evaluation i (RCCL's stream) overlaps the kernels of evaluation i+1 (our stream); work.wait() only orders the
+    # streams, the host never blocks inside the timed loop
+    sends = [torch.zeros(F, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda") for _ in range(2)]
+    outs = [out, torch.zeros_like(out)]
     works = [None, None]
 
     inner = max(1, args.inner)
@@ -276,9 +278,8 @@ def run_odometry128k(args, D, api, ctx):
         b = i % 2
         if works[b] is not None:
             works[b].wait()
-        bufs[b].zero_()  # non-owned rows must be zero before the sum
-        fset.linearize_device_async(pose_sets[i % len(pose_sets)], bufs[b].data_ptr(), rank * F)
-        works[b] = D.dist.all_reduce(bufs[b], async_op=True)  # RCCL sum over xGMI of the [world*F x 29] block array
+        fset.linearize_device_async(pose_sets[i % len(pose_sets)], sends[b].data_ptr(), 0)
+        works[b] = D.dist.all_gather_into_tensor(outs[b], sends[b], async_op=True)  # RCCL over xGMI: [world x F x 29] on every rank
 
     def step(i):
         for k in range(inner):
@@ -326,7 +327,7 @@ def run_odometry128k(args, D, api, ctx):
                 "factors_per_gpu": F, "points_per_factor": int(np.mean(n_pts)), "voxels_per_factor": int(np.mean(n_vox)),
                 "voxel_resolution_m": args.resolution, "factor_type": "binary", "linearize_passes_per_step": inner,
                 "factor_linearizations_per_step": inner * F * world,
-                "collective": "rccl_all_reduce[world*F x 29] f64" if world > 1 else "none", "device": ctx.device_info()["name"],
+                "collective": "rccl_all_gather[world x F x 29] f64" if world > 1 else "none", "device": ctx.device_info()["name"],
             },
             "roofline": roofline, "sync_single_factor_calls_per_s": 1e3 / sync_ms_c, "sync_single_factor_calls_per_s_via_python": sync_rate,
             # BASELINE.json configs[1] also names the single-factor loop {set pose, linearize, read the record back}:
@@ -429,7 +430,7 @@ def make_merged_submaps(api, ctx, n_submaps, frames_per_submap, rings, azimuths,
 
 def run_global256(args, D, api, ctx, extra_only=False):
     """configs[3] / metric M2: all-pairs matching cost over 256 MERGED submaps (general-covariance clouds, 1.0 m voxel maps), pair list
-    sharded over the ranks, RCCL all-reduce of the per-pair blocks (global_mapping.cpp:430-484 evaluates these factors one device, one
+    sharded over the ranks, RCCL all-gather of the per-pair blocks (global_mapping.cpp:430-484 evaluates these factors one device, one
     stream pool; the sharding is the new part).  value = seconds per evaluation of the whole cost (error + H/b of every pair)."""
     from glim_amd import multi, synth
 
@@ -450,18 +451,22 @@ def run_global256(args, D, api, ctx, extra_only=False):
     for f in ev.owned():
         i, j = pairs[f]
         fset.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i], clouds[j]))
-    blocks = torch.zeros(len(pairs), api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+    # every rank sends only the rows it owns (shards padded to the longest): one all-gather over xGMI, half the bytes of the zero-padded
+    # all-reduce of a dense [pairs x 29] array, nothing to zero; the factor-ordered array is one index_select on the device
+    max_rows, index = ev.gather_layout()
+    send = torch.zeros(max_rows, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(D.world * max_rows, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+    index_t = torch.as_tensor(index, device="cuda")
     local_poses = deltas[ev.lo:ev.hi]
+    result = {}
 
     def step(_):
-        if D.collective:
-            blocks.zero_()
-        fset.linearize_device_async(local_poses, blocks.data_ptr(), ev.lo)
-        multi.allreduce_blocks(blocks)
+        ev.gather_device(fset, deltas, send, gathered)
+        result["blocks"] = gathered.index_select(0, index_t)
 
     steps = max(args.steps, 20) if extra_only else args.steps
     elapsed = timed_steps(D, step, steps, max(args.warmup, 3))
-    host = blocks.cpu().numpy()
+    host = result["blocks"].cpu().numpy()
     n_pts = [costs[f] for f in ev.owned()]
     n_vox = [vmaps[pairs[f][0]].voxelmap_info()["num_voxels"] for f in ev.owned()]
     roof = roofline_of(fset, local_poses, n_pts, n_vox, 5)
@@ -482,7 +487,8 @@ def run_global256(args, D, api, ctx, extra_only=False):
                    "pairs": len(pairs), "pairs_this_rank": ev.hi - ev.lo, "mean_points_per_submap": float(np.mean(sizes)),
                    "mean_inlier_fraction": float(host[:, 0].mean() / np.mean(costs)),
                    "total_error": float(host[:, 1].sum()), "factor_linearizations_per_s": len(pairs) / sec,
-                   "collective": f"rccl_all_reduce[{len(pairs)} x 29] f64 ({len(pairs) * 29 * 8 / 1e6:.1f} MB)" if D.world > 1 else "none"},
+                   "collective": (f"rccl_all_gather[{D.world} x {max_rows} x 29] f64 ({D.world * max_rows * 29 * 8 / 1e6:.1f} MB gathered per rank)"
+                                  if D.world > 1 else "none")},
         "roofline": roof,
     }
 
@@ -645,7 +651,7 @@ def main():
     from glim_amd import api
 
     # One dedicated (non-default) torch stream is made current for the whole run and handed to the library: our kernels, torch's tensor
-    # ops (zero_) and the ordering points of RCCL's collectives (work.wait / the implicit wait of a synchronous all_reduce) are then all
+    # ops and the ordering points of RCCL's collectives (work.wait / the implicit wait of a synchronous collective) are then all
     # on the same stream, in program order.
     stream = D.torch.cuda.Stream()
     D.torch.cuda.set_stream(stream)

@@ -3,10 +3,11 @@
 The reference is single-device (no NCCL/MPI anywhere); this is the MI355X-native extension BASELINE.json's
 north_star asks for.  One process per GPU (`torch.distributed`; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 Clouds and voxel maps are replicated on every GPU (they are tiny next to 288 GB of HBM); only the FACTOR LIST is sharded, so no
-point data ever crosses xGMI.  Each rank writes the compact 29-double record of its own factors into its rows of a dense
-[n_factors x 29] FP64 array (all other rows zero) and ONE all-reduce(sum) completes the cost on every rank.  The binary factor's
-target-side blocks are expanded from the compact source block after the reduction (glim_amd_expand_compact), which keeps the
-message at 232 B per factor instead of 976 B.
+point data ever crosses xGMI.  Each rank writes the compact 29-double record of its own factors into a send buffer and ONE all-gather
+of the owned rows completes the cost on every rank (`gather_device` / `gather_host`: shards are padded to the longest one; half the
+bytes of the zero-padded all-reduce(sum) over a dense [n_factors x 29] array, which `evaluate_*` still offer -- semantically the same
+exchange, and the form BASELINE's north_star names).  The binary factor's target-side blocks are expanded from the compact source block
+after the exchange (glim_amd_expand_compact), which keeps the message at 232 B per factor instead of 976 B.
 """
 import numpy as np
 
@@ -63,6 +64,49 @@ class ShardedCostEvaluator:
 
     def owned(self):
         return range(self.lo, self.hi)
+
+    # ---- all-gather form: every rank sends only the rows it owns -------------------------------------------------------------------
+    def gather_layout(self):
+        """(max_rows, index): shards are padded to max_rows rows; row f of the assembled array is row index[f] of the gathered
+        [world_size * max_rows x 29] array."""
+        b = shard_bounds(self.costs, self.world_size)
+        max_rows = max(1, max(b[r + 1] - b[r] for r in range(self.world_size)))
+        index = np.empty(self.n, dtype=np.int64)
+        for r in range(self.world_size):
+            index[b[r]:b[r + 1]] = r * max_rows + np.arange(b[r + 1] - b[r])
+        return max_rows, index
+
+    def gather_host(self, local_rows):
+        """CPU/gloo form of the all-gather exchange: local_rows is [(hi-lo) x 29]; returns the assembled [n x 29] array on every rank."""
+        import torch
+        import torch.distributed as dist
+
+        max_rows, index = self.gather_layout()
+        send = torch.zeros(max_rows, COMPACT, dtype=torch.float64)
+        if self.hi > self.lo:
+            send[: self.hi - self.lo] = torch.as_tensor(np.asarray(local_rows, dtype=np.float64).reshape(self.hi - self.lo, COMPACT))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [torch.empty_like(send) for _ in range(self.world_size)]
+            dist.all_gather(parts, send)
+            gathered = torch.cat(parts, dim=0)
+        else:
+            gathered = send
+        return gathered[torch.as_tensor(index)]
+
+    def gather_device(self, fset, poses, send, gathered):
+        """GPU/RCCL form: `fset` holds this rank's factors; `send` is a [max_rows x 29] and `gathered` a [world_size * max_rows x 29]
+        float64 CUDA tensor (gather_layout()).  The finalise kernel writes the owned rows straight into `send`; one all-gather over xGMI
+        fills `gathered` on every rank (index it with gather_layout()[1] for the factor order).  Everything is enqueued on the current
+        stream; nothing is zeroed."""
+        import torch.distributed as dist
+
+        if self.hi > self.lo:
+            fset.linearize_device_async(poses[self.lo:self.hi], send.data_ptr(), 0)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_gather_into_tensor(gathered, send)
+        else:
+            gathered[: send.shape[0]].copy_(send)
+        return gathered
 
     def evaluate_host(self, local_rows):
         """CPU/gloo form: local_rows is [(hi-lo) x 29]; returns the reduced [n x 29] array on every rank."""

@@ -29,6 +29,23 @@ def test_shard_bounds_are_contiguous_and_balanced():
     assert multi.shard_bounds([1] * 8, 8) == list(range(9))
 
 
+def test_gather_layout_places_every_factor_once():
+    from glim_amd import multi
+
+    rng = np.random.default_rng(1)
+    for n, w in [(1, 2), (5, 8), (17, 2), (100, 8), (32640, 8), (32640, 3)]:
+        costs = rng.integers(1000, 70000, size=n)
+        b = multi.shard_bounds(costs, w)
+        max_rows, index = multi.ShardedCostEvaluator(costs, 0, w).gather_layout()
+        assert max_rows == max(b[r + 1] - b[r] for r in range(w)) and len(np.unique(index)) == n
+        for r in range(w):
+            assert np.array_equal(index[b[r]:b[r + 1]], r * max_rows + np.arange(b[r + 1] - b[r]))
+        # a single rank gathers nothing: the assembled array is its own rows
+        ev1 = multi.ShardedCostEvaluator(costs, 0, 1)
+        rows = rng.normal(size=(n, multi.COMPACT))
+        assert np.array_equal(ev1.gather_host(rows).numpy(), rows)
+
+
 def test_c_abi_shard_bounds_equals_python_rule():
     """The single-process multi-device entry (glim_amd_multi_set_factors) shards with glim_amd_shard_bounds; the one-process-per-GPU harness
     (glim_amd/multi.py) with shard_bounds: same rule, same boundaries."""
@@ -90,6 +107,9 @@ def _worker(rank, world, port, q):
         hip = dict(np.load(os.path.join(ROOT, "tests", "golden", "hip_rows.npz")))
         hip_blocks = ev.evaluate_host(hip["rows"][ev.lo:ev.hi]).numpy()
         assert np.array_equal(hip_blocks, hip["rows"])
+        # the all-gather form of the exchange (owned rows only, shards padded to the longest) assembles the same array
+        assert np.array_equal(ev.gather_host(hip["rows"][ev.lo:ev.hi]).numpy(), hip["rows"])
+        assert np.array_equal(ev.gather_host(np.array(rows).reshape(-1, multi.COMPACT)).numpy(), blocks)
         hip_maps = [orc.VoxelMap(1.0).insert(p, c.astype(np.float64)) for p, c in zip(scans, hip["covs"])]
         for f, (i, j) in enumerate(pairs):
             got = api.expand_compact(hip_blocks[f], hip["deltas"][f], api.FACTOR_BINARY)
