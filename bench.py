@@ -469,7 +469,10 @@ def run_global256(args, D, api, ctx, extra_only=False):
     host = result["blocks"].cpu().numpy()
     n_pts = [costs[f] for f in ev.owned()]
     n_vox = [vmaps[pairs[f][0]].voxelmap_info()["num_voxels"] for f in ev.owned()]
-    roof = roofline_of(fset, local_poses, n_pts, n_vox, 5)
+    traffic = measured_traffic("global256") if (S, args.submap_frames, args.submap_rings, args.submap_azimuths) == (256, 4, 40, 512) else None
+    if traffic:
+        traffic = (traffic[0] * len(n_pts), traffic[1])  # measured per factor (PMC passes over all 32 640 pairs), scaled to this rank's share
+    roof = roofline_of(fset, local_poses, n_pts, n_vox, 5, traffic)
     roof["kernel"] = "vgicp_kernel<LINEARIZE, general 36 B/pt>"
     # own-layout bytes: what this kernel must move at least -- 36 B per source point + one 64-byte sector per (factor, touched voxel)
     own = float(sum(36 * n + 64 * v for n, v in zip(n_pts, n_vox)))

@@ -9,6 +9,10 @@ from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+# optional 4th / 5th / 6th argument: workload tag (traffic file suffix + the tag bench.py looks up), stream bytes per point, points per launch
+TAG = sys.argv[4] if len(sys.argv) > 4 else "odometry128k"
+STREAM_BPP = float(sys.argv[5]) if len(sys.argv) > 5 else 24.0
+POINTS = float(sys.argv[6]) if len(sys.argv) > 6 else F * 131072.0
 os.makedirs(dst, exist_ok=True)
 
 
@@ -60,7 +64,7 @@ if os.path.exists(bench) and os.path.getsize(bench):
 # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B although the requests of a wide stream are 128 B -- double it.  The
 # request-size counters give the same correction directly: bytes = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B (separate PMC pass); both are
 # recorded, the request counters are the figure used (they need no assumption about which part of the reads is "wide").
-tj = os.path.join(dst, "traffic.json")
+tj = os.path.join(dst, "traffic.json" if TAG == "odometry128k" else f"traffic_{TAG}.json")
 dom = next((r for r in rows if "vgicp_kernel" in r["kernel"]), None)
 out = {}
 if dom:
@@ -82,7 +86,8 @@ if dom:
     wr = (write_kb or 0.0) * 1024.0
     if read is not None:
         out = {
-            "workload": f"odometry128k (bench.py default, F={F}), plane-form source clouds",
+            "workload": (f"odometry128k (bench.py default, F={F}), plane-form source clouds" if TAG == "odometry128k"
+                         else f"{TAG} (bench.py --workload {TAG}, {F} factors per launch, {STREAM_BPP:.0f} B/pt stream)"),
             "kernel": dom["kernel"][dom["kernel"].find("vgicp_kernel"):].split("(")[0],
             "kernel_avg_us_rocprof": dom["avg_us"],
             "source": "rocprofv3 --pmc passes of tools/profile.sh (FETCH_SIZE; WRITE_SIZE; TCC_EA0_RDREQ_{32,64,128}B_sum), averages over the launches of the dominant kernel",
@@ -92,7 +97,7 @@ if dom:
             "read_bytes_per_launch_from_2x_fetch_size": None if fetch_kb is None else 2.0 * fetch_kb * 1024.0,
             "write_bytes_per_launch": wr, "traffic_bytes_per_launch": read + wr,
             "factors_per_launch_when_measured": F, "traffic_bytes_per_factor": (read + wr) / F,
-            "stream_bytes_per_launch": 24.0 * F * 131072, "gather_bytes_per_launch": read - 24.0 * F * 131072,
+            "stream_bytes_per_launch": STREAM_BPP * POINTS, "gather_bytes_per_launch": read - STREAM_BPP * POINTS,
         }
         json.dump(out, open(tj, "w"), indent=1)
 print(json.dumps({"kernels": len(rows), "dominant": dom and {k: dom[k] for k in ("grid", "calls", "avg_us")}, "traffic_per_factor": out.get("traffic_bytes_per_factor")}))
