@@ -65,7 +65,7 @@ def measured_traffic(workload_tag):
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic*.json"))):
         try:
             t = json.load(open(f))
             if workload_tag in t.get("workload", ""):

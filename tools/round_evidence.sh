@@ -1,24 +1,31 @@
 #!/bin/bash
-# Everything profiles/<tag>/ is built from, in one gpurun call (run from the repo root on the GPU box):
-#   tools/round_evidence.sh r01
-# 1. tools/profile.sh: rocprofv3 kernel trace + stats, then the separate FETCH_SIZE / WRITE_SIZE passes, of the default bench
-# 2. the default bench line (with cpu_baseline) and the other workloads
-# 3. rocprofv3 kernel stats of the preprocessing front end
-# Summaries are made afterwards with tools/summarize_profile.py (CPU side).
-TAG=${1:-r01}
+# Everything profiles/<tag>/ is built from, in one gpurun call (run from the repo root on the GPU box):   tools/round_evidence.sh r02_final
+#  1. the -m gpu test-suite                      2. tools/profile.sh: rocprofv3 kernel trace + stats, then the separate PMC passes, of the default bench
+#  3. the default bench line (with cpu_baseline and m2_global256) and the other workloads; tools/batch_sweep.py
+#  4. PMC passes of the global256 workload (general kernel)
+# The raw rocprofv3 output is summarised HERE (tools/summarize_profile.py) and deleted: gpurun copies at most 64 MiB back.
+TAG=${1:-r02_final}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/evidence_$TAG
 mkdir -p $OUT
-timeout 400 bash $REPO/tools/profile.sh $TAG > $OUT/profile.log 2>&1 < /dev/null
 cd $REPO
-timeout 200 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null
+(timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $OUT/gputest.log
+timeout 500 bash $REPO/tools/profile.sh $TAG > $OUT/profile.log 2>&1 < /dev/null
+cd $REPO
+python tools/summarize_profile.py gpurun_out/prof_$TAG $OUT 128 > $OUT/summarize.log 2>&1
+rm -rf gpurun_out/prof_$TAG
+timeout 250 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null
 for w in submap20 global256 rgbd300k frontend128k; do
   timeout 300 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err < /dev/null
 done
-cd /tmp && export TMPDIR=/tmp
-for m in random voxelgrid; do
-  timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pp_$m -- python $REPO/tools/preprocess_prof.py $m > $OUT/pp_$m.log 2>&1 < /dev/null
-done
-ls $OUT
-tail -2 $OUT/bench.err
-cat $OUT/bench.json
+timeout 200 python tools/batch_sweep.py > $OUT/batch_sweep.json 2> $OUT/batch_sweep.err < /dev/null
+if [ -z "$SKIP_GLOBAL256_PMC" ]; then
+  SKIP_FETCH_PASS=1 BENCH_ARGS="--workload global256 --steps 3 --warmup 1 --no-cpu-baseline" timeout 600 bash $REPO/tools/profile.sh ${TAG}_g > $OUT/profile_g.log 2>&1 < /dev/null
+  cd $REPO
+  mkdir -p $OUT/global256
+  python tools/summarize_profile.py gpurun_out/prof_${TAG}_g $OUT/global256 32640 global256 36 2029810471 >> $OUT/summarize.log 2>&1
+  rm -rf gpurun_out/prof_${TAG}_g
+fi
+du -sh $REPO/gpurun_out
+cat $OUT/gputest.log | tail -3
+cut -c1-400 $OUT/bench.json
