@@ -8,6 +8,7 @@ class GaussianFactor {
 public:
   typedef std::shared_ptr<GaussianFactor> shared_ptr;
   virtual ~GaussianFactor() {}
+  std::map<Key, Matrix> hessianBlockDiagonal() const;
 };
 class HessianFactor : public GaussianFactor {
 public:

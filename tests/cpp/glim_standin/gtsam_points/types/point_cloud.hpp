@@ -20,5 +20,9 @@ struct PointCloud {  // raw-pointer view
   bool has_points() const { return points != nullptr; }
   bool has_covs() const { return covs != nullptr; }
   bool has_normals() const { return normals != nullptr; }
+  bool has_times() const { return times != nullptr; }
+  bool has_intensities() const { return intensities != nullptr; }
+  void save(const std::string& path) const;
+  void save_compact(const std::string& path) const;
 };
 }  // namespace gtsam_points

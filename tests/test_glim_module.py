@@ -1,5 +1,5 @@
-"""The outer plugin ABI: GLIM's own GPU odometry module source compiled UNMODIFIED against the drop-in include tree
-adapters/gtsam_points_hip, and that tree driven on the GPU the way the module drives gtsam_points.
+"""The outer plugin ABI: GLIM's own GPU module sources -- odometry_estimation_gpu.cpp, sub_mapping.cpp, global_mapping.cpp -- compiled
+UNMODIFIED against the drop-in include tree adapters/gtsam_points_hip, and that tree driven on the GPU the way the modules drive gtsam_points.
 
   * compile test (only where /root/reference exists): /root/reference/src/glim/odometry/odometry_estimation_gpu.cpp + adapters/glim/
     odometry_estimation_hip_create.cpp -> object files that reference this library's symbols and export create_odometry_estimation_module.
@@ -34,6 +34,36 @@ def test_reference_odometry_module_source_compiles_unmodified_against_the_hip_he
     subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c"] + INCLUDES + ["-I" + os.path.join(REF, "include"),
                                                                                 os.path.join(ROOT, "adapters", "glim", "odometry_estimation_hip_create.cpp"), "-o", create])
     assert " T create_odometry_estimation_module" in subprocess.run(["nm", create], capture_output=True, text=True, check=True).stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "glim", "mapping")), reason="the reference tree is not present on this machine")
+@pytest.mark.parametrize("unit, create, symbol, members", [
+    ("sub_mapping", "sub_mapping_hip_create.cpp", "create_sub_mapping_module", ["glim::SubMapping::insert_keyframe", "glim::SubMapping::create_submap"]),
+    ("global_mapping", "global_mapping_hip_create.cpp", "create_global_mapping_module",
+     ["glim::GlobalMapping::create_matching_cost_factors", "glim::GlobalMapping::insert_submap"]),
+])
+def test_reference_mapping_module_sources_compile_unmodified_against_the_hip_headers(tmp_path, unit, create, symbol, members):
+    """sub_mapping.cpp / global_mapping.cpp are part of libglim; their GPU branches sit inside #ifdef GTSAM_POINTS_USE_CUDA (sub_mapping.cpp:86-87,
+    165-171, 300-310, 393-399; global_mapping.cpp:110, 253-266, 322-335, 448-466, 743-748, 860).  A HIP build defines that macro and puts the
+    drop-in tree first: the reference translation units compile without an edit and their GPU call sites resolve to this library."""
+    src = os.path.join(REF, "src", "glim", "mapping", unit + ".cpp")
+    obj = str(tmp_path / (unit + ".o"))
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c", "-DGTSAM_POINTS_USE_CUDA"] + INCLUDES + ["-I" + os.path.join(REF, "include"), src, "-o", obj])
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
+    # the GPU branches were compiled (not preprocessed away) and resolved to the shim tree / the C ABI underneath
+    assert "gtsam_points::IntegratedVGICPFactorGPU::IntegratedVGICPFactorGPU(unsigned long, unsigned long, std::shared_ptr<gtsam_points::GaussianVoxelMap const> const&" in syms
+    assert "gtsam_points::PointCloudGPU::clone(gtsam_points::PointCloud const&, CUstream_st*)" in syms
+    assert "gtsam_points::GaussianVoxelMapGPU::GaussianVoxelMapGPU(float, int, int, double, CUstream_st*)" in syms
+    assert "gtsam_points::StreamTempBufferRoundRobin::StreamTempBufferRoundRobin(int)" in syms
+    assert "U glim_amd_cloud_create" in syms and "U glim_amd_voxelmap_insert" in syms and "U glim_amd_factor_set_add" in syms
+    if unit == "global_mapping":
+        assert "gtsam_points::overlap_gpu(" in syms and "U glim_amd_overlap" in syms
+    for m in members:
+        assert m in syms, m
+    entry = str(tmp_path / "create.o")
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c", "-DGTSAM_POINTS_USE_CUDA"] + INCLUDES + ["-I" + os.path.join(REF, "include"),
+                                                                                                          os.path.join(ROOT, "adapters", "glim", create), "-o", entry])
+    assert f" T {symbol}" in subprocess.run(["nm", entry], capture_output=True, text=True, check=True).stdout
 
 
 def _build_shim_test(tmp_path):
