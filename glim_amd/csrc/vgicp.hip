@@ -11,7 +11,7 @@
 //   M = (C_B + R C_A R^T)^-1,  r = mu_B - q,  e = r^T M r
 //   H_ss += J_s^T M J_s,  b_s += J_s^T M r,   J_s = [R hat(p) | -R]
 //
-// Two algebraic restructurings keep the kernel HBM-bound (DESIGN.md "K4"):
+// Two algebraic restructurings keep the per-point work small (DESIGN.md "K4"):
 //   (1) the rotation is factored out of the Jacobian: J_s = [R hat(p) | -R] = [hat(q') | -I] diag(R, R) with q' = R p = q - t, so the
 //       kernel accumulates H' = sum J'^T M J' = [[-Q M Q, Q M], [(Q M)^T, M]] (Q = hat(q')) and b' = [u x q'; -u], u = M r, in the
 //       target frame -- 21 + 6 + 1 sums per point -- and the finalise step applies diag(R, R) once per factor in FP64.  For
@@ -476,13 +476,13 @@ __device__ __forceinline__ void rotate_priority(int step) {
   }
 }
 
-// MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences and
-// Mahalanobis matrices frozen at the linearisation pose.  U: points per loop trip.  MINW: occupancy hint (waves per SIMD).
-//
-// The loop is software-pipelined and branch-free on the hot path: the coalesced point/covariance loads of trip t+1 and the
-// 48-byte voxel-slot gathers of trip t are issued back to back BEFORE the algebra of trip t, every lane runs the algebra
-// and the accumulation is predicated by `hit` (93 % of lanes hit, so predication beats divergence); the only branch left is
-// the rare hash-collision re-probe.  Each lane thus exposes one gather round trip per trip instead of three dependent ones.
+// The fused factor kernel.  MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences
+// and Mahalanobis matrices frozen at the linearisation pose.  PLANE: plane-form source stream (24 B/pt) or general (36 B/pt).  INLINE: the
+// pose of a single-factor set arrives in the kernel arguments.
+// One block = one (factor, chunk) row of the plan; its lanes walk the factor's points in 256-point hands dealt round robin to the factor's
+// blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane runs the algebra (a lane
+// without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  block_offset: first plan row of
+// this launch's segment; blocks_per_round: blocks the device takes per dispatch round (its CUs), for the priority phase.
 template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
 __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
