@@ -1,6 +1,6 @@
 // knn.hip -- kernel group K2: exact k-nearest-neighbour search on the device.
 // Replaces CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221, a nanoflann kd-tree):
-// for every point the k nearest points among ALL points including itself (buffers pre-filled with i, :197), ascending
+// for every point the k nearest points among ALL points including itself, ascending
 // squared distance; ties are ordered by ascending index (the oracle's rule; the reference leaves exact ties to the kd-tree).
 //
 // Distances are evaluated in FP64 as (dx*dx + dy*dy) + dz*dz on the FP32-representable inputs -- the same expression, in
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(int n, const float4
     const int valid = min(n, K);
 #pragma unroll
     for (int j = 0; j < K; j++)
-      if (j < k) out[(size_t)i * k + j] = (j < valid) ? best.idx[j] : i;
+      if (j < k) out[(size_t)i * k + j] = (j < valid) ? best.idx[j] : 0;  // fewer than k points: the reference's result vector stays 0 there (:193, :200)
   }
 }
 

@@ -184,7 +184,8 @@ int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const 
                               uint32_t* vals_out);
 
 /* kNN on device: CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221).
- * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> padded with i.
+ * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> the tail is 0 (what the
+ * reference's zero-initialised result vector holds there, cloud_preprocessor.cpp:193, :200).
  * Result stays on the device inside the cloud (and is copied to neighbors_out, n x k, when not NULL). */
 int glim_amd_cloud_find_neighbors(glim_amd_cloud* cloud, int k, int32_t* neighbors_out);
 /* upload caller-provided neighbours (n x k) instead; GLIM_AMD_ERR_INVALID if any index is outside [0, n). */

@@ -52,6 +52,9 @@ def ref_lib():
         L.ref_covariance_estimate.argtypes = [dp, C.c_int, ip, C.c_int, C.c_int, dp, dp, C.c_int]
         L.ref_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
         L.ref_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
+        if hasattr(L, "ref_preprocess"):
+            L.ref_preprocess.restype = C.c_int
+            L.ref_preprocess.argtypes = [dp, dp, dp, C.c_int, C.POINTER(PreprocessParams), dp, dp, dp, ip, dp, C.c_int]
         _ref = L
     return _ref
 
@@ -470,8 +473,11 @@ def find_inliers(points_xyz, k, std_mul, num_threads=0):
     return idx[:m].copy()
 
 
-def preprocess(points_xyz, times, intensities=None, params=None, neighbors=True, num_threads=0):
-    """CloudPreprocessor::preprocess_impl.  Returns dict(points N'x3, times, intensities|None, neighbors|None)."""
+def preprocess(points_xyz, times, intensities=None, params=None, neighbors=True, num_threads=0, ref=False):
+    """CloudPreprocessor::preprocess_impl.  Returns dict(points N'x3, times, intensities|None, neighbors|None).
+    ref=True: the reference's own cloud_preprocessor.cpp (oracle/_ref, ref_preprocess_shim.cpp) instead of the restatement; its three
+    gtsam_points sampling calls are answered by the restatement's functions, everything else is the reference's code (also returns
+    `scan_end_time`, for stamp = 0, and `k_neighbors`)."""
     prm = params if params is not None else preprocess_params()
     p4 = points4(points_xyz)
     n = p4.shape[0]
@@ -479,6 +485,14 @@ def preprocess(points_xyz, times, intensities=None, params=None, neighbors=True,
     it = _f64(intensities, (n,)) if intensities is not None else None
     op, ot, oi = np.zeros((max(n, 1), 4)), np.zeros(max(n, 1)), np.zeros(max(n, 1))
     nb = np.zeros((max(n, 1), prm.k_correspondences), dtype=np.int32) if neighbors else None
+    if ref:
+        meta = np.zeros(2)
+        m = ref_lib().ref_preprocess(_dp(p4), _dp(t), _dp(it) if it is not None else None, n, C.byref(prm), _dp(op), _dp(ot), _dp(oi),
+                                     _ip(nb) if nb is not None else None, _dp(meta), int(num_threads))
+        if m < 0:
+            raise ValueError("the reference preprocessor threw")
+        return dict(points=op[:m, :3].copy(), times=ot[:m].copy(), intensities=oi[:m].copy() if it is not None else None,
+                    neighbors=nb[:m].copy() if nb is not None else None, scan_end_time=float(meta[0]), k_neighbors=int(meta[1]))
     m = lib().orc_preprocess(_dp(p4), _dp(t), _dp(it) if it is not None else None, n, C.byref(prm), _dp(op), _dp(ot), _dp(oi),
                              _ip(nb) if nb is not None else None, int(num_threads))
     return dict(points=op[:m, :3].copy(), times=ot[:m].copy(), intensities=oi[:m].copy() if it is not None else None,

@@ -3,7 +3,7 @@
 // oracle/_ref/libglim_ref.so = /root/reference/src/glim/common/cloud_covariance_estimation.cpp + cloud_deskewing.cpp compiled UNMODIFIED from
 // where they lie (oracle/Makefile, target `ref`) against the stand-in headers of oracle/ref_standin/ (Eigen, GTSAM, gtsam_points and spdlog are not
 // installed in this image), plus this file.  The signatures mirror orc_covariance_estimate / orc_deskew_* (vgicp_oracle.h) so the tests can
-// run the restatement and the reference code side by side on the same arrays.
+// run the restatement and the reference code side by side on the same arrays.  (cloud_preprocessor.cpp: ref_preprocess_shim.cpp.)
 #include <glim/common/cloud_covariance_estimation.hpp>
 #include <glim/common/cloud_deskewing.hpp>
 

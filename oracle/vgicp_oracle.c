@@ -149,7 +149,9 @@ void orc_knn_bruteforce(const double* pts, int n, int k, int32_t* out, int num_t
     int cnt = 0;
     const int kk = k > 64 ? 64 : k;
     for (int j = 0; j < n; j++) knn_push(bd, bi, &cnt, kk, sqdist3(pts + 4 * i, pts + 4 * j), j);
-    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : i; /* :197 pre-fill with i */
+    /* fewer than k points: the tail is 0 -- the reference pre-fills its scratch indices with i (:197) but copies only the FOUND ones
+     * into the zero-initialised result (:193, :200): pinned by the compiled reference, tests/test_ref.py */
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : 0;
   }
 }
 
@@ -251,7 +253,7 @@ void orc_knn_grid(const double* pts, int n, int k, double cell, int32_t* out, in
         }
       }
     }
-    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : i;
+    for (int j = 0; j < k; j++) out[(size_t)i * k + j] = (j < cnt) ? bi[j] : 0; /* see orc_knn_bruteforce */
   }
   free(start);
   free(cid);

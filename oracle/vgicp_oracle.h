@@ -51,7 +51,8 @@ void orc_pose_inverse(const double* A12, double* Ainv12);
 /* ---- kNN (row a1)  src/glim/preprocess/cloud_preprocessor.cpp:190-221 --------------------------- */
 /* For every i the k nearest points among all N points INCLUDING i itself, ascending squared distance,
  * ties broken by ascending index (oracle rule; the reference's nanoflann order on exact ties is
- * implementation defined).  If fewer than k points exist the tail stays i (cloud_preprocessor.cpp:197).
+ * implementation defined).  If fewer than k points exist the tail is 0: the reference copies only the found indices into its
+ * zero-initialised result vector (cloud_preprocessor.cpp:193, :200; the pre-fill with i of :197 never reaches the output).
  * points: N x 4 doubles.  out: N x k int32.  Brute force O(N^2). */
 void orc_knn_bruteforce(const double* points4, int n, int k, int32_t* out, int num_threads);
 /* Same result through a uniform grid (exact; cell size `cell`, <=0 picks one from the density). */

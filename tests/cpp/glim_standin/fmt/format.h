@@ -1,4 +1,5 @@
 #pragma once
+#include <sstream>
 #include <string>
 namespace fmt {
 template <class... A>

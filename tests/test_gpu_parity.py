@@ -308,7 +308,7 @@ def test_knn_and_covariances_on_device_match_oracle(api, ctx, orc, small_pair):
     assert ok.mean() > 0.9
     np.testing.assert_allclose(covs[ok], rc[ok], rtol=0, atol=1e-5)
     np.testing.assert_allclose(normals[ok], rn[ok], rtol=0, atol=1e-5)
-    # fewer points than k: padded with the query index (cloud_preprocessor.cpp:197)
+    # fewer points than k: the tail is 0, like the reference's zero-initialised result vector (cloud_preprocessor.cpp:193, :200)
     tiny = api.PointCloudGPU.clone(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), ctx=ctx)
     np.testing.assert_array_equal(tiny.find_neighbors(5), orc.knn(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), 5))
 

@@ -140,11 +140,13 @@ def test_knn_brute_vs_grid_vs_ckdtree(orc):
     np.testing.assert_array_equal(np.sort(nb_b, 1), np.sort(ii, 1))
 
 
-def test_knn_fewer_points_than_k_pads_with_self(orc):
+def test_knn_fewer_points_than_k_leaves_the_tail_zero(orc):
+    """cloud_preprocessor.cpp:193-200: the result vector is zero-initialised and only the found indices are copied into it (the compiled
+    reference pins this: tests/test_ref.py)."""
     pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32)
     nb = orc.knn(pts, 5, method="brute")
     np.testing.assert_array_equal(nb[0], [0, 1, 2, 0, 0])
-    np.testing.assert_array_equal(nb[2], [2, 0, 1, 2, 2])
+    np.testing.assert_array_equal(nb[2], [2, 0, 1, 0, 0])
     np.testing.assert_array_equal(orc.knn(pts, 5, method="grid"), nb)
 
 

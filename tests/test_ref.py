@@ -128,3 +128,121 @@ def test_hip_deskew_matches_reference_generated_vectors(gold):
         ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
         assert np.all(np.abs(xyz.astype(np.float64) - want) <= ulp), name  # within one FP32 ulp of the FP64 reference value
         assert np.mean(xyz == want.astype(np.float32)) > 0.99, name
+
+
+# ---- scan preprocessing: the reference's own cloud_preprocessor.cpp (in-tree half; row a1 contract) --------------------
+@pytest.fixture(scope="module")
+def gold_pre():
+    return dict(np.load(os.path.join(HERE, "golden", "ref_preprocess.npz")))
+
+
+def _pre_module():
+    import sys
+
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden_ref_preprocess
+
+    return make_golden_ref_preprocess
+
+
+def _has_ref_preprocess(orc):
+    return orc.ref_lib() is not None and hasattr(orc.ref_lib(), "ref_preprocess")
+
+
+def test_oracle_preprocess_reproduces_reference_generated_vectors_bit_for_bit(orc, gold_pre):
+    """tests/golden/ref_preprocess.npz was produced by CloudPreprocessor::preprocess of /root/reference, compiled unmodified; the restatement
+    orc_preprocess must reproduce every surviving point, stamp, intensity, their order and the neighbour lists (also on boxes without the
+    reference tree)."""
+    mod = _pre_module()
+    out = mod.compute(orc, gold_pre, ref=False)
+    for k, v in out.items():
+        np.testing.assert_array_equal(v, gold_pre[k], err_msg=k)
+    # the fixture exercises what it claims: near / far / non-finite points dropped, the cropbox and the outlier filter remove points, the global
+    # shutter zeroes the stamps, stamps are ascending otherwise
+    n_in = len(gold_pre["points"])
+    assert len(gold_pre["voxelgrid.points"]) < n_in - 20
+    assert len(gold_pre["cropbox_lidar.points"]) < len(gold_pre["voxelgrid.points"]) and len(gold_pre["cropbox_imu.points"]) < len(gold_pre["voxelgrid.points"])
+    assert len(gold_pre["outliers.points"]) < len(gold_pre["voxelgrid.points"])
+    assert np.all(gold_pre["global_shutter.times"] == 0.0) and np.all(np.diff(gold_pre["voxelgrid.times"]) > 0)
+    assert np.isfinite(gold_pre["voxelgrid.points"]).all()
+    assert gold_pre["range_window.neighbors"].shape[1] == 8
+    d = np.linalg.norm(gold_pre["range_window.points"], axis=1)
+    assert d.min() > 5.0 and d.max() < 25.0
+
+
+def test_compiled_reference_preprocessor_reproduces_its_own_fixture(orc, gold_pre):
+    if not _has_ref_preprocess(orc):
+        pytest.skip("oracle/_ref is not built here and /root/reference is absent")
+    out = _pre_module().compute(orc, gold_pre, ref=True)
+    for k, v in out.items():
+        np.testing.assert_array_equal(v, gold_pre[k], err_msg=k)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_restatement_equals_compiled_reference_preprocessor_on_random_and_edge_inputs(orc, seed):
+    if not _has_ref_preprocess(orc):
+        pytest.skip("oracle/_ref is not built here and /root/reference is absent")
+    rng = np.random.default_rng(seed)
+    mod = _pre_module()
+
+    def both(pts, times, inten, prm):
+        a = orc.preprocess(pts, times, inten, prm)
+        b = orc.preprocess(pts, times, inten, prm, ref=True)
+        for k in ("points", "times", "neighbors"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        if inten is not None:
+            np.testing.assert_array_equal(a["intensities"], b["intensities"])
+        assert b["k_neighbors"] == prm.k_correspondences
+        assert b["scan_end_time"] == (b["times"][-1] if len(b["times"]) else 0.0)  # stamp = 0 in the shim
+        return b
+
+    n = 3000
+    pts = rng.uniform(-40, 40, size=(n, 3)) * [1.0, 1.0, 0.15]
+    times = rng.permutation(np.sort(rng.uniform(0, 0.1, n)))
+    inten = rng.uniform(0, 255, n)
+    for name in mod.CASES:
+        both(pts, times, inten, mod.params_of(orc, name))
+    both(pts, times, None, mod.params_of(orc, "voxelgrid"))  # no intensities
+    # points exactly ON the distance thresholds are dropped (strict comparisons, cloud_preprocessor.cpp:124) and points exactly on the faces of
+    # the crop box count as inside (>= / <=, :146, :154); voxel size far below the spacing so that every point survives the sampling as itself
+    edge = np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, 1.0], [100.0, 0, 0], [0, 60.0, 80.0], [2.0, 0, 0], [-2.0, 3.0, 0.5], [5.0, 5.0, 2.0], [-5.0, 0.0, 0.0],
+                     [5.0000001, 0, 0], [4.0, 4.0, 2.0000001], [7.0, 1.0, 0.0], [0.5, 0.5, 0.5], [30.0, -20.0, 1.0]])
+    et = np.arange(len(edge)) * 1e-3
+    r = both(edge, et, None, orc.preprocess_params(use_random_grid_downsampling=0, downsample_resolution=1e-3, distance_near_thresh=1.0, distance_far_thresh=100.0,
+                                                   k_correspondences=5))
+    kept = {tuple(p) for p in r["points"]}
+    assert (1.0, 0.0, 0.0) not in kept and (100.0, 0.0, 0.0) not in kept and (0.0, 60.0, 80.0) not in kept and (0.5, 0.5, 0.5) not in kept
+    r = both(edge, et, None, orc.preprocess_params(use_random_grid_downsampling=0, downsample_resolution=1e-3, distance_near_thresh=0.1, enable_cropbox_filter=1,
+                                                   crop_bbox_min=(-5, -5, -2), crop_bbox_max=(5, 5, 2), k_correspondences=5))
+    kept = {tuple(p) for p in r["points"]}
+    assert (5.0, 5.0, 2.0) not in kept and (-5.0, 0.0, 0.0) not in kept and (5.0000001, 0.0, 0.0) in kept and (4.0, 4.0, 2.0000001) in kept
+    # fewer points than k: the unfilled slots of a neighbour row are 0 -- the scratch indices are pre-filled with i (:197) but only the FOUND ones
+    # are copied into the zero-initialised result (:193, :200); nothing survives; empty input
+    r = both(edge[5:8], et[5:8], None, orc.preprocess_params(use_random_grid_downsampling=0, downsample_resolution=1e-3, k_correspondences=10))
+    assert r["neighbors"].shape == (3, 10) and np.all(r["neighbors"][:, 3:] == 0)
+    assert len(both(edge[:3], et[:3], None, orc.preprocess_params(use_random_grid_downsampling=0, downsample_resolution=1e-3, distance_near_thresh=1.0))["points"]) == 0
+    assert len(both(np.zeros((0, 3)), np.zeros(0), None, orc.preprocess_params(use_random_grid_downsampling=0, downsample_resolution=0.5))["points"]) == 0
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_matches_reference_generated_vectors(gold_pre, orc):
+    """glim_amd_preprocess against the vectors the reference's own CloudPreprocessor produced: surviving points (FP64), stamps, intensities and their
+    order bit for bit in every configuration; neighbour lists where the survivors are FP32-representable (the samplers that SELECT points -- the
+    device kNN runs on the FP32 image of the cloud, so for voxel-averaged points it is compared on that image)."""
+    from glim_amd import api
+
+    mod = _pre_module()
+    ctx = api.Context(0, 1)
+    for name, kw in mod.CASES.items():
+        kw = dict(kw)
+        if kw.get("crop_bbox_frame_imu"):
+            kw["T_imu_lidar"] = orc.se3_exp(np.array(mod.T_IMU_LIDAR_XI))
+        g = api.PointCloudGPU.preprocess(gold_pre["points"], gold_pre["times"], gold_pre["intensities"], api.preprocess_params(**kw), ctx=ctx)
+        got = g.download_frame()
+        for k in ("points", "times", "intensities"):
+            np.testing.assert_array_equal(got[k], gold_pre[f"{name}.{k}"], err_msg=f"{name}.{k}")
+        if kw.get("use_random_grid_downsampling"):
+            np.testing.assert_array_equal(got["neighbors"], gold_pre[f"{name}.neighbors"], err_msg=name)
+        else:
+            xyz, _, _ = g.download(covs=False, normals=False)
+            np.testing.assert_array_equal(got["neighbors"], orc.knn(xyz.astype(np.float64), got["k_neighbors"]), err_msg=name)
