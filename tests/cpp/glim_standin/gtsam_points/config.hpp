@@ -3,3 +3,6 @@
 // libglim defines it on the command line (adapters/gtsam_points_hip/README.md)
 #define GTSAM_POINTS_VERSION_MAJOR 1
 #define GTSAM_POINTS_VERSION_MINOR 2
+#define GTSAM_POINTS_VERSION_PATCH 2
+#define GTSAM_POINTS_VERSION_STRING "1.2.2"
+#define GTSAM_POINTS_GIT_HASH "stand-in"

@@ -10,6 +10,8 @@
 
 #include <gtsam/inference/Symbol.h>
 #include <gtsam/nonlinear/NonlinearFactorGraph.h>
+#include <gtsam_points/cuda/cuda_device_prop.hpp>
+#include <gtsam_points/cuda/cuda_memory.hpp>
 #include <gtsam_points/cuda/cuda_stream.hpp>
 #include <gtsam_points/cuda/nonlinear_factor_set_gpu.hpp>
 #include <gtsam_points/cuda/nonlinear_factor_set_gpu_create.hpp>
@@ -161,6 +163,12 @@ int main() {
   const double ov_single = gtsam_points::overlap_gpu(voxelmaps[1], frame1, delta, *stream);
   REQUIRE(ov_multi >= ov_single && ov_single > 0.5 && ov_multi <= 1.0);
   REQUIRE(gtsam_points::overlap_auto(voxelmaps[1], frame1, delta) == ov_single);
+  // src/glim/util/debug.cpp:84 and src/glim/viewer/memory_monitor.cpp:39: device names and memory figures through the same headers
+  const std::vector<std::string> devices = gtsam_points::cuda_device_names();
+  REQUIRE(!devices.empty() && !devices[0].empty());
+  size_t gpu_free = 0, gpu_total = 0;
+  gtsam_points::cuda_mem_get_info(&gpu_free, &gpu_total);
+  REQUIRE(gpu_total > (size_t)64 << 30 && gpu_free > 0 && gpu_free <= gpu_total);  // an MI355X carries 288 GB
   std::printf("test_shim OK (inlier fractions %.3f %.3f %.3f, overlap %.3f)\n", (double)want[0].num_inliers / 30000.0, (double)want[1].num_inliers / 30000.0,
               (double)want[2].num_inliers / 30000.0, ov_single);
   return 0;

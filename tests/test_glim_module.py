@@ -66,6 +66,22 @@ def test_reference_mapping_module_sources_compile_unmodified_against_the_hip_hea
     assert f" T {symbol}" in subprocess.run(["nm", entry], capture_output=True, text=True, check=True).stdout
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "glim", "util")), reason="the reference tree is not present on this machine")
+@pytest.mark.parametrize("unit, wants", [
+    ("util/debug.cpp", ["gtsam_points::cuda_device_names", "U glim_amd_device_count", "U glim_amd_device_info"]),
+    ("viewer/memory_monitor.cpp", ["gtsam_points::cuda_mem_get_info", "U glim_amd_device_info"]),
+])
+def test_reference_device_info_call_sites_compile_unmodified(tmp_path, unit, wants):
+    """The two remaining non-viewer files that name the GPU library: the system-info dump (src/glim/util/debug.cpp:81-89, cuda_device_names) and
+    the memory monitor (src/glim/viewer/memory_monitor.cpp:36-47, cuda_mem_get_info) resolve to glim_amd_device_info through the shim tree."""
+    obj = str(tmp_path / "unit.o")
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-w", "-c", "-DGTSAM_POINTS_USE_CUDA"] + INCLUDES + ["-I" + os.path.join(REF, "include"),
+                                                                                                          os.path.join(REF, "src", "glim", unit), "-o", obj])
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True, check=True).stdout
+    for w in wants:
+        assert w in syms, w
+
+
 def _build_shim_test(tmp_path):
     from glim_amd import _lib
 
