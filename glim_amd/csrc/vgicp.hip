@@ -239,6 +239,79 @@ struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: liv
   float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
 
+// Opt-in variant (round-2 experiment, measured -1.5 % on the bench workload, kept out of the default build: DESIGN.md 4.1(d)): the point
+// transform in FP32 with an exactness guard instead of FP64.  Build with -DGLIM_AMD_K4_F32_TRANSFORM=1 (tools/ab_variant.sh).
+#ifndef GLIM_AMD_K4_F32_TRANSFORM
+#define GLIM_AMD_K4_F32_TRANSFORM 0
+#endif
+#if GLIM_AMD_K4_F32_TRANSFORM
+// FP32 image of the linearisation pose and of the voxel grid, plus the constants of the exactness guard below (wave-uniform).
+struct Pose32 {
+  float tx, ty, tz;  // translation
+  float inv_res, res;
+  float ke, ce;      // guard: E = ke * (|px| + |py| + |pz|) + ce,  ke = 2^-21 / res,  ce = ke * max |t|
+  float ecap;        // largest E for which the FP32 residual is accepted: 2^-14 m in voxel units
+};
+
+// FP64 transform of one point with the oracle's fma order, its voxel and its position inside the voxel relative to the centre.
+__device__ __forceinline__ void exact_cell(const double* __restrict__ T, double inv_res, float px, float py, float pz, int& cx, int& cy, int& cz, float& dx,
+                                           float& dy, float& dz, float& qx, float& qy, float& qz) {
+  double x, y, z;
+  transform_point_d(T, (double)px, (double)py, (double)pz, x, y, z);
+  const double tx = x * inv_res, ty = y * inv_res, tz = z * inv_res;
+  const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+  cx = __double2int_rz(fx); cy = __double2int_rz(fy); cz = __double2int_rz(fz);  // out-of-range values saturate and fail the key range check
+  dx = (float)(tx - fx) - 0.5f; dy = (float)(ty - fy) - 0.5f; dz = (float)(tz - fz) - 0.5f;
+  qx = (float)x; qy = (float)y; qz = (float)z;
+}
+
+// q = R p + t, its voxel (cx, cy, cz), its position inside the voxel relative to the centre (dx, dy, dz in voxel units).
+//
+// The voxel coordinate must be the one the CPU factor gets from FP64 arithmetic (bit-exact correspondences are the parity contract), but FP64
+// and its conversions issue at half the FP32 rate on gfx950 (tools/ubench/valu_rate.hip: 2.4-2.5 vs 1.0-1.25 ticks per wave instruction).
+// So the transform runs in FP32 with a proof obligation attached: with R, t, 1/res rounded to FP32 and three fused multiply-adds per
+// axis, the FP32 voxel position t32 differs from the FP64 one by less than 6.1 * 2^-24 * (|px| + |py| + |pz| + |t|) / res (one rounding of
+// each input, one per fma, one for the product with 1/res; |R_ij| <= 1).  If t32 lies at least E = 8 * 2^-24 * (...) / res inside its unit
+// interval on all three axes, floor(t32) IS the FP64 coordinate (tests/test_fp32_guard.py checks the claim on the CPU, adversarial points
+// included).  Lanes closer than E to a voxel face (about 3e-4 of all points at 0.5 m voxels and 60 m range; also NaNs and coordinates
+// beyond 2^20 voxels) take the FP64 path, as a wave-uniform branch.  Residuals of FP32 lanes carry the FP32 transform's rounding
+// (<= 3.6e-7 of |p|_1 + |t|, like the reference's GPU kernels) instead of FP64's; the FP32 path is only taken where that stays below
+// 2^-14 m (|p|_1 + |t|_inf <= 128 m: every point of a sensor-centred scan); maps far from the origin keep the FP64 residual.
+__device__ __forceinline__ void locate_point(const double* __restrict__ Tl, double inv_res, const Pose32& P, const Rot32& R, float px, float py, float pz, int& cx,
+                                             int& cy, int& cz, float& dx, float& dy, float& dz, float& qx, float& qy, float& qz) {
+  qx = fmaf(R.r00, px, fmaf(R.r01, py, fmaf(R.r02, pz, P.tx)));
+  qy = fmaf(R.r10, px, fmaf(R.r11, py, fmaf(R.r12, pz, P.ty)));
+  qz = fmaf(R.r20, px, fmaf(R.r21, py, fmaf(R.r22, pz, P.tz)));
+  const float ux = qx * P.inv_res, uy = qy * P.inv_res, uz = qz * P.inv_res;
+  const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+  cx = (int)fx; cy = (int)fy; cz = (int)fz;
+  dx = (ux - fx) - 0.5f; dy = (uy - fy) - 0.5f; dz = (uz - fz) - 0.5f;
+  const float E = fmaf(fabsf(px) + fabsf(py) + fabsf(pz), P.ke, P.ce);
+  const bool exact = (fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) <= 0.5f - E) && (E <= P.ecap);  // false for NaN
+  if (__any(!exact)) {
+    int ex, ey, ez;
+    float edx, edy, edz, eqx, eqy, eqz;
+    exact_cell(Tl, inv_res, px, py, pz, ex, ey, ez, edx, edy, edz, eqx, eqy, eqz);
+    if (!exact) {
+      cx = ex; cy = ey; cz = ez;
+      dx = edx; dy = edy; dz = edz;
+      qx = eqx; qy = eqy; qz = eqz;
+    }
+  }
+}
+
+__device__ __forceinline__ Pose32 make_pose32(const double* __restrict__ T, double res, double inv_res) {
+  Pose32 P;
+  P.tx = (float)T[3]; P.ty = (float)T[7]; P.tz = (float)T[11];
+  P.inv_res = (float)inv_res;
+  P.res = (float)res;
+  P.ke = 4.76837158203125e-7f * P.inv_res;  // 2^-21 / res
+  P.ce = P.ke * fmaxf(fabsf(P.tx), fmaxf(fabsf(P.ty), fabsf(P.tz))) * 1.0000002f;
+  P.ecap = 6.103515625e-5f * P.inv_res;  // 2^-14 m
+  return P;
+}
+#endif
+
 // What a point carries from the probe stage (trip t-1) to the algebra stage (trip t) of the pipelined loop.
 template <bool PLANE>
 struct Probe {
@@ -255,6 +328,15 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
                                                     const double* __restrict__ Te, const Rot32& R, bool validate, int last) {
   Probe<PLANE> o;
   const bool ok = in_trip && (i < d.n);
+#if GLIM_AMD_K4_F32_TRANSFORM
+  const Pose32 P32 = make_pose32(Tl, d.res, d.inv_res);  // wave-uniform, hoisted out of the loop by the compiler
+  int cx, cy, cz;
+  float dx32, dy32, dz32, qx, qy, qz;
+  locate_point(Tl, d.inv_res, P32, R, pt.p.x, pt.p.y, pt.p.z, cx, cy, cz, dx32, dy32, dz32, qx, qy, qz);
+  o.qp0 = qx - P32.tx;
+  o.qp1 = qy - P32.ty;
+  o.qp2 = qz - P32.tz;
+#else
   double qx, qy, qz;
   transform_point_d(Tl, (double)pt.p.x, (double)pt.p.y, (double)pt.p.z, qx, qy, qz);
   const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
@@ -265,6 +347,7 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
   // in-voxel fraction for free
   const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
   const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
+#endif
   // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
   const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
   bool keep = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
@@ -276,10 +359,16 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
     o.qr1 = (float)(ey - ((double)cy + 0.5) * d.res);
     o.qr2 = (float)(ez - ((double)cz + 0.5) * d.res);
   } else {
+#if GLIM_AMD_K4_F32_TRANSFORM
+    o.qr0 = dx32 * P32.res;
+    o.qr1 = dy32 * P32.res;
+    o.qr2 = dz32 * P32.res;
+#else
     const float resf = (float)d.res;
     o.qr0 = ((float)(tx - fx) - 0.5f) * resf;
     o.qr1 = ((float)(ty - fy) - 0.5f) * resf;
     o.qr2 = ((float)(tz - fz) - 0.5f) * resf;
+#endif
   }
   if (PLANE) {
     // C_A = I - (1 - 1e-3) n n^T  =>  R C_A R^T = I - (1 - 1e-3) m m^T with m = R n
@@ -588,9 +677,18 @@ __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, con
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
   const float4 p4 = d.pts[i];
+#if GLIM_AMD_K4_F32_TRANSFORM
+  // the same arithmetic as the fused kernels (locate_point), so what this entry reports is what they used
+  const Rot32 R32 = {(float)pose[0], (float)pose[1], (float)pose[2], (float)pose[4], (float)pose[5], (float)pose[6], (float)pose[8], (float)pose[9], (float)pose[10]};
+  const Pose32 P32 = make_pose32(pose, d.res, d.inv_res);
+  int cx, cy, cz;
+  float dx32, dy32, dz32, qx, qy, qz;
+  locate_point(pose, d.inv_res, P32, R32, p4.x, p4.y, p4.z, cx, cy, cz, dx32, dy32, dz32, qx, qy, qz);
+#else
   double qx, qy, qz;
   transform_point_d(pose, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
   const int cx = fast_floor_d(qx * d.inv_res), cy = fast_floor_d(qy * d.inv_res), cz = fast_floor_d(qz * d.inv_res);
+#endif
   bool hit = find_slot(d.buckets, d.num_buckets, pack_key(cx, cy, cz)) >= 0;
   if (hit && (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals) {
     const float4 nn = d.normals[i];

@@ -13,7 +13,7 @@ import tempfile
 def main():
     src, pat = sys.argv[1], sys.argv[2]
     with tempfile.NamedTemporaryFile(suffix=".s") as f:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "--cuda-device-only", "-S", src, "-o", f.name],
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "--cuda-device-only", "-S", *sys.argv[4:], src, "-o", f.name],
                               stderr=subprocess.DEVNULL)
         lines = open(f.name).read().splitlines()
     names = [l.split()[1] for l in lines if l.strip().startswith(".amdhsa_kernel ") and pat in l]
