@@ -132,7 +132,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_sharded_equals_unsharded_gloo_world2():
     import torch.multiprocessing as mp
 
@@ -147,8 +147,49 @@ def test_sharded_equals_unsharded_gloo_world2():
     for p in procs:
         p.start()
     for p in procs:
-        p.join(240)
+        p.join(420)
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 12  # contiguous shards covering all 12 factors
     assert all(r[3] < 1e-9 for r in res)
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from glim_amd import multi
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        # (number of factors, costs): fewer factors than ranks (some rank owns nothing), one dominant factor, ragged shards
+        for case, costs in enumerate([[7.0, 3.0], [1.0], [100.0, 1.0, 1.0, 1.0, 1.0], list(np.random.default_rng(5).integers(1, 9, size=23))]):
+            n = len(costs)
+            rows = np.random.default_rng(100 + case).normal(size=(n, multi.COMPACT))  # the same array on every rank
+            ev = multi.ShardedCostEvaluator(costs, rank, world)
+            ok = ok and np.array_equal(ev.gather_host(rows[ev.lo:ev.hi]).numpy(), rows)
+            ok = ok and np.array_equal(ev.evaluate_host(rows[ev.lo:ev.hi]).numpy(), rows)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ragged_and_empty_shards_gloo_world3():
+    """Three ranks, factor lists shorter than / not divisible by the world size: a rank that owns no factor still takes part in both forms of the
+    exchange and every rank assembles the full array."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(3)) == [(0, True), (1, True), (2, True)]
