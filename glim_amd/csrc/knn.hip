@@ -571,11 +571,24 @@ __global__ __launch_bounds__(256) void half_box_kernel(int n, int C, const float
   }
 }
 
-template <int K>
+// F32MASK: the mask pass of a chunk scan runs in FP32 on the float4 records themselves (the scheme of the pair-lane kernel below, which states
+// the error bound): "d32 <= thr * (1 + 2e-6)" can only ADD candidates, and every accepted candidate is re-evaluated with the oracle's FP64
+// expression before it is offered to the list, so the lists stay bit-identical -- 64 x 6 full-rate FP32 operations and one 16-byte LDS read
+// per candidate instead of 64 x 6 half-rate FP64 operations and three 8-byte reads.  The host only selects it when the cloud's extent keeps
+// FP32 squared distances finite.  (131 072-pt scan 0.495 -> 0.460 ms, 307 104-pt depth frame 0.766 -> 0.718 ms, same box.)
+// Where a wavefront's time goes (per-wavefront counters of GLIM_AMD_KNN_DEBUG, least-squares fit over the 2048 wavefronts of a 131 072-pt
+// scan, tools/knn_debug.py): 47 us fixed (the walk over the 32 groups of chunk boxes, the seeds) + 2.7 us per scanned chunk (x 10.9) +
+// 0.51 us per insertion round (x 116): the lock-step insertion rounds are 44 % of the mean wavefront and 60 % of the slowest one.  Measured
+// against this kernel on one box and NOT adopted (profiles/r02/probe/knn_chunk_variants_ab.txt; all bit-identical): the mask pass reading the
+// candidates with v_readlane instead of LDS (-1 %); branch-free insertion (K compares + selects, or min / max for the distances) instead of
+// the early-exit bubble, with one or two candidates per round (+17 ... +28 %); issuing the box loads of the next group, the points of the
+// next candidate chunk and the first three chunks ahead of their use, with the per-lane box test fed by v_readlane (+4 %).
+template <int K, bool F32MASK>
 __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const float4* __restrict__ sorted, const float* __restrict__ box, int k,
                                                         int32_t* __restrict__ out, int* __restrict__ dbg) {
-  __shared__ double s_xyz[4][CHUNK][3];
-  __shared__ int s_idx[4][CHUNK];
+  __shared__ double s_xyz[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK][3];
+  __shared__ int s_idx[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK];
+  __shared__ float4 s_pt[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + w;
   if (c >= C) return;  // whole wavefront
@@ -584,7 +597,8 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   const bool live = self >= 0;
   // padding lanes of the last chunk query the chunk's first point, so that they never widen the search
   const float4 q0 = sorted[c * CHUNK];
-  const double qx = live ? (double)q4.x : (double)q0.x, qy = live ? (double)q4.y : (double)q0.y, qz = live ? (double)q4.z : (double)q0.z;
+  const float qxf = live ? q4.x : q0.x, qyf = live ? q4.y : q0.y, qzf = live ? q4.z : q0.z;
+  const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
   TopK<K> best;
   best.init(self);
   int dbg_tiles = 0, dbg_pops = 0;
@@ -594,15 +608,32 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   // records which ones pass its k-th best of the moment in a 64-bit mask (inclusive test, so ties are kept); (2) the lanes pop
   // their masks together -- the K-step insertion then runs max-popcount times per chunk instead of once per candidate, and for
   // most chunks after the first three nobody has anything to insert.
+  // candidate j of the staged chunk: its index (< 0: padding) and its exact squared distance
+  auto cand_idx = [&](int j) -> int {
+    if constexpr (F32MASK) return __float_as_int(s_pt[w][j].w);
+    else return s_idx[w][j];
+  };
+  auto cand_dist = [&](int j) -> double {
+    if constexpr (F32MASK) {
+      const float4 cp = s_pt[w][j];
+      return sqdist(qx, qy, qz, (double)cp.x, (double)cp.y, (double)cp.z);
+    } else {
+      return sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
+    }
+  };
   auto scan_chunk = [&](int cc, bool need, bool seed) {
     const float4 p = sorted[cc * CHUNK + lane];
     dbg_tiles++;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    s_xyz[w][lane][0] = (double)p.x;
-    s_xyz[w][lane][1] = (double)p.y;
-    s_xyz[w][lane][2] = (double)p.z;
-    s_idx[w][lane] = __float_as_int(p.w);
+    if constexpr (F32MASK) {
+      s_pt[w][lane] = p;
+    } else {
+      s_xyz[w][lane][0] = (double)p.x;
+      s_xyz[w][lane][1] = (double)p.y;
+      s_xyz[w][lane][2] = (double)p.z;
+      s_idx[w][lane] = __float_as_int(p.w);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     unsigned long long seeded = 0ull;
@@ -615,21 +646,38 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         const int off = (t & 1) ? ((t + 1) >> 1) : -(t >> 1);
         const int j = (lane + off) & (CHUNK - 1);
         seeded |= 1ull << j;
-        const int idx = s_idx[w][j];
-        if (idx >= 0) best.push(sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]), idx);
+        const int idx = cand_idx(j);
+        if (idx >= 0) best.push(cand_dist(j), idx);
       }
     }
     const double thr = need ? best.d[K - 1] : -1.0;  // lanes that do not need this chunk accept nothing
     unsigned int mlo = 0u, mhi = 0u;
+    if constexpr (F32MASK) {
+      // FP32 image of the bound, inflated beyond the FP32 evaluation error (see knn_pair_kernel); -1 stays negative, +inf stays +inf
+      const float thr32 = (float)(thr * 1.000002) + 1e-37f;
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-      const double d = sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
-      mlo |= (d <= thr ? 1u : 0u) << j;
-    }
+      for (int j = 0; j < 32; j++) {
+        const float4 cp = s_pt[w][j];
+        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
+        mlo |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
+      }
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-      const double d = sqdist(qx, qy, qz, s_xyz[w][32 + j][0], s_xyz[w][32 + j][1], s_xyz[w][32 + j][2]);
-      mhi |= (d <= thr ? 1u : 0u) << j;
+      for (int j = 0; j < 32; j++) {
+        const float4 cp = s_pt[w][32 + j];
+        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
+        mhi |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const double d = sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
+        mlo |= (d <= thr ? 1u : 0u) << j;
+      }
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const double d = sqdist(qx, qy, qz, s_xyz[w][32 + j][0], s_xyz[w][32 + j][1], s_xyz[w][32 + j][2]);
+        mhi |= (d <= thr ? 1u : 0u) << j;
+      }
     }
     unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
     while (__any(m != 0ull)) {
@@ -637,8 +685,9 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       if (m != 0ull) {
         const int j = (int)__builtin_ctzll(m);
         m &= m - 1ull;
-        const int idx = s_idx[w][j];
-        if (idx >= 0) best.push(sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]), idx);
+        const int idx = cand_idx(j);
+        // (F32MASK: a candidate the inflated FP32 bound let through is settled by the exact (distance, index) test of push)
+        if (idx >= 0) best.push(cand_dist(j), idx);
       }
     }
   };
@@ -698,8 +747,14 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
 }
 
 template <int K>
-void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg) {
-  knn_chunk_kernel<K><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool f32mask) {
+#ifdef GLIM_AMD_KNN_KEEP_F64MASK  // development builds: the all-FP64 mask pass as a cross-check (GLIM_AMD_KNN_F64MASK=1 selects it)
+  if (!f32mask) {
+    knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+    return;
+  }
+#endif
+  knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
 }
 
 // ---- pair-lane variant (default): 32 queries per wavefront, two lanes per query ------------------------------------------------------------
@@ -915,8 +970,13 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // bound shared through LDS (ds_min_u64) and the lists merged by rank at the end -- bit-identical lists, but 0.73 / 0.62 ms against 0.50 ms
   // at 131 072 points and 1.06 / 1.19 against 0.77 ms at 307 104: every list has to be filled and pruned on its own, so the total work grows
   // faster than the longest wavefront shrinks.
+  // The FP32 mask passes of both chunk kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than 1e18 m is
+  // answered by the exhaustive FP64 kernel instead.
+  const bool f32mask = getenv("GLIM_AMD_KNN_F64MASK") == nullptr;
   const bool pair_lanes = !dbg.p && k <= 16 && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
-  if (k > 0 && pair_lanes) {
+  if (k > 0 && !(ext < 1e18f)) {
+    DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
+  } else if (k > 0 && pair_lanes) {
     DeviceTemp box32;
     GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
     half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
@@ -924,7 +984,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
-    DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>());  // k == 0: ordering only
+    DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), f32mask);  // k == 0: ordering only
   }
   GA_HIP(hipGetLastError());
   if (dbg.p) {

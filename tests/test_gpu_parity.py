@@ -480,9 +480,10 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc, monkeypatch):
     np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
 
 
-@pytest.mark.parametrize("name", ["lattice", "identical", "offset", "two_scales"])
+@pytest.mark.parametrize("name", ["lattice", "identical", "offset", "two_scales", "astronomic"])
 def test_knn_exact_on_degenerate_distributions(api, ctx, orc, monkeypatch, name):
-    """Exact ties everywhere (lattice), all points identical, a cloud far from the origin, 1000x density contrast: both device paths."""
+    """Exact ties everywhere (lattice), all points identical, a cloud far from the origin, 1000x density contrast: both device paths.
+    "astronomic": an extent beyond 1e18 m, where FP32 squared distances overflow -- the chunk path must hand over to the exhaustive FP64 kernel."""
     rng = np.random.default_rng(5)
     if name == "lattice":
         pts = np.stack(np.meshgrid(np.arange(20), np.arange(20), np.arange(15), indexing="ij"), -1).reshape(-1, 3) * 0.25
@@ -490,6 +491,8 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, monkeypatch, name)
         pts = np.tile([[1.0, 2.0, 3.0]], (3000, 1))
     elif name == "offset":
         pts = rng.uniform(-1, 1, (6000, 3)) + [1e5, -2e5, 3e4]
+    elif name == "astronomic":
+        pts = rng.uniform(-1, 1, (3000, 3)) * 2e18
     else:
         pts = np.vstack([rng.normal(size=(4000, 3)) * 0.01, rng.uniform(-50, 50, (3000, 3))])
     pts = pts.astype(np.float32)
@@ -503,5 +506,7 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, monkeypatch, name)
             np.testing.assert_array_equal(g.find_neighbors(k), orc.knn(pts.astype(np.float64), k, method="brute"))
         monkeypatch.delenv(variant)
     monkeypatch.delenv("GLIM_AMD_KNN_CHUNKS")
+    if name == "astronomic":
+        return
     monkeypatch.setenv("GLIM_AMD_KNN_GRID", "1")
     np.testing.assert_array_equal(g.find_neighbors(10), ref)

@@ -19,3 +19,12 @@ worst = np.argsort(-d[:, 2])[:6]
 print("slowest wavefronts (chunk, tiles, rounds, us, box extent m):", [(int(c), int(d[c, 0]), int(d[c, 1]), round(d[c, 2] * 0.01, 1), d[c, 3] / 1000.0) for c in worst])
 print("box extent m: p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(d[:, 3] / 1000.0, [50, 90, 99, 100])))
 print("corr(time, tiles) %.2f  corr(time, rounds) %.2f" % (np.corrcoef(d[:, 2], d[:, 0])[0, 1], np.corrcoef(d[:, 2], d[:, 1])[0, 1]))
+# where a wavefront's time goes: least-squares fit  time = c0 + a * tiles + b * rounds  (c0: what every wavefront pays -- the walk over the groups)
+A = np.stack([np.ones(len(d)), d[:, 0], d[:, 1]], axis=1).astype(np.float64)
+t_us = d[:, 2] * 0.01
+coef, *_ = np.linalg.lstsq(A, t_us, rcond=None)
+res = t_us - A @ coef
+print("fit: time_us = %.1f + %.2f * tiles + %.3f * rounds   (R^2 %.3f; mean split: fixed %.1f, tiles %.1f, rounds %.1f us)" %
+      (coef[0], coef[1], coef[2], 1.0 - res.var() / t_us.var(), coef[0], coef[1] * d[:, 0].mean(), coef[2] * d[:, 1].mean()))
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], d)

@@ -1,7 +1,19 @@
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 sys.path.insert(0, '.')
 from glim_amd import api, synth
 from oracle import oracle as orc
+CHECK = os.environ.get('KNN_TIME_NOCHECK') is None  # timing only: skip the oracle comparison
+
+
+def ref_knn(pts):  # the oracle's lists, cached across the processes of one A/B session (same seeded points every time)
+    path = '/tmp/knn_ref_%d.npy' % len(pts)
+    if os.path.exists(path):
+        return np.load(path)
+    ref = orc.knn(pts, 10)
+    np.save(path, ref)
+    return ref
+
+
 ctx = api.Context(0, 1)
 scene = synth.Scene.default()
 for rings, az in ((128, 1024), (64, 1024)):
@@ -12,8 +24,7 @@ for rings, az in ((128, 1024), (64, 1024)):
     for _ in range(5): g.find_neighbors(10, download=False)
     dt = (time.perf_counter() - t) / 5
     nb = g.find_neighbors(10)
-    ref = orc.knn(pts, 10)
-    print(len(pts), 'knn ms', dt * 1e3, 'exact', bool((nb == ref).all()))
+    print(len(pts), 'knn ms', dt * 1e3, 'exact', bool((nb == ref_knn(pts)).all()) if CHECK else 'unchecked', flush=True)
     t = time.perf_counter(); g.estimate_covariances(10); print(' cov ms', (time.perf_counter() - t) * 1e3)
     t = time.perf_counter(); vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g); print(' vmap ms', (time.perf_counter() - t) * 1e3)
 # dense depth camera frame (config 5)
@@ -25,5 +36,5 @@ g.find_neighbors(10, download=False)
 t = time.perf_counter()
 for _ in range(5): g.find_neighbors(10, download=False)
 dt = (time.perf_counter() - t) / 5
-nb = g.find_neighbors(10); ref = orc.knn(pts, 10)
-print(len(pts), 'rgbd knn ms', dt * 1e3, 'exact', bool((nb == ref).all()), 'set-exact', bool((np.sort(nb,1)==np.sort(ref,1)).all()))
+nb = g.find_neighbors(10)
+print(len(pts), 'rgbd knn ms', dt * 1e3, 'exact', bool((nb == ref_knn(pts)).all()) if CHECK else 'unchecked', flush=True)
