@@ -655,6 +655,64 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
     if constexpr (F32MASK) {
       // FP32 image of the bound, inflated beyond the FP32 evaluation error (see knn_pair_kernel); -1 stays negative, +inf stays +inf
       const float thr32 = (float)(thr * 1.000002) + 1e-37f;
+#ifdef GLIM_AMD_KNN_SELECT
+      // Experiment for round 3, NOT yet run on a GPU (tools/knn_model.py "select_bits" emulates this code step by step on the CPU: lists unchanged,
+      // insertion rounds 116 -> 50 per wavefront and 395 -> 140 for the slowest at 2.5 selections per wavefront; with 2-3.5 us per selection the
+      // modelled wavefront goes 135 -> ~108 us on average and 323 -> ~213 us for the slowest one, which is what the launch lasts).  The lock-step insertion loop below lasts as long as the lane with the most accepted candidates, and a
+      // lane whose bound is still loose accepts most of a chunk although only a handful end up in its list.  So the 64 FP32 distances are kept
+      // in registers and every lane first finds, by bisection over FP32 bit patterns, a threshold t with
+      //     #(list entries with d <= t) + #(accepted candidates with d32 <= t) >= K;
+      // candidates with d32 > t * (1 + 2e-6) are then dropped without being popped: once the others are inserted the list holds K entries whose
+      // exact distances are <= t * (1 + 3e-7), strictly below the exact distance of every dropped candidate (> t * (1 + 2e-6) * (1 - 3e-7)).
+      float dv[CHUNK];
+#pragma unroll
+      for (int j = 0; j < CHUNK; j++) {
+        const float4 cp = s_pt[w][j];
+        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
+        dv[j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      }
+#pragma unroll
+      for (int j = 0; j < 32; j++) mlo |= (dv[j] <= thr32 ? 1u : 0u) << j;
+#pragma unroll
+      for (int j = 0; j < 32; j++) mhi |= (dv[32 + j] <= thr32 ? 1u : 0u) << j;
+      {
+        const unsigned long long m0 = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
+        constexpr int SELECT_MIN = 12;  // below this many accepted candidates in every lane the selection costs more than it saves (model)
+        if (__any(__popcll(m0) > SELECT_MIN)) {
+          const float inf32 = __int_as_float(0x7f800000);
+          // only candidates that are up for insertion count (rejected at thr, seeded and padding candidates become +inf)
+#pragma unroll
+          for (int j = 0; j < CHUNK; j++) dv[j] = ((m0 >> j) & 1ull) ? dv[j] : inf32;
+          auto count_le = [&](float t) -> int {
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < CHUNK; j++) cnt += dv[j] <= t ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < K; j++) cnt += best.d[j] <= (double)t ? 1 : 0;
+            return cnt;
+          };
+          unsigned int hi = __float_as_uint(fminf(thr32, 3.4028234e38f));  // a list that is not full yet searches below FLT_MAX
+          const bool sel = need && count_le(__uint_as_float(hi)) >= K;
+          unsigned int lo = hi > (16u << 23) ? hi - (16u << 23) : 0u;  // 16 octaves below the bound; invariant: count_le(hi) >= K
+          for (int step = 0; step < 8; step++) {                        // 2^27 bit patterns -> 2^19: t within 6 % of the smallest valid one
+            const unsigned int mid = lo + ((hi - lo) >> 1);
+            const bool ok = count_le(__uint_as_float(mid)) >= K;
+            hi = ok ? mid : hi;
+            lo = ok ? lo : mid + 1u;
+          }
+          const float keep = __uint_as_float(hi) * 1.000002f + 1e-37f;
+          unsigned int klo = 0u, khi = 0u;
+#pragma unroll
+          for (int j = 0; j < 32; j++) klo |= (dv[j] <= keep ? 1u : 0u) << j;
+#pragma unroll
+          for (int j = 0; j < 32; j++) khi |= (dv[32 + j] <= keep ? 1u : 0u) << j;
+          if (sel) {  // (seeded / rejected / padding candidates are +inf here: never kept)
+            mlo = klo;
+            mhi = khi;
+          }
+        }
+      }
+#else
 #pragma unroll
       for (int j = 0; j < 32; j++) {
         const float4 cp = s_pt[w][j];
@@ -667,6 +725,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
         mhi |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
       }
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < 32; j++) {
