@@ -322,7 +322,7 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
     (void)hipGetLastError();
     return GLIM_AMD_ERR_NOMEM;
   }
-  return m->run_all([&](int d) -> int {
+  const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
     GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[d]));
     for (int64_t f = m->bounds[d]; f < m->bounds[d + 1]; f++)
@@ -332,6 +332,12 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
     GA_HIP(hipStreamSynchronize(m->ctxs[d]->stream()));
     return (int)GLIM_AMD_OK;
   });
+  if (rc != GLIM_AMD_OK) {  // no half-built factor list: the handle is back to "no factors"
+    release_factors(m);
+    m->bounds.clear();
+    m->flags.clear();
+  }
+  return rc;
 }
 
 int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
@@ -349,11 +355,18 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   }
   if (!T) return GLIM_AMD_ERR_INVALID;
   const size_t slot = (size_t)m->max_rows * COMPACT;
+  // Two rounds over the workers: the kernels are enqueued first and the collective only if EVERY device managed to -- a device that failed
+  // before its ncclAllGather would leave the others waiting in theirs for ever.  (The first round only enqueues; the extra hand-over between
+  // the host threads costs ~20 us per evaluation.)
+  GA_TRY(m->run_all([&](int d) -> int {
+    GA_HIP(hipSetDevice(m->devices[d]));
+    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
+    if (hi > lo) GA_TRY(glim_amd_factor_set_linearize_device_async(m->sets[d], T + 12 * lo, m->d_gather[d], (int64_t)d * m->max_rows));
+    return (int)GLIM_AMD_OK;
+  }));
   const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
     hipStream_t st = m->ctxs[d]->stream();
-    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
-    if (hi > lo) GA_TRY(glim_amd_factor_set_linearize_device_async(m->sets[d], T + 12 * lo, m->d_gather[d], (int64_t)d * m->max_rows));
     if (m->use_rccl) {
       // in place: this device's slot is both the send buffer and its own segment of the receive buffer
       const ncclResult_t r = rccl().AllGather(m->d_gather[d] + (size_t)d * slot, m->d_gather[d], slot, ncclDouble, m->comms[d], st);
