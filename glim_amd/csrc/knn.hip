@@ -571,6 +571,42 @@ __global__ __launch_bounds__(256) void half_box_kernel(int n, int C, const float
   }
 }
 
+#ifdef GLIM_AMD_KNN_GROUPBOX
+// Experiment for round 3, NOT yet run on a GPU: boxes of the groups of 64 chunks, stored behind the chunk boxes (box[6 * (C + g) ...]).  A query
+// chunk first tests the (<= 256) group boxes against its search radius after the first three scans and walks only the groups that pass -- 3.0 of
+// 32 on average for a 131 072-pt scan (tools/knn_model.py), where the walk over all groups is most of the ~47 us every wavefront pays today.
+// A group box contains its chunk boxes and the radius only shrinks, so no chunk that the walk would have scanned is lost.
+__global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict__ box /* [C + G][6] */) {
+  const int g = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int G = (C + CHUNK - 1) / CHUNK;
+  if (g >= G) return;
+  const int cc = g * CHUNK + lane;
+  const float inf = __int_as_float(0x7f800000);
+  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  if (cc < C) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = box[6 * (size_t)cc + a];
+      hi[a] = box[6 * (size_t)cc + 3 + a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      box[6 * (size_t)(C + g) + a] = lo[a];
+      box[6 * (size_t)(C + g) + 3 + a] = hi[a];
+    }
+  }
+}
+#endif
+
 // F32MASK: the mask pass of a chunk scan runs in FP32 on the float4 records themselves (the scheme of the pair-lane kernel below, which states
 // the error bound): "d32 <= thr * (1 + 2e-6)" can only ADD candidates, and every accepted candidate is re-evaluated with the oracle's FP64
 // expression before it is offered to the list, so the lists stay bit-identical -- 64 x 6 full-rate FP32 operations and one 16-byte LDS read
@@ -761,9 +797,32 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   // sparse query next to a dense patch can meet ever closer tiles and insert all 64 candidates of each: one such wavefront took
   // 985 us against a mean of 170 us.)
   const int G = (C + CHUNK - 1) / CHUNK, gc = c / CHUNK;
+#ifdef GLIM_AMD_KNN_GROUPBOX
+  unsigned long long gmask[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // groups worth walking (all of them beyond 256 groups)
+  if (G <= 256) {
+    double r20 = best.d[K - 1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r20 = fmax(r20, __shfl_xor(r20, off, 64));
+    const float R0 = (float)(sqrt(r20) * 1.000001) + 1e-30f;
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+      const int g = wd * 64 + lane;
+      bool okg = g < G;
+      if (okg) {
+        const float* b = box + 6 * (size_t)(C + g);
+#pragma unroll
+        for (int a = 0; a < 3; a++) okg = okg && (b[a] <= qhi[a] + R0) && (b[3 + a] >= qlo[a] - R0);
+      }
+      gmask[wd] = __ballot(okg);
+    }
+  }
+#endif
   for (int t = 0; t < 2 * G; t++) {
     const int gi = (t & 1) ? gc + ((t + 1) >> 1) : gc - (t >> 1);
     if (gi < 0 || gi >= G) continue;
+#ifdef GLIM_AMD_KNN_GROUPBOX
+    if (G <= 256 && !((gmask[gi >> 6] >> (gi & 63)) & 1ull)) continue;
+#endif
     const int g0 = gi * CHUNK;
     // wave-wide search radius: the largest k-th best distance among the lanes (+inf while some list is not full)
     double r2 = best.d[K - 1];
@@ -993,7 +1052,11 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(pool_malloc(&vb.p, (size_t)n * sizeof(unsigned int)));
   GA_HIP(pool_malloc(&hist.p, radix_sort_scratch_bytes(n)));
   GA_HIP(pool_malloc(&sorted.p, (size_t)C * CHUNK * sizeof(float4)));
+#ifdef GLIM_AMD_KNN_GROUPBOX
+  GA_HIP(pool_malloc(&box.p, ((size_t)C + (size_t)(C + CHUNK - 1) / CHUNK) * 6 * sizeof(float)));  // chunk boxes, then group boxes
+#else
   GA_HIP(pool_malloc(&box.p, (size_t)C * 6 * sizeof(float)));
+#endif
   GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
   const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
@@ -1043,6 +1106,9 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
+#ifdef GLIM_AMD_KNN_GROUPBOX
+    group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box.as<float>());
+#endif
     DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), f32mask);  // k == 0: ordering only
   }
   GA_HIP(hipGetLastError());
