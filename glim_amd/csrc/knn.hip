@@ -943,6 +943,49 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
     // -1 stays negative, +inf stays +inf
     const float thr32 = (float)(thr * 1.000002) + 1e-37f;
     unsigned int m = 0u;
+#ifdef GLIM_AMD_KNN_SELECT
+    // the per-lane threshold selection of knn_chunk_kernel (see there), over this lane's 32 candidates and ITS OWN list: a candidate that cannot
+    // enter the lane's list cannot be among the K best of the two lists merged at the end either
+    float dv[QCH];
+#pragma unroll
+    for (int j = 0; j < QCH; j++) {
+      const float4 cp = s_pt[w][base + j];
+      const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
+      dv[j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      m |= (dv[j] <= thr32 ? 1u : 0u) << j;
+    }
+    m &= ~seeded;
+    {
+      constexpr int SELECT_MIN = 12;
+      if (__any(__popc(m) > SELECT_MIN)) {
+        const float inf32 = __int_as_float(0x7f800000);
+#pragma unroll
+        for (int j = 0; j < QCH; j++) dv[j] = ((m >> j) & 1u) ? dv[j] : inf32;
+        auto count_le = [&](float t) -> int {
+          int cnt = 0;
+#pragma unroll
+          for (int j = 0; j < QCH; j++) cnt += dv[j] <= t ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < K; j++) cnt += best.d[j] <= (double)t ? 1 : 0;
+          return cnt;
+        };
+        unsigned int hi = __float_as_uint(fminf(thr32, 3.4028234e38f));
+        const bool sel = need && count_le(__uint_as_float(hi)) >= K;
+        unsigned int lo = hi > (16u << 23) ? hi - (16u << 23) : 0u;
+        for (int step = 0; step < 8; step++) {
+          const unsigned int mid = lo + ((hi - lo) >> 1);
+          const bool ok = count_le(__uint_as_float(mid)) >= K;
+          hi = ok ? mid : hi;
+          lo = ok ? lo : mid + 1u;
+        }
+        const float keep = __uint_as_float(hi) * 1.000002f + 1e-37f;
+        unsigned int km = 0u;
+#pragma unroll
+        for (int j = 0; j < QCH; j++) km |= (dv[j] <= keep ? 1u : 0u) << j;
+        if (sel) m = km;
+      }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < QCH; j++) {
       const float4 cp = s_pt[w][base + j];
@@ -951,6 +994,7 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
       m |= (d32 <= thr32 ? 1u : 0u) << j;
     }
     m &= ~seeded;
+#endif
     while (__any(m != 0u)) {
       double d = __longlong_as_double(0x7ff0000000000000ll);
       int idx = 0x7fffffff;
