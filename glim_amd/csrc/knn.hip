@@ -32,6 +32,8 @@ constexpr int TILE = 1024;
 #endif
 constexpr int MAX_RING = GLIM_AMD_KNN_MAX_RING;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int K>
 struct TopK {
   double d[K];
@@ -624,7 +626,17 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
                                                         int32_t* __restrict__ out, int* __restrict__ dbg) {
   __shared__ double s_xyz[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK][3];
   __shared__ int s_idx[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK];
+#ifdef GLIM_AMD_KNN_PKMASK
+  // Experiment for round 3, NOT yet run on a GPU: candidate coordinates planar in LDS, so that two consecutive candidates load as one register
+  // pair and the mask pass runs on packed FP32 (v_pk_add / v_pk_mul / v_pk_fma: 3 instead of 6 arithmetic instructions per candidate).  The
+  // per-component operations and their order are those of the scalar pass, so every d32 is bit-identical.
+  __shared__ __attribute__((aligned(8))) float s_px[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1], s_py[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1],
+      s_pz[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
+  __shared__ int s_pi[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
+  __shared__ float4 s_pt[1][1];
+#else
   __shared__ float4 s_pt[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
+#endif
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + w;
   if (c >= C) return;  // whole wavefront
@@ -646,13 +658,21 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   // most chunks after the first three nobody has anything to insert.
   // candidate j of the staged chunk: its index (< 0: padding) and its exact squared distance
   auto cand_idx = [&](int j) -> int {
+#ifdef GLIM_AMD_KNN_PKMASK
+    if constexpr (F32MASK) return s_pi[w][j];
+#else
     if constexpr (F32MASK) return __float_as_int(s_pt[w][j].w);
+#endif
     else return s_idx[w][j];
   };
   auto cand_dist = [&](int j) -> double {
     if constexpr (F32MASK) {
+#ifdef GLIM_AMD_KNN_PKMASK
+      return sqdist(qx, qy, qz, (double)s_px[w][j], (double)s_py[w][j], (double)s_pz[w][j]);
+#else
       const float4 cp = s_pt[w][j];
       return sqdist(qx, qy, qz, (double)cp.x, (double)cp.y, (double)cp.z);
+#endif
     } else {
       return sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
     }
@@ -663,7 +683,14 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if constexpr (F32MASK) {
+#ifdef GLIM_AMD_KNN_PKMASK
+      s_px[w][lane] = p.x;
+      s_py[w][lane] = p.y;
+      s_pz[w][lane] = p.z;
+      s_pi[w][lane] = __float_as_int(p.w);
+#else
       s_pt[w][lane] = p;
+#endif
     } else {
       s_xyz[w][lane][0] = (double)p.x;
       s_xyz[w][lane][1] = (double)p.y;
@@ -701,12 +728,23 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       // candidates with d32 > t * (1 + 2e-6) are then dropped without being popped: once the others are inserted the list holds K entries whose
       // exact distances are <= t * (1 + 3e-7), strictly below the exact distance of every dropped candidate (> t * (1 + 2e-6) * (1 - 3e-7)).
       float dv[CHUNK];
+#ifdef GLIM_AMD_KNN_PKMASK
+#pragma unroll
+      for (int j = 0; j < CHUNK; j += 2) {
+        const v2f dx = v2f{qxf, qxf} - *reinterpret_cast<const v2f*>(&s_px[w][j]), dy = v2f{qyf, qyf} - *reinterpret_cast<const v2f*>(&s_py[w][j]),
+                  dz = v2f{qzf, qzf} - *reinterpret_cast<const v2f*>(&s_pz[w][j]);
+        const v2f d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        dv[j] = d.x;
+        dv[j + 1] = d.y;
+      }
+#else
 #pragma unroll
       for (int j = 0; j < CHUNK; j++) {
         const float4 cp = s_pt[w][j];
         const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
         dv[j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
       }
+#endif
 #pragma unroll
       for (int j = 0; j < 32; j++) mlo |= (dv[j] <= thr32 ? 1u : 0u) << j;
 #pragma unroll
@@ -747,6 +785,16 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
             mhi = khi;
           }
         }
+      }
+#elif defined(GLIM_AMD_KNN_PKMASK)
+#pragma unroll
+      for (int j = 0; j < CHUNK; j += 2) {
+        const v2f dx = v2f{qxf, qxf} - *reinterpret_cast<const v2f*>(&s_px[w][j]), dy = v2f{qyf, qyf} - *reinterpret_cast<const v2f*>(&s_py[w][j]),
+                  dz = v2f{qzf, qzf} - *reinterpret_cast<const v2f*>(&s_pz[w][j]);
+        const v2f d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        const unsigned int two = (d.x <= thr32 ? 1u : 0u) | (d.y <= thr32 ? 2u : 0u);
+        if (j < 32) mlo |= two << j;
+        else mhi |= two << (j - 32);
       }
 #else
 #pragma unroll
