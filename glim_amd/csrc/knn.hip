@@ -780,9 +780,9 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
           for (int j = 0; j < 32; j++) klo |= (dv[j] <= keep ? 1u : 0u) << j;
 #pragma unroll
           for (int j = 0; j < 32; j++) khi |= (dv[32 + j] <= keep ? 1u : 0u) << j;
-          if (sel) {  // (seeded / rejected / padding candidates are +inf here: never kept)
-            mlo = klo;
-            mhi = khi;
+          if (sel) {  // seeded / rejected / padding candidates are +inf here; the AND keeps them out even if `keep` overflowed to +inf
+            mlo = klo & (unsigned int)m0;
+            mhi = khi & (unsigned int)(m0 >> 32);
           }
         }
       }
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
         unsigned int km = 0u;
 #pragma unroll
         for (int j = 0; j < QCH; j++) km |= (dv[j] <= keep ? 1u : 0u) << j;
-        if (sel) m = km;
+        if (sel) m &= km;
       }
     }
 #else

@@ -183,7 +183,7 @@ def run(pts, order="index", seeds=K + 2, verbose=False, seed_mode="wrap", levels
                     lo = np.where(ok, lo, mid + 1)
                 keep = (hi.astype(np.uint32).view(f32) * f32(1.000002) + f32(1e-37)).astype(f32)
                 km = dv <= keep[:, None]
-                m[sel] = km[sel]
+                m[sel] &= km[sel]
             if select_slack is not None and tiles[c] <= level_scans:
                 # per-lane threshold selection by bisection on the FP32 distances held in registers: the K-th of (list + accepted) found to a relative
                 # slack; everything beyond it is dropped without being popped
