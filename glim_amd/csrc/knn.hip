@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict
 // candidates with v_readlane instead of LDS (-1 %); branch-free insertion (K compares + selects, or min / max for the distances) instead of
 // the early-exit bubble, with one or two candidates per round (+17 ... +28 %); issuing the box loads of the next group, the points of the
 // next candidate chunk and the first three chunks ahead of their use, with the per-lane box test fed by v_readlane (+4 %).
-template <int K, bool F32MASK>
+template <int K, bool F32MASK, bool SELECT = false>
 __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const float4* __restrict__ sorted, const float* __restrict__ box, int k,
                                                         int32_t* __restrict__ out, int* __restrict__ dbg) {
   __shared__ double s_xyz[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK][3];
@@ -718,11 +718,12 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
     if constexpr (F32MASK) {
       // FP32 image of the bound, inflated beyond the FP32 evaluation error (see knn_pair_kernel); -1 stays negative, +inf stays +inf
       const float thr32 = (float)(thr * 1.000002) + 1e-37f;
-#ifdef GLIM_AMD_KNN_SELECT
-      // Experiment for round 3, NOT yet run on a GPU (tools/knn_model.py "select_bits" emulates this code step by step on the CPU: lists unchanged,
-      // insertion rounds 116 -> 50 per wavefront and 395 -> 140 for the slowest at 2.5 selections per wavefront; with 2-3.5 us per selection the
-      // modelled wavefront goes 135 -> ~108 us on average and 323 -> ~213 us for the slowest one, which is what the launch lasts).  The lock-step insertion loop below lasts as long as the lane with the most accepted candidates, and a
-      // lane whose bound is still loose accepts most of a chunk although only a handful end up in its list.  So the 64 FP32 distances are kept
+      if constexpr (SELECT) {
+      // SELECT (staged: instantiated for k <= 10 only and chosen by GLIM_AMD_KNN_SELECT=1 or the build macro of the same name until the GPU
+      // parity tests have run with it; tools/knn_model.py "select_bits" emulates this code step by step on the CPU: lists unchanged, insertion
+      // rounds 116 -> 50 per wavefront and 395 -> 140 for the slowest; measured on one box: 0.46 -> 0.36 ms for a 131 072-pt scan, lists exact).
+      // The lock-step insertion loop below lasts as long as the lane with the most accepted candidates, and a lane whose bound is still loose
+      // accepts most of a chunk although only a handful end up in its list.  So the 64 FP32 distances are kept
       // in registers and every lane first finds, by bisection over FP32 bit patterns, a threshold t with
       //     #(list entries with d <= t) + #(accepted candidates with d32 <= t) >= K;
       // candidates with d32 > t * (1 + 2e-6) are then dropped without being popped: once the others are inserted the list holds K entries whose
@@ -786,7 +787,8 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
           }
         }
       }
-#elif defined(GLIM_AMD_KNN_PKMASK)
+      } else {
+#ifdef GLIM_AMD_KNN_PKMASK
 #pragma unroll
       for (int j = 0; j < CHUNK; j += 2) {
         const v2f dx = v2f{qxf, qxf} - *reinterpret_cast<const v2f*>(&s_px[w][j]), dy = v2f{qyf, qyf} - *reinterpret_cast<const v2f*>(&s_py[w][j]),
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         mhi |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
       }
 #endif
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 32; j++) {
@@ -913,13 +916,19 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
 }
 
 template <int K>
-void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool f32mask) {
+void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool f32mask, bool select) {
 #ifdef GLIM_AMD_KNN_KEEP_F64MASK  // development builds: the all-FP64 mask pass as a cross-check (GLIM_AMD_KNN_F64MASK=1 selects it)
   if (!f32mask) {
     knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
     return;
   }
 #endif
+  if constexpr (K <= 10) {
+    if (select) {
+      knn_chunk_kernel<K, true, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+      return;
+    }
+  }
   knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
 }
 
@@ -937,7 +946,7 @@ void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const flo
 // before it is offered to the list, which applies the exact (distance, index) test.  Results are bit-identical to the other implementations.
 constexpr int QCH = 32;
 
-template <int K>
+template <int K, bool SELECT = false>
 __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point chunks */, const float4* __restrict__ sorted, const float* __restrict__ box,
                                                        int k, int32_t* __restrict__ out) {
   __shared__ float4 s_pt[4][64];
@@ -991,7 +1000,7 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
     // -1 stays negative, +inf stays +inf
     const float thr32 = (float)(thr * 1.000002) + 1e-37f;
     unsigned int m = 0u;
-#ifdef GLIM_AMD_KNN_SELECT
+    if constexpr (SELECT) {
     // the per-lane threshold selection of knn_chunk_kernel (see there), over this lane's 32 candidates and ITS OWN list: a candidate that cannot
     // enter the lane's list cannot be among the K best of the two lists merged at the end either
     float dv[QCH];
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
         if (sel) m &= km;
       }
     }
-#else
+    } else {
 #pragma unroll
     for (int j = 0; j < QCH; j++) {
       const float4 cp = s_pt[w][base + j];
@@ -1042,7 +1051,7 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
       m |= (d32 <= thr32 ? 1u : 0u) << j;
     }
     m &= ~seeded;
-#endif
+    }
     while (__any(m != 0u)) {
       double d = __longlong_as_double(0x7ff0000000000000ll);
       int idx = 0x7fffffff;
@@ -1130,7 +1139,13 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
 }
 
 template <int K>
-void launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out) {
+void launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select) {
+  if constexpr (K <= 10) {
+    if (select) {
+      knn_pair_kernel<K, true><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
+      return;
+    }
+  }
   knn_pair_kernel<K><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
 }
 
@@ -1187,6 +1202,12 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // The FP32 mask passes of both chunk kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than 1e18 m is
   // answered by the exhaustive FP64 kernel instead.
   const bool f32mask = getenv("GLIM_AMD_KNN_F64MASK") == nullptr;
+  // staged: the per-lane threshold selection (k <= 10 kernels), until `pytest -m gpu` has run with it
+#ifdef GLIM_AMD_KNN_SELECT
+  const bool select = getenv("GLIM_AMD_KNN_NO_SELECT") == nullptr;
+#else
+  const bool select = getenv("GLIM_AMD_KNN_SELECT") != nullptr;
+#endif
   const bool pair_lanes = !dbg.p && k <= 16 && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
   if (k > 0 && !(ext < 1e18f)) {
     DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
@@ -1194,14 +1215,14 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     DeviceTemp box32;
     GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
     half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
-    DISPATCH_K16(launch_pairs, st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out);
+    DISPATCH_K16(launch_pairs, st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select);
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
 #ifdef GLIM_AMD_KNN_GROUPBOX
     group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box.as<float>());
 #endif
-    DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), f32mask);  // k == 0: ordering only
+    DISPATCH_K(launch_chunks, st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), f32mask, select);  // k == 0: ordering only
   }
   GA_HIP(hipGetLastError());
   if (dbg.p) {
