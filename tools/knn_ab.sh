@@ -26,6 +26,11 @@ case "$1" in
       echo "== $v" >> gpurun_out/knn_ab/ab.txt
       GLIM_AMD_LIB=build/ab/$v/libglim_amd.so timeout 30 python tools/knn_time.py 2>&1 | grep knn >> gpurun_out/knn_ab/ab.txt
     done
+    # the shipped library: default, and the run-time switches of the staged selection with either chunk kernel forced
+    for e in "" "GLIM_AMD_KNN_SELECT=1" "GLIM_AMD_KNN_SELECT=1 GLIM_AMD_KNN_WAVE64=1" "GLIM_AMD_KNN_SELECT=1 GLIM_AMD_KNN_PAIR=1" "GLIM_AMD_KNN_WAVE64=1" "GLIM_AMD_KNN_PAIR=1"; do
+      echo "== shipped library, env: ${e:-default}" >> gpurun_out/knn_ab/ab.txt
+      env $e timeout 30 python tools/knn_time.py 2>&1 | grep knn >> gpurun_out/knn_ab/ab.txt
+    done
     cat gpurun_out/knn_ab/ab.txt
     if [ -f build/ab/full/libglim_amd.so ]; then
       GLIM_AMD_LIB=build/ab/full/libglim_amd.so timeout 200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_edge_cases.py tests/test_preprocess.py -q -x -m gpu -k "knn or neighb or covar or frontend or rgbd or preprocess" 2>&1 | tail -5 | tee gpurun_out/knn_ab/tests.txt
