@@ -6,8 +6,12 @@ Gates (BASELINE.json north_star / SURVEY.md 8d):
   * Gauss-Newton step delta = -(H + lambda I)^-1 b within 1e-4 m / 1e-4 rad of the oracle's, per iteration
   * kNN index sets exact; covariances within 1e-5 (FP32 storage)
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -539,3 +543,22 @@ def test_knn_staged_threshold_selection_is_exact(api, ctx, orc, monkeypatch):
                 monkeypatch.setenv(variant, "1")
                 np.testing.assert_array_equal(g.find_neighbors(k), ref, err_msg=f"{name} k={k} {variant}")
                 monkeypatch.delenv(variant)
+
+
+@pytest.mark.xfail(strict=False, reason="staged compile-time variants of the kNN chunk kernel (-DGLIM_AMD_KNN_SELECT / _GROUPBOX / _PKMASK, k = 10 builds of "
+                                        "tools/knn_variant.sh): not the shipped code path; built and checked here so that every GPU test run says whether they are still exact")
+@pytest.mark.parametrize("flags", [("-DGLIM_AMD_KNN_PKMASK",), ("-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK")])
+def test_knn_staged_compile_time_variants_stay_exact(flags):
+    """Builds a k = 10 variant library next to the shipped one (hipcc is part of the image) and runs tools/knn_time.py with it in a separate process:
+    131 072-pt scan, 65 536-pt scan and 307 104-pt depth frame, every neighbour list compared with the oracle's."""
+    import subprocess
+    import sys
+
+    name = "t_" + "_".join(f.split("_")[-1].lower() for f in flags)
+    subprocess.check_call([os.path.join(ROOT, "tools", "knn_variant.sh"), name, *flags], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=600)
+    env = dict(os.environ, GLIM_AMD_LIB=os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if "knn ms" in l]
+    print("\n".join(lines))
+    assert out.returncode == 0 and len(lines) == 3, out.stdout + out.stderr
+    assert all("exact True" in l for l in lines), lines
