@@ -75,6 +75,31 @@ def measured_traffic(workload_tag):
     return best
 
 
+def staged_knn_probe(api, ctx, xyz):
+    """Outside every timed region: find_neighbors on one scan with the shipped chunk kernel and with the staged per-lane threshold selection
+    (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the GPU parity tests have run with it), and whether the
+    two neighbour lists are identical.  Never fails the bench."""
+    try:
+        g = api.PointCloudGPU.clone(xyz, ctx=ctx)
+        res = {}
+        for tag, val in (("default", None), ("staged_select", "1")):
+            os.environ.pop("GLIM_AMD_KNN_SELECT", None)
+            if val is not None:
+                os.environ["GLIM_AMD_KNN_SELECT"] = val
+            g.find_neighbors(10, download=False)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                g.find_neighbors(10, download=False)
+            res[tag] = ((time.perf_counter() - t0) / 10 * 1e3, g.find_neighbors(10))
+        g.close()
+        return {"points": int(len(xyz)), "k": 10, "ms_default": res["default"][0], "ms_staged_select": res["staged_select"][0],
+                "lists_equal": bool(np.array_equal(res["default"][1], res["staged_select"][1]))}
+    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
+        return {"error": repr(e)}
+    finally:
+        os.environ.pop("GLIM_AMD_KNN_SELECT", None)
+
+
 def make_frames(api, ctx, poses, rings, azimuths, frame_id0=0, k=10):
     """Synthetic scans uploaded to the device with kNN + covariances computed there."""
     from glim_amd import synth
@@ -342,6 +367,7 @@ def run_odometry128k(args, D, api, ctx):
             # the comparison configs[1] names: ONE factor per call on both sides (the batched figure divided by the CPU rate is reported too)
             result["speedup_vs_cpu_baseline"] = (1e3 / sync_ms_c) / base["value"]
             result["batched_speedup_vs_cpu_baseline"] = value / base["value"]
+            result["staged"] = {"knn_threshold_selection": staged_knn_probe(api, ctx, clouds[0].download(covs=False, normals=False)[0])}
     return result
 
 
