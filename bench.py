@@ -75,11 +75,12 @@ def measured_traffic(workload_tag):
     return best
 
 
-def staged_knn_probe(api, ctx, xyz):
+def staged_knn_probe(api, ctx, cloud):
     """Outside every timed region: find_neighbors on one scan with the shipped chunk kernel and with the staged per-lane threshold selection
     (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the GPU parity tests have run with it), and whether the
     two neighbour lists are identical.  Never fails the bench."""
     try:
+        xyz = cloud.download(covs=False, normals=False)[0]
         g = api.PointCloudGPU.clone(xyz, ctx=ctx)
         res = {}
         for tag, val in (("default", None), ("staged_select", "1")):
@@ -367,7 +368,7 @@ def run_odometry128k(args, D, api, ctx):
             # the comparison configs[1] names: ONE factor per call on both sides (the batched figure divided by the CPU rate is reported too)
             result["speedup_vs_cpu_baseline"] = (1e3 / sync_ms_c) / base["value"]
             result["batched_speedup_vs_cpu_baseline"] = value / base["value"]
-            result["staged"] = {"knn_threshold_selection": staged_knn_probe(api, ctx, clouds[0].download(covs=False, normals=False)[0])}
+            result["staged"] = {"knn_threshold_selection": staged_knn_probe(api, ctx, clouds[0])}
     return result
 
 
