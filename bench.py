@@ -75,30 +75,19 @@ def measured_traffic(workload_tag):
     return best
 
 
-def staged_knn_probe(api, ctx, cloud):
-    """Outside every timed region: find_neighbors on one scan with the shipped chunk kernel and with the staged per-lane threshold selection
-    (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the GPU parity tests have run with it), and whether the
-    two neighbour lists are identical.  Never fails the bench."""
+def staged_knn_probe():
+    """Outside every timed region and in a process of its own (tools/knn_select_probe.py): find_neighbors on one scan with the shipped chunk kernel
+    and with the staged per-lane threshold selection (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the
+    GPU parity tests have run with it), and whether the two neighbour lists are identical.  Never fails the bench."""
+    import subprocess
+
     try:
-        xyz = cloud.download(covs=False, normals=False)[0]
-        g = api.PointCloudGPU.clone(xyz, ctx=ctx)
-        res = {}
-        for tag, val in (("default", None), ("staged_select", "1")):
-            os.environ.pop("GLIM_AMD_KNN_SELECT", None)
-            if val is not None:
-                os.environ["GLIM_AMD_KNN_SELECT"] = val
-            g.find_neighbors(10, download=False)
-            t0 = time.perf_counter()
-            for _ in range(10):
-                g.find_neighbors(10, download=False)
-            res[tag] = ((time.perf_counter() - t0) / 10 * 1e3, g.find_neighbors(10))
-        g.close()
-        return {"points": int(len(xyz)), "k": 10, "ms_default": res["default"][0], "ms_staged_select": res["staged_select"][0],
-                "lists_equal": bool(np.array_equal(res["default"][1], res["staged_select"][1]))}
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_select_probe.py")], capture_output=True, text=True, timeout=180, env=env)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
     except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
         return {"error": repr(e)}
-    finally:
-        os.environ.pop("GLIM_AMD_KNN_SELECT", None)
 
 
 def make_frames(api, ctx, poses, rings, azimuths, frame_id0=0, k=10):
@@ -368,7 +357,7 @@ def run_odometry128k(args, D, api, ctx):
             # the comparison configs[1] names: ONE factor per call on both sides (the batched figure divided by the CPU rate is reported too)
             result["speedup_vs_cpu_baseline"] = (1e3 / sync_ms_c) / base["value"]
             result["batched_speedup_vs_cpu_baseline"] = value / base["value"]
-            result["staged"] = {"knn_threshold_selection": staged_knn_probe(api, ctx, clouds[0])}
+            result["staged"] = {"knn_threshold_selection": staged_knn_probe()}
     return result
 
 
