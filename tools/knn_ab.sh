@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of the kNN chunk-kernel variants that are staged behind compile-time macros in glim_amd/csrc/knn.hip (k = 10 builds).
+# Same-box A/B of the kNN chunk-kernel variants that are staged behind compile-time macros in glim_amd/csrc/knn_chunks.hip / knn_pairs.hip (k = 10 builds).
 #   here (CPU):   tools/knn_ab.sh build            -> build/ab/{kp0,sel,gb_sel,pk,all3}/libglim_amd.so
 #   on the GPU:   gpurun --timeout 120 -- 'tools/knn_ab.sh run'      (timings + exactness against the oracle; then the kNN parity tests with the
 #                                                                    full variant library, which needs all k: tools/knn_ab.sh full builds it)
@@ -15,10 +15,14 @@ case "$1" in
     ;;
   full)  # every k, all three macros: the library the parity tests should be run with before the macros become the default
     mkdir -p build/ab/full
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -DGLIM_AMD_KNN_SELECT -DGLIM_AMD_KNN_GROUPBOX -DGLIM_AMD_KNN_PKMASK \
-      -c glim_amd/csrc/knn.hip -o build/ab/full/knn.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/ab/full/knn.o $(ls glim_amd/csrc/*.o | grep -v /knn.o) -ldl -lpthread -o build/ab/full/libglim_amd.so
-    rm build/ab/full/knn.o
+    for f in knn knn_chunks knn_pairs; do
+      /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -DGLIM_AMD_KNN_SELECT -DGLIM_AMD_KNN_GROUPBOX -DGLIM_AMD_KNN_PKMASK \
+        -c glim_amd/csrc/$f.hip -o build/ab/full/$f.o &
+    done
+    wait
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/ab/full/knn.o build/ab/full/knn_chunks.o build/ab/full/knn_pairs.o \
+      $(ls glim_amd/csrc/*.o | grep -v '/knn[_a-z]*\.o') -ldl -lpthread -o build/ab/full/libglim_amd.so
+    rm build/ab/full/knn.o build/ab/full/knn_chunks.o build/ab/full/knn_pairs.o
     ;;
   run)
     mkdir -p gpurun_out/knn_ab

@@ -1,4 +1,4 @@
-"""CPU model of the Hilbert-chunk kNN kernel (glim_amd/csrc/knn.hip, knn_chunk_kernel): reproduces the per-wavefront work counters the
+"""CPU model of the Hilbert-chunk kNN kernel (glim_amd/csrc/knn_chunks.hip, knn_chunk_kernel): reproduces the per-wavefront work counters the
 kernel dumps with GLIM_AMD_KNN_DEBUG -- chunks scanned ("tiles") and lock-step insertion rounds -- for a given cloud, so that changes of
 the visiting order / seeding can be evaluated without a GPU (the counters explain 83 % of the wavefront times: tools/knn_debug.py).
 Not part of the product and not an oracle: a design tool.
@@ -162,7 +162,7 @@ def run(pts, order="index", seeds=K + 2, verbose=False, seed_mode="wrap", levels
                     done |= take
                 m = best_m
             if select_bits is not None and m.sum(axis=1).max() > select_bits[1]:
-                # the -DGLIM_AMD_KNN_SELECT code of knn.hip, step by step: bisection over FP32 bit patterns (select_bits[0] steps, 16 octaves below the
+                # the -DGLIM_AMD_KNN_SELECT code of knn_chunks.hip, step by step: bisection over FP32 bit patterns (select_bits[0] steps, 16 octaves below the
                 # bound), counting list entries (FP64) and accepted candidates (FP32); candidates beyond keep = t * 1.000002f + 1e-37f are dropped
                 f32 = np.float32
                 run.selections[c] += 1
