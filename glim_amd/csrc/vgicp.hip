@@ -223,6 +223,9 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   }
 }
 
+#ifndef GLIM_AMD_K4_SKIP_ALLMISS
+#define GLIM_AMD_K4_SKIP_ALLMISS 0  // staged experiment (pipe_trip): skip gather + algebra of wavefront trips without any correspondence
+#endif
 #ifndef GLIM_AMD_K4_TIMING
 #define GLIM_AMD_K4_TIMING 0  // diagnostic build: per-block start / end time stamps and placement (tools/k4_timing.py)
 #endif
@@ -522,7 +525,18 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   }
   const bool in1 = (k1 == cur.key);
   const bool hit = (cur.key != EMPTY_KEY) && (k0 == cur.key || in1);
+#if GLIM_AMD_K4_SKIP_ALLMISS
+  // Staged for the next round, NOT yet run on a GPU: a wavefront trip in which no lane has a correspondence skips the record gather and the
+  // algebra (its lanes would add exact zeros).  In Hilbert order misses come in runs: 17 % of the trips of the 256-submap all-pairs cost
+  // (inlier fraction 0.69) have no hit at all (tools/miss_model.py, profiles/r02/probe/miss_model.txt).
+  const unsigned long long hit_lanes = __ballot(hit);
+  wave_inliers += __popcll(hit_lanes);
+  // general (36 B/pt) kernel only: under the plane-form kernel's 96-register cap the branch makes the allocator spill
+  const bool any_hit = PLANE || hit_lanes != 0ull;  // wave-uniform: a scalar branch
+#else
   wave_inliers += __popcll(__ballot(hit));  // wave-uniform count: scalar registers, no per-lane counter
+  constexpr bool any_hit = true;
+#endif
   // every lane reads a record (way 0 of the last bucket when there is no hit) so the wavefront does not diverge
   const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
 #if GLIM_AMD_ABLATE == 1 || GLIM_AMD_ABLATE == 4
@@ -530,6 +544,14 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   const float4 r0 = make_float4(0.01f * cur.qp0, 0.01f, -0.02f, 1.0f);
   const float4 r1 = make_float4(0.01f, 0.02f, 0.9f, 0.03f);
   const float r2 = 0.8f + 0.001f * cur.qp1;
+#elif GLIM_AMD_K4_SKIP_ALLMISS
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  if (any_hit) {
+    r0 = gld4(rp);
+    r1 = gld4(rp + 16);
+    r2 = gld1(rp + 32);
+  }
 #else
   const float4 r0 = gld4(rp);        // mx my mz c00
   const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
@@ -540,7 +562,7 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   // (3) stream loads of point it+AHEAD+1
   nxt = load_point<PLANE>(d, (unsigned int)min(pc.base + (it + AHEAD + 1) * pc.stride, pc.last));
   // (4) algebra of point `it`
-  accumulate_point<MODE, PLANE>(acc, hit, r0, r1, r2, cur, pc.R);
+  if (any_hit) accumulate_point<MODE, PLANE>(acc, hit, r0, r1, r2, cur, pc.R);
   // The key gather the NEXT trip resolves is consumed HERE, at the very end of this trip, and nowhere earlier: without this pin the
   // register allocator recycles two of its destination registers as algebra temporaries and copies them out mid-trip, which puts the
   // s_waitcnt for the HBM gather 85 instructions after its issue instead of a whole trip.
