@@ -562,3 +562,22 @@ def test_knn_staged_compile_time_variants_stay_exact(flags):
     print("\n".join(lines))
     assert out.returncode == 0 and len(lines) == 3, out.stdout + out.stderr
     assert all("exact True" in l for l in lines), lines
+
+
+@pytest.mark.xfail(strict=False, reason="staged compile-time variant of the factor kernel (-DGLIM_AMD_K4_SKIP_ALLMISS=1: wavefront trips without any correspondence skip "
+                                        "gather + algebra in the general kernel): not the shipped code path; built and checked here in every GPU test run")
+def test_factor_kernel_staged_skip_of_all_miss_trips_keeps_parity():
+    """Builds the variant library (tools/ab_variant.sh recompiles vgicp.hip) and runs, in a separate process with it, the parity tests that put
+    the GENERAL kernel to work: merged submaps (configs[3]), mixed plane / general sets, and the plane-vs-general cross-check."""
+    import subprocess
+    import sys
+
+    subprocess.check_call([os.path.join(ROOT, "tools", "ab_variant.sh"), "t_skipallmiss", "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=900)
+    env = dict(os.environ, GLIM_AMD_LIB=os.path.join(ROOT, "build", "ab", "t_skipallmiss", "libglim_amd.so"))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(ROOT, "tests", "test_gpu_configs.py") + "::test_config3_global_mapping_on_merged_submaps",
+                          os.path.join(ROOT, "tests", "test_gpu_configs.py") + "::test_mixed_plane_and_general_sources_in_one_set",
+                          os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_plane_form_kernel_matches_general_kernel_and_oracle"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-2000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
