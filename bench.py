@@ -90,6 +90,29 @@ def staged_knn_probe():
         return {"error": repr(e)}
 
 
+def staged_m2_probe(m2_default_ms):
+    """Outside every timed region, in processes of their own: the 256-submap cost with the staged factor-kernel variant that skips wavefront trips
+    without any correspondence (-DGLIM_AMD_K4_SKIP_ALLMISS=1; tools/ab_variant.sh builds it next to the shipped library in a few
+    seconds), next to this run's own figure.  Same box, same inputs, sequential.  Never fails the bench."""
+    import subprocess
+
+    try:
+        name = "b_skipallmiss"
+        subprocess.run([os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=600, check=True)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST")}
+        env["GLIM_AMD_LIB"] = os.path.join(ROOT, "build", "ab", name, "libglim_amd.so")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "global256", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
+        r = json.loads(lines[-1])
+        return {"ms_default": m2_default_ms, "ms_staged_skip_all_miss_trips": r["ms_per_step"], "kernel_ms_staged": r.get("roofline", {}).get("kernel_ms"),
+                "total_error_staged": r.get("config", {}).get("total_error")}
+    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
+        return {"error": repr(e)}
+
+
 def make_frames(api, ctx, poses, rings, azimuths, frame_id0=0, k=10):
     """Synthetic scans uploaded to the device with kNN + covariances computed there."""
     from glim_amd import synth
@@ -687,6 +710,8 @@ def main():
         m2 = run_global256(args, D, api, ctx, extra_only=True)
         if result is not None and m2 is not None:
             result["m2_global256"] = {k: m2[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")}
+            if not args.no_cpu_baseline and os.environ.get("GLIM_AMD_LIB") is None:
+                result.setdefault("staged", {})["k4_skip_all_miss_trips_m2"] = staged_m2_probe(m2["ms_per_step"])
     D.finish()
     sys.stdout.flush()
     if D.rank == 0 and result is not None:
