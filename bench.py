@@ -90,6 +90,32 @@ def staged_knn_probe():
         return {"error": repr(e)}
 
 
+def staged_knn_variants_probe():
+    """Outside every timed region, in processes of their own: tools/knn_time.py (find_neighbors on a 131 072-pt scan, a 65 536-pt scan and a 307 104-pt
+    depth frame, every list compared with the oracle's) with the shipped library and with a k = 10 build that has all three staged kNN macros on
+    (tools/knn_variant.sh).  Never fails the bench."""
+    import re
+    import subprocess
+
+    def run(lib):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
+        if lib:
+            env["GLIM_AMD_LIB"] = lib
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        rows = re.findall(r"^(\d+) (?:rgbd )?knn ms ([0-9.]+) exact (\w+)", out.stdout, flags=re.M)
+        if len(rows) != 3:
+            return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
+        return {"ms": {n: float(ms) for n, ms, _ in rows}, "exact": all(e == "True" for _, _, e in rows)}
+
+    try:
+        name = "b_knn_all3"
+        subprocess.run([os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
+                       cwd=ROOT, capture_output=True, timeout=600, check=True)
+        return {"shipped": run(None), "select_groupbox_pkmask": run(os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))}
+    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
+        return {"error": repr(e)}
+
+
 def staged_m2_probe(m2_default_ms):
     """Outside every timed region, in processes of their own: the 256-submap cost with the staged factor-kernel variant that skips wavefront trips
     without any correspondence (-DGLIM_AMD_K4_SKIP_ALLMISS=1; tools/ab_variant.sh builds it next to the shipped library in a few
@@ -380,7 +406,7 @@ def run_odometry128k(args, D, api, ctx):
             # the comparison configs[1] names: ONE factor per call on both sides (the batched figure divided by the CPU rate is reported too)
             result["speedup_vs_cpu_baseline"] = (1e3 / sync_ms_c) / base["value"]
             result["batched_speedup_vs_cpu_baseline"] = value / base["value"]
-            result["staged"] = {"knn_threshold_selection": staged_knn_probe()}
+            result["staged"] = {"knn_threshold_selection": staged_knn_probe(), "knn_compile_time_variants": staged_knn_variants_probe()}
     return result
 
 
