@@ -109,7 +109,7 @@ def staged_knn_variants_probe():
 
     try:
         name = "b_knn_all3"
-        subprocess.run([os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
                        cwd=ROOT, capture_output=True, timeout=180, check=True)
         return {"shipped": run(None), "select_groupbox_pkmask": run(os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))}
     except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
@@ -124,7 +124,7 @@ def staged_m2_probe(m2_default_ms):
 
     try:
         name = "b_skipallmiss"
-        subprocess.run([os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=180, check=True)
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=180, check=True)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST")}
         env["GLIM_AMD_LIB"] = os.path.join(ROOT, "build", "ab", name, "libglim_amd.so")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "global256", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],

@@ -555,7 +555,7 @@ def test_knn_staged_compile_time_variants_stay_exact(flags):
     import sys
 
     name = "t_" + "_".join(f.split("_")[-1].lower() for f in flags)
-    subprocess.check_call([os.path.join(ROOT, "tools", "knn_variant.sh"), name, *flags], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=600)
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "knn_variant.sh"), name, *flags], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=600)
     env = dict(os.environ, GLIM_AMD_LIB=os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in out.stdout.splitlines() if "knn ms" in l]
@@ -572,7 +572,7 @@ def test_factor_kernel_staged_skip_of_all_miss_trips_keeps_parity():
     import subprocess
     import sys
 
-    subprocess.check_call([os.path.join(ROOT, "tools", "ab_variant.sh"), "t_skipallmiss", "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=900)
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), "t_skipallmiss", "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, stdout=subprocess.DEVNULL, timeout=900)
     env = dict(os.environ, GLIM_AMD_LIB=os.path.join(ROOT, "build", "ab", "t_skipallmiss", "libglim_amd.so"))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           os.path.join(ROOT, "tests", "test_gpu_configs.py") + "::test_config3_global_mapping_on_merged_submaps",
