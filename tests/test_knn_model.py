@@ -37,3 +37,18 @@ def test_chunk_model_and_staged_selection_are_exact(orc, name):
         _, rounds1, out1 = km.run(pts, "index", select_bits=(8, 0))  # selection in every scan that accepted anything
     np.testing.assert_array_equal(out1, ref)
     assert rounds1.sum() <= rounds0.sum()  # dropping candidates can only shorten the lock-step insertion loops
+
+
+@pytest.mark.parametrize("name", ["lattice", "offset", "few", "duplicates"])
+def test_pair_lane_model_and_staged_selection_are_exact(orc, name):
+    """The same for the pair-lane kernel (tools/knn_pair_model.py): two lists per query over disjoint candidates, each lane selecting over its OWN
+    list, merged at the end."""
+    import knn_pair_model as pm
+
+    pts = _cases()[name].astype(np.float32)
+    ref = orc.knn(pts.astype(np.float64), pm.K, method="brute")
+    rounds0, out0 = pm.run(pts)
+    np.testing.assert_array_equal(out0, ref)
+    rounds1, out1 = pm.run(pts, select=(8, 0))
+    np.testing.assert_array_equal(out1, ref)
+    assert rounds1.sum() <= rounds0.sum()
