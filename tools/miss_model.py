@@ -2,8 +2,13 @@
 source stream that all miss the target voxel map -- for pairs of the 256-submap all-pairs cost (bench.py --workload global256: merged submaps of four
 40 x 512 scans on a 2 m grid, 1.0 m voxels).  Such a trip adds exact zeros; -DGLIM_AMD_K4_SKIP_ALLMISS=1 lets the general kernel skip its record gather
 and algebra.  A design tool, no GPU needed."""
-import sys, numpy as np
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from glim_amd import synth
 from glim_amd.se3 import se3_exp
 from knn_model import hilbert_keys
