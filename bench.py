@@ -75,6 +75,14 @@ def measured_traffic(workload_tag):
     return best
 
 
+T_PROCESS_START = time.time()
+PROBE_DEADLINE_S = 150.0  # the staged probes below only start while the whole run is younger than this: a slow (cold) box skips them
+
+
+def _probe_time_left():
+    return PROBE_DEADLINE_S - (time.time() - T_PROCESS_START)
+
+
 def staged_knn_probe():
     """Outside every timed region and in a process of its own (tools/knn_select_probe.py): find_neighbors on one scan with the shipped chunk kernel
     and with the staged per-lane threshold selection (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the
@@ -82,6 +90,8 @@ def staged_knn_probe():
     import subprocess
 
     try:
+        if _probe_time_left() < 15:
+            return {"skipped": "time budget of the default run"}
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_select_probe.py")], capture_output=True, text=True, timeout=90, env=env)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -108,6 +118,8 @@ def staged_knn_variants_probe():
         return {"ms": {n: float(ms) for n, ms, _ in rows}, "exact": all(e == "True" for _, _, e in rows)}
 
     try:
+        if _probe_time_left() < 40:
+            return {"skipped": "time budget of the default run"}
         name = "b_knn_all3"
         subprocess.run(["bash", os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
                        cwd=ROOT, capture_output=True, timeout=180, check=True)
@@ -123,6 +135,8 @@ def staged_m2_probe(m2_default_ms):
     import subprocess
 
     try:
+        if _probe_time_left() < 45:
+            return {"skipped": "time budget of the default run"}
         name = "b_skipallmiss"
         subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=180, check=True)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST")}
