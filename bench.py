@@ -93,7 +93,7 @@ def staged_knn_probe():
         if _probe_time_left() < 15:
             return {"skipped": "time budget of the default run"}
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_select_probe.py")], capture_output=True, text=True, timeout=90, env=env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_select_probe.py")], capture_output=True, text=True, timeout=60, env=env)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         return json.loads(lines[-1]) if lines else {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
     except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
@@ -111,7 +111,7 @@ def staged_knn_variants_probe():
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
         if lib:
             env["GLIM_AMD_LIB"] = lib
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=90)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=60)
         rows = re.findall(r"^(\d+) (?:rgbd )?knn ms ([0-9.]+) exact (\w+)", out.stdout, flags=re.M)
         if len(rows) != 3:
             return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
@@ -122,7 +122,7 @@ def staged_knn_variants_probe():
             return {"skipped": "time budget of the default run"}
         name = "b_knn_all3"
         subprocess.run(["bash", os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
-                       cwd=ROOT, capture_output=True, timeout=180, check=True)
+                       cwd=ROOT, capture_output=True, timeout=90, check=True)
         return {"shipped": run(None), "select_groupbox_pkmask": run(os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))}
     except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
         return {"error": repr(e)}
@@ -138,11 +138,11 @@ def staged_m2_probe(m2_default_ms):
         if _probe_time_left() < 45:
             return {"skipped": "time budget of the default run"}
         name = "b_skipallmiss"
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=180, check=True)
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=60, check=True)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST")}
         env["GLIM_AMD_LIB"] = os.path.join(ROOT, "build", "ab", name, "libglim_amd.so")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "global256", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
-                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not lines:
             return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
