@@ -16,6 +16,8 @@ submaps, pair list sharded over the ranks, one RCCL all-reduce of the [pairs x 2
 evaluation.  The weak-scaling form of M1 (every rank owns its own F factors + an all-reduce per pass) is reported next to it as `m1_weak`.
 
 Other workloads (parity-test configurations of BASELINE.json, selectable for evidence; never the default line):
+  --workload odometry_frame  GLIM's live odometry call pattern per frame (fresh 34-factor set per optimiser iteration, overlap_gpu keyframe
+                         loops, clone + 2 voxel maps) at 10 000-pt and 131 072-pt frames: microseconds per call, inside the library
   --workload submap20    configs[2]: 20 keyframes x 65 536 pts, 190 pairs x 2 voxel levels = 380 binary factors per bundle
   --workload global256   configs[3]: 256 submaps x 65 536 pts, all 32 640 pairs, 1.0 m voxels, pair list sharded over the
                          ranks + RCCL all-reduce (strong scaling; metric M2 = seconds per cost evaluation)
@@ -60,8 +62,22 @@ def effective_cores():
     return n
 
 
+def kernel_source_id():
+    """Identity of the factor kernel this process runs: SHA-256 over the sources and build flags that decide its code (vgicp.hip, the two
+    headers it includes, the Makefile).  tools/summarize_profile.py stamps it into profiles/*/traffic*.json, so a PMC figure measured on
+    another version of the kernel is recognised instead of being quoted silently."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("vgicp.hip", "device_math.hpp", "internal.hpp", "Makefile"):
+        h.update(open(os.path.join(ROOT, "glim_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload_tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*/traffic.json)."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*/traffic*.json; the PMC counters
+    need separate rocprofv3 runs, so they cannot be collected inside this process).  Returns (bytes per factor, file, measured on this
+    kernel version?) for the NEWEST matching file, or None."""
     import glob
 
     best = None
@@ -69,88 +85,10 @@ def measured_traffic(workload_tag):
         try:
             t = json.load(open(f))
             if workload_tag in t.get("workload", ""):
-                best = (t["traffic_bytes_per_factor"], os.path.relpath(f, ROOT))
+                best = (t["traffic_bytes_per_factor"], os.path.relpath(f, ROOT), t.get("kernel_source_id") == kernel_source_id())
         except Exception:
             pass
     return best
-
-
-T_PROCESS_START = time.time()
-PROBE_DEADLINE_S = 150.0  # the staged probes below only start while the whole run is younger than this: a slow (cold) box skips them
-
-
-def _probe_time_left():
-    return PROBE_DEADLINE_S - (time.time() - T_PROCESS_START)
-
-
-def staged_knn_probe():
-    """Outside every timed region and in a process of its own (tools/knn_select_probe.py): find_neighbors on one scan with the shipped chunk kernel
-    and with the staged per-lane threshold selection (GLIM_AMD_KNN_SELECT=1, DESIGN.md 9.3 -- compiled into the library, off by default until the
-    GPU parity tests have run with it), and whether the two neighbour lists are identical.  Never fails the bench."""
-    import subprocess
-
-    try:
-        if _probe_time_left() < 15:
-            return {"skipped": "time budget of the default run"}
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_select_probe.py")], capture_output=True, text=True, timeout=60, env=env)
-        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        return json.loads(lines[-1]) if lines else {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
-    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
-        return {"error": repr(e)}
-
-
-def staged_knn_variants_probe():
-    """Outside every timed region, in processes of their own: tools/knn_time.py (find_neighbors on a 131 072-pt scan, a 65 536-pt scan and a 307 104-pt
-    depth frame, every list compared with the oracle's) with the shipped library and with a k = 10 build that has all three staged kNN macros on
-    (tools/knn_variant.sh).  Never fails the bench."""
-    import re
-    import subprocess
-
-    def run(lib):
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GLIM_AMD_KNN_SELECT")}
-        if lib:
-            env["GLIM_AMD_LIB"] = lib
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "knn_time.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=60)
-        rows = re.findall(r"^(\d+) (?:rgbd )?knn ms ([0-9.]+) exact (\w+)", out.stdout, flags=re.M)
-        if len(rows) != 3:
-            return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
-        return {"ms": {n: float(ms) for n, ms, _ in rows}, "exact": all(e == "True" for _, _, e in rows)}
-
-    try:
-        if _probe_time_left() < 40:
-            return {"skipped": "time budget of the default run"}
-        name = "b_knn_all3"
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "knn_variant.sh"), name, "-DGLIM_AMD_KNN_SELECT", "-DGLIM_AMD_KNN_GROUPBOX", "-DGLIM_AMD_KNN_PKMASK"],
-                       cwd=ROOT, capture_output=True, timeout=90, check=True)
-        return {"shipped": run(None), "select_groupbox_pkmask": run(os.path.join(ROOT, "build", "ab", name, "libglim_amd.so"))}
-    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
-        return {"error": repr(e)}
-
-
-def staged_m2_probe(m2_default_ms):
-    """Outside every timed region, in processes of their own: the 256-submap cost with the staged factor-kernel variant that skips wavefront trips
-    without any correspondence (-DGLIM_AMD_K4_SKIP_ALLMISS=1; tools/ab_variant.sh builds it next to the shipped library in a few
-    seconds), next to this run's own figure.  Same box, same inputs, sequential.  Never fails the bench."""
-    import subprocess
-
-    try:
-        if _probe_time_left() < 45:
-            return {"skipped": "time budget of the default run"}
-        name = "b_skipallmiss"
-        subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_variant.sh"), name, "-DGLIM_AMD_K4_SKIP_ALLMISS=1"], cwd=ROOT, capture_output=True, timeout=60, check=True)
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_FORCE_DIST")}
-        env["GLIM_AMD_LIB"] = os.path.join(ROOT, "build", "ab", name, "libglim_amd.so")
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "global256", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
-                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
-        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        if not lines:
-            return {"error": f"rc {out.returncode}: {out.stderr[-300:]}"}
-        r = json.loads(lines[-1])
-        return {"ms_default": m2_default_ms, "ms_staged_skip_all_miss_trips": r["ms_per_step"], "kernel_ms_staged": r.get("roofline", {}).get("kernel_ms"),
-                "total_error_staged": r.get("config", {}).get("total_error")}
-    except Exception as e:  # noqa: BLE001 -- a probe, not a measurement the line depends on
-        return {"error": repr(e)}
 
 
 def make_frames(api, ctx, poses, rings, azimuths, frame_id0=0, k=10):
@@ -183,14 +121,17 @@ def roofline_of(fset, poses, n_pts, n_vox, iters, traffic=None):
     achieved = algo / (ms_kernel * 1e-3) / 1e9
     out = {
         "bound": "hbm", "kernel": "vgicp_kernel<LINEARIZE>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable_6.29TBs": achieved / HBM_ACHIEVABLE_GBS,
+        "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
         "algorithmic_bytes_per_launch": algo, "kernel_ms": ms_kernel, "linearize_ms": ms_lin,
-        "kernel_ms_rounds": [round(float(r[0]), 5) for r in rounds],
+        "kernel_ms_rounds": [round(float(r[0]), 5) for r in rounds], "kernel_source_id": kernel_source_id(),
     }
     if traffic:
-        # the honest companion of `frac`: bytes the kernel really pulled through the L2 (PMC passes) over the same launch time
+        # the honest companion of `frac`: bytes the kernel really pulled through the L2 (PMC passes) over the same launch time -- also
+        # against the 6.29 TB/s copy rate a streaming kernel can reach on this part (MI355X_MICROARCH.md)
+        out["traffic_measured_on_this_kernel_version"] = bool(traffic[2])
         out["frac_measured_traffic"] = traffic[0] / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["frac_measured_traffic_of_6.29TBs_copy_rate"] = traffic[0] / (ms_kernel * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS
     if out["frac"] > 1.0:
         out["note"] = ("algorithmic bytes (48 B/pt reference layout, every factor counted separately) exceed what the kernel pulls from HBM: it "
                        "streams 24-40 B/pt and, when many factors share clouds / maps, re-reads them from L2 and the 256 MiB Infinity Cache")
@@ -209,20 +150,30 @@ def cpu_baseline_and_parity(api, target_cloud, source_cloud, delta12, resolution
     vm = orc.VoxelMap(resolution).insert(tgt_xyz, tgt_cov.astype(np.float64))
     p4 = orc.points4(src_xyz)
     c16 = orc.covs16(src_cov.astype(np.float64))
+    tp4 = orc.points4(tgt_xyz)
+    tc16 = orc.covs16(tgt_cov.astype(np.float64))
     T = np.ascontiguousarray(delta12)
     L = orc.Linearized6()
     lib = orc.lib()
     cores = min(orc.max_threads(), effective_cores())
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    # TIMING runs on a second build of the same restatement with SURVEY 8d's flags (-O3 -march=native, compiled on this box); the parity
+    # check below always uses the bit-exact checker build
+    fast = orc.fast_lib()
+    tlib, tmap = lib, vm._h
+    if fast is not None:
+        tlib, tmap = fast, C.c_void_p(fast.orc_voxelmap_create(float(resolution)))
+        fast.orc_voxelmap_insert(tmap, dp(tp4), dp(tc16), len(tp4))
 
     def run(threads, budget):
-        lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(L), None)  # warm
+        Lt = orc.Linearized6()
+        tlib.orc_vgicp_linearize(tmap, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(Lt), None)  # warm
         n, t0 = 0, time.perf_counter()
         while True:
-            lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(L), None)
+            tlib.orc_vgicp_linearize(tmap, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(Lt), None)
             n += 1
             dt = time.perf_counter() - t0
-            if dt >= budget or n >= 2000:
+            if dt >= budget or n >= 4000:
                 return n / dt, n
 
     rate_all, n_all = run(cores, budget_s)
@@ -231,6 +182,10 @@ def cpu_baseline_and_parity(api, target_cloud, source_cloud, delta12, resolution
         if r2 > rate_all:
             rate_all, n_all, cores = r2, n2, cores // 2
     rate_ref, _ = run(min(2, cores), budget_s / 4)  # the reference's shipped num_threads (config_odometry_cpu.json:36)
+    rate_1, _ = run(1, budget_s / 6)
+    if fast is not None:
+        fast.orc_voxelmap_destroy(tmap)
+    lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), cores, C.byref(L), None)  # the checker build: the parity reference
     ref = orc._lin_to_dict(L)
     d_got = np.linalg.solve(gpu_result["H_ss"], -gpu_result["b_s"])
     d_ref = np.linalg.solve(ref["H_ss"], -ref["b_s"])
@@ -242,7 +197,8 @@ def cpu_baseline_and_parity(api, target_cloud, source_cloud, delta12, resolution
     base = {
         "value": rate_all, "unit": "calls/s", "cores": cores, "kind": "port",
         "sample": f"{n_all} linearize() calls of one {len(p4)}-pt factor (oracle/vgicp_oracle.c, OpenMP guided,8, usable host cores = min(affinity, cgroup quota))",
-        "value_2_threads": rate_ref,
+        "build": "gcc -O3 -march=native -fopenmp (oracle.fast_lib)" if fast is not None else "gcc -O2 -march=x86-64-v3 -ffp-contract=off (the checker build: no compiler for the -O3 build)",
+        "value_2_threads": rate_ref, "value_1_thread": rate_1, "points_per_s_per_core": rate_1 * len(p4),
     }
     return base, parity
 
@@ -377,7 +333,7 @@ def run_odometry128k(args, D, api, ctx):
     value = world * F * inner * args.steps / elapsed
     traffic = measured_traffic("odometry128k") if (args.rings, args.azimuths) == (128, 1024) else None
     if traffic:
-        traffic = (traffic[0] * F, traffic[1])  # measured per factor (PMC passes), scaled to this launch
+        traffic = (traffic[0] * F, traffic[1], traffic[2])  # measured per factor (PMC passes), scaled to this launch
     result = None
     roofline = roofline_of(fset, pose_sets[0], n_pts, n_vox, 40, traffic)
     if rank == 0:
@@ -392,13 +348,25 @@ def run_odometry128k(args, D, api, ctx):
         for _ in range(n_sync):
             got = single.linearize_poses(T1)[0]
         sync_rate = n_sync / (time.perf_counter() - t1)
-        sync_ms_c = single.profile_sync(T1, iters=500)
+        sync_ms_c = single.profile_sync(T1, iters=1000)
+        ctx.set_diag("host_finalize=0")  # the two-dispatch form of the same call (fused kernel + device finalise + completion word), for reference
+        sync_ms_dev = single.profile_sync(T1, iters=500)
+        got_dev = single.linearize_poses(T1)[0]
+        ctx.set_diag("")
+        single_loop = {"calls_per_s": 1e3 / sync_ms_c, "us_per_call": sync_ms_c * 1e3, "calls": 1000,
+                       "what": "one 131072-pt factor per call: pose + descriptor in the kernel arguments, ONE launch, partial rows summed on the host as they "
+                               "arrive (FP64, the device finalise's order), 232-B record on the host",
+                       "us_per_call_device_finalise": sync_ms_dev * 1e3,
+                       "host_and_device_finalise_bit_identical": bool(all(np.array_equal(got[k], got_dev[k]) for k in ("H_ss", "b_s")) and got["error"] == got_dev["error"]
+                                                                      and got["num_inliers"] == got_dev["num_inliers"])}
         result = {
             "metric": "vgicp_linearize_calls_per_s", "value": value, "unit": "calls/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "headline_form": f"batched: {F} factors per NonlinearFactorSetGPU::linearize, inputs and results device-resident; the synchronous "
-                             "single-factor loop of configs[1] is `single_factor_loop`, the cold batched rate `value_cold`",
+            "headline_form": f"`value` = batched: {F} factors per NonlinearFactorSetGPU::linearize, inputs and results device-resident.  BASELINE configs[1] "
+                             "literally names the synchronous single-factor loop: that figure is `single_factor_loop` (calls_per_s / us_per_call), and "
+                             "`speedup_vs_cpu_baseline` is computed on IT; `value_cold` is the batched rate right after start-up",
+            "single_factor_loop": single_loop,
             "value_cold": value_cold, "timed_region_s": elapsed,
             "config": {
                 "workload": "configs[1] odometry128k: 131072-pt spinning-LiDAR scans vs 0.5 m voxel maps, batched VGICP linearize",
@@ -408,10 +376,6 @@ def run_odometry128k(args, D, api, ctx):
                 "collective": "rccl_all_gather[world x F x 29] f64" if world > 1 else "none", "device": ctx.device_info()["name"],
             },
             "roofline": roofline, "sync_single_factor_calls_per_s": 1e3 / sync_ms_c, "sync_single_factor_calls_per_s_via_python": sync_rate,
-            # BASELINE.json configs[1] also names the single-factor loop {set pose, linearize, read the record back}:
-            # it is latency, not throughput -- reported here next to `value`, which is the batched form GLIM's NonlinearFactorSetGPU uses
-            "single_factor_loop": {"calls_per_s": 1e3 / sync_ms_c, "us_per_call": sync_ms_c * 1e3, "calls": 500,
-                                   "what": "one 131072-pt factor per call: pose in, fused kernel + FP64 finalise, 232-B record on the host, host sync"},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline_and_parity(api, clouds[0], clouds[1], deltas[0], args.resolution, got)
@@ -420,8 +384,123 @@ def run_odometry128k(args, D, api, ctx):
             # the comparison configs[1] names: ONE factor per call on both sides (the batched figure divided by the CPU rate is reported too)
             result["speedup_vs_cpu_baseline"] = (1e3 / sync_ms_c) / base["value"]
             result["batched_speedup_vs_cpu_baseline"] = value / base["value"]
-            result["staged"] = {"knn_threshold_selection": staged_knn_probe(), "knn_compile_time_variants": staged_knn_variants_probe()}
     return result
+
+
+def run_odometry_frame(args, D, api, ctx):
+    """GLIM's LIVE odometry call pattern (src/glim/odometry/odometry_estimation_gpu.cpp, shipped config_odometry_gpu.json), per frame:
+      create_frame (:86-107)      PointCloudGPU::clone of the frame (points + CPU covariances) + voxelmap_levels = 2 GaussianVoxelMapGPU::insert
+      create_factors (:128-206)   (full_connection_window_size 2 + max_num_keyframes 15) x 2 levels = 34 factors, surface validation ON
+      optimiser                   per iteration a FRESH NonlinearFactorSetGPU: add(34 factors); linearize  (:383-385 and the linearisation hook)
+      update_keyframes_overlap    one 15-target overlap_gpu per frame (:224-231); on a new keyframe beyond the limit the elimination loop (:262-281):
+                                  15 single-target calls + 14 x (one single-target + one 13-target call) = 43 overlap_gpu calls
+    at the shipped 10 000-pt frames (config_preprocess.json:24 random_downsample_target) and at configs[1]'s 131 072-pt scans.  Every figure is
+    microseconds of WALL time per call, measured inside the library (no binding overhead); `plan_cache=0` is the behaviour before the plan cache."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    K, WIN, LEVELS, ITERS = 15, 2, 2, args.opt_iters
+    out = {}
+    for label, rings, azimuths, keep in (("frames_10000_pts", 128, 1024, 10000), ("frames_131072_pts", 128, 1024, None)):
+        dirs = synth.lidar_directions(rings, azimuths)
+        poses = synth.arc_trajectory(K + WIN + 1, step=0.4, yaw_step_deg=1.5)
+        rng = np.random.default_rng(3)
+        frames, host = [], []
+        for i, T in enumerate(poses):
+            pts = synth.scan(scene, T, dirs, 500 + i)
+            if keep:
+                pts = pts[np.sort(rng.choice(len(pts), keep, replace=False))]
+            g = api.PointCloudGPU.clone(pts, ctx=ctx)
+            g.find_neighbors(10, download=False)
+            g.estimate_covariances(10)
+            frames.append(g)
+            host.append(pts)
+        # adaptive base resolution as create_frame computes it (:90-93) with the shipped config_odometry_gpu.json:54-59 values: the median range
+        # of <= 256 samples between dmin 5 m and dmax 20 m maps to 0.25 m ... 0.5 m; voxelmap_scaling_factor 2 per level
+        res0 = api.adaptive_voxel_resolution(api.median_distance(host[-1]), 0.25, 0.5, 5.0, 20.0)
+        levels = [res0 * 2.0 ** lv for lv in range(LEVELS)]
+        vmaps = [[api.GaussianVoxelMapGPU(r, ctx=ctx).insert(g) for r in levels] for g in frames[:-1]]
+        cur, cur_pose = frames[-1], poses[-1]
+        factors, deltas = [], []
+        for t in range(len(frames) - 1 - WIN, len(frames) - 1):      # the sliding window: binary factors
+            for lv in range(LEVELS):
+                f = api.IntegratedVGICPFactorGPU(t, 99, vmaps[t][lv], cur)
+                f.set_enable_surface_validation(True)
+                factors.append(f)
+                deltas.append(api.pose12(synth.relative_pose(poses[t], cur_pose)))
+        for t in range(K):                                           # the keyframes: unary factors against their fixed poses
+            for lv in range(LEVELS):
+                f = api.IntegratedVGICPFactorGPU(poses[t], 99, vmaps[t][lv], cur)
+                f.set_enable_surface_validation(True)
+                factors.append(f)
+                deltas.append(api.pose12(synth.relative_pose(poses[t], cur_pose)))
+        deltas = np.stack(deltas)
+        nf = len(factors)
+        r = {"points_per_frame": cur.size(), "factors_per_frame": nf, "voxel_resolutions_m": [round(x, 3) for x in levels]}
+        # --- the optimiser's linearisation, three ways
+        r["fresh_set_linearize_us"] = api.profile_fresh_sets(factors, deltas, iters=300, ctx=ctx)
+        ctx.set_diag("plan_cache=0")
+        r["fresh_set_linearize_us_without_plan_cache"] = api.profile_fresh_sets(factors, deltas, iters=60, ctx=ctx)
+        ctx.set_diag("")
+        pset = api.NonlinearFactorSetGPU(ctx)
+        for f in factors:
+            pset.add(f)
+        r["persistent_set_linearize_us"] = pset.profile_sync(deltas, iters=300) * 1e3
+        k_ms, lin_ms = pset.profile(deltas, iters=50)
+        r["device_us"] = {"fused_kernels": k_ms * 1e3, "kernels_plus_finalise": lin_ms * 1e3}
+        r["host_enqueue_and_wake_up_us"] = r["persistent_set_linearize_us"] - lin_ms * 1e3
+        r["plan_lookup_and_set_management_us"] = r["fresh_set_linearize_us"] - r["persistent_set_linearize_us"]
+        # --- overlap_gpu: the per-frame 15-target call, a single-target call, the 43-call elimination loop as separate calls and as ONE batch
+        kf_maps = [vmaps[t][-1] for t in range(K)]
+        kf_delta = [synth.relative_pose(poses[t], cur_pose) for t in range(K)]
+        r["overlap_15_targets_us"] = api.overlap_profile([(kf_maps, cur, kf_delta)], iters=300, ctx=ctx)
+        r["overlap_1_target_us"] = api.overlap_profile([(kf_maps[:1], cur, kf_delta[:1])], iters=300, ctx=ctx)
+        loop = [([kf_maps[i]], cur, [kf_delta[i]]) for i in range(K)]
+        for i in range(K - 1):
+            loop.append(([kf_maps[i]], cur, [kf_delta[i]]))
+            others = [j for j in range(K - 1) if j != i]
+            loop.append(([kf_maps[j] for j in others], frames[i], [synth.relative_pose(poses[j], poses[i]) for j in others]))
+        r["keyframe_elimination_loop_calls"] = len(loop)
+        r["keyframe_elimination_loop_separate_calls_us"] = float(sum(api.overlap_profile([q], iters=40, ctx=ctx) for q in loop))
+        r["keyframe_elimination_loop_one_batch_us"] = api.overlap_profile(loop, iters=100, ctx=ctx)
+        batch = api.overlap_gpu_batch(loop, ctx=ctx)
+        single = [api.overlap_gpu(q[0], q[1], q[2]) for q in loop]
+        r["batch_equals_separate_calls"] = bool(batch == single)
+        # --- create_frame: clone of a frame that arrives with CPU covariances + the two map builds (PCIe upload included)
+        xyz, c32, n32 = cur.download()
+        p64, c64, n64 = host[-1].astype(np.float64), c32.astype(np.float64), n32.astype(np.float64)
+        reps = 30
+        t_clone = t_maps = 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            g = api.PointCloudGPU.clone(p64, c64, n64, ctx=ctx)
+            t1 = time.perf_counter()
+            ms = [api.GaussianVoxelMapGPU(rr, ctx=ctx).insert(g) for rr in levels]
+            t2 = time.perf_counter()
+            t_clone += t1 - t0
+            t_maps += t2 - t1
+            for m in ms:
+                m.close()
+            g.close()
+        r["create_frame_us"] = {"clone_upload_pack": t_clone / reps * 1e6, "two_voxelmap_inserts": t_maps / reps * 1e6}
+        frame_us = r["create_frame_us"]["clone_upload_pack"] + r["create_frame_us"]["two_voxelmap_inserts"] + ITERS * r["fresh_set_linearize_us"] + r["overlap_15_targets_us"]
+        r["frame_us"] = {"optimiser_iterations": ITERS, "ordinary_frame": frame_us, "new_keyframe_frame": frame_us + r["keyframe_elimination_loop_separate_calls_us"],
+                         "new_keyframe_frame_batched_loop": frame_us + r["keyframe_elimination_loop_one_batch_us"]}
+        # parity of this configuration (surface validation ON has no CPU counterpart: checked against the same factors with it OFF <= inliers)
+        out[label] = r
+        pset.close()
+        for row in vmaps:
+            for m in row:
+                m.close()
+        for g in frames:
+            g.close()
+    main_r = out["frames_10000_pts"]
+    return {
+        "metric": "odometry_frame_us", "value": main_r["frame_us"]["ordinary_frame"], "unit": "us", "n_gpus": 1, "steps": 300, "warmup": 5,
+        "ms_per_step": main_r["frame_us"]["ordinary_frame"] * 1e-3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "GLIM OdometryEstimationGPU call pattern per frame: clone + 2 voxel maps + optimiser iterations x (fresh 34-factor set: add, linearize) + "
+                               "15-target overlap; keyframe elimination loop (43 overlap calls) on new keyframes", **out},
+    }
 
 
 def run_submap20(args, D, api, ctx):
@@ -507,6 +586,106 @@ def make_merged_submaps(api, ctx, n_submaps, frames_per_submap, rings, azimuths,
     return out
 
 
+def sampled_pair_parity(api, fset, owned, pairs, deltas, clouds, records, n_sample=64, n_corr=8):
+    """configs[3] at its own size, against the checker: >= 64 of this rank's pairs -- the 16 with the fewest inliers (far / barely overlapping),
+    the 16 with the most (near), 32 spread over the quantiles in between -- are linearised by the FP64 oracle on the downloaded merged clouds
+    (the FP32 image the factor consumes): inlier counts equal, damped Gauss-Newton step within 1e-4, correspondences bit-exact on `n_corr` of
+    them.  `records`: this evaluation's compact rows in factor order.  Outside every timed region."""
+    from oracle import oracle as orc
+
+    owned = np.asarray(list(owned))
+    inl = records[owned, 0]
+    order = np.argsort(inl, kind="stable")
+    pick = list(dict.fromkeys(list(order[:16]) + list(order[-16:]) + list(order[np.linspace(0, len(order) - 1, 32).astype(int)])))[:n_sample]
+    corr_pick = set(pick[:: max(1, len(pick) // n_corr)][:n_corr])
+    host, maps = {}, {}
+
+    def cloud(i):
+        if i not in host:
+            xyz, c32, _ = clouds[i].download(normals=False)
+            host[i] = (xyz, c32.astype(np.float64))
+        return host[i]
+
+    worst, inliers_equal, corr_ok, n_corr_done, n_step, zero_inlier = 0.0, True, True, 0, 0, 0
+    for k in pick:
+        f = int(owned[k])
+        i, j = pairs[f]
+        if i not in maps:
+            maps[i] = orc.VoxelMap(1.0).insert(*cloud(i))
+        xyz, cov = cloud(j)
+        delta = np.eye(4)
+        delta[:3, :4] = deltas[f].reshape(3, 4)
+        ref = orc.vgicp_linearize(maps[i], xyz, cov, delta, want_corr=(k in corr_pick))
+        got = api.expand_compact(records[f], deltas[f], api.FACTOR_BINARY)
+        inliers_equal = inliers_equal and int(got["num_inliers"]) == int(ref["num_inliers"])
+        zero_inlier += int(ref["num_inliers"] == 0)
+        if ref["num_inliers"] >= 100:
+            lam = 1e-6 * np.trace(ref["H_ss"]) / 6
+            d_got = np.linalg.solve(got["H_ss"] + lam * np.eye(6), -got["b_s"])
+            d_ref = np.linalg.solve(ref["H_ss"] + lam * np.eye(6), -ref["b_s"])
+            worst = max(worst, float(np.abs(d_got - d_ref).max()))
+            n_step += 1
+        if k in corr_pick:
+            c = fset.correspondences(int(k), delta)
+            hit = c[:, 3] > 0
+            corr_ok = corr_ok and np.array_equal(hit, ref["corr"][:, 3] > 0) and np.array_equal(c[hit, :3], ref["corr"][hit, :3])
+            n_corr_done += 1
+    return {"pairs_checked": len(pick), "inlier_counts_equal": bool(inliers_equal), "gn_steps_compared": n_step, "max_pose_delta_err": worst, "tolerance": 1e-4,
+            "correspondence_lists_compared": n_corr_done, "correspondences_bit_exact": bool(corr_ok), "zero_inlier_pairs_in_sample": zero_inlier,
+            "inlier_fraction_range_of_sample": [float(inl[pick].min() / max(1, clouds[0].size())), float(inl[pick].max() / max(1, clouds[0].size()))],
+            "checker": "oracle/vgicp_oracle.c (FP64) on the downloaded FP32 merged clouds, 1.0 m CPU voxel maps"}
+
+
+def predict_scaling(api, ctx, multi, pairs, deltas, clouds, vmaps, costs_points, records, t1_ms, torch):
+    """What one GPU can say about 2 / 4 / 8: every contiguous shard of the pair list is evaluated ALONE on this GPU (kernels + finalise,
+    device-resident results) and timed; max over the shards of a world size = that world's compute time, t1 / max = its compute-only
+    strong-scaling bound (no collective, no launch skew).  Two cost models for the shard boundaries: source points (the shipped rule) and
+    a least-squares fit t ~ a * points + b * inliers over the measured shards (with skip-all-miss trips a factor's cost follows its hits)."""
+    n = len(pairs)
+    inliers = records[:, 0]
+
+    def time_shard(lo, hi):
+        if hi <= lo:
+            return 0.0
+        fs = api.NonlinearFactorSetGPU(ctx)
+        for f in range(lo, hi):
+            i, j = pairs[f]
+            fs.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i], clouds[j]))
+        out = torch.zeros(hi - lo, api._lib.COMPACT_DOUBLES, dtype=torch.float64, device="cuda")
+        P = deltas[lo:hi]
+        for _ in range(2):
+            fs.linearize_device_async(P, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            fs.linearize_device_async(P, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        fs.close()
+        return ms
+
+    def sweep(costs):
+        res, samples = {}, []
+        for world in (2, 4, 8):
+            b = multi.shard_bounds(costs, world)
+            ms = [time_shard(b[r], b[r + 1]) for r in range(world)]
+            for r in range(world):
+                samples.append((float(np.sum(costs_points[b[r]:b[r + 1]])), float(np.sum(inliers[b[r]:b[r + 1]])), ms[r]))
+            res[str(world)] = {"shard_ms": [round(m, 3) for m in ms], "max_over_mean": float(max(ms) / np.mean(ms)),
+                               "compute_only_speedup_bound": float(t1_ms / max(ms)), "pairs_per_shard": [int(b[r + 1] - b[r]) for r in range(world)]}
+        return res, samples
+
+    by_points, samples = sweep(np.asarray(costs_points, dtype=np.float64))
+    A = np.array([[p, i] for p, i, _ in samples])
+    coef, *_ = np.linalg.lstsq(A, np.array([m for _, _, m in samples]), rcond=None)
+    fitted = np.maximum(1e-12, coef[0] * np.asarray(costs_points, dtype=np.float64) + coef[1] * inliers)
+    by_fit, _ = sweep(fitted) if coef[0] > 0 and coef[1] > 0 else ({}, None)
+    return {"one_gpu_ms": t1_ms, "what": "each contiguous shard of the pair list evaluated alone on this one GPU; speedup bound = one-GPU time / slowest shard (compute only)",
+            "cost_model_points": by_points,
+            "cost_model_fit": {"ms_per_million_points": float(coef[0] * 1e6), "ms_per_million_inliers": float(coef[1] * 1e6), "worlds": by_fit}}
+
+
 def run_global256(args, D, api, ctx, extra_only=False):
     """configs[3] / metric M2: all-pairs matching cost over 256 MERGED submaps (general-covariance clouds, 1.0 m voxel maps), pair list
     sharded over the ranks, RCCL all-gather of the per-pair blocks (global_mapping.cpp:430-484 evaluates these factors one device, one
@@ -544,13 +723,43 @@ def run_global256(args, D, api, ctx, extra_only=False):
         result["blocks"] = gathered.index_select(0, index_t)
 
     steps = max(args.steps, 20) if extra_only else args.steps
+    exchange = {"form": "one all-gather of the whole shard"}
+    if D.collective and not args.no_split:
+        # Second form of the same exchange: the shard as two factor sets, so that the all-gather of the first half (RCCL's stream) overlaps the
+        # kernels of the second (our stream).  Which of the two is faster depends on the node (xGMI latency against ~1/8 of the kernels), so
+        # both run 5 evaluations here, outside the timed region, and the K timed steps use the faster one; both calibration times are reported.
+        _, h_rows, index_h = ev.halves_layout()
+        index_h_t = torch.as_tensor(index_h, device="cuda")
+        halves = []
+        for lo_h, hi_h in ev.halves_ranges():
+            fs = api.NonlinearFactorSetGPU(ctx)
+            for f in range(lo_h, hi_h):
+                fs.add(api.IntegratedVGICPFactorGPU(pairs[f][0], pairs[f][1], vmaps[pairs[f][0]], clouds[pairs[f][1]]))
+            halves.append(fs)
+
+        def step_split(_):
+            ev.gather_device_halves(halves[0], halves[1], deltas, send, gathered)
+            result["blocks"] = gathered.index_select(0, index_h_t)
+
+        t_plain = timed_steps(D, step, 5, 2) / 5
+        t_split = timed_steps(D, step_split, 5, 2) / 5
+        exchange = {"calibration_ms": {"whole_shard": t_plain * 1e3, "two_halves_overlapped": t_split * 1e3}}
+        if t_split < t_plain:  # max over ranks on both sides: every rank takes the same decision
+            step = step_split
+            exchange["form"] = "two halves: all-gather of the first overlaps the kernels of the second"
+        else:
+            exchange["form"] = "one all-gather of the whole shard"
     elapsed = timed_steps(D, step, steps, max(args.warmup, 3))
     host = result["blocks"].cpu().numpy()
+    # where the time of one evaluation goes on THIS rank (HIP events on our stream, outside the timed region): kernels + finalise, the
+    # all-gather, the index_select into factor order -- and the same exchange with the shard split in two so that the gather of the first
+    # half overlaps the kernels of the second (what the N > 1 timed loop would gain from it)
+    breakdown = ev.profile_device(fset, deltas, send, gathered, index_t, reps=5)
     n_pts = [costs[f] for f in ev.owned()]
     n_vox = [vmaps[pairs[f][0]].voxelmap_info()["num_voxels"] for f in ev.owned()]
     traffic = measured_traffic("global256") if (S, args.submap_frames, args.submap_rings, args.submap_azimuths) == (256, 4, 40, 512) else None
     if traffic:
-        traffic = (traffic[0] * len(n_pts), traffic[1])  # measured per factor (PMC passes over all 32 640 pairs), scaled to this rank's share
+        traffic = (traffic[0] * len(n_pts), traffic[1], traffic[2])  # measured per factor (PMC passes over all 32 640 pairs), scaled to this rank's share
     roof = roofline_of(fset, local_poses, n_pts, n_vox, 5, traffic)
     roof["kernel"] = "vgicp_kernel<LINEARIZE, general 36 B/pt>"
     # own-layout bytes: what this kernel must move at least -- 36 B per source point + one 64-byte sector per (factor, touched voxel)
@@ -558,10 +767,21 @@ def run_global256(args, D, api, ctx, extra_only=False):
     roof["frac_own_bytes"] = own / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     roof["note"] = ("the pairs of one rank share 256 clouds / maps (0.6 GB): most re-reads are served by the 256 MiB Infinity Cache and L2, so "
                     "fractions above 1 are cache bandwidth, not HBM")
+    parity = sampled_pair_parity(api, fset, ev.owned(), pairs, deltas, clouds, host) if not args.no_cpu_baseline else None
+    per_rank = None
+    if D.collective:
+        t = torch.tensor([breakdown["kernels_ms"], breakdown["all_gather_ms"], breakdown["index_select_ms"], float(ev.hi - ev.lo)], dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(t) for _ in range(D.world)]
+        D.dist.all_gather(allt, t)
+        per_rank = [dict(zip(["kernels_ms", "all_gather_ms", "index_select_ms", "pairs"], x.cpu().tolist())) for x in allt]
     if D.rank != 0:
         return None
     sec = elapsed / steps
+    predicted = None
+    if D.world == 1 and not args.no_predict:
+        predicted = predict_scaling(api, ctx, multi, pairs, deltas, clouds, vmaps, costs, host, sec * 1e3, torch)
     return {
+        "parity": parity, "predicted_scaling": predicted, "rank_breakdown": per_rank if per_rank else [breakdown], "exchange": exchange,
         "metric": "multi_scan_cost_eval_s", "value": sec, "unit": "s", "n_gpus": D.world, "steps": steps, "warmup": max(args.warmup, 3),
         "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[3] global256: {S} merged submaps (merge_frames of {args.submap_frames} keyframes, 0.1 m) x {int(np.mean(sizes))} pts, "
@@ -706,7 +926,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=["odometry128k", "submap20", "global256", "rgbd300k", "frontend128k"],
+    ap.add_argument("--opt-iters", type=int, default=3, help="odometry_frame: optimiser iterations (fresh-set linearisations) per frame")
+    ap.add_argument("--workload", default=None, choices=["odometry128k", "odometry_frame", "submap20", "global256", "rgbd300k", "frontend128k"],
                     help="default: odometry128k (M1) on one GPU, global256 (M2, strong scaling) on several")
     ap.add_argument("--inner", type=int, default=256, help="odometry128k: linearisation passes per step")
     ap.add_argument("--submap-frames", type=int, default=4, help="global256: keyframes merged into one submap")
@@ -721,6 +942,8 @@ def main():
     ap.add_argument("--frames", type=int, default=300, help="rgbd300k / frontend128k: frames in the timed stream")
     ap.add_argument("--target", type=int, default=10000, help="frontend128k: random_downsample_target (config_preprocess.json ships 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="global256 on several GPUs: do not try the two-halves form of the exchange")
+    ap.add_argument("--no-predict", action="store_true", help="global256 on one GPU: skip the per-shard timing behind `predicted_scaling`")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version there at init) are
@@ -739,7 +962,7 @@ def main():
     D.torch.cuda.set_stream(stream)
     ctx = api.Context(D.local_rank, 1, external_stream=stream.cuda_stream)
     workload = args.workload or ("odometry128k" if D.world == 1 else "global256")
-    runner = {"odometry128k": run_odometry128k, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k,
+    runner = {"odometry128k": run_odometry128k, "odometry_frame": run_odometry_frame, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k,
               "frontend128k": run_frontend128k}[workload]
     result = runner(args, D, api, ctx)
     if args.workload is None and D.world > 1:
@@ -749,9 +972,8 @@ def main():
     elif args.workload is None and not args.no_m2:
         m2 = run_global256(args, D, api, ctx, extra_only=True)
         if result is not None and m2 is not None:
-            result["m2_global256"] = {k: m2[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")}
-            if not args.no_cpu_baseline and os.environ.get("GLIM_AMD_LIB") is None:
-                result.setdefault("staged", {})["k4_skip_all_miss_trips_m2"] = staged_m2_probe(m2["ms_per_step"])
+            result["m2_global256"] = {k: m2[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline", "parity", "predicted_scaling",
+                                                         "rank_breakdown", "exchange") if k in m2}
     D.finish()
     sys.stdout.flush()
     if D.rank == 0 and result is not None:

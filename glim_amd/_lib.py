@@ -86,6 +86,8 @@ SYMBOLS = {
     "glim_amd_ctx_create": (_i, [_i, _i, _vp, _pp]),
     "glim_amd_ctx_destroy": (_i, [_vp]),
     "glim_amd_ctx_synchronize": (_i, [_vp]),
+    "glim_amd_ctx_set_diag": (_i, [_vp, C.c_char_p]),
+    "glim_amd_ctx_get_diag": (_i, [_vp, C.c_char_p, _sz]),
     "glim_amd_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
     "glim_amd_cloud_create": (_i, [_vp, _i64, _dp, _dp, _dp, _pp]),
     "glim_amd_cloud_create_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _pp]),
@@ -130,6 +132,9 @@ SYMBOLS = {
     "glim_amd_factor_set_profile_sync": (_i, [_vp, _dp, _i, _fp]),
     "glim_amd_factor_set_profile_lm": (_i, [_vp, _dp, _i, _fp, _fp]),
     "glim_amd_overlap": (_i, [_vp, _i32, _pp, _dp, _vp, _dp]),
+    "glim_amd_overlap_batch": (_i, [_vp, _i32, _ip, _pp, _dp, _pp, _dp]),
+    "glim_amd_overlap_profile": (_i, [_vp, _i32, _ip, _pp, _dp, _pp, _i, _fp]),
+    "glim_amd_factor_set_profile_fresh": (_i, [_vp, _i32, _pp, _pp, C.POINTER(C.c_uint32), _dp, _i, _fp]),
     "glim_amd_multi_create": (_i, [_ip, _i32, _pp]),
     "glim_amd_multi_destroy": (_i, [_vp]),
     "glim_amd_multi_info": (_i, [_vp, _ip, _ip, _lp]),

@@ -65,6 +65,15 @@ class Context:
     def synchronize(self):
         check(lib().glim_amd_ctx_synchronize(self._h), "glim_amd_ctx_synchronize")
 
+    def set_diag(self, key_values=""):
+        """Diagnostic switches of this context ("key=value,key=value"; "" restores the process defaults): include/glim_amd.h."""
+        check(lib().glim_amd_ctx_set_diag(self._h, key_values.encode()), "glim_amd_ctx_set_diag")
+
+    def get_diag(self):
+        buf = C.create_string_buffer(1024)
+        check(lib().glim_amd_ctx_get_diag(self._h, buf, 1024), "glim_amd_ctx_get_diag")
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(","))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         free, total, cus = C.c_size_t(), C.c_size_t(), C.c_int()
@@ -767,3 +776,47 @@ def overlap_gpu(target_voxelmaps, source, deltas, ctx=None):
 
 
 overlap_auto = overlap_gpu
+
+
+def _overlap_args(queries):
+    nt = np.array([len(q[0]) for q in queries], dtype=np.int32)
+    maps = [m._h.value for q in queries for m in q[0]]
+    hs = (C.c_void_p * len(maps))(*maps)
+    srcs = (C.c_void_p * len(queries))(*[q[1]._h.value for q in queries])
+    T = np.ascontiguousarray(np.stack([pose12(d) for q in queries for d in q[2]]))
+    return nt, hs, srcs, T
+
+
+def overlap_profile(queries, iters=200, ctx=None):
+    """microseconds per glim_amd_overlap_batch call answering `queries` ([(voxelmaps[], source, deltas[]), ...]), timed inside the library."""
+    ctx = ctx or queries[0][1].ctx
+    nt, hs, srcs, T = _overlap_args(queries)
+    us = C.c_float()
+    check(lib().glim_amd_overlap_profile(ctx._h, len(queries), _ip(nt), hs, _dp(T), srcs, int(iters), C.byref(us)), "glim_amd_overlap_profile")
+    return us.value
+
+
+def profile_fresh_sets(factors, T_target_source, iters=200, ctx=None):
+    """GLIM's live pattern -- a fresh NonlinearFactorSetGPU per linearisation: create, add every factor, linearize, destroy -- timed inside
+    the library; microseconds per iteration.  factors: IntegratedVGICPFactorGPU objects; T_target_source: n x 12."""
+    ctx = ctx or factors[0].source.ctx
+    n = len(factors)
+    maps = (C.c_void_p * n)(*[f.target_voxelmap._h.value for f in factors])
+    srcs = (C.c_void_p * n)(*[f.source._h.value for f in factors])
+    flags = (C.c_uint32 * n)(*[f.flags() for f in factors])
+    T = np.ascontiguousarray(T_target_source, dtype=np.float64)
+    us = C.c_float()
+    check(lib().glim_amd_factor_set_profile_fresh(ctx._h, n, maps, srcs, flags, _dp(T), int(iters), C.byref(us)), "glim_amd_factor_set_profile_fresh")
+    return us.value
+
+
+def overlap_gpu_batch(queries, ctx=None):
+    """Many overlap_gpu calls in ONE launch (the keyframe-selection loops of odometry_estimation_gpu.cpp:262-281 issue K of them back to
+    back): queries = [(target_voxelmaps[], source, deltas[]), ...] -> list of overlaps."""
+    if not queries:
+        return []
+    ctx = ctx or queries[0][1].ctx
+    nt, hs, srcs, T = _overlap_args(queries)
+    out = np.zeros(len(queries), dtype=np.float64)
+    check(lib().glim_amd_overlap_batch(ctx._h, len(queries), _ip(nt), hs, _dp(T), srcs, _dp(out)), "glim_amd_overlap_batch")
+    return out.tolist()

@@ -275,6 +275,7 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->ctx) {
     (void)hipSetDevice(c->ctx->device);
     c->ctx->quiesce();  // asynchronous factor launches may still be reading this cloud: its memory goes back to the pool below
+    c->ctx->mutation_epoch++;  // factor sets re-validate their plans
   }
   if (c->gs0) (void)pool_free(c->gs0);
   if (c->gs1) (void)pool_free(c->gs1);

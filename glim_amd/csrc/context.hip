@@ -1,5 +1,7 @@
 // context.hip -- library, error and context entry points of the C ABI (include/glim_amd.h).
 #include <atomic>
+#include <cstdlib>
+#include <string>
 
 #include "internal.hpp"
 
@@ -13,11 +15,122 @@ void set_hip_error(hipError_t e, const char* what) {
   (void)hipGetLastError();  // clear the sticky error
 }
 
+// ---- diagnostic switches (internal.hpp "Diag") --------------------------------------------------------------------------------
+namespace {
+struct DiagKey {
+  const char* name;
+  int Diag::*field;
+  const char* const* words;  // value words (index = value), or null for a plain integer
+  int lo, hi;
+};
+const char* const kPathWords[] = {"auto", "grid", "chunks", "brute", nullptr};
+const char* const kKernelWords[] = {"auto", "wave64", "pair", nullptr};
+const DiagKey kDiagKeys[] = {
+  {"knn_path", &Diag::knn_path, kPathWords, 0, 3},
+  {"knn_kernel", &Diag::knn_kernel, kKernelWords, 0, 2},
+  {"knn_select", &Diag::knn_select, nullptr, 0, 1},
+  {"plane", &Diag::plane, nullptr, 0, 1},
+  {"curve_order", &Diag::curve_order, nullptr, 0, 1},
+  {"ppt", &Diag::ppt, nullptr, 0, 256},
+  {"poll", &Diag::poll, nullptr, 0, 1},
+  {"inline_pose", &Diag::inline_pose, nullptr, 0, 1},
+  {"bucket_factor", &Diag::bucket_factor, nullptr, 0, 64},
+  {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
+  {"host_finalize", &Diag::host_finalize, nullptr, 0, 1},
+  {"pool", &Diag::pool, nullptr, 0, 1},
+  {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
+  {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},
+};
+}  // namespace
+
+int diag_parse(Diag& d, const char* key_values) {
+  Diag out = d;
+  std::string s = key_values ? key_values : "";
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) return GLIM_AMD_ERR_INVALID;
+    const std::string key = item.substr(0, eq), val = item.substr(eq + 1);
+    if (key == "knn_debug") {
+      if (val.size() >= sizeof(out.knn_debug)) return GLIM_AMD_ERR_INVALID;
+      snprintf(out.knn_debug, sizeof(out.knn_debug), "%s", val.c_str());
+      continue;
+    }
+    bool found = false;
+    for (const DiagKey& k : kDiagKeys) {
+      if (key != k.name) continue;
+      int v = -1;
+      if (k.words) {
+        for (int i = 0; k.words[i]; i++)
+          if (val == k.words[i]) v = i;
+      } else {
+        char* e = nullptr;
+        const long lv = strtol(val.c_str(), &e, 10);
+        if (e != val.c_str() && *e == 0) v = (int)lv;
+      }
+      if (v < k.lo || v > k.hi) return GLIM_AMD_ERR_INVALID;
+      out.*(k.field) = v;
+      found = true;
+    }
+    if (!found) return GLIM_AMD_ERR_INVALID;
+  }
+  d = out;
+  return GLIM_AMD_OK;
+}
+
+int diag_print(const Diag& d, char* buf, size_t len) {
+  std::string s;
+  for (const DiagKey& k : kDiagKeys) {
+    if (!s.empty()) s += ",";
+    s += k.name;
+    s += "=";
+    const int v = d.*(k.field);
+    if (k.words) s += k.words[v];
+    else s += std::to_string(v);
+  }
+  if (d.knn_debug[0]) s += std::string(",knn_debug=") + d.knn_debug;
+  if (!buf || len < s.size() + 1) return GLIM_AMD_ERR_INVALID;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return GLIM_AMD_OK;
+}
+
+const Diag& process_diag() {
+  static const Diag d = [] {
+    Diag x;
+    if (const char* env = getenv("GLIM_AMD_DIAG")) {
+      if (diag_parse(x, env) != GLIM_AMD_OK) fprintf(stderr, "[glim_amd] GLIM_AMD_DIAG=\"%s\" not understood: ignored\n", env);
+    }
+    return x;
+  }();
+  return d;
+}
+
 }  // namespace glim_amd
 
 using namespace glim_amd;
 
 extern "C" {
+
+int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values) {
+  if (!ctx) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!key_values || !key_values[0]) {  // back to the process defaults
+    ctx->diag = process_diag();
+    return GLIM_AMD_OK;
+  }
+  return diag_parse(ctx->diag, key_values);
+}
+
+int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len) {
+  if (!ctx) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  return diag_print(ctx->diag, buf, len);
+}
 
 int glim_amd_version(void) { return GLIM_AMD_VERSION; }
 
@@ -58,6 +171,7 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
   glim_amd_ctx* ctx = new glim_amd_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
+  ctx->diag = process_diag();
   if (external_stream) {
     ctx->owns_streams = false;
     ctx->streams.push_back((hipStream_t)external_stream);
@@ -86,6 +200,7 @@ int glim_amd_ctx_destroy(glim_amd_ctx* ctx) {
   if (ctx->live_children.load() != 0) return GLIM_AMD_ERR_STATE;  // children must be destroyed first; the context stays valid
   (void)hipSetDevice(ctx->device);
   for (auto s : ctx->streams) (void)hipStreamSynchronize(s);
+  ctx_release_factor_resources(ctx);
   if (ctx->owns_streams)
     for (auto s : ctx->streams) (void)hipStreamDestroy(s);
   if (--g_live_contexts == 0) pool_trim(ctx->device);  // last context gone: give the cached device memory back
@@ -122,7 +237,7 @@ int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t*
 // Device memory pool (per device, process-wide): hipMalloc / hipFree cost 10-100+ us each and hipFree synchronises the
 // device, which is what made the per-frame path (upload -> kNN -> covariance -> voxel map) jittery (p99 46 ms on the 300k-point
 // stream).  Freed blocks are cached by size and handed back to later requests of a similar size; every API call that frees
-// scratch has synchronised its stream before returning, so re-use is ordered.  GLIM_AMD_NO_POOL=1 disables the cache.
+// scratch has synchronised its stream before returning, so re-use is ordered.  GLIM_AMD_DIAG="pool=0" disables the cache.
 // ---------------------------------------------------------------------------------------------------------------------
 #include <map>
 #include <unordered_map>
@@ -143,7 +258,7 @@ DevicePool& pool_of(int device) {
 }
 constexpr size_t kMaxCachedBytes = 32ull << 30;
 bool pool_disabled() {
-  static const bool off = getenv("GLIM_AMD_NO_POOL") != nullptr;
+  static const bool off = process_diag().pool == 0;
   return off;
 }
 }  // namespace
@@ -165,8 +280,6 @@ hipError_t pool_malloc_impl(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
-  static const bool trace = getenv("GLIM_AMD_POOL_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "[glim_amd pool] miss: hipMalloc(%zu)\n", want);
   hipError_t e = hipMalloc(p, want);
   if (e != hipSuccess && !pool_disabled()) {  // out of memory: drop the cache and retry once
     (void)hipGetLastError();

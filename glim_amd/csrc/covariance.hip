@@ -6,9 +6,19 @@
 // Per point (FP64, like the reference):  s = sum p_j, S = sum p_j p_j^T over the first k_neighbors neighbours (:84-89);
 // mean = s/k, cov = (S - mean s^T)/k (:91-92, population form); eigenvector e0 of the smallest eigenvalue by the closed-form
 // trigonometric solver the reference calls (Eigen SelfAdjointEigenSolver::computeDirect, :183); regularised covariance
-// V diag(1e-3,1,1) V^T = I - (1 - 1e-3) e0 e0^T (V orthonormal), so only e0 is needed; normal = e0 flipped so p.n <= 0 (:98-101).
+// V diag(1e-3,1,1) V^T = I - (1 - 1e-3) e0 e0^T, so only e0 is needed: computeDirect's V is orthonormal to rounding in every branch (two
+// unit kernel vectors of shifted matrices and their normalised cross product), and tests/test_ref.py checks on the COMPILED reference that
+// its own covariance differs from I - 0.999 n n^T built from its own normal by < 1e-12 on every point, degenerate neighbourhoods included.
+// normal = e0 flipped so p.n <= 0 (:98-101).
 // One thread per point; the neighbour gathers are 16-byte loads that hit L2 (neighbours are spatially close).
 #include "internal.hpp"
+
+// Every FP64 expression below is evaluated with separate roundings, in the order of the reference's code (Eigen's computeDirect as restated
+// in oracle/vgicp_oracle.c: eig3_roots, eig3_extract_kernel, orc_eigen3_direct): the sums, the shifted / scaled matrix, the characteristic
+// polynomial and the cross products then have the reference's bits, and what is left between the two eigenvectors is the last-place
+// difference of atan2 / cos / sin between the device's and the host's math library, amplified by 1 / (eigenvalue gap) -- below 1e-5 unless
+// the two smallest eigenvalues agree to ~1e-11 of the largest (tests/test_ref.py reports the fraction).
+#pragma clang fp contract(off)
 
 using namespace glim_amd;
 
@@ -138,7 +148,11 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->covA) GA_HIP(pool_malloc(&c->covA, nn * sizeof(float4)));
   if (!c->covB) GA_HIP(pool_malloc(&c->covB, nn * sizeof(float2)));
   if (!c->normals) GA_HIP(pool_malloc(&c->normals, nn * sizeof(float4)));
-  // general factor streams built from earlier covariances are stale now
+  // General factor streams built from earlier covariances are stale now, and factor plans hold their addresses: wait for asynchronous
+  // launches that may still read them, then give the cloud a new identity so that every plan built from the old streams is rebuilt.
+  ctx->quiesce();
+  c->uid = next_uid();
+  ctx->mutation_epoch++;
   if (c->gs0) { (void)pool_free(c->gs0); c->gs0 = nullptr; }
   if (c->gs1) { (void)pool_free(c->gs1); c->gs1 = nullptr; }
   if (c->gs2) { (void)pool_free(c->gs2); c->gs2 = nullptr; }

@@ -57,12 +57,32 @@ int cloud_curve_rank(::glim_amd_cloud* c, hipStream_t st);
 int ensure_factor_streams(::glim_amd_cloud* c, hipStream_t st);
 // plane-form test of a freshly uploaded cloud with covariances and normals (cloud.hip): sets c->plane_form
 int detect_plane_form(::glim_amd_cloud* c, hipStream_t st);
-// diagnostic switches of the per-call path, read from the environment ONCE per process (vgicp.hip); the plan-time switches
-// (GLIM_AMD_NO_PLANE, GLIM_AMD_PPT, ...) are read when a factor set builds its plan
-struct CallSwitches {
-  bool no_poll, no_inline_pose;
+// Diagnostic / tuning switches.  None is needed in production; they exist for A/B measurements and for the cross-checks of the parity
+// tests.  ONE structure per context: initialised at glim_amd_ctx_create from the process defaults -- the single environment variable
+// GLIM_AMD_DIAG="key=value,key=value", parsed once per process -- and changed per context with glim_amd_ctx_set_diag (same syntax).
+// No other getenv exists in the library.
+struct Diag {
+  int knn_path = 0;       // knn_path=auto|grid|chunks|brute     which kNN implementation answers glim_amd_cloud_find_neighbors
+  int knn_kernel = 0;     // knn_kernel=auto|wave64|pair         64-query or pair-lane chunk kernel
+  int knn_select = 1;     // knn_select=0|1                      per-lane threshold selection of the chunk kernels (k <= 10)
+  int plane = 1;          // plane=0|1                           plane-form (24 B/pt) factor kernel for plane-form clouds
+  int curve_order = 1;    // curve_order=0|1                     factor streams in the Hilbert order of the cloud
+  int ppt = 0;            // ppt=<n>                             points per thread of the factor kernel (0: one resident set of blocks)
+  int poll = 1;           // poll=0|1                            host-mapped completion word for small synchronous calls
+  int inline_pose = 1;    // inline_pose=0|1                     pose of a single-factor set in the kernel arguments
+  int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
+  int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
+  int host_finalize = 1;  // host_finalize=0|1                   synchronous single-factor call: partial rows summed on the host as they arrive
+  int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
+  int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
+  int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
+  char knn_debug[256] = "";   // knn_debug=<file>                dump per-wavefront work counters of the 64-query chunk kernel
 };
-const CallSwitches& call_switches();
+enum { KNN_PATH_AUTO = 0, KNN_PATH_GRID = 1, KNN_PATH_CHUNKS = 2, KNN_PATH_BRUTE = 3 };
+enum { KNN_KERNEL_AUTO = 0, KNN_KERNEL_WAVE64 = 1, KNN_KERNEL_PAIR = 2 };
+const Diag& process_diag();                        // GLIM_AMD_DIAG, parsed once
+int diag_parse(Diag& d, const char* key_values);   // GLIM_AMD_OK or GLIM_AMD_ERR_INVALID (unknown key / bad value); d untouched on error
+int diag_print(const Diag& d, char* buf, size_t len);
 
 // stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
 size_t radix_sort_scratch_bytes(int n);
@@ -134,13 +154,23 @@ struct FactorDesc {
   int ppt;                  // points per thread: chunk = 256 * ppt consecutive points per block
 };
 
-// Pose of a single-factor set passed by value in the kernel arguments: the synchronous per-factor call then needs no
-// host-to-device copy at all (valid == 0: poses are read from the device array as usual).
-struct InlinePose {
+// Pose AND descriptor of a single-factor set passed by value in the kernel arguments: the synchronous per-factor call of the odometry
+// then needs no host-to-device copy, and its blocks no dependent blockmap -> descriptor -> stream load chain (two memory round trips
+// of a kernel that lasts five).  valid == 0: poses, descriptors and the block map are read from device memory as usual.
+struct InlineArgs {
   double m[12];
   int valid;
   int pad;
+  FactorDesc d;
 };
+
+// Identity of a cloud / voxel map as a factor plan sees it: a fresh value at creation and after every change that invalidates descriptors
+// built from the object (covariances re-estimated, map re-inserted).  Values never recur, so a cached plan can never match a new object
+// that happens to live at a recycled address.
+inline uint64_t next_uid() {
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1);
+}
 
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
 constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
@@ -150,6 +180,7 @@ constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
 // ---------------------------------------------------------------------------------------------------------------
 // C-ABI object definitions (opaque to callers)
 // ---------------------------------------------------------------------------------------------------------------
+struct FactorPlan;
 struct glim_amd_ctx {
   std::atomic<int> live_children{0};  // clouds, voxel maps, factor sets and search indices created from this context and not yet destroyed
   int device = 0;
@@ -161,10 +192,20 @@ struct glim_amd_ctx {
   // set by the *_async entry points: device work may still be reading buffers when the call returns, so the next call that recycles
   // device memory of this context (destroy / re-plan) synchronises the streams first (quiesce)
   std::atomic<bool> async_pending{false};
+  // bumped whenever a cloud / voxel map of this context changes identity or dies: a factor set re-validates its plan only then
+  std::atomic<uint64_t> mutation_epoch{1};
+  std::vector<FactorPlan*> plan_cache;  // idle factor plans, most recently released first (vgicp.hip; guarded by mu)
+  // overlap scratch (vgicp.hip), allocated on first use: per-query arrival counters on the device, results + completion word in host-mapped memory
+  static constexpr int OV_MAX_QUERIES = 1024;
+  unsigned long long* ov_counters = nullptr;  // [OV_MAX_QUERIES] packed (arrived blocks << 32 | hits), then the queries-done word
+  unsigned int* ov_host = nullptr;            // pinned: [0] completion word, [1 + q] hits of query q
+  unsigned int* ov_host_dev = nullptr;
+  unsigned int ov_seq = 0;
   void quiesce() {
     if (async_pending.exchange(false))
       for (auto s : streams) (void)hipStreamSynchronize(s);
   }
+  glim_amd::Diag diag;  // diagnostic switches of this context (internal.hpp "Diag")
   hipStream_t stream() const { return streams[0]; }
   hipStream_t round_robin() {
     hipStream_t s = streams[next_stream];
@@ -195,6 +236,7 @@ struct CtxRef {
 
 struct glim_amd_cloud {
   CtxRef ctx;
+  uint64_t uid = glim_amd::next_uid();
   int64_t n = 0;
   float4* pts = nullptr;
   float4* covA = nullptr;
@@ -241,11 +283,57 @@ struct glim_amd_cloud {
 
 struct glim_amd_voxelmap {
   CtxRef ctx;
+  uint64_t uid = glim_amd::next_uid();
   double resolution = 0.0;
   double inv_resolution = 0.0;
   int32_t num_voxels = 0;
   uint32_t num_buckets = 0;  // 0 until insert()
   glim_amd::VoxelBucket* buckets = nullptr;
+};
+
+// Device plan of a factor list: descriptors, the block -> (factor, chunk) map, partial rows, pose / result staging.  Building one costs
+// six pool allocations, three uploads and a stream synchronise, and GLIM builds a FRESH NonlinearFactorSetGPU for every linearisation
+// (odometry_estimation_gpu.cpp:383-385; the optimisers' hook does clear -> add(graph) -> linearize per iteration), so plans are cached
+// per context, keyed on the (voxel map, cloud, flags) list: a set that is cleared or destroyed parks its plan in ctx->plan_cache and the
+// next set with the same list adopts it with no device work at all.
+struct PlanKey {
+  uint64_t target_uid, source_uid;
+  uint32_t flags, pad;
+  bool operator==(const PlanKey& o) const { return target_uid == o.target_uid && source_uid == o.source_uid && flags == o.flags; }
+};
+struct FactorPlan {
+  std::vector<PlanKey> key;
+  int built_plane = 1, built_ppt = 0;  // plan-time diagnostic switches the plan was built with
+  // rows [0, plane_rows) = blocks of factors whose source cloud is plane-form (24 B/pt kernel), rows [plane_rows, total_rows) = blocks of
+  // the other factors (36 B/pt kernel); each segment is its own launch
+  int points_per_thread = 1;
+  int max_rows_per_factor = 0;    // most blocks (partial rows) any factor of the plan owns: picks the finalise kernel's width
+  int plane_rows = 0, total_rows = 0;
+  glim_amd::FactorDesc* d_descs = nullptr;
+  int2* d_blockmap = nullptr;     // total_rows x int2, then the rows[] index (int per block)
+  float* d_partials = nullptr;
+  double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
+  double* d_compact = nullptr;    // n x COMPACT
+  // pinned pose staging: a ring, because an asynchronous call returns while its host-to-device copy may still be reading the slot
+  static constexpr int POSE_RING = 4;
+  double* h_poses = nullptr;      // POSE_RING x (2 x n x 12)
+  hipEvent_t pose_events[POSE_RING] = {nullptr, nullptr, nullptr, nullptr};
+  bool pose_pending[POSE_RING] = {false, false, false, false};
+  int pose_slot = 0;
+  double* h_compact = nullptr;       // pinned, host-mapped
+  double* h_compact_dev = nullptr;   // device view of h_compact (small sets: results land in host memory, no D2H copy)
+  int* d_done = nullptr;             // finalise-block arrival counter (polling fast path)
+  unsigned int* h_flag = nullptr;    // host-mapped completion word, written by the last finalise block
+  unsigned int* h_flag_dev = nullptr;
+  unsigned int poll_seq = 0;
+  // single-factor plans: host-mapped partial rows + one arrival word per row (the synchronous call sums the rows on the host while the
+  // blocks are still finishing: one launch, no finalise dispatch -- vgicp.hip run_sync)
+  float* h_rows = nullptr;           // total_rows x PARTIAL_STRIDE floats, then total_rows arrival words
+  float* h_rows_dev = nullptr;
+  size_t cap_factors = 0, cap_blocks = 0;
+  std::vector<glim_amd::FactorDesc> h_descs;
+  hipStream_t last_stream = nullptr;  // stream of the last enqueue
+  bool maybe_busy = false;            // an asynchronous enqueue may still be running on last_stream
 };
 
 struct glim_amd_factor_set {
@@ -257,35 +345,14 @@ struct glim_amd_factor_set {
     uint32_t flags;
   };
   std::vector<Entry> entries;
-  bool dirty = true;  // device plan needs a rebuild
-  // device plan: rows [0, plane_rows) = blocks of factors whose source cloud is plane-form (24 B/pt kernel), rows [plane_rows,
-  // total_rows) = blocks of the other factors (36 B/pt kernel); each segment is its own launch
-  int points_per_thread = 1;
-  int max_rows_per_factor = 0;    // most blocks (partial rows) any factor of the plan owns: picks the finalise kernel's width
-  int plane_rows = 0, total_rows = 0;
-  glim_amd::FactorDesc* d_descs = nullptr;
-  int2* d_blockmap = nullptr;
-  float* d_partials = nullptr;
-  double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
-  double* d_compact = nullptr;    // n x COMPACT
-  // pinned pose staging: a ring, because an asynchronous call returns while its host-to-device copy may still be reading the slot
-  static constexpr int POSE_RING = 4;
-  double* h_poses = nullptr;      // POSE_RING x (2 x n x 12)
-  hipEvent_t pose_events[POSE_RING] = {nullptr, nullptr, nullptr, nullptr};
-  bool pose_pending[POSE_RING] = {false, false, false, false};
-  int pose_slot = 0;
-  double* h_compact = nullptr;    // pinned, host-mapped
-  int* d_done = nullptr;             // finalise-block arrival counter (polling fast path)
-  unsigned int* h_flag = nullptr;    // host-mapped completion word, written by the last finalise block
-  unsigned int* h_flag_dev = nullptr;
-  unsigned int poll_seq = 0;
-  glim_amd::InlinePose inline_pose{};  // single-factor sets: the pose rides in the kernel arguments
-  double* h_compact_dev = nullptr;  // device view of h_compact (small sets: results land in host memory, no D2H copy)
-  size_t cap_factors = 0, cap_blocks = 0;
-  std::vector<glim_amd::FactorDesc> h_descs;
+  bool dirty = true;             // the entry list changed since the plan was built / adopted
+  uint64_t seen_epoch = 0;       // ctx->mutation_epoch when the plan was last validated
+  FactorPlan* plan = nullptr;    // owned while set; parked in ctx->plan_cache on clear / destroy
+  glim_amd::InlineArgs inline_args{};  // single-factor sets: pose + descriptor ride in the kernel arguments
 };
 
 namespace glim_amd {
 int factor_set_prepare(glim_amd_factor_set* set);
-void factor_set_release_plan(glim_amd_factor_set* set);
+void factor_set_park_plan(glim_amd_factor_set* set);   // plan -> ctx->plan_cache (caller holds ctx->mu)
+void ctx_release_factor_resources(glim_amd_ctx* ctx);  // frees every cached plan and the overlap scratch (context being destroyed)
 }  // namespace glim_amd

@@ -8,10 +8,10 @@
 //
 // Three implementations, same result:
 //   * curve-ordered chunks (default, knn_curve): Hilbert sort, 64-point chunks with boxes, one wavefront per chunk streaming the
-//     candidate chunks through LDS (knn_chunks.hip, knn_pairs.hip); adapts to the local density by construction.  0.46 ms for a
-//     131 072-point LiDAR scan, 0.72 ms for a 307 104-point depth frame on MI355X.
-//   * hashed uniform grid (GLIM_AMD_KNN_GRID=1, knn_grid): counting sort into cells, ring walk per query with exactness bound and
-//     coarser retry levels: 0.85 / 1.11 ms; kept for cross-checking.
+//     candidate chunks through LDS (knn_chunks.hip, knn_pairs.hip); adapts to the local density by construction.  0.36 ms for a
+//     131 072-point LiDAR scan, 0.60 ms for a 307 104-point depth frame on MI355X.
+//   * hashed uniform grid (clouds below 24 576 points; diag knn_path=grid, knn_grid): counting sort into cells, ring walk per query with
+//     exactness bound and coarser retry levels: 0.85 / 1.11 ms at the two sizes above; also the cross-check of the chunk path.
 //   * exhaustive: LDS-tiled scan of every point (tiny clouds, and the grid path's last resort).
 #include <algorithm>
 #include <cmath>
@@ -26,10 +26,7 @@ using namespace glim_amd;
 namespace {
 
 constexpr int TILE = 1024;
-#ifndef GLIM_AMD_KNN_MAX_RING
-#define GLIM_AMD_KNN_MAX_RING 6
-#endif
-constexpr int MAX_RING = GLIM_AMD_KNN_MAX_RING;
+constexpr int MAX_RING = 6;
 
 // ---- exhaustive scan.  `queries` (optional): list of point indices to answer; otherwise every point. ----
 template <int K>
@@ -101,7 +98,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float4* 
 }
 
 // ---- grid query: one lane per point, in cell order ----
-// What bounds this kernel on MI355X (per-query counters, GLIM_AMD_KNN_DEBUG): a wavefront lasts as long as its slowest lane, and a
+// What bounds this kernel on MI355X (per-query counters of a diagnostic build): a wavefront lasts as long as its slowest lane, and a
 // scan is far from uniformly dense -- the mean query of a 131 072-point LiDAR scan sees 278 candidates, the cells next to the sensor
 // 4000 (p99), so the few wavefronts that hold those queries set the kernel time (0.8 of the 0.95 ms).  Tried and measured slower:
 // G = 2 / 4 / 8 lanes per query with a shuffle merge of their top-K lists (1.2 / 1.4-1.8 / 2.4 ms: the walk is not latency-bound,
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
                                                        const unsigned long long* __restrict__ keys, unsigned int mask, const int* __restrict__ starts,
                                                        const int* __restrict__ counts, int k, int32_t* __restrict__ out, int* __restrict__ unresolved,
                                                        int* __restrict__ stats, const float4* __restrict__ pts, const int* __restrict__ queries,
-                                                       int num_queries, int max_ring, int* __restrict__ dbg) {
+                                                       int num_queries, int max_ring) {
   // first pass: every point in cell order (queries == nullptr); retry passes on a coarser grid: the listed points only
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= (queries ? num_queries : n)) return;
@@ -139,10 +136,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
   TopK<K> best;
   best.init(self);
   bool done = false;
-  int dbg_cand = 0, dbg_probe = 0, dbg_ring = 0;
-  const long long dbg_t0 = dbg ? wall_clock64() : 0;
   for (int ring = 0; ring <= max_ring; ring++) {
-    dbg_ring = ring;
     if (ring >= 1) {
       const double reach = (double)(ring - 1) * h * 0.999999 + margin;  // every unscanned point is at least this far
       if (best.d[K - 1] < reach * reach) {                               // strict: an unscanned tie could carry a smaller index
@@ -170,7 +164,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
           int found = -1;
           for (;;) {
             const unsigned long long kk = keys[sl];
-            dbg_probe++;
             if (kk == key) {
               found = (int)sl;
               break;
@@ -180,7 +173,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
           }
           if (found < 0) continue;
           const int b = starts[found], e = b + counts[found];
-          dbg_cand += e - b;
           // four candidates per trip, loads issued back to back
           int j = b;
           for (; j + 4 <= e; j += 4) {
@@ -196,12 +188,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, const float4* __re
           }
         }
       }
-  }
-  if (dbg) {  // GLIM_AMD_KNN_DEBUG: per-query work counters (candidates, table probes, last ring, 10 ns ticks)
-    dbg[4 * (size_t)self + 0] = dbg_cand;
-    dbg[4 * (size_t)self + 1] = dbg_probe;
-    dbg[4 * (size_t)self + 2] = dbg_ring;
-    dbg[4 * (size_t)self + 3] = (int)(wall_clock64() - dbg_t0);
   }
   if (!done) {
     // the (2 max_ring + 1)^3 cube was scanned: accept only if that already proves the result, else hand over to the exhaustive kernel
@@ -257,11 +243,11 @@ void launch_brute(hipStream_t st, int n, const float4* pts, int k, int32_t* out,
 }
 template <int K>
 void launch_grid(hipStream_t st, int n, const float4* sorted, double h, const unsigned long long* keys, unsigned int mask, const int* starts,
-                 const int* counts, int k, int32_t* out, int* unresolved, int* stats, const float4* pts, const int* queries, int nq, int max_ring, int* dbg) {
+                 const int* counts, int k, int32_t* out, int* unresolved, int* stats, const float4* pts, const int* queries, int nq, int max_ring) {
   const int work = queries ? nq : n;
   if (work > 0)
     knn_grid_kernel<K><<<(work + 255) / 256, 256, 0, st>>>(n, sorted, h, 1.0 / h, keys, mask, starts, counts, k, out, unresolved, stats, pts, queries, nq,
-                                                           max_ring, dbg);
+                                                           max_ring);
 }
 
 
@@ -310,10 +296,8 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   double ext[3];
   for (int a = 0; a < 3; a++) ext[a] = std::max(1e-6, (double)unordered(h_bb[3 + a]) - (double)unordered(h_bb[a]));
   const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
-  double ppc = 3.0;  // target points per occupied cell of the level-0 grid
-  if (const char* env = getenv("GLIM_AMD_KNN_PPC")) ppc = std::max(0.25, atof(env));
+  const double ppc = 3.0;  // target points per occupied cell of the level-0 grid
   double h = std::sqrt(ppc * 2.0 * area / (double)n);
-  if (const char* env = getenv("GLIM_AMD_KNN_CELL")) h = atof(env);
   const double max_abs = std::max({std::fabs((double)unordered(h_bb[0])), std::fabs((double)unordered(h_bb[1])), std::fabs((double)unordered(h_bb[2])),
                                    std::fabs((double)unordered(h_bb[3])), std::fabs((double)unordered(h_bb[4])), std::fabs((double)unordered(h_bb[5]))});
   const double h_min = max_abs / 1.0e6 + 1e-9;  // keep cell coordinates inside the 21-bit key range
@@ -337,16 +321,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   // finished exhaustively.  Measured alternatives on MI355X (131 072-pt LiDAR scan / 307 104-pt depth frame, ms): starting 8x finer
   // with 2 rings per level 2.8 / 2.2, 4x finer 2.1 / 2.0, this schedule 0.97 / 1.22 -- every extra level costs a grid rebuild and a
   // latency-bound pass (~0.5 ms), which outweighs the shorter candidate lists of the dense cells next to the sensor.
-  DeviceTemp dbg_buf;  // GLIM_AMD_KNN_DEBUG=<file>: per-query work counters of level 0 (candidates, probes, last ring, 10 ns ticks), int32[n][4]
-  if (getenv("GLIM_AMD_KNN_DEBUG")) {
-    GA_HIP(pool_malloc(&dbg_buf.p, (size_t)n * 4 * sizeof(int)));
-    GA_HIP(hipMemsetAsync(dbg_buf.p, 0, (size_t)n * 4 * sizeof(int), st));
-  }
-  double fine = 1.0;
-  if (const char* env = getenv("GLIM_AMD_KNN_FINE")) fine = std::max(1.0, atof(env));
-  int level_ring = MAX_RING;
-  if (const char* env = getenv("GLIM_AMD_KNN_RING")) level_ring = std::max(1, std::min(MAX_RING, atoi(env)));
-  if (!getenv("GLIM_AMD_KNN_CELL")) h = std::max(h / fine, h_min);
+  const int level_ring = MAX_RING;
   int h_stats[4] = {0, 0, 0, 0};
   int* todo = (int*)unresolved_a.p;
   int* next = (int*)unresolved_b.p;
@@ -363,20 +338,12 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
     GA_HIP(hipMemsetAsync((int*)g.stats.p + 2, 0, sizeof(int), st));
     const bool last = (double)level_ring * h * 4.0 > diag;  // the next level could not do better than the exhaustive kernel
     DISPATCH_K(launch_grid, st, n, (const float4*)g.sorted.p, h, (const unsigned long long*)g.keys.p, g.T - 1, (const int*)g.starts.p,
-               (const int*)g.counts.p, k, out, next, (int*)g.stats.p, pts, first ? (const int*)nullptr : todo, num_todo, last ? MAX_RING : level_ring, dbg_buf.as<int>());
+               (const int*)g.counts.p, k, out, next, (int*)g.stats.p, pts, first ? (const int*)nullptr : todo, num_todo, last ? MAX_RING : level_ring);
     GA_HIP(hipGetLastError());
     GA_HIP(hipMemcpyAsync(h_stats, g.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     GA_HIP(hipStreamSynchronize(st));
     first = false;
     num_todo = h_stats[2];
-    if (dbg_buf.p && (num_todo == 0 || level == 0)) {
-      std::vector<int> hd((size_t)n * 4);
-      GA_HIP(hipMemcpy(hd.data(), dbg_buf.p, hd.size() * sizeof(int), hipMemcpyDeviceToHost));
-      if (FILE* f = fopen(getenv("GLIM_AMD_KNN_DEBUG"), "wb")) {
-        fwrite(hd.data(), sizeof(int), hd.size(), f);
-        fclose(f);
-      }
-    }
     if (num_todo == 0) return GLIM_AMD_OK;
     std::swap(todo, next);
     if ((double)MAX_RING * h > diag) break;  // the next cube would cover everything anyway: finish exhaustively
@@ -522,11 +489,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(pool_malloc(&vb.p, (size_t)n * sizeof(unsigned int)));
   GA_HIP(pool_malloc(&hist.p, radix_sort_scratch_bytes(n)));
   GA_HIP(pool_malloc(&sorted.p, (size_t)C * CHUNK * sizeof(float4)));
-#ifdef GLIM_AMD_KNN_GROUPBOX
-  GA_HIP(pool_malloc(&box.p, ((size_t)C + (size_t)(C + CHUNK - 1) / CHUNK) * 6 * sizeof(float)));  // chunk boxes, then group boxes
-#else
-  GA_HIP(pool_malloc(&box.p, (size_t)C * 6 * sizeof(float)));
-#endif
+  GA_HIP(pool_malloc(&box.p, ((size_t)C + (size_t)(C + CHUNK - 1) / CHUNK) * 6 * sizeof(float)));  // chunk boxes, then the boxes of the groups of 64 chunks
   GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
   const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
@@ -541,8 +504,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     ext = std::max(ext, unordered(h_bb[3 + a]) - lo[a]);
   }
   if (!(ext >= 0.f) || !std::isfinite(ext) || !std::isfinite(lo[0]) || !std::isfinite(lo[1]) || !std::isfinite(lo[2])) return GLIM_AMD_ERR_RANGE;
-  int bits = n < 32768 ? 8 : 13;  // per axis: 24-bit keys / 3 sort passes for small clouds, 39 bits / 5 passes otherwise; the order only affects speed
-  if (const char* env = getenv("GLIM_AMD_KNN_CURVE_BITS")) bits = std::max(4, std::min(21, atoi(env)));
+  const int bits = n < 32768 ? 8 : 13;  // per axis: 24-bit keys / 3 sort passes for small clouds, 39 bits / 5 passes otherwise; the order only affects speed
   const unsigned int qmax = (1u << bits) - 1u;
   const float scale = ext > 0.f ? (float)qmax / ext : 0.f;
   curve_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, lo[0], lo[1], lo[2], scale, qmax, bits, ka.as<unsigned long long>(), stats.as<int>());
@@ -552,26 +514,21 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
                           hist.as<int>(), &ks, &order));
   curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), rank);
   DeviceTemp dbg;
-  if (getenv("GLIM_AMD_KNN_DEBUG")) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
+  const Diag& diag = ctx->diag;
+  if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
   // Which of the two chunk kernels: both are tail-bound -- the launch lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt
   // scan: mean wavefront 157 us, kernel 266 us; 41 % VALU utilisation) -- and the pair-lane kernel shortens the average wavefront by only ~18 %
   // for ~20-34 % more instructions (the lock-step insertion loop costs max-over-lanes rounds either way).  It wins where the 64-query kernel
   // leaves SIMDs empty (65 536 points: 204 -> 165 us kernel, 0.44 -> 0.33 ms per call), ties at 131 072 and loses at 307 200 (517 -> 785 us).
-  // GLIM_AMD_KNN_WAVE64=1 / GLIM_AMD_KNN_PAIR=1 force one or the other.
+  // diag knn_kernel=wave64 / pair forces one or the other.
   // Also measured and removed: 2 / 4 wavefronts per query chunk, each owning every 2nd / 4th candidate chunk with its own top-k list, the query's
   // bound shared through LDS (ds_min_u64) and the lists merged by rank at the end -- bit-identical lists, but 0.73 / 0.62 ms against 0.50 ms
   // at 131 072 points and 1.06 / 1.19 against 0.77 ms at 307 104: every list has to be filled and pruned on its own, so the total work grows
   // faster than the longest wavefront shrinks.
   // The FP32 mask passes of both chunk kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than 1e18 m is
   // answered by the exhaustive FP64 kernel instead.
-  const bool f32mask = getenv("GLIM_AMD_KNN_F64MASK") == nullptr;
-  // staged: the per-lane threshold selection (k <= 10 kernels), until `pytest -m gpu` has run with it
-#ifdef GLIM_AMD_KNN_SELECT
-  const bool select = getenv("GLIM_AMD_KNN_NO_SELECT") == nullptr;
-#else
-  const bool select = getenv("GLIM_AMD_KNN_SELECT") != nullptr;
-#endif
-  const bool pair_lanes = !dbg.p && k <= 16 && getenv("GLIM_AMD_KNN_WAVE64") == nullptr && (n <= 98304 || getenv("GLIM_AMD_KNN_PAIR") != nullptr);
+  const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
+  const bool pair_lanes = !dbg.p && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
   if (k > 0 && !(ext < 1e18f)) {
     DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
   } else if (k > 0 && pair_lanes) {
@@ -582,13 +539,13 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
-    knn_launch_chunks(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), f32mask, select);  // k == 0: ordering only
+    knn_launch_chunks(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), select);  // k == 0: ordering only
   }
   GA_HIP(hipGetLastError());
   if (dbg.p) {
     std::vector<int> hd((size_t)C * 4);
     GA_HIP(hipMemcpy(hd.data(), dbg.p, hd.size() * sizeof(int), hipMemcpyDeviceToHost));
-    if (FILE* f = fopen(getenv("GLIM_AMD_KNN_DEBUG"), "wb")) {
+    if (FILE* f = fopen(diag.knn_debug, "wb")) {
       fwrite(hd.data(), sizeof(int), hd.size(), f);
       fclose(f);
     }
@@ -606,7 +563,7 @@ namespace glim_amd {
 // Hilbert rank of every point of a cloud that has none yet (clouds whose neighbours came from the host or from the grid path).
 // Caller holds ctx->mu.  Tiny clouds and clouds with non-finite points simply stay in arrival order.
 int cloud_curve_rank(glim_amd_cloud* c, hipStream_t st) {
-  if (c->curve_rank || c->n < 4096 || c->n > (int64_t)(1 << 28) || getenv("GLIM_AMD_NO_CURVE_ORDER") != nullptr) return GLIM_AMD_OK;
+  if (c->curve_rank || c->n < 4096 || c->n > (int64_t)(1 << 28) || !c->ctx->diag.curve_order) return GLIM_AMD_OK;
   GA_HIP(pool_malloc(&c->curve_rank, (size_t)c->n * sizeof(unsigned int)));
   const int rc = knn_curve(c->ctx, st, (int)c->n, c->pts, 0, nullptr, c->curve_rank);
   if (rc != GLIM_AMD_OK) {
@@ -636,18 +593,19 @@ int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_o
   if (c->n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
   const int n = (int)c->n;
   hipStream_t st = ctx->stream();
-  const bool brute = n <= 2048 || n <= 2 * k || getenv("GLIM_AMD_KNN_BRUTE") != nullptr;
+  const Diag& diag = ctx->diag;
+  const bool brute = n <= 2048 || n <= 2 * k || diag.knn_path == KNN_PATH_BRUTE;
   if (brute) {
     DISPATCH_K(launch_brute, st, n, c->pts, k, c->neighbors, (const int*)nullptr, n);
     GA_HIP(hipGetLastError());
   } else {
     // below ~24k points the chunk kernel's 47-odd blocks leave most of the chip idle and its sort passes are pure latency: the grid
     // path is 0.09 ms faster on a 12 000-point preprocessed scan, level at 42k-58k points, 1.4-1.7x slower from 131k points up
-    const bool grid = getenv("GLIM_AMD_KNN_GRID") != nullptr || (n < 24576 && getenv("GLIM_AMD_KNN_CHUNKS") == nullptr);
+    const bool grid = diag.knn_path == KNN_PATH_GRID || (n < 24576 && diag.knn_path != KNN_PATH_CHUNKS);
     if (grid) GA_TRY(knn_grid(ctx, st, n, c->pts, k, c->neighbors));
     else {
       // the Hilbert rank of every point is kept: estimate_covariances writes the factor's plane-form stream in that order
-      if (!c->curve_rank && getenv("GLIM_AMD_NO_CURVE_ORDER") == nullptr) GA_HIP(pool_malloc(&c->curve_rank, (size_t)n * sizeof(unsigned int)));
+      if (!c->curve_rank && diag.curve_order) GA_HIP(pool_malloc(&c->curve_rank, (size_t)n * sizeof(unsigned int)));
       GA_TRY(knn_curve(ctx, st, n, c->pts, k, c->neighbors, c->curve_rank));
     }
   }

@@ -5,11 +5,10 @@ using namespace glim_amd;
 
 namespace {
 
-#ifdef GLIM_AMD_KNN_GROUPBOX
-// Experiment for round 3, NOT yet run on a GPU: boxes of the groups of 64 chunks, stored behind the chunk boxes (box[6 * (C + g) ...]).  A query
-// chunk first tests the (<= 256) group boxes against its search radius after the first three scans and walks only the groups that pass -- 3.0 of
-// 32 on average for a 131 072-pt scan (tools/knn_model.py), where the walk over all groups is most of the ~47 us every wavefront pays today.
-// A group box contains its chunk boxes and the radius only shrinks, so no chunk that the walk would have scanned is lost.
+// Boxes of the groups of 64 chunks, stored behind the chunk boxes (box[6 * (C + g) ...]).  A query chunk tests the (<= 256) group boxes
+// against its search radius after the first three scans and walks only the groups that pass -- 3.0 of 32 on average for a 131 072-pt scan --
+// where the walk over all groups used to be most of the ~47 us every wavefront paid whatever it scanned.  A group box contains its chunk
+// boxes and the radius only shrinks, so no chunk that the full walk would have scanned is lost.
 __global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict__ box /* [C + G][6] */) {
   const int g = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const int G = (C + CHUNK - 1) / CHUNK;
@@ -39,36 +38,33 @@ __global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict
     }
   }
 }
-#endif
 
-// F32MASK: the mask pass of a chunk scan runs in FP32 on the float4 records themselves (the scheme of the pair-lane kernel below, which states
-// the error bound): "d32 <= thr * (1 + 2e-6)" can only ADD candidates, and every accepted candidate is re-evaluated with the oracle's FP64
-// expression before it is offered to the list, so the lists stay bit-identical -- 64 x 6 full-rate FP32 operations and one 16-byte LDS read
-// per candidate instead of 64 x 6 half-rate FP64 operations and three 8-byte reads.  The host only selects it when the cloud's extent keeps
-// FP32 squared distances finite.  (131 072-pt scan 0.495 -> 0.460 ms, 307 104-pt depth frame 0.766 -> 0.718 ms, same box.)
-// Where a wavefront's time goes (per-wavefront counters of GLIM_AMD_KNN_DEBUG, least-squares fit over the 2048 wavefronts of a 131 072-pt
-// scan, tools/knn_debug.py): 47 us fixed (the walk over the 32 groups of chunk boxes, the seeds) + 2.7 us per scanned chunk (x 10.9) +
-// 0.51 us per insertion round (x 116): the lock-step insertion rounds are 44 % of the mean wavefront and 60 % of the slowest one.  Measured
-// against this kernel on one box and NOT adopted (profiles/r02/probe/knn_chunk_variants_ab.txt; all bit-identical): the mask pass reading the
-// candidates with v_readlane instead of LDS (-1 %); branch-free insertion (K compares + selects, or min / max for the distances) instead of
-// the early-exit bubble, with one or two candidates per round (+17 ... +28 %); issuing the box loads of the next group, the points of the
-// next candidate chunk and the first three chunks ahead of their use, with the per-lane box test fed by v_readlane (+4 %).
-template <int K, bool F32MASK, bool SELECT = false>
+// One wavefront answers the 64 queries of chunk c by streaming candidate chunks through LDS.
+//
+// Mask pass in packed FP32: the candidate coordinates lie x / y / z-planar in LDS, so two consecutive candidates load as one register pair
+// and the 64 x 3 subtract / multiply / fma steps run as v_pk_* (two per instruction).  d32 = fl((qx - x)^2 + ...) differs from the exact
+// squared distance by < 4 ulp-relative (3e-7), so "d32 <= thr * (1 + 2e-6)" can only ADD candidates, and every accepted candidate is
+// re-evaluated with the oracle's FP64 expression before it is offered to the list: the lists stay bit-identical.  The host only takes this
+// kernel when the cloud's extent keeps FP32 squared distances finite.
+//
+// SELECT (k <= 10): the lock-step insertion loop lasts as long as the lane with the most accepted candidates, and a lane whose bound is
+// still loose accepts most of a chunk although only a handful end up in its list.  So the 64 FP32 distances stay in registers and every
+// lane first finds, by bisection over FP32 bit patterns, a threshold t with
+//     #(list entries with d <= t) + #(accepted candidates with d32 <= t) >= K;
+// candidates with d32 > t * (1 + 2e-6) are dropped without being popped: once the others are inserted the list holds K entries whose exact
+// distances are <= t * (1 + 3e-7), strictly below the exact distance of every dropped candidate (> t * (1 + 2e-6) * (1 - 3e-7)).
+// Insertion rounds 116 -> 50 per wavefront, 395 -> 140 for the slowest (tools/knn_model.py emulates this code step by step on the CPU:
+// tests/test_knn_model.py); 131 072-pt scan 0.46 -> 0.36 ms, 307 104-pt depth frame 0.72 -> 0.60 ms with the group boxes and the packed
+// mask pass (profiles/r02/probe/knn_select_groupbox_ab.txt, BENCH_r02 `staged`).
+//
+// Measured against this kernel and NOT adopted (profiles/r02/probe/knn_chunk_variants_ab.txt; all bit-identical): candidates read with
+// v_readlane instead of LDS (-1 %); branch-free insertion (K compares + selects, or min / max on the distances) instead of the early-exit
+// bubble, one or two candidates per round (+17 ... +28 %); loads issued one step ahead of their use (+4 %); an all-FP64 mask pass (+8 %).
+template <int K, bool SELECT>
 __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const float4* __restrict__ sorted, const float* __restrict__ box, int k,
                                                         int32_t* __restrict__ out, int* __restrict__ dbg) {
-  __shared__ double s_xyz[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK][3];
-  __shared__ int s_idx[F32MASK ? 1 : 4][F32MASK ? 1 : CHUNK];
-#ifdef GLIM_AMD_KNN_PKMASK
-  // Experiment for round 3, NOT yet run on a GPU: candidate coordinates planar in LDS, so that two consecutive candidates load as one register
-  // pair and the mask pass runs on packed FP32 (v_pk_add / v_pk_mul / v_pk_fma: 3 instead of 6 arithmetic instructions per candidate).  The
-  // per-component operations and their order are those of the scalar pass, so every d32 is bit-identical.
-  __shared__ __attribute__((aligned(8))) float s_px[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1], s_py[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1],
-      s_pz[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
-  __shared__ int s_pi[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
-  __shared__ float4 s_pt[1][1];
-#else
-  __shared__ float4 s_pt[F32MASK ? 4 : 1][F32MASK ? CHUNK : 1];
-#endif
+  __shared__ __attribute__((aligned(8))) float s_px[4][CHUNK], s_py[4][CHUNK], s_pz[4][CHUNK];
+  __shared__ int s_pi[4][CHUNK];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + w;
   if (c >= C) return;  // whole wavefront
@@ -84,51 +80,22 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   int dbg_tiles = 0, dbg_pops = 0;
   const long long dbg_t0 = dbg ? wall_clock64() : 0;
 
-  // Stream chunk cc through LDS.  Two phases keep the hot loop free of branches: (1) every lane evaluates all 64 candidates and
-  // records which ones pass its k-th best of the moment in a 64-bit mask (inclusive test, so ties are kept); (2) the lanes pop
-  // their masks together -- the K-step insertion then runs max-popcount times per chunk instead of once per candidate, and for
-  // most chunks after the first three nobody has anything to insert.
   // candidate j of the staged chunk: its index (< 0: padding) and its exact squared distance
-  auto cand_idx = [&](int j) -> int {
-#ifdef GLIM_AMD_KNN_PKMASK
-    if constexpr (F32MASK) return s_pi[w][j];
-#else
-    if constexpr (F32MASK) return __float_as_int(s_pt[w][j].w);
-#endif
-    else return s_idx[w][j];
-  };
-  auto cand_dist = [&](int j) -> double {
-    if constexpr (F32MASK) {
-#ifdef GLIM_AMD_KNN_PKMASK
-      return sqdist(qx, qy, qz, (double)s_px[w][j], (double)s_py[w][j], (double)s_pz[w][j]);
-#else
-      const float4 cp = s_pt[w][j];
-      return sqdist(qx, qy, qz, (double)cp.x, (double)cp.y, (double)cp.z);
-#endif
-    } else {
-      return sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
-    }
-  };
+  auto cand_idx = [&](int j) -> int { return s_pi[w][j]; };
+  auto cand_dist = [&](int j) -> double { return sqdist(qx, qy, qz, (double)s_px[w][j], (double)s_py[w][j], (double)s_pz[w][j]); };
+  // Stream chunk cc through LDS.  Two phases keep the hot loop free of branches: (1) every lane evaluates all 64 candidates and records
+  // which ones pass its k-th best of the moment in a 64-bit mask (inclusive test, so ties are kept); (2) the lanes pop their masks
+  // together -- the K-step insertion then runs max-popcount times per chunk instead of once per candidate, and for most chunks after the
+  // first three nobody has anything to insert.
   auto scan_chunk = [&](int cc, bool need, bool seed) {
     const float4 p = sorted[cc * CHUNK + lane];
     dbg_tiles++;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if constexpr (F32MASK) {
-#ifdef GLIM_AMD_KNN_PKMASK
-      s_px[w][lane] = p.x;
-      s_py[w][lane] = p.y;
-      s_pz[w][lane] = p.z;
-      s_pi[w][lane] = __float_as_int(p.w);
-#else
-      s_pt[w][lane] = p;
-#endif
-    } else {
-      s_xyz[w][lane][0] = (double)p.x;
-      s_xyz[w][lane][1] = (double)p.y;
-      s_xyz[w][lane][2] = (double)p.z;
-      s_idx[w][lane] = __float_as_int(p.w);
-    }
+    s_px[w][lane] = p.x;
+    s_py[w][lane] = p.y;
+    s_pz[w][lane] = p.z;
+    s_pi[w][lane] = __float_as_int(p.w);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     unsigned long long seeded = 0ull;
@@ -146,22 +113,11 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       }
     }
     const double thr = need ? best.d[K - 1] : -1.0;  // lanes that do not need this chunk accept nothing
+    // FP32 image of the bound, inflated beyond the FP32 evaluation error; -1 stays negative, +inf stays +inf
+    const float thr32 = (float)(thr * 1.000002) + 1e-37f;
     unsigned int mlo = 0u, mhi = 0u;
-    if constexpr (F32MASK) {
-      // FP32 image of the bound, inflated beyond the FP32 evaluation error (see knn_pair_kernel); -1 stays negative, +inf stays +inf
-      const float thr32 = (float)(thr * 1.000002) + 1e-37f;
-      if constexpr (SELECT) {
-      // SELECT (staged: instantiated for k <= 10 only and chosen by GLIM_AMD_KNN_SELECT=1 or the build macro of the same name until the GPU
-      // parity tests have run with it; tools/knn_model.py "select_bits" emulates this code step by step on the CPU: lists unchanged, insertion
-      // rounds 116 -> 50 per wavefront and 395 -> 140 for the slowest; measured on one box: 0.46 -> 0.36 ms for a 131 072-pt scan, lists exact).
-      // The lock-step insertion loop below lasts as long as the lane with the most accepted candidates, and a lane whose bound is still loose
-      // accepts most of a chunk although only a handful end up in its list.  So the 64 FP32 distances are kept
-      // in registers and every lane first finds, by bisection over FP32 bit patterns, a threshold t with
-      //     #(list entries with d <= t) + #(accepted candidates with d32 <= t) >= K;
-      // candidates with d32 > t * (1 + 2e-6) are then dropped without being popped: once the others are inserted the list holds K entries whose
-      // exact distances are <= t * (1 + 3e-7), strictly below the exact distance of every dropped candidate (> t * (1 + 2e-6) * (1 - 3e-7)).
+    if constexpr (SELECT) {
       float dv[CHUNK];
-#ifdef GLIM_AMD_KNN_PKMASK
 #pragma unroll
       for (int j = 0; j < CHUNK; j += 2) {
         const v2f dx = v2f{qxf, qxf} - *reinterpret_cast<const v2f*>(&s_px[w][j]), dy = v2f{qyf, qyf} - *reinterpret_cast<const v2f*>(&s_py[w][j]),
@@ -170,57 +126,46 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         dv[j] = d.x;
         dv[j + 1] = d.y;
       }
-#else
-#pragma unroll
-      for (int j = 0; j < CHUNK; j++) {
-        const float4 cp = s_pt[w][j];
-        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
-        dv[j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      }
-#endif
 #pragma unroll
       for (int j = 0; j < 32; j++) mlo |= (dv[j] <= thr32 ? 1u : 0u) << j;
 #pragma unroll
       for (int j = 0; j < 32; j++) mhi |= (dv[32 + j] <= thr32 ? 1u : 0u) << j;
-      {
-        const unsigned long long m0 = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
-        constexpr int SELECT_MIN = 12;  // below this many accepted candidates in every lane the selection costs more than it saves (model)
-        if (__any(__popcll(m0) > SELECT_MIN)) {
-          const float inf32 = __int_as_float(0x7f800000);
-          // only candidates that are up for insertion count (rejected at thr, seeded and padding candidates become +inf)
+      const unsigned long long m0 = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
+      constexpr int SELECT_MIN = 12;  // below this many accepted candidates in every lane the selection costs more than it saves (model)
+      if (__any(__popcll(m0) > SELECT_MIN)) {
+        const float inf32 = __int_as_float(0x7f800000);
+        // only candidates that are up for insertion count (rejected at thr, seeded and padding candidates become +inf)
 #pragma unroll
-          for (int j = 0; j < CHUNK; j++) dv[j] = ((m0 >> j) & 1ull) ? dv[j] : inf32;
-          auto count_le = [&](float t) -> int {
-            int cnt = 0;
+        for (int j = 0; j < CHUNK; j++) dv[j] = ((m0 >> j) & 1ull) ? dv[j] : inf32;
+        auto count_le = [&](float t) -> int {
+          int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < CHUNK; j++) cnt += dv[j] <= t ? 1 : 0;
+          for (int j = 0; j < CHUNK; j++) cnt += dv[j] <= t ? 1 : 0;
 #pragma unroll
-            for (int j = 0; j < K; j++) cnt += best.d[j] <= (double)t ? 1 : 0;
-            return cnt;
-          };
-          unsigned int hi = __float_as_uint(fminf(thr32, 3.4028234e38f));  // a list that is not full yet searches below FLT_MAX
-          const bool sel = need && count_le(__uint_as_float(hi)) >= K;
-          unsigned int lo = hi > (16u << 23) ? hi - (16u << 23) : 0u;  // 16 octaves below the bound; invariant: count_le(hi) >= K
-          for (int step = 0; step < 8; step++) {                        // 2^27 bit patterns -> 2^19: t within 6 % of the smallest valid one
-            const unsigned int mid = lo + ((hi - lo) >> 1);
-            const bool ok = count_le(__uint_as_float(mid)) >= K;
-            hi = ok ? mid : hi;
-            lo = ok ? lo : mid + 1u;
-          }
-          const float keep = __uint_as_float(hi) * 1.000002f + 1e-37f;
-          unsigned int klo = 0u, khi = 0u;
+          for (int j = 0; j < K; j++) cnt += best.d[j] <= (double)t ? 1 : 0;
+          return cnt;
+        };
+        unsigned int hi = __float_as_uint(fminf(thr32, 3.4028234e38f));  // a list that is not full yet searches below FLT_MAX
+        const bool sel = need && count_le(__uint_as_float(hi)) >= K;
+        unsigned int lo = hi > (16u << 23) ? hi - (16u << 23) : 0u;  // 16 octaves below the bound; invariant: count_le(hi) >= K
+        for (int step = 0; step < 8; step++) {                        // 2^27 bit patterns -> 2^19: t within 6 % of the smallest valid one
+          const unsigned int mid = lo + ((hi - lo) >> 1);
+          const bool ok = count_le(__uint_as_float(mid)) >= K;
+          hi = ok ? mid : hi;
+          lo = ok ? lo : mid + 1u;
+        }
+        const float keep = __uint_as_float(hi) * 1.000002f + 1e-37f;
+        unsigned int klo = 0u, khi = 0u;
 #pragma unroll
-          for (int j = 0; j < 32; j++) klo |= (dv[j] <= keep ? 1u : 0u) << j;
+        for (int j = 0; j < 32; j++) klo |= (dv[j] <= keep ? 1u : 0u) << j;
 #pragma unroll
-          for (int j = 0; j < 32; j++) khi |= (dv[32 + j] <= keep ? 1u : 0u) << j;
-          if (sel) {  // seeded / rejected / padding candidates are +inf here; the AND keeps them out even if `keep` overflowed to +inf
-            mlo = klo & (unsigned int)m0;
-            mhi = khi & (unsigned int)(m0 >> 32);
-          }
+        for (int j = 0; j < 32; j++) khi |= (dv[32 + j] <= keep ? 1u : 0u) << j;
+        if (sel) {  // seeded / rejected / padding candidates are +inf here; the AND keeps them out even if `keep` overflowed to +inf
+          mlo = klo & (unsigned int)m0;
+          mhi = khi & (unsigned int)(m0 >> 32);
         }
       }
-      } else {
-#ifdef GLIM_AMD_KNN_PKMASK
+    } else {
 #pragma unroll
       for (int j = 0; j < CHUNK; j += 2) {
         const v2f dx = v2f{qxf, qxf} - *reinterpret_cast<const v2f*>(&s_px[w][j]), dy = v2f{qyf, qyf} - *reinterpret_cast<const v2f*>(&s_py[w][j]),
@@ -230,32 +175,6 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         if (j < 32) mlo |= two << j;
         else mhi |= two << (j - 32);
       }
-#else
-#pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const float4 cp = s_pt[w][j];
-        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
-        mlo |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
-      }
-#pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const float4 cp = s_pt[w][32 + j];
-        const float dx = qxf - cp.x, dy = qyf - cp.y, dz = qzf - cp.z;
-        mhi |= (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr32 ? 1u : 0u) << j;
-      }
-#endif
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const double d = sqdist(qx, qy, qz, s_xyz[w][j][0], s_xyz[w][j][1], s_xyz[w][j][2]);
-        mlo |= (d <= thr ? 1u : 0u) << j;
-      }
-#pragma unroll
-      for (int j = 0; j < 32; j++) {
-        const double d = sqdist(qx, qy, qz, s_xyz[w][32 + j][0], s_xyz[w][32 + j][1], s_xyz[w][32 + j][2]);
-        mhi |= (d <= thr ? 1u : 0u) << j;
-      }
     }
     unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & ~seeded;
     while (__any(m != 0ull)) {
@@ -264,7 +183,7 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
         const int j = (int)__builtin_ctzll(m);
         m &= m - 1ull;
         const int idx = cand_idx(j);
-        // (F32MASK: a candidate the inflated FP32 bound let through is settled by the exact (distance, index) test of push)
+        // a candidate the inflated FP32 bound let through is settled by the exact (distance, index) test of push
         if (idx >= 0) best.push(cand_dist(j), idx);
       }
     }
@@ -280,7 +199,6 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
   // sparse query next to a dense patch can meet ever closer tiles and insert all 64 candidates of each: one such wavefront took
   // 985 us against a mean of 170 us.)
   const int G = (C + CHUNK - 1) / CHUNK, gc = c / CHUNK;
-#ifdef GLIM_AMD_KNN_GROUPBOX
   unsigned long long gmask[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // groups worth walking (all of them beyond 256 groups)
   if (G <= 256) {
     double r20 = best.d[K - 1];
@@ -299,13 +217,10 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
       gmask[wd] = __ballot(okg);
     }
   }
-#endif
   for (int t = 0; t < 2 * G; t++) {
     const int gi = (t & 1) ? gc + ((t + 1) >> 1) : gc - (t >> 1);
     if (gi < 0 || gi >= G) continue;
-#ifdef GLIM_AMD_KNN_GROUPBOX
     if (G <= 256 && !((gmask[gi >> 6] >> (gi & 63)) & 1ull)) continue;
-#endif
     const int g0 = gi * CHUNK;
     // wave-wide search radius: the largest k-th best distance among the lanes (+inf while some list is not full)
     double r2 = best.d[K - 1];
@@ -348,31 +263,23 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
 }
 
 template <int K>
-void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool f32mask, bool select) {
-#ifdef GLIM_AMD_KNN_KEEP_F64MASK  // development builds: the all-FP64 mask pass as a cross-check (GLIM_AMD_KNN_F64MASK=1 selects it)
-  if (!f32mask) {
-    knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
-    return;
-  }
-#endif
-  if constexpr (K <= 10) {
+void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool select) {
+  if constexpr (K <= 10) {  // the selection keeps 64 distances in registers next to the list: beyond k = 10 it spills
     if (select) {
-      knn_chunk_kernel<K, true, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+      knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
       return;
     }
   }
-  knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+  knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
 }
 
 }  // namespace
 
 namespace glim_amd {
 
-void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool f32mask, bool select) {
-#ifdef GLIM_AMD_KNN_GROUPBOX
+void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select) {
   group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box);
-#endif
-  DISPATCH_K(launch_chunks, st, n, C, sorted, box, k, out, dbg, f32mask, select);
+  DISPATCH_K(launch_chunks, st, n, C, sorted, box, k, out, dbg, select);
 }
 
 }  // namespace glim_amd

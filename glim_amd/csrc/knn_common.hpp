@@ -8,9 +8,9 @@
 #include "internal.hpp"
 
 namespace glim_amd {
-// 64-query chunk kernel over the Hilbert-ordered points (`sorted`, C chunks of 64 with boxes `box`; with -DGLIM_AMD_KNN_GROUPBOX `box` also has
-// room for the group boxes, which this call fills first).  dbg: optional per-wavefront counters.  f32mask / select: see knn_chunks.hip.
-void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool f32mask, bool select);
+// 64-query chunk kernel over the Hilbert-ordered points (`sorted`, C chunks of 64 with boxes `box`, which also has room for the boxes of the
+// groups of 64 chunks: this call fills them first).  dbg: optional per-wavefront counters.  select: see knn_chunks.hip.
+void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select);
 // pair-lane kernel over 32-point half chunks (C32 of them, boxes `box32`); k <= 16
 void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select);
 }  // namespace glim_amd
@@ -60,10 +60,6 @@ __device__ __forceinline__ double sqdist(double qx, double qy, double qz, double
 }
 
 
-#ifdef GLIM_AMD_DEV_K10  // development builds only (tools/isa_stats.py turn-around): instantiate the k = 10 kernels alone
-#define DISPATCH_K(FN, ...) FN<10>(__VA_ARGS__)
-#define DISPATCH_K16(FN, ...) FN<10>(__VA_ARGS__)
-#else
 // k <= 16 only (the pair-lane kernel keeps two top-k lists per query in registers: beyond 16 entries it spills)
 #define DISPATCH_K16(FN, ...)                    \
   do {                                           \
@@ -79,7 +75,5 @@ __device__ __forceinline__ double sqdist(double qx, double qy, double qz, double
     else if (k <= 24) FN<24>(__VA_ARGS__);       \
     else FN<32>(__VA_ARGS__);                    \
   } while (0)
-
-#endif
 
 }  // namespace

@@ -5,9 +5,9 @@ using namespace glim_amd;
 
 namespace {
 
-// ---- pair-lane variant (default): 32 queries per wavefront, two lanes per query ------------------------------------------------------------
-// The 64-query kernel above leaves a 131 072-point scan with 2048 wavefronts -- two per SIMD -- each a serial ~25 000-instruction chain,
-// i.e. latency-bound with nothing to overlap.  Here a wavefront answers the 32 queries of a 32-point chunk and lanes l and l + 32 serve the
+// ---- pair-lane variant (clouds up to 98 304 points): 32 queries per wavefront, two lanes per query ----------------------------------------
+// The 64-query kernel (knn_chunks.hip) leaves a 65 536-point keyframe with 1024 wavefronts -- one per SIMD -- each a serial chain of tens of
+// thousands of instructions, i.e. latency-bound with nothing to overlap.  Here a wavefront answers the 32 queries of a 32-point chunk and lanes l and l + 32 serve the
 // SAME query: every step streams TWO candidate chunks through LDS, the lower half of the wavefront scans the first, the upper half the second,
 // so a (query, candidate) pair is still evaluated exactly once but there are twice as many wavefronts of half the length.  The two lanes of a
 // query keep separate top-k lists over disjoint candidate sets and share their pruning threshold: the k-th best of the union is at most the
@@ -17,7 +17,7 @@ namespace {
 // The mask pass runs in FP32: d32 = fl((qx - x)^2 + ...) differs from the exact squared distance by < 4 ulp-relative (3e-7), so
 // "d32 <= thr * (1 + 2e-6)" can only ADD false candidates; every accepted candidate is re-evaluated in FP64 with the oracle's expression
 // before it is offered to the list, which applies the exact (distance, index) test.  Results are bit-identical to the other implementations.
-template <int K, bool SELECT = false>
+template <int K, bool SELECT>
 __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point chunks */, const float4* __restrict__ sorted, const float* __restrict__ box,
                                                        int k, int32_t* __restrict__ out) {
   __shared__ float4 s_pt[4][64];
@@ -217,7 +217,7 @@ void launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const fl
       return;
     }
   }
-  knn_pair_kernel<K><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
+  knn_pair_kernel<K, false><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
 }
 
 }  // namespace

@@ -11,7 +11,15 @@
 //     to glim_amd_linearized6 (binary blocks by the adjoint identity) in the original factor order.
 // librccl is opened lazily with dlopen: libglim_amd.so has no link-time dependency on it, and single-device users never load it.
 #include <dlfcn.h>
+// Only function pointers into librccl are used (dlopen below), so a ROCm install without the RCCL development headers still builds this
+// library: the handful of types and enumerators the calls need are then declared here with RCCL's own values.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -30,6 +38,7 @@ struct RcclApi {
   void* handle = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok() const { return CommInitAll && CommDestroy && AllGather; }
@@ -46,6 +55,7 @@ RcclApi& rccl() {
     if (!api.handle) return;
     api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(api.handle, "ncclCommInitAll"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
   });
@@ -77,6 +87,7 @@ struct glim_amd_multi {
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
   bool use_rccl = false;
+  bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
   std::vector<Worker*> workers;
 
   // run fn(device index) on every device's worker thread concurrently; first non-zero return code wins
@@ -126,6 +137,7 @@ void worker_loop(Worker* w, int device) {
 void release_factors(glim_amd_multi* m) {
   for (int d = 0; d < m->ndev; d++) {
     (void)hipSetDevice(m->devices[d]);
+    if (d < (int)m->ctxs.size() && m->ctxs[d]) (void)glim_amd_ctx_synchronize(m->ctxs[d]);  // asynchronous linearisations write into d_gather
     if (d < (int)m->sets.size() && m->sets[d]) (void)glim_amd_factor_set_destroy(m->sets[d]);
     if (d < (int)m->d_gather.size() && m->d_gather[d]) (void)pool_free(m->d_gather[d]);
   }
@@ -190,8 +202,9 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
     m->ctxs.push_back(ctx);
   }
   // RCCL: one communicator per device, created together in this process.  A single device still goes through the collective (it is a
-  // copy there) unless GLIM_AMD_MULTI_NO_RCCL is set, so that the path the 8-GPU node takes is the path a 1-GPU box tests.
-  if (getenv("GLIM_AMD_MULTI_NO_RCCL") == nullptr && rccl().ok()) {
+  // copy there) unless diag multi_rccl=0 (GLIM_AMD_DIAG), so that the path the 8-GPU node takes is the path a 1-GPU box tests.
+  const Diag& diag = process_diag();
+  if (diag.multi_rccl && rccl().ok()) {
     m->comms.assign(num_devices, nullptr);
     const ncclResult_t r = rccl().CommInitAll(m->comms.data(), num_devices, m->devices.data());
     if (r == ncclSuccess) {
@@ -201,7 +214,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
       snprintf(msg, sizeof(msg), "ncclCommInitAll: %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "error");
       set_hip_error(hipErrorUnknown, msg);
       m->comms.clear();
-      if (num_devices > 1 && getenv("GLIM_AMD_MULTI_ALLOW_HOST_GATHER") == nullptr) {
+      if (num_devices > 1 && !diag.multi_host_gather) {
         for (auto c : m->ctxs) (void)glim_amd_ctx_destroy(c);
         delete m;
         return GLIM_AMD_ERR_HIP;  // refuse to silently fall back to a PCIe gather on a multi-device node
@@ -309,19 +322,25 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
     if (target_map_ids[f] < 0 || target_map_ids[f] >= nmaps || source_cloud_ids[f] < 0 || source_cloud_ids[f] >= nclouds) return GLIM_AMD_ERR_INVALID;
     costs[(size_t)f] = (double)m->clouds[0][source_cloud_ids[f]]->n;
   }
-  release_factors(m);
-  m->bounds.assign(m->ndev + 1, 0);
-  GA_TRY(glim_amd_shard_bounds(costs.data(), num_factors, m->ndev, m->bounds.data()));
+  release_factors(m);  // the handle is at "no factors" from here until everything below has succeeded
+  m->nf = 0;
+  m->bounds.clear();
+  m->flags.clear();
+  std::vector<int64_t> bounds((size_t)m->ndev + 1, 0);
+  GA_TRY(glim_amd_shard_bounds(costs.data(), num_factors, m->ndev, bounds.data()));
+  int64_t max_rows = 1;
+  for (int d = 0; d < m->ndev; d++) max_rows = std::max<int64_t>(max_rows, bounds[(size_t)d + 1] - bounds[(size_t)d]);
+  const size_t gather_doubles = (size_t)m->ndev * (size_t)max_rows * COMPACT;
+  if (pinned_malloc(&m->h_gather, gather_doubles * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    m->h_gather = nullptr;
+    return GLIM_AMD_ERR_NOMEM;
+  }
+  m->bounds = bounds;
   m->flags.assign((size_t)num_factors, 0u);
   for (int64_t f = 0; f < num_factors; f++) m->flags[(size_t)f] = flags ? flags[f] : 0u;
   m->nf = num_factors;
-  m->max_rows = 1;
-  for (int d = 0; d < m->ndev; d++) m->max_rows = std::max<int64_t>(m->max_rows, m->bounds[d + 1] - m->bounds[d]);
-  const size_t gather_doubles = (size_t)m->ndev * (size_t)m->max_rows * COMPACT;
-  if (pinned_malloc(&m->h_gather, gather_doubles * sizeof(double)) != hipSuccess) {
-    (void)hipGetLastError();
-    return GLIM_AMD_ERR_NOMEM;
-  }
+  m->max_rows = max_rows;
   const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
     GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[d]));
@@ -334,6 +353,7 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   });
   if (rc != GLIM_AMD_OK) {  // no half-built factor list: the handle is back to "no factors"
     release_factors(m);
+    m->nf = 0;
     m->bounds.clear();
     m->flags.clear();
   }
@@ -354,6 +374,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
     return GLIM_AMD_OK;
   }
   if (!T) return GLIM_AMD_ERR_INVALID;
+  if (m->broken) return GLIM_AMD_ERR_STATE;
   const size_t slot = (size_t)m->max_rows * COMPACT;
   // Two rounds over the workers: the kernels are enqueued first and the collective only if EVERY device managed to -- a device that failed
   // before its ncclAllGather would leave the others waiting in theirs for ever.  (The first round only enqueues; the extra hand-over between
@@ -382,7 +403,19 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
     GA_HIP(hipStreamSynchronize(st));
     return (int)GLIM_AMD_OK;
   });
-  GA_TRY(rc);
+  if (rc != GLIM_AMD_OK) {
+    // A device that failed before or inside its ncclAllGather leaves the others blocked in theirs: abort every communicator so that their
+    // streams drain, and retire the handle (a communicator cannot be used after an abort).
+    if (m->use_rccl && rccl().CommAbort) {
+      for (auto& c : m->comms)
+        if (c) {
+          (void)rccl().CommAbort(c);
+          c = nullptr;
+        }
+      m->broken = true;
+    }
+    return rc;
+  }
   double total = 0.0;
   for (int d = 0; d < m->ndev; d++)
     for (int64_t f = m->bounds[d]; f < m->bounds[d + 1]; f++) {

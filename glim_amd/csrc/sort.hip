@@ -184,14 +184,9 @@ void launch_pass(hipStream_t st, int B, int stride, const unsigned long long* ki
   }
 }
 
-inline int block_target() {
-  static const int t = [] {
-    const char* e = getenv("GLIM_AMD_RS_BLOCKS");  // tuning knob: largest grid the tile choice aims for (<= RS_FUSED_MAX_BLOCKS)
-    const int v = e ? atoi(e) : 128;  // measured on MI355X, 131 072 pairs: 64 blocks 16.5 us / pass, 128: 14.8, 256: 18.9 (every block reads the whole table)
-    return std::max(1, std::min(v, RS_FUSED_MAX_BLOCKS));
-  }();
-  return t;
-}
+// largest grid the tile choice aims for: measured on MI355X, 131 072 pairs: 64 blocks 16.5 us / pass, 128: 14.8, 256: 18.9 (every block
+// reads the whole table)
+inline int block_target() { return std::min(128, RS_FUSED_MAX_BLOCKS); }
 inline int pick_rounds(int n) {
   for (int r = 1; r < 8; r <<= 1)
     if ((n + RS_THREADS * r - 1) / (RS_THREADS * r) <= block_target()) return r;

@@ -37,10 +37,6 @@ using namespace glim_amd;
 
 namespace {
 
-#ifndef GLIM_AMD_ABLATE
-#define GLIM_AMD_ABLATE 0  // profiling-only variants (tools/ablate.sh): 1 no gathers, 3 no algebra, 4 key gather only
-#endif
-
 constexpr int BLOCK = 256;
 constexpr int NACC = 28;  // FP32 accumulators per thread (see layout below); slot 28 of a partial row = inlier count (int bits)
 
@@ -112,9 +108,53 @@ struct FinalizeArgs {
   long long out_row_offset;
   int* done_counter;         // finished factors of this launch (polling fast path)
   unsigned int* host_flag;   // host-mapped completion word or null
+  unsigned int* row_flags;   // host-finalised single-factor call: one arrival word per partial row (host-mapped), else null
   unsigned int seq;
   int num_factors;
 };
+
+// The last step of a linearisation, shared by the device finalise kernel and by the host-finalised single-factor call so that both give
+// the same bits: the kernel accumulated H' = sum J'^T M J' and b' = sum J'^T M r for J' = [hat(R p) | -I] in the target frame; with
+// J_s = J' diag(R, R):  H_ss = diag(R, R)^T H' diag(R, R), b_s = diag(R, R)^T b', i.e. every 3x3 block B' becomes R^T B' R and every
+// 3-vector R^T v.  No fma contraction (host and device compilers would contract differently).
+__host__ __device__ inline void rotate_block(const double* B, const double* R, double* O) {
+#pragma clang fp contract(off)
+  double BR[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) BR[3 * r + c] = B[3 * r] * R[c] + B[3 * r + 1] * R[3 + c] + B[3 * r + 2] * R[6 + c];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) O[3 * r + c] = R[r] * BR[c] + R[3 + r] * BR[3 + c] + R[6 + r] * BR[6 + c];  // (R^T BR)[r][c]
+}
+// part 0..2: rotate block Hww / Hwv / Hvv of the 32 summed accumulators `sum` into `rot` (accumulator layout); part 3: the two vectors
+__host__ __device__ inline void rotate_part(int part, const double* sum, const double* T, double* rot) {
+#pragma clang fp contract(off)
+  double R[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
+  if (part < 3) {
+    double B[9], O[9];
+    if (part == 0) {
+      B[0] = sum[0]; B[1] = sum[1]; B[2] = sum[2]; B[3] = sum[1]; B[4] = sum[3]; B[5] = sum[4]; B[6] = sum[2]; B[7] = sum[4]; B[8] = sum[5];
+    } else if (part == 1) {
+      for (int i = 0; i < 9; i++) B[i] = sum[6 + i];
+    } else {
+      B[0] = sum[15]; B[1] = sum[16]; B[2] = sum[17]; B[3] = sum[16]; B[4] = sum[18]; B[5] = sum[19]; B[6] = sum[17]; B[7] = sum[19]; B[8] = sum[20];
+    }
+    rotate_block(B, R, O);
+    if (part == 0) {
+      rot[0] = O[0]; rot[1] = O[1]; rot[2] = O[2]; rot[3] = O[4]; rot[4] = O[5]; rot[5] = O[8];
+    } else if (part == 1) {
+      for (int i = 0; i < 9; i++) rot[6 + i] = O[i];
+    } else {
+      rot[15] = O[0]; rot[16] = O[1]; rot[17] = O[2]; rot[18] = O[4]; rot[19] = O[5]; rot[20] = O[8];
+    }
+  } else {
+    for (int c = 0; c < 3; c++) {
+      rot[21 + c] = R[c] * sum[21] + R[3 + c] * sum[22] + R[6 + c] * sum[23];   // R^T (sum u x q')
+      rot[24 + c] = R[c] * sum[24] + R[3 + c] * sum[25] + R[6 + c] * sum[26];   // R^T (sum u)
+    }
+  }
+}
 
 // Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 32 * G threads of ONE block.  Thread (g, j),
 // g = tid / 32, j = tid % 32, sums rows g, g + G, g + 2 G, ... of value j; the G group sums are then added in group order.  The
@@ -155,51 +195,8 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   if (t == 0) o[0] = s_sum[28];
   if (t == 1) o[1] = s_sum[27];
   if (mode == MODE_LINEARIZE) {
-    // The kernel accumulated H' = sum J'^T M J' and b' = sum J'^T M r for J' = [hat(R p) | -I] in the target frame; with
-    // J_s = J' diag(R, R):  H_ss = diag(R, R)^T H' diag(R, R), b_s = diag(R, R)^T b', i.e. every 3x3 block B' becomes R^T B' R and
-    // every 3-vector R^T v.  Thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors; the results land in s_sum.
     __shared__ double s_rot[32];
-    if (t < 4) {
-      double R[9];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
-      if (t < 3) {
-        double B[9];
-        if (t == 0) {
-          B[0] = s_sum[0]; B[1] = s_sum[1]; B[2] = s_sum[2]; B[3] = s_sum[1]; B[4] = s_sum[3]; B[5] = s_sum[4]; B[6] = s_sum[2]; B[7] = s_sum[4]; B[8] = s_sum[5];
-        } else if (t == 1) {
-#pragma unroll
-          for (int i = 0; i < 9; i++) B[i] = s_sum[6 + i];
-        } else {
-          B[0] = s_sum[15]; B[1] = s_sum[16]; B[2] = s_sum[17]; B[3] = s_sum[16]; B[4] = s_sum[18]; B[5] = s_sum[19]; B[6] = s_sum[17]; B[7] = s_sum[19]; B[8] = s_sum[20];
-        }
-        double BR[9], O[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) BR[3 * r + c] = B[3 * r] * R[c] + B[3 * r + 1] * R[3 + c] + B[3 * r + 2] * R[6 + c];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) O[3 * r + c] = R[r] * BR[c] + R[3 + r] * BR[3 + c] + R[6 + r] * BR[6 + c];  // (R^T BR)[r][c]
-        if (t == 0) {
-          s_rot[0] = O[0]; s_rot[1] = O[1]; s_rot[2] = O[2]; s_rot[3] = O[4]; s_rot[4] = O[5]; s_rot[5] = O[8];
-        } else if (t == 1) {
-#pragma unroll
-          for (int i = 0; i < 9; i++) s_rot[6 + i] = O[i];
-        } else {
-          s_rot[15] = O[0]; s_rot[16] = O[1]; s_rot[17] = O[2]; s_rot[18] = O[4]; s_rot[19] = O[5]; s_rot[20] = O[8];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          s_rot[21 + c] = R[c] * s_sum[21] + R[3 + c] * s_sum[22] + R[6 + c] * s_sum[23];   // R^T (sum u x q')
-          s_rot[24 + c] = R[c] * s_sum[24] + R[3 + c] * s_sum[25] + R[6 + c] * s_sum[26];   // R^T (sum u)
-        }
-      }
-    }
+    if (t < 4) rotate_part(t, s_sum, T, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
     __syncthreads();
     if (t < 21) o[2 + t] = s_rot[c_acc_of_upper[t]];
     if (t >= 21 && t < 24) o[2 + t] = s_rot[t];          // b_w = R^T sum u x q'
@@ -222,13 +219,6 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
     }
   }
 }
-
-#ifndef GLIM_AMD_K4_SKIP_ALLMISS
-#define GLIM_AMD_K4_SKIP_ALLMISS 0  // staged experiment (pipe_trip): skip gather + algebra of wavefront trips without any correspondence
-#endif
-#ifndef GLIM_AMD_K4_TIMING
-#define GLIM_AMD_K4_TIMING 0  // diagnostic build: per-block start / end time stamps and placement (tools/k4_timing.py)
-#endif
 
 // resident waves per SIMD the register allocation aims for: the plane-form kernel fits 96 VGPRs (5 waves), the general one needs 99 (4 waves)
 #ifndef GLIM_AMD_MINW_PLANE
@@ -407,11 +397,7 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
   }
   o.key = keep ? (((unsigned long long)ux << (2 * KEY_BITS)) | ((unsigned long long)uy << KEY_BITS) | (unsigned long long)uz) : EMPTY_KEY;
   o.bkt = __umulhi(hsh, d.num_buckets);
-#if GLIM_AMD_ABLATE == 1
-  o.head = make_float4(__uint_as_float((unsigned int)o.key), __uint_as_float((unsigned int)(o.key >> 32)), 0.f, 0.f);
-#else
   o.head = gld4(reinterpret_cast<const char*>(d.buckets) + o.bkt * 128u);  // both keys of the home bucket (32-bit offset: <= 2^25 buckets)
-#endif
   return o;
 }
 
@@ -432,10 +418,6 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
   }
   // residual mu - q, both relative to the voxel centre
   const float rx = r0.x - s.qr0, ry = r0.y - s.qr1, rz = r0.z - s.qr2;
-#if GLIM_AMD_ABLATE == 3
-  acc[0] += rx + ry + rz + r0.w + r1.x + r1.y + r1.z + r1.w + r2c22 + t00 + t01 + t02 + t11 + t12 + t22 + s.qp0;
-  return;
-#endif
   // S = C_B + R C_A R^T (symmetric).  A lane without a match has read SOME record of the table -- another voxel's, or the zeros of an empty
   // way (voxelmap.hip initialises every record) -- so everything up to the determinant is finite for it too; idet = 0 (a select, not a
   // product) then zeroes its contributions exactly.  No per-coefficient selects.
@@ -525,38 +507,22 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   }
   const bool in1 = (k1 == cur.key);
   const bool hit = (cur.key != EMPTY_KEY) && (k0 == cur.key || in1);
-#if GLIM_AMD_K4_SKIP_ALLMISS
-  // Staged for the next round, NOT yet run on a GPU: a wavefront trip in which no lane has a correspondence skips the record gather and the
-  // algebra (its lanes would add exact zeros).  In Hilbert order misses come in runs: 17 % of the trips of the 256-submap all-pairs cost
-  // (inlier fraction 0.69) have no hit at all (tools/miss_model.py, profiles/r02/probe/miss_model.txt).
+  // A wavefront trip in which no lane has a correspondence skips the record gather and the algebra (its lanes would add exact zeros, so the
+  // sums are bit-identical).  In Hilbert order misses come in runs: 17 % of the trips of the 256-submap all-pairs cost (inlier fraction
+  // 0.69) have no hit at all; 13.9 -> 12.2 ms for that evaluation (BENCH_r02 `staged`).  General (36 B/pt) kernel only: under the
+  // plane-form kernel's 96-register cap the branch makes the allocator spill, and scan-to-scan factors have few all-miss trips.
   const unsigned long long hit_lanes = __ballot(hit);
-  wave_inliers += __popcll(hit_lanes);
-  // general (36 B/pt) kernel only: under the plane-form kernel's 96-register cap the branch makes the allocator spill
+  wave_inliers += __popcll(hit_lanes);  // wave-uniform count: scalar registers, no per-lane counter
   const bool any_hit = PLANE || hit_lanes != 0ull;  // wave-uniform: a scalar branch
-#else
-  wave_inliers += __popcll(__ballot(hit));  // wave-uniform count: scalar registers, no per-lane counter
-  constexpr bool any_hit = true;
-#endif
   // every lane reads a record (way 0 of the last bucket when there is no hit) so the wavefront does not diverge
   const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
-#if GLIM_AMD_ABLATE == 1 || GLIM_AMD_ABLATE == 4
-  (void)rp;
-  const float4 r0 = make_float4(0.01f * cur.qp0, 0.01f, -0.02f, 1.0f);
-  const float4 r1 = make_float4(0.01f, 0.02f, 0.9f, 0.03f);
-  const float r2 = 0.8f + 0.001f * cur.qp1;
-#elif GLIM_AMD_K4_SKIP_ALLMISS
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2 = 0.f;
   if (any_hit) {
-    r0 = gld4(rp);
-    r1 = gld4(rp + 16);
-    r2 = gld1(rp + 32);
+    r0 = gld4(rp);        // mx my mz c00
+    r1 = gld4(rp + 16);   // c01 c02 c11 c12
+    r2 = gld1(rp + 32);   // c22
   }
-#else
-  const float4 r0 = gld4(rp);        // mx my mz c00
-  const float4 r1 = gld4(rp + 16);   // c01 c02 c11 c12
-  const float r2 = gld1(rp + 32);    // c22
-#endif
   // (2) probe of point it+AHEAD (a lane past its last point probes with EMPTY_KEY at a clamped, valid address)
   pr = probe_point<FROZEN, PLANE>(d, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
   // (3) stream loads of point it+AHEAD+1
@@ -589,7 +555,7 @@ __device__ __forceinline__ void rotate_priority(int step) {
 
 // The fused factor kernel.  MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences
 // and Mahalanobis matrices frozen at the linearisation pose.  PLANE: plane-form source stream (24 B/pt) or general (36 B/pt).  INLINE: the
-// pose of a single-factor set arrives in the kernel arguments.
+// pose and the descriptor of a single-factor set arrive in the kernel arguments (block b is chunk b of factor 0).
 // One block = one (factor, chunk) row of the plan; its lanes walk the factor's points in 256-point hands dealt round robin to the factor's
 // blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane runs the algebra (a lane
 // without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  block_offset: first plan row of
@@ -597,18 +563,16 @@ __device__ __forceinline__ void rotate_priority(int step) {
 template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
 __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
-                                                          float* __restrict__ partials, const InlinePose ip, const FinalizeArgs fa, int block_offset,
+                                                          float* __restrict__ partials, const InlineArgs ip, const FinalizeArgs fa, int block_offset,
                                                           int blocks_per_round) {
   __shared__ float s_red[4][PARTIAL_STRIDE];
-#if GLIM_AMD_K4_TIMING
-  const unsigned long long timing_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-#endif
   const int gblock = block_offset + (int)blockIdx.x;  // row of this block in the plan (the plane-form and the general segment are separate launches)
-  const int2 bm = blockmap[gblock];
+  // INLINE (single-factor sets): pose and descriptor are read from the kernel arguments (scalar loads from the kernarg segment), the block
+  // map is the identity -- no dependent blockmap -> descriptor load chain in front of the first stream load
+  const int2 bm = INLINE ? make_int2(0, gblock) : blockmap[gblock];
   const int f = bm.x;
   if (f < 0) return;  // padding block of the XCD-aware map
-  const FactorDesc d = descs[f];
-  // INLINE (single-factor sets): the pose is read from the kernel arguments (scalar registers), no device pose array involved
+  const FactorDesc d = INLINE ? ip.d : descs[f];
   const double* Tl = INLINE ? ip.m : poses_lin + 12 * (size_t)f;
   const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
 
@@ -669,29 +633,23 @@ __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_
     float v = 0.f;
     const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
     if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
-#if GLIM_AMD_K4_TIMING
-    // diagnostic build (tools/k4_timing.py): when and where this block ran, in the three spare slots of its partial row
-    if (j >= 29) {
-      unsigned int xcc, hwid;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-      const unsigned int w = j == 29 ? (unsigned int)timing_t0 : (j == 30 ? (unsigned int)t1 : ((xcc & 0xfu) << 16) | (hwid & 0xffffu));
-      v = __uint_as_float(w);
-    }
-#endif
     partials[(size_t)gblock * PARTIAL_STRIDE + j] = v;
+    if (INLINE && fa.row_flags) {
+      // host-finalised single-factor call: `partials` is host-mapped memory; this wavefront's row store is complete (release at system
+      // scope waits for the write acknowledgement) before the row's arrival word says so.  The host sums the rows as they arrive.
+      if (j == 0) __hip_atomic_store(fa.row_flags + gblock, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
 // Finalisation: one block of 32 * G threads per factor.
 template <int G>
 __global__ __launch_bounds__(32 * G) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
-                                                          int mode, const double* __restrict__ poses_lin, const InlinePose ip) {
+                                                          int mode, const double* __restrict__ poses_lin, const InlineArgs ip) {
   __shared__ double s_part[G][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int f = blockIdx.x;
-  const FactorDesc d = descs[f];
+  const FactorDesc d = ip.valid ? ip.d : descs[f];
   finalize_factor<G>(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
 }
 
@@ -732,24 +690,60 @@ struct OverlapTarget {
   double inv_res;
   double T[12];
 };
+// One overlap query = one source cloud against a list of (map, delta) targets (odometry_estimation_gpu.cpp:224-231, :248).
+struct OverlapQuery {
+  const float4* pts;
+  int n;
+  int first_target, num_targets;
+  int first_block, num_blocks;  // blocks [first_block, first_block + num_blocks) of the launch walk this query's points
+  int pad;
+};
+constexpr int OVERLAP_INLINE_TARGETS = 16;
+struct OverlapInline {  // single-query call: everything in the kernel arguments, nothing to upload
+  OverlapQuery q;
+  OverlapTarget t[OVERLAP_INLINE_TARGETS];
+};
 
-// K6: a point counts once if ANY (map_j, delta_j) contains it (odometry_estimation_gpu.cpp:224-231).
-__global__ __launch_bounds__(BLOCK) void overlap_kernel(int n, const float4* __restrict__ pts, const OverlapTarget* __restrict__ targets,
-                                                         int num_targets, unsigned int* __restrict__ hits) {
+// K6: a point counts once if ANY (map_j, delta_j) contains it.  One launch answers any number of queries; completion without a stream
+// synchronise or a read-back copy: every block adds (1 << 32 | its hits) to its query's 64-bit counter with ONE returning atomic, the block
+// that sees all the others' arrivals writes the query's total into host-mapped memory, resets the counter for the next call and -- when it
+// also completes the last query -- publishes the call's sequence number, on which the host spins.
+template <bool INLINE>
+__global__ __launch_bounds__(BLOCK) void overlap_kernel(const OverlapInline in, const OverlapQuery* __restrict__ queries, const OverlapTarget* __restrict__ targets,
+                                                         const int* __restrict__ block_query, int num_queries, unsigned long long* __restrict__ counters,
+                                                         unsigned int* __restrict__ queries_done, unsigned int* __restrict__ h_hits,
+                                                         unsigned int* __restrict__ h_flag, unsigned int seq) {
+  __shared__ int s_tmp[16];
+  const int qi = INLINE ? 0 : block_query[blockIdx.x];
+  const OverlapQuery q = INLINE ? in.q : queries[qi];
+  const OverlapTarget* tg = INLINE ? in.t : targets + q.first_target;
   int mine = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 p4 = pts[i];
-    for (int t = 0; t < num_targets; t++) {
+  const int chunk = (int)blockIdx.x - q.first_block;
+  for (int i = chunk * BLOCK + (int)threadIdx.x; i < q.n; i += q.num_blocks * BLOCK) {
+    const float4 p4 = q.pts[i];
+    for (int t = 0; t < q.num_targets; t++) {
       double qx, qy, qz;
-      transform_point_d(targets[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
-      if (find_slot(targets[t].buckets, targets[t].num_buckets, voxel_key(qx, qy, qz, targets[t].inv_res)) >= 0) {
+      transform_point_d(tg[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
+      if (find_slot(tg[t].buckets, tg[t].num_buckets, voxel_key(qx, qy, qz, tg[t].inv_res)) >= 0) {
         mine++;
         break;
       }
     }
   }
-  const float v = wave_sum_to_lane63((float)mine);  // per-thread counts are tiny: exact in FP32
-  if ((threadIdx.x & 63) == 63 && v > 0.f) atomicAdd(hits, (unsigned int)v);
+  const int block_hits = block_reduce_i<2>(mine, s_tmp);
+  if (threadIdx.x == 0) {
+    const unsigned long long prev = atomicAdd(counters + qi, (1ull << 32) | (unsigned long long)(unsigned int)block_hits);
+    if ((int)(prev >> 32) == q.num_blocks - 1) {
+      counters[qi] = 0ull;  // every block of this query has arrived: nobody touches the counter again in this launch
+      h_hits[qi] = (unsigned int)prev + (unsigned int)block_hits;
+      __threadfence_system();
+      const unsigned int done = INLINE ? 0u : atomicAdd(queries_done, 1u);
+      if (INLINE || (int)done == num_queries - 1) {
+        if (!INLINE) *queries_done = 0u;
+        __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 void hat3(const double* a, double* H) {
@@ -766,34 +760,71 @@ void hat3(const double* a, double* H) {
 // -----------------------------------------------------------------------------------------------------------------
 namespace glim_amd {
 
-const CallSwitches& call_switches() {
-  static const CallSwitches s = {getenv("GLIM_AMD_NO_POLL") != nullptr, getenv("GLIM_AMD_NO_INLINE_POSE") != nullptr};
-  return s;
+namespace {
+
+constexpr size_t PLAN_CACHE_MAX = 16;    // idle plans kept per context
+constexpr int HOST_ROWS_MAX = 2048;      // most partial rows a host-finalised single-factor plan may have
+
+void plan_free(FactorPlan* p) {
+  if (!p) return;
+  // nothing enqueued earlier (asynchronous entry points included) may still be using the buffers that go back to the pool
+  if (p->maybe_busy && p->last_stream) (void)hipStreamSynchronize(p->last_stream);
+  if (p->d_descs) (void)pool_free(p->d_descs);
+  if (p->d_blockmap) (void)pool_free(p->d_blockmap);
+  if (p->d_partials) (void)pool_free(p->d_partials);
+  if (p->d_poses) (void)pool_free(p->d_poses);
+  if (p->d_compact) (void)pool_free(p->d_compact);
+  if (p->d_done) (void)pool_free(p->d_done);
+  if (p->h_poses) (void)pinned_free(p->h_poses);
+  if (p->h_compact) (void)pinned_free(p->h_compact);
+  if (p->h_flag) (void)pinned_free(p->h_flag);
+  if (p->h_rows) (void)pinned_free(p->h_rows);
+  for (int i = 0; i < FactorPlan::POSE_RING; i++)
+    if (p->pose_events[i]) (void)hipEventDestroy(p->pose_events[i]);
+  delete p;
 }
 
-void factor_set_release_plan(glim_amd_factor_set* set) {
-  // the plan's buffers go back to the pool: nothing enqueued earlier (asynchronous entry points included) may still be using them
-  if (set->d_descs && set->stream) (void)hipStreamSynchronize(set->stream);
-  if (set->d_descs) (void)pool_free(set->d_descs);
-  if (set->d_blockmap) (void)pool_free(set->d_blockmap);
-  if (set->d_partials) (void)pool_free(set->d_partials);
-  if (set->d_poses) (void)pool_free(set->d_poses);
-  if (set->d_compact) (void)pool_free(set->d_compact);
-  if (set->d_done) (void)pool_free(set->d_done);
-  if (set->h_poses) (void)pinned_free(set->h_poses);
-  if (set->h_compact) (void)pinned_free(set->h_compact);
-  set->d_descs = nullptr;
-  set->d_blockmap = nullptr;
-  set->d_partials = nullptr;
-  set->d_poses = nullptr;
-  set->d_compact = nullptr;
-  set->d_done = nullptr;
-  set->h_poses = nullptr;
-  set->h_compact = nullptr;
-  set->h_compact_dev = nullptr;
-  for (int i = 0; i < glim_amd_factor_set::POSE_RING; i++) set->pose_pending[i] = false;
-  set->cap_factors = set->cap_blocks = 0;
+template <class T>
+bool host_device_view(T* host, T** dev) {
+  *dev = nullptr;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(dev), host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    *dev = nullptr;
+    return false;
+  }
+  return true;
 }
+
+}  // namespace
+
+void ctx_release_factor_resources(glim_amd_ctx* ctx) {
+  for (FactorPlan* p : ctx->plan_cache) plan_free(p);
+  ctx->plan_cache.clear();
+  if (ctx->ov_counters) (void)pool_free(ctx->ov_counters);
+  if (ctx->ov_host) (void)pinned_free(ctx->ov_host);
+  ctx->ov_counters = nullptr;
+  ctx->ov_host = nullptr;
+  ctx->ov_host_dev = nullptr;
+}
+
+// The set gives up its plan: parked in the context's cache (most recent first) for the next set with the same factor list.
+void factor_set_park_plan(glim_amd_factor_set* set) {
+  FactorPlan* p = set->plan;
+  set->plan = nullptr;
+  if (!p) return;
+  glim_amd_ctx* ctx = set->ctx;
+  if (!ctx->diag.plan_cache) {
+    plan_free(p);
+    return;
+  }
+  ctx->plan_cache.insert(ctx->plan_cache.begin(), p);
+  while (ctx->plan_cache.size() > PLAN_CACHE_MAX) {
+    plan_free(ctx->plan_cache.back());
+    ctx->plan_cache.pop_back();
+  }
+}
+
+namespace {
 
 // Build the device plan: factor descriptors, chunking, and the block -> (factor, chunk) map.
 // Factors whose source cloud is plane-form take the 24 B/pt kernel, the others the general 36 B/pt kernel -- decided per factor, so one
@@ -802,22 +833,22 @@ void factor_set_release_plan(glim_amd_factor_set* set) {
 // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"); when a segment holds enough factors,
 // all chunks of one factor are given rows of one residue class so that the factor's voxel table stays in a single XCD's 4 MiB L2.
 // This is a speed-only choice: any placement is correct.
-int factor_set_prepare(glim_amd_factor_set* set) {
-  if (!set->dirty) return GLIM_AMD_OK;
+int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   const int nf = (int)set->entries.size();
   glim_amd_ctx* ctx = set->ctx;
-  const bool allow_plane = getenv("GLIM_AMD_NO_PLANE") == nullptr;
+  const Diag& diag = ctx->diag;
+  const bool allow_plane = diag.plane != 0;
   // Grid sizing: the plane-form and the general factors are separate launches (segments); each aims for ONE resident set of blocks
   // (num_cus x waves per SIMD of that kernel variant) with equal work each, so every lane reduces its 28 accumulators exactly once; each
   // factor gets blocks in proportion to its points.  (Finer grids were measured level: 1280 blocks 142.7 us, 2560 142.6, 5120 138.6,
   // 10240 142.9 per 128 factors.)
   long long seg_points[2] = {0, 0};
-  long long seg_target[2] = {(long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_PLANE, (long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_GENERAL};
-  if (const char* env = getenv("GLIM_AMD_TARGET_BLOCKS")) seg_target[0] = seg_target[1] = std::max(1, atoi(env));
-  int forced_ppt = 0;
-  if (const char* env = getenv("GLIM_AMD_PPT")) forced_ppt = std::max(1, std::min(256, atoi(env)));
+  const long long seg_target[2] = {(long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_PLANE, (long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_GENERAL};
+  const int forced_ppt = diag.ppt;
 
-  set->h_descs.assign(nf, FactorDesc());
+  plan->built_plane = diag.plane;
+  plan->built_ppt = diag.ppt;
+  plan->h_descs.assign(nf, FactorDesc());
   std::vector<int> nblocks(nf);
   for (int f = 0; f < nf; f++) {
     const auto& e = set->entries[f];
@@ -831,7 +862,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     } else {
       GA_TRY(ensure_factor_streams(src, set->stream));
     }
-    FactorDesc& d = set->h_descs[f];
+    FactorDesc& d = plan->h_descs[f];
     d.pts = src->pts;
     d.normals = src->has_normals ? src->normals : nullptr;
     d.plane = (allow_plane && src->plane_form && src->pn4 && src->n2) ? 1 : 0;
@@ -855,7 +886,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     seg_points[d.plane ? 0 : 1] += d.n;
   }
   for (int f = 0; f < nf; f++) {
-    FactorDesc& d = set->h_descs[f];
+    FactorDesc& d = plan->h_descs[f];
     int ppt = forced_ppt;
     if (!ppt) {
       const long long target_blocks = seg_target[d.plane ? 0 : 1], total_points = seg_points[d.plane ? 0 : 1];
@@ -866,17 +897,16 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     nblocks[f] = std::max(1, (d.n + BLOCK * ppt - 1) / (BLOCK * ppt));
     d.num_blocks = nblocks[f];
   }
-  set->points_per_thread = nf ? set->h_descs[0].ppt : 1;
-  set->max_rows_per_factor = nf ? *std::max_element(nblocks.begin(), nblocks.end()) : 0;
+  plan->points_per_thread = nf ? plan->h_descs[0].ppt : 1;
+  plan->max_rows_per_factor = nf ? *std::max_element(nblocks.begin(), nblocks.end()) : 0;
 
   // block map: the plane-form segment first, then the general one
   std::vector<int2> blockmap;
-  const bool want_xcd = getenv("GLIM_AMD_NO_XCD_MAP") == nullptr;
   int seg_rows[2] = {0, 0};
   for (int seg = 0; seg < 2; seg++) {  // seg 0: plane-form factors, seg 1: the others
     std::vector<int> fs;
     for (int f = 0; f < nf; f++)
-      if ((set->h_descs[f].plane != 0) == (seg == 0)) fs.push_back(f);
+      if ((plan->h_descs[f].plane != 0) == (seg == 0)) fs.push_back(f);
     // Locality order: factors that stream the SAME source cloud become neighbours in the plan (sources in order of first appearance, the
     // caller's order inside a group).  The resident blocks are the next ~1000 rows of the plan, so neighbours run together and all but
     // the first of them find the 2 MB source stream in L2 / the 256 MiB Infinity Cache instead of HBM: the all-pairs cost of 256 merged
@@ -886,11 +916,11 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     {
       std::unordered_map<const void*, int> first_use;
       std::vector<int> group(nf, 0);
-      for (int f : fs) group[f] = first_use.emplace(set->h_descs[f].s0, f).first->second;
+      for (int f : fs) group[f] = first_use.emplace(plan->h_descs[f].s0, f).first->second;
       std::stable_sort(fs.begin(), fs.end(), [&](int a, int b) { return group[a] < group[b]; });
     }
     const size_t base = blockmap.size();
-    if (fs.size() < 16 || !want_xcd) {
+    if (fs.size() < 16) {
       for (int f : fs)
         for (int c = 0; c < nblocks[f]; c++) blockmap.push_back(make_int2(f, c));
     } else {
@@ -914,57 +944,112 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   // rows[]: for each factor the plan rows that hold its partial sums, in chunk order
   long long total_blocks = 0;
   for (int f = 0; f < nf; f++) {
-    set->h_descs[f].first_block = (int)total_blocks;
+    plan->h_descs[f].first_block = (int)total_blocks;
     total_blocks += nblocks[f];
   }
   std::vector<int> rows((size_t)total_blocks);
   for (size_t b = 0; b < blockmap.size(); b++) {
     if (blockmap[b].x < 0) continue;
-    rows[(size_t)set->h_descs[blockmap[b].x].first_block + blockmap[b].y] = (int)b;
+    rows[(size_t)plan->h_descs[blockmap[b].x].first_block + blockmap[b].y] = (int)b;
   }
 
-  factor_set_release_plan(set);
-  set->plane_rows = seg_rows[0];
-  set->total_rows = (int)blockmap.size();
+  plan->plane_rows = seg_rows[0];
+  plan->total_rows = (int)blockmap.size();
   const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
-  GA_HIP(pool_malloc(&set->d_descs, nfa * sizeof(FactorDesc)));
-  GA_HIP(pool_malloc(&set->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
-  GA_HIP(pool_malloc(&set->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
-  GA_HIP(pool_malloc(&set->d_poses, nfa * 24 * sizeof(double)));
-  GA_HIP(pool_malloc(&set->d_compact, nfa * COMPACT * sizeof(double)));
-  GA_HIP(pool_malloc(&set->d_done, sizeof(int)));
-  GA_HIP(hipMemsetAsync(set->d_done, 0, sizeof(int), set->stream));
-  if (!set->h_flag) {
-    if (pinned_malloc(&set->h_flag, 64) == hipSuccess) {
-      *set->h_flag = 0;
-      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_flag_dev), set->h_flag, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)pinned_free(set->h_flag);
-        set->h_flag = nullptr;
-        set->h_flag_dev = nullptr;
+  GA_HIP(pool_malloc(&plan->d_descs, nfa * sizeof(FactorDesc)));
+  GA_HIP(pool_malloc(&plan->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
+  GA_HIP(pool_malloc(&plan->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
+  GA_HIP(pool_malloc(&plan->d_poses, nfa * 24 * sizeof(double)));
+  GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
+  GA_HIP(pool_malloc(&plan->d_done, sizeof(int)));
+  GA_HIP(hipMemsetAsync(plan->d_done, 0, sizeof(int), set->stream));
+  if (pinned_malloc(&plan->h_flag, 64) == hipSuccess) {
+    *plan->h_flag = 0;
+    if (!host_device_view(plan->h_flag, &plan->h_flag_dev)) {
+      (void)pinned_free(plan->h_flag);
+      plan->h_flag = nullptr;
+    }
+  } else {
+    (void)hipGetLastError();
+    plan->h_flag = nullptr;
+  }
+  GA_HIP(pinned_malloc(&plan->h_poses, (size_t)FactorPlan::POSE_RING * nfa * 24 * sizeof(double)));
+  GA_HIP(pinned_malloc(&plan->h_compact, nfa * COMPACT * sizeof(double)));
+  (void)host_device_view(plan->h_compact, &plan->h_compact_dev);
+  if (nf == 1 && plan->total_rows <= HOST_ROWS_MAX) {
+    // single-factor plan: host-mapped partial rows + arrival words for the host-finalised synchronous call (run_sync)
+    const size_t bytes = (size_t)plan->total_rows * (PARTIAL_STRIDE * sizeof(float) + sizeof(unsigned int));
+    if (pinned_malloc(&plan->h_rows, bytes) == hipSuccess) {
+      memset(plan->h_rows, 0, bytes);
+      if (!host_device_view(plan->h_rows, &plan->h_rows_dev)) {
+        (void)pinned_free(plan->h_rows);
+        plan->h_rows = nullptr;
       }
     } else {
       (void)hipGetLastError();
-      set->h_flag = nullptr;
+      plan->h_rows = nullptr;
     }
   }
-  GA_HIP(pinned_malloc(&set->h_poses, (size_t)glim_amd_factor_set::POSE_RING * nfa * 24 * sizeof(double)));
-  GA_HIP(pinned_malloc(&set->h_compact, nfa * COMPACT * sizeof(double)));
-  set->h_compact_dev = nullptr;
-  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&set->h_compact_dev), set->h_compact, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    set->h_compact_dev = nullptr;
-  }
-  set->cap_factors = nfa;
-  set->cap_blocks = nba;
+  plan->cap_factors = nfa;
+  plan->cap_blocks = nba;
   if (nf > 0) {
-    GA_HIP(hipMemcpyAsync(set->d_descs, set->h_descs.data(), (size_t)nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipMemcpyAsync(set->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipMemcpyAsync(reinterpret_cast<char*>(set->d_blockmap) + nba * sizeof(int2), rows.data(), rows.size() * sizeof(int),
+    GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), (size_t)nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipMemcpyAsync(plan->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipMemcpyAsync(reinterpret_cast<char*>(plan->d_blockmap) + nba * sizeof(int2), rows.data(), rows.size() * sizeof(int),
                           hipMemcpyHostToDevice, set->stream));
     GA_HIP(hipStreamSynchronize(set->stream));  // the staging vectors above die with this scope
   }
+  plan->last_stream = set->stream;
+  plan->maybe_busy = false;
+  return GLIM_AMD_OK;
+}
+
+void make_key(const glim_amd_factor_set* set, std::vector<PlanKey>& key) {
+  key.resize(set->entries.size());
+  for (size_t f = 0; f < key.size(); f++) key[f] = PlanKey{set->entries[f].target->uid, set->entries[f].source->uid, set->entries[f].flags, 0u};
+}
+
+}  // namespace
+
+// Make set->plan the device plan of set->entries.  Caller holds ctx->mu.  Steady state (nothing changed since the last call): two
+// compares.  Changed list: the context's cache of idle plans is searched for the same (map, cloud, flags) list first -- GLIM's
+// clear -> add -> linearize per optimiser iteration then costs no allocation, no upload and no synchronise.
+int factor_set_prepare(glim_amd_factor_set* set) {
+  glim_amd_ctx* ctx = set->ctx;
+  const uint64_t epoch = ctx->mutation_epoch.load();
+  const Diag& diag = ctx->diag;
+  if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt) return GLIM_AMD_OK;
+  std::vector<PlanKey> key;
+  make_key(set, key);
+  auto usable = [&](const FactorPlan* p) { return p->key == key && p->built_plane == diag.plane && p->built_ppt == diag.ppt; };
+  if (set->plan && !usable(set->plan)) factor_set_park_plan(set);
+  if (!set->plan && diag.plan_cache) {
+    for (size_t i = 0; i < ctx->plan_cache.size(); i++) {
+      if (!usable(ctx->plan_cache[i])) continue;
+      set->plan = ctx->plan_cache[i];
+      ctx->plan_cache.erase(ctx->plan_cache.begin() + (long)i);
+      // work a previous owner enqueued asynchronously on another stream must not overlap this set's use of the same buffers
+      if (set->plan->maybe_busy && set->plan->last_stream && set->plan->last_stream != set->stream) {
+        GA_HIP(hipStreamSynchronize(set->plan->last_stream));
+        set->plan->maybe_busy = false;
+      }
+      break;
+    }
+  }
+  if (!set->plan) {
+    FactorPlan* p = new FactorPlan();
+    p->key = key;
+    const int rc = plan_build(set, p);
+    if (rc != GLIM_AMD_OK) {
+      plan_free(p);
+      return rc;
+    }
+    set->plan = p;
+  }
+  set->inline_args.valid = 0;
+  if (set->entries.size() == 1) set->inline_args.d = set->plan->h_descs[0];
   set->dirty = false;
+  set->seen_epoch = epoch;
   return GLIM_AMD_OK;
 }
 
@@ -972,59 +1057,69 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 
 namespace {
 
-const int* rows_ptr(const glim_amd_factor_set* set) {
-  return reinterpret_cast<const int*>(reinterpret_cast<const char*>(set->d_blockmap) + set->cap_blocks * sizeof(int2));
+const int* rows_ptr(const FactorPlan* plan) {
+  return reinterpret_cast<const int*>(reinterpret_cast<const char*>(plan->d_blockmap) + plan->cap_blocks * sizeof(int2));
 }
 
 FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long long row_offset, bool poll) {
+  const FactorPlan* plan = set->plan;
   FinalizeArgs fa;
-  fa.rows = rows_ptr(set);
+  fa.rows = rows_ptr(plan);
   fa.out = out;
   fa.out_row_offset = row_offset;
-  fa.done_counter = set->d_done;
-  fa.host_flag = poll ? set->h_flag_dev : nullptr;
-  fa.seq = set->poll_seq;
+  fa.done_counter = plan->d_done;
+  fa.host_flag = poll ? plan->h_flag_dev : nullptr;
+  fa.row_flags = nullptr;
+  fa.seq = plan->poll_seq;
   fa.num_factors = (int)set->entries.size();
   return fa;
 }
 
 template <int MODE, bool FROZEN, bool INLINE>
-void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa) {
-  const double* lin = set->d_poses;
-  const double* ev = set->d_poses + set->entries.size() * 12;
-  if (set->plane_rows > 0)
-    vgicp_kernel<MODE, FROZEN, true, INLINE><<<set->plane_rows, BLOCK, 0, set->stream>>>(set->d_descs, lin, ev, set->d_blockmap, set->d_partials,
-                                                                                       set->inline_pose, fa, 0, std::max(1, set->ctx->num_cus));
-  if (set->total_rows > set->plane_rows)
-    vgicp_kernel<MODE, FROZEN, false, INLINE><<<set->total_rows - set->plane_rows, BLOCK, 0, set->stream>>>(
-      set->d_descs, lin, ev, set->d_blockmap, set->d_partials, set->inline_pose, fa, set->plane_rows, std::max(1, set->ctx->num_cus));
+void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa, float* partials) {
+  const FactorPlan* plan = set->plan;
+  const double* lin = plan->d_poses;
+  const double* ev = plan->d_poses + set->entries.size() * 12;
+  const int per_round = std::max(1, set->ctx->num_cus);
+  if (plan->plane_rows > 0)
+    vgicp_kernel<MODE, FROZEN, true, INLINE><<<plan->plane_rows, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, 0,
+                                                                                        per_round);
+  if (plan->total_rows > plan->plane_rows)
+    vgicp_kernel<MODE, FROZEN, false, INLINE><<<plan->total_rows - plan->plane_rows, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials,
+                                                                                                              set->inline_args, fa, plan->plane_rows, per_round);
 }
 
-// the fused kernel(s) alone (no finalisation): used by the profiling entry point
-void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const FinalizeArgs& fa) {
-  const bool inl = set->inline_pose.valid != 0;
+// the fused kernel(s) alone (no finalisation); partials: the plan's device rows, or the host-mapped rows of a host-finalised call
+void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const FinalizeArgs& fa, float* partials) {
+  const bool inl = set->inline_args.valid != 0;
   if (mode == MODE_LINEARIZE) {
-    if (inl) launch_segments<MODE_LINEARIZE, false, true>(set, fa);
-    else launch_segments<MODE_LINEARIZE, false, false>(set, fa);
+    if (inl) launch_segments<MODE_LINEARIZE, false, true>(set, fa, partials);
+    else launch_segments<MODE_LINEARIZE, false, false>(set, fa, partials);
   } else if (frozen) {
-    launch_segments<MODE_ERROR, true, false>(set, fa);
+    launch_segments<MODE_ERROR, true, false>(set, fa, partials);
   } else {
-    if (inl) launch_segments<MODE_ERROR, false, true>(set, fa);
-    else launch_segments<MODE_ERROR, false, false>(set, fa);
+    if (inl) launch_segments<MODE_ERROR, false, true>(set, fa, partials);
+    else launch_segments<MODE_ERROR, false, false>(set, fa, partials);
   }
+  set->plan->last_stream = set->stream;
 }
 
-// enqueue (no sync): poses already in d_poses / the inline pose; writes compact records to `out` rows [row_offset, row_offset + n).
+// width of the device finalise (and of the host-side restatement of its summation order): 32 row groups when one factor is spread
+// over the whole chip, 8 for sets whose factors own a handful of rows each
+int finalize_groups(const FactorPlan* plan) { return plan->max_rows_per_factor > 128 ? 32 : 8; }
+
+// enqueue (no sync): poses already in d_poses / the inline arguments; writes compact records to `out` rows [row_offset, row_offset + n).
 // Two or three launches: the fused kernel per plan segment + the FP64 finalise.
 int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll) {
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
+  FactorPlan* plan = set->plan;
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
-  launch_vgicp(set, mode, frozen, fa);
-  if (set->max_rows_per_factor > 128)
-    finalize_kernel<32><<<nf, 1024, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
+  launch_vgicp(set, mode, frozen, fa, plan->d_partials);
+  if (finalize_groups(plan) == 32)
+    finalize_kernel<32><<<nf, 1024, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, plan->d_poses, set->inline_args);
   else
-    finalize_kernel<8><<<nf, 256, 0, set->stream>>>(set->d_descs, set->d_partials, fa, mode, set->d_poses, set->inline_pose);
+    finalize_kernel<8><<<nf, 256, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, plan->d_poses, set->inline_args);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
@@ -1034,26 +1129,27 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
 // completed (event), so back-to-back asynchronous calls never see each other's poses.
 int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, bool async_call) {
   const size_t nf = set->entries.size();
-  set->inline_pose.valid = 0;
-  if (nf == 1 && !T_eval && !call_switches().no_inline_pose) {
-    memcpy(set->inline_pose.m, T_lin, 12 * sizeof(double));
-    set->inline_pose.valid = 1;
+  FactorPlan* plan = set->plan;
+  set->inline_args.valid = 0;
+  if (nf == 1 && !T_eval && set->ctx->diag.inline_pose) {
+    memcpy(set->inline_args.m, T_lin, 12 * sizeof(double));
+    set->inline_args.valid = 1;
     return GLIM_AMD_OK;
   }
-  const int slot = set->pose_slot;
-  set->pose_slot = (slot + 1) % glim_amd_factor_set::POSE_RING;
-  if (set->pose_pending[slot]) {
-    GA_HIP(hipEventSynchronize(set->pose_events[slot]));
-    set->pose_pending[slot] = false;
+  const int slot = plan->pose_slot;
+  plan->pose_slot = (slot + 1) % FactorPlan::POSE_RING;
+  if (plan->pose_pending[slot]) {
+    GA_HIP(hipEventSynchronize(plan->pose_events[slot]));
+    plan->pose_pending[slot] = false;
   }
-  double* h = set->h_poses + (size_t)slot * set->cap_factors * 24;
+  double* h = plan->h_poses + (size_t)slot * plan->cap_factors * 24;
   memcpy(h, T_lin, nf * 12 * sizeof(double));
   if (T_eval) memcpy(h + nf * 12, T_eval, nf * 12 * sizeof(double));
-  GA_HIP(hipMemcpyAsync(set->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
+  GA_HIP(hipMemcpyAsync(plan->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
   if (async_call) {
-    if (!set->pose_events[slot]) GA_HIP(hipEventCreateWithFlags(&set->pose_events[slot], hipEventDisableTiming));
-    GA_HIP(hipEventRecord(set->pose_events[slot], set->stream));
-    set->pose_pending[slot] = true;
+    if (!plan->pose_events[slot]) GA_HIP(hipEventCreateWithFlags(&plan->pose_events[slot], hipEventDisableTiming));
+    GA_HIP(hipEventRecord(plan->pose_events[slot], set->stream));
+    plan->pose_pending[slot] = true;
   }
   return GLIM_AMD_OK;
 }
@@ -1066,42 +1162,126 @@ inline void cpu_relax() {
 #endif
 }
 
-// One synchronous evaluation (linearise or error) of the whole set: results in set->h_compact when this returns.
-// Small sets (the per-frame odometry case): the finalise kernel writes the 232-byte records straight into host-mapped pinned memory and
-// then publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of paying a stream-synchronise
-// round trip -- no device-to-host copy, and for a single factor no host-to-device copy either.  The context mutex is held only while
-// the work is enqueued, so factor sets of one context (different streams of its pool) overlap on the device when driven from
-// different host threads, like the reference's StreamTempBufferRoundRobin factors.
+// spin until *word == value (acquire); false after ~200 ms
+bool spin_until(const volatile unsigned int* word, unsigned int value) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long spins = 0;; spins++) {
+    if (*word == value) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    cpu_relax();
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+  }
+}
+
+// Host side of the host-finalised single-factor call: the fixed-order FP64 sum of finalize_factor<G> over the factor's partial rows, taken
+// as the rows ARRIVE in host-mapped memory (row c belongs to group c % G and the rows of a group are added in ascending order; the group
+// sums are then added in group order), followed by the shared rotate_part: the record has the bits the device finalise would produce.
+int host_finalize_rows(glim_amd_factor_set* set, int mode, unsigned int seq, double* o) {
+  const FactorPlan* plan = set->plan;
+  const int nb = plan->total_rows, G = finalize_groups(plan);
+  const float* rows = plan->h_rows;
+  const volatile unsigned int* flags = reinterpret_cast<const volatile unsigned int*>(plan->h_rows + (size_t)nb * PARTIAL_STRIDE);
+  double part[32][PARTIAL_STRIDE];
+  for (int g = 0; g < G; g++)
+    for (int j = 0; j < PARTIAL_STRIDE; j++) part[g][j] = 0.0;
+  for (int c = 0; c < nb; c++) {
+    if (flags[c] != seq && !spin_until(flags + c, seq)) {
+      // a block that has not reported after 200 ms: wait for the stream, then the row must be there
+      GA_HIP(hipStreamSynchronize(set->stream));
+      if (flags[c] != seq) return GLIM_AMD_ERR_STATE;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const float* r = rows + (size_t)c * PARTIAL_STRIDE;
+    double* p = part[c % G];
+    for (int j = 0; j < PARTIAL_STRIDE; j++) p[j] += (double)r[j];
+  }
+  double sum[PARTIAL_STRIDE];
+  for (int j = 0; j < PARTIAL_STRIDE; j++) {
+    double t = 0.0;
+    for (int g = 0; g < G; g++) t += part[g][j];
+    sum[j] = t;
+  }
+  o[0] = sum[28];
+  o[1] = sum[27];
+  if (mode == MODE_LINEARIZE) {
+    static const int acc_of_upper[21] = {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20};  // == c_acc_of_upper
+    double rot[32];
+    for (int part_i = 0; part_i < 4; part_i++) rotate_part(part_i, sum, set->inline_args.m, rot);
+    for (int t = 0; t < 21; t++) o[2 + t] = rot[acc_of_upper[t]];
+    for (int t = 21; t < 24; t++) o[2 + t] = rot[t];
+    for (int t = 24; t < 27; t++) o[2 + t] = -rot[t];
+  } else {
+    for (int t = 2; t < COMPACT; t++) o[t] = 0.0;
+  }
+  return GLIM_AMD_OK;
+}
+
+// One synchronous evaluation (linearise or error) of the whole set: results in plan->h_compact when this returns.
+//  * single factor (the per-frame odometry call BASELINE configs[1] names): ONE launch.  Pose and descriptor ride in the kernel arguments,
+//    every block stores its partial row straight into host-mapped memory followed by the row's arrival word, and the host adds the rows up
+//    in the device finalise's order while the remaining blocks are still running -- no second dispatch, no atomics, no copies.
+//  * small sets: the finalise kernel writes the 232-byte records into host-mapped pinned memory and then publishes a sequence number
+//    there; the host spins on that word (sub-microsecond wake-up) instead of paying a stream-synchronise round trip.
+//  * large sets: device records + one copy + stream synchronise.
+// The context mutex is held only while the work is enqueued, so factor sets of one context (different streams of its pool) overlap on
+// the device when driven from different host threads, like the reference's StreamTempBufferRoundRobin factors.
 int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval) {
   const size_t nf = set->entries.size();
-  bool poll = false;
+  bool poll = false, host_rows = false;
+  unsigned int seq = 0;
+  FactorPlan* plan = nullptr;
   {
     std::lock_guard<std::mutex> lock(set->ctx->mu);
     GA_HIP(hipSetDevice(set->ctx->device));
     GA_TRY(factor_set_prepare(set));
+    plan = set->plan;
     GA_TRY(upload_poses(set, T_lin, T_eval, false));
-    const bool mapped = set->h_compact_dev && nf <= 1024;
-    poll = mapped && set->h_flag && !call_switches().no_poll;
-    if (poll) set->poll_seq++;
-    GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? set->h_compact_dev : set->d_compact, 0, poll));
-    if (!mapped) GA_HIP(hipMemcpyAsync(set->h_compact, set->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
-  }
-  bool done = false;
-  if (poll) {
-    const auto t0 = std::chrono::steady_clock::now();
-    volatile unsigned int* flag = set->h_flag;
-    for (unsigned long spins = 0;; spins++) {
-      if (*flag == set->poll_seq) {
-        done = true;
-        break;
-      }
-      cpu_relax();
-      if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;  // fall back
+    const Diag& diag = set->ctx->diag;
+    host_rows = plan->h_rows && set->inline_args.valid && diag.host_finalize && diag.poll;
+    if (host_rows) {
+      seq = ++plan->poll_seq;
+      FinalizeArgs fa = finalize_args(set, nullptr, 0, false);
+      fa.row_flags = reinterpret_cast<unsigned int*>(plan->h_rows_dev + (size_t)plan->total_rows * PARTIAL_STRIDE);
+      fa.seq = seq;
+      launch_vgicp(set, mode, false, fa, plan->h_rows_dev);
+      GA_HIP(hipGetLastError());
+    } else {
+      const bool mapped = plan->h_compact_dev && nf <= 1024;
+      poll = mapped && plan->h_flag && diag.poll;
+      if (poll) seq = ++plan->poll_seq;
+      GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll));
+      if (!mapped) GA_HIP(hipMemcpyAsync(plan->h_compact, plan->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
   }
-  if (!done) GA_HIP(hipStreamSynchronize(set->stream));
+  if (host_rows) return host_finalize_rows(set, mode, seq, plan->h_compact);
+  if (!(poll && spin_until(plan->h_flag, seq))) GA_HIP(hipStreamSynchronize(set->stream));
   return GLIM_AMD_OK;
+}
+
+int overlap_scratch(glim_amd_ctx* ctx, hipStream_t st) {
+  if (ctx->ov_counters) return GLIM_AMD_OK;
+  const size_t cbytes = (size_t)glim_amd_ctx::OV_MAX_QUERIES * sizeof(unsigned long long) + 64;
+  GA_HIP(pool_malloc(&ctx->ov_counters, cbytes));
+  GA_HIP(hipMemsetAsync(ctx->ov_counters, 0, cbytes, st));
+  GA_HIP(pinned_malloc(&ctx->ov_host, (size_t)(1 + glim_amd_ctx::OV_MAX_QUERIES) * sizeof(unsigned int)));
+  memset(ctx->ov_host, 0, (size_t)(1 + glim_amd_ctx::OV_MAX_QUERIES) * sizeof(unsigned int));
+  if (!host_device_view(ctx->ov_host, &ctx->ov_host_dev)) return GLIM_AMD_ERR_HIP;
+  return GLIM_AMD_OK;
+}
+
+void fill_overlap_target(OverlapTarget& o, const glim_amd_voxelmap* m, const double* T12) {
+  o.buckets = m->buckets;
+  o.num_buckets = m->num_buckets;
+  o.pad = 0;
+  o.inv_res = m->inv_resolution;
+  memcpy(o.T, T12, 12 * sizeof(double));
+}
+
+// blocks a query's points are spread over: one atomic per block ends the query, so few fat blocks (at most one per CU)
+int overlap_blocks(const glim_amd_ctx* ctx, int64_t n) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((n + 2 * BLOCK - 1) / (2 * BLOCK), std::max(1, ctx->num_cus)));
 }
 
 }  // namespace
@@ -1122,12 +1302,11 @@ int glim_amd_factor_set_create(glim_amd_ctx* ctx, glim_amd_factor_set** out) {
 
 int glim_amd_factor_set_destroy(glim_amd_factor_set* set) {
   if (!set) return GLIM_AMD_OK;
-  (void)hipSetDevice(set->ctx->device);
-  (void)hipStreamSynchronize(set->stream);
-  factor_set_release_plan(set);
-  for (int i = 0; i < glim_amd_factor_set::POSE_RING; i++)
-    if (set->pose_events[i]) (void)hipEventDestroy(set->pose_events[i]);
-  if (set->h_flag) (void)pinned_free(set->h_flag);
+  {
+    std::lock_guard<std::mutex> lock(set->ctx->mu);
+    (void)hipSetDevice(set->ctx->device);
+    factor_set_park_plan(set);  // idle plans wait in the context's cache for the next set with the same factor list
+  }
   delete set;
   return GLIM_AMD_OK;
 }
@@ -1220,7 +1399,8 @@ int glim_amd_factor_set_linearize(glim_amd_factor_set* set, const double* T, gli
   if (nf == 0) return GLIM_AMD_OK;
   if (!T || !out) return GLIM_AMD_ERR_INVALID;
   GA_TRY(run_sync(set, MODE_LINEARIZE, T, nullptr));
-  for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(set->h_compact + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
+  const double* rec = set->plan->h_compact;
+  for (size_t f = 0; f < nf; f++) glim_amd_expand_compact(rec + f * COMPACT, T + 12 * f, set->entries[f].flags, &out[f]);
   return GLIM_AMD_OK;
 }
 
@@ -1266,6 +1446,7 @@ int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const d
   GA_TRY(factor_set_prepare(set));
   GA_TRY(upload_poses(set, T, nullptr, true));
   set->ctx->async_pending.store(true);  // clouds / maps destroyed later must wait for this work (glim_amd_ctx::quiesce)
+  set->plan->maybe_busy = true;         // ... and so must whoever frees or adopts this plan from another stream
   return enqueue(set, MODE_LINEARIZE, false, out_device, out_row_offset, false);
 }
 
@@ -1277,9 +1458,10 @@ int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, con
   // T_lin == NULL: correspondences at the evaluation pose (one pose per factor); otherwise frozen at T_lin and evaluated at T_eval
   if (T_lin) GA_TRY(run_sync(set, MODE_ERROR, T_lin, T_eval));
   else GA_TRY(run_sync(set, MODE_ERROR, T_eval, nullptr));
+  const double* rec = set->plan->h_compact;
   for (size_t f = 0; f < nf; f++) {
-    errors[f] = set->h_compact[f * COMPACT + 1];
-    if (inliers) inliers[f] = (int64_t)llround(set->h_compact[f * COMPACT]);
+    errors[f] = rec[f * COMPACT + 1];
+    if (inliers) inliers[f] = (int64_t)llround(rec[f * COMPACT]);
   }
   return GLIM_AMD_OK;
 }
@@ -1289,7 +1471,7 @@ int glim_amd_factor_set_correspondences(glim_amd_factor_set* set, int32_t fi, co
   std::lock_guard<std::mutex> lock(set->ctx->mu);
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
-  const FactorDesc d = set->h_descs[fi];
+  const FactorDesc d = set->plan->h_descs[fi];
   if (d.n == 0) return GLIM_AMD_OK;
   if (!corr) return GLIM_AMD_ERR_INVALID;
   double* d_pose = nullptr;
@@ -1320,39 +1502,23 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
   GA_TRY(upload_poses(set, T, nullptr, false));
+  FactorPlan* plan = set->plan;
   hipEvent_t e0, e1;
   GA_HIP(hipEventCreate(&e0));
   GA_HIP(hipEventCreate(&e1));
   // warm-up (clocks, caches, TLBs)
-  for (int i = 0; i < 10; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, set->d_compact, 0, false));
+  for (int i = 0; i < 10; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, plan->d_compact, 0, false));
   GA_HIP(hipStreamSynchronize(set->stream));
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));
-  const FinalizeArgs fa_prof = finalize_args(set, set->d_compact, 0, false);
-  for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof);
+  const FinalizeArgs fa_prof = finalize_args(set, plan->d_compact, 0, false);
+  for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof, plan->d_partials);
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (ms_kernel) *ms_kernel = ms / (float)iters;
-#if GLIM_AMD_K4_TIMING
-  if (const char* path = getenv("GLIM_AMD_K4_TIMING_DUMP")) {
-    // rows of (factor, chunk, start, end [10 ns ticks], xcc << 16 | HW_ID) of the LAST launch above
-    std::vector<float> hp((size_t)set->total_rows * PARTIAL_STRIDE);
-    std::vector<int2> hb((size_t)set->total_rows);
-    GA_HIP(hipMemcpy(hp.data(), set->d_partials, hp.size() * sizeof(float), hipMemcpyDeviceToHost));
-    GA_HIP(hipMemcpy(hb.data(), set->d_blockmap, hb.size() * sizeof(int2), hipMemcpyDeviceToHost));
-    if (FILE* fp = fopen(path, "wb")) {
-      for (int r = 0; r < set->total_rows; r++) {
-        unsigned int rec[5] = {(unsigned int)hb[r].x, (unsigned int)hb[r].y, 0, 0, 0};
-        memcpy(&rec[2], &hp[(size_t)r * PARTIAL_STRIDE + 29], 3 * sizeof(unsigned int));
-        fwrite(rec, sizeof(rec), 1, fp);
-      }
-      fclose(fp);
-    }
-  }
-#endif
   GA_HIP(hipEventRecord(e0, set->stream));
-  for (int i = 0; i < iters; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, set->d_compact, 0, false));
+  for (int i = 0; i < iters; i++) GA_TRY(enqueue(set, MODE_LINEARIZE, false, plan->d_compact, 0, false));
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -1362,52 +1528,144 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   return GLIM_AMD_OK;
 }
 
-int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T,
-                     const glim_amd_cloud* source, double* overlap) {
-  if (!ctx || num_targets <= 0 || !targets || !T || !source || !overlap) return GLIM_AMD_ERR_INVALID;
-  for (int t = 0; t < num_targets; t++) {
-    if (!targets[t] || targets[t]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
-    if (!targets[t]->buckets) return GLIM_AMD_ERR_STATE;
-  }
-  if (source->ctx != ctx) return GLIM_AMD_ERR_INVALID;
-  if (source->n == 0) {
-    *overlap = 0.0;
-    return GLIM_AMD_OK;
+// One launch, no allocation, no copy, no stream synchronise: descriptors in the kernel arguments (single query, <= 16 targets) or read by the
+// kernel from a pinned staging block (batches), results and the completion word in host-mapped memory.
+int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
+                           const double* T, const glim_amd_cloud* const* sources, double* overlaps) {
+  if (!ctx || num_queries <= 0 || !num_targets || !targets || !T || !sources || !overlaps) return GLIM_AMD_ERR_INVALID;
+  if (num_queries > glim_amd_ctx::OV_MAX_QUERIES) return GLIM_AMD_ERR_UNSUPPORTED;
+  int64_t total_targets = 0;
+  for (int q = 0; q < num_queries; q++) {
+    if (num_targets[q] <= 0 || !sources[q] || sources[q]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
+    for (int t = 0; t < num_targets[q]; t++) {
+      const glim_amd_voxelmap* m = targets[total_targets + t];
+      if (!m || m->ctx != ctx) return GLIM_AMD_ERR_INVALID;
+      if (!m->buckets) return GLIM_AMD_ERR_STATE;
+    }
+    total_targets += num_targets[q];
   }
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream();
-  std::vector<OverlapTarget> h(num_targets);
-  for (int t = 0; t < num_targets; t++) {
-    h[t].buckets = targets[t]->buckets;
-    h[t].num_buckets = targets[t]->num_buckets;
-    h[t].pad = 0;
-    h[t].inv_res = targets[t]->inv_resolution;
-    memcpy(h[t].T, T + 12 * (size_t)t, 12 * sizeof(double));
+  GA_TRY(overlap_scratch(ctx, st));
+  // queries with an empty source are answered here (0.0) and take no part in the launch
+  std::vector<int> live;
+  for (int q = 0; q < num_queries; q++) {
+    overlaps[q] = 0.0;
+    if (sources[q]->n > 0) live.push_back(q);
   }
-  OverlapTarget* d_t = nullptr;
-  unsigned int* d_hits = nullptr;
-  GA_HIP(pool_malloc(&d_t, (size_t)num_targets * sizeof(OverlapTarget)));
-  hipError_t e = pool_malloc(&d_hits, sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMemsetAsync(d_hits, 0, sizeof(unsigned int), st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_t, h.data(), (size_t)num_targets * sizeof(OverlapTarget), hipMemcpyHostToDevice, st);
-  unsigned int hits = 0;
-  if (e == hipSuccess) {
-    const int n = (int)source->n;
-    const int blocks = std::min((n + BLOCK - 1) / BLOCK, std::max(1, ctx->num_cus) * 8);
-    overlap_kernel<<<blocks, BLOCK, 0, st>>>(n, source->pts, d_t, num_targets, d_hits);
-    e = hipGetLastError();
+  if (live.empty()) return GLIM_AMD_OK;
+  const unsigned int seq = ++ctx->ov_seq;
+  std::vector<int64_t> first_target((size_t)num_queries);
+  {
+    int64_t acc = 0;
+    for (int q = 0; q < num_queries; q++) {
+      first_target[(size_t)q] = acc;
+      acc += num_targets[q];
+    }
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(&hits, d_hits, sizeof(hits), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)pool_free(d_t);
-  if (d_hits) (void)pool_free(d_hits);
-  if (e != hipSuccess) {
-    set_hip_error(e, "overlap");
+  const OverlapInline none{};
+  if (live.size() == 1 && num_targets[live[0]] <= OVERLAP_INLINE_TARGETS) {
+    const int q = live[0];
+    OverlapInline in{};
+    in.q.pts = sources[q]->pts;
+    in.q.n = (int)sources[q]->n;
+    in.q.first_target = 0;
+    in.q.num_targets = num_targets[q];
+    in.q.first_block = 0;
+    in.q.num_blocks = overlap_blocks(ctx, sources[q]->n);
+    for (int t = 0; t < num_targets[q]; t++) fill_overlap_target(in.t[t], targets[first_target[(size_t)q] + t], T + 12 * (first_target[(size_t)q] + t));
+    overlap_kernel<true><<<in.q.num_blocks, BLOCK, 0, st>>>(in, nullptr, nullptr, nullptr, 1, ctx->ov_counters, nullptr, ctx->ov_host_dev + 1, ctx->ov_host_dev, seq);
+    GA_HIP(hipGetLastError());
+    if (!spin_until(ctx->ov_host, seq)) GA_HIP(hipStreamSynchronize(st));
+    overlaps[q] = (double)ctx->ov_host[1] / (double)sources[q]->n;
+    return GLIM_AMD_OK;
+  }
+  // batch: queries, targets and the block -> query table in one pinned block the kernel reads directly
+  int total_blocks = 0;
+  std::vector<OverlapQuery> hq(live.size());
+  int64_t live_targets = 0;
+  for (size_t i = 0; i < live.size(); i++) {
+    const int q = live[i];
+    hq[i].pts = sources[q]->pts;
+    hq[i].n = (int)sources[q]->n;
+    hq[i].first_target = (int)live_targets;
+    hq[i].num_targets = num_targets[q];
+    hq[i].first_block = total_blocks;
+    hq[i].num_blocks = overlap_blocks(ctx, sources[q]->n);
+    hq[i].pad = 0;
+    total_blocks += hq[i].num_blocks;
+    live_targets += num_targets[q];
+  }
+  const size_t qbytes = hq.size() * sizeof(OverlapQuery), tbytes = (size_t)live_targets * sizeof(OverlapTarget), bbytes = (size_t)total_blocks * sizeof(int);
+  char* stage = nullptr;
+  GA_HIP(pinned_malloc(&stage, qbytes + tbytes + bbytes));
+  char* stage_dev = nullptr;
+  if (!host_device_view(stage, &stage_dev)) {
+    (void)pinned_free(stage);
     return GLIM_AMD_ERR_HIP;
   }
-  *overlap = (double)hits / (double)source->n;
+  memcpy(stage, hq.data(), qbytes);
+  OverlapTarget* ht = reinterpret_cast<OverlapTarget*>(stage + qbytes);
+  int* hb = reinterpret_cast<int*>(stage + qbytes + tbytes);
+  for (size_t i = 0; i < live.size(); i++) {
+    const int q = live[i];
+    for (int t = 0; t < num_targets[q]; t++)
+      fill_overlap_target(ht[hq[i].first_target + t], targets[first_target[(size_t)q] + t], T + 12 * (first_target[(size_t)q] + t));
+    for (int b = 0; b < hq[i].num_blocks; b++) hb[hq[i].first_block + b] = (int)i;
+  }
+  unsigned int* queries_done = reinterpret_cast<unsigned int*>(ctx->ov_counters + glim_amd_ctx::OV_MAX_QUERIES);
+  overlap_kernel<false><<<total_blocks, BLOCK, 0, st>>>(none, reinterpret_cast<const OverlapQuery*>(stage_dev), reinterpret_cast<const OverlapTarget*>(stage_dev + qbytes),
+                                                        reinterpret_cast<const int*>(stage_dev + qbytes + tbytes), (int)live.size(), ctx->ov_counters, queries_done,
+                                                        ctx->ov_host_dev + 1, ctx->ov_host_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !spin_until(ctx->ov_host, seq)) e = hipStreamSynchronize(st);
+  (void)pinned_free(stage);
+  if (e != hipSuccess) {
+    set_hip_error(e, "overlap_batch");
+    return GLIM_AMD_ERR_HIP;
+  }
+  for (size_t i = 0; i < live.size(); i++) overlaps[live[i]] = (double)ctx->ov_host[1 + i] / (double)sources[live[i]]->n;
   return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
+                                      const uint32_t* flags, const double* T, int iters, float* us_per_iteration) {
+  if (!ctx || n <= 0 || !targets || !sources || !T || iters <= 0 || !us_per_iteration) return GLIM_AMD_ERR_INVALID;
+  std::vector<glim_amd_linearized6> out((size_t)n);
+  auto once = [&]() -> int {
+    glim_amd_factor_set* set = nullptr;
+    GA_TRY(glim_amd_factor_set_create(ctx, &set));
+    int rc = GLIM_AMD_OK;
+    for (int f = 0; f < n && rc == GLIM_AMD_OK; f++) rc = glim_amd_factor_set_add(set, targets[f], sources[f], flags ? flags[f] : 0u, nullptr);
+    if (rc == GLIM_AMD_OK) rc = glim_amd_factor_set_linearize(set, T, out.data());
+    (void)glim_amd_factor_set_destroy(set);
+    return rc;
+  };
+  for (int i = 0; i < 5; i++) GA_TRY(once());
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) GA_TRY(once());
+  const auto t1 = std::chrono::steady_clock::now();
+  *us_per_iteration = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_overlap_profile(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets, const double* T,
+                             const glim_amd_cloud* const* sources, int iters, float* us_per_call) {
+  if (!ctx || num_queries <= 0 || iters <= 0 || !us_per_call) return GLIM_AMD_ERR_INVALID;
+  std::vector<double> ov((size_t)num_queries);
+  for (int i = 0; i < 5; i++) GA_TRY(glim_amd_overlap_batch(ctx, num_queries, num_targets, targets, T, sources, ov.data()));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_overlap_batch(ctx, num_queries, num_targets, targets, T, sources, ov.data()));
+  const auto t1 = std::chrono::steady_clock::now();
+  *us_per_call = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T,
+                     const glim_amd_cloud* source, double* overlap) {
+  if (!source || !overlap) return GLIM_AMD_ERR_INVALID;
+  return glim_amd_overlap_batch(ctx, 1, &num_targets, targets, T, &source, overlap);
 }
 
 }  // extern "C"

@@ -213,6 +213,7 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
     (void)hipSetDevice(m->ctx->device);
     m->ctx->quiesce();  // asynchronous factor launches may still be reading this table
   }
+  if (m->ctx) m->ctx->mutation_epoch++;  // factor sets re-validate their plans
   if (m->buckets) (void)pool_free(m->buckets);
   delete m;
   return GLIM_AMD_OK;
@@ -250,10 +251,12 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   const int num_voxels = h_stats[0];
   // buckets per voxel (default 6: x-adjacent voxel pairs share a bucket -- device_math.hpp GLIM_AMD_PAIR_SHIFT -- so about 0.1 pairs per
   // bucket, and a pair finds its home bucket taken by another pair about 1 % of the time)
-  unsigned long long bucket_factor = 6;
-  if (const char* env = getenv("GLIM_AMD_BUCKET_FACTOR")) bucket_factor = (unsigned long long)std::max(1, atoi(env));
+  // The table is addressed with 32-bit byte offsets (<= 2^25 buckets = 4 GiB): beyond 5.6 M voxels the factor drops step by step to 2
+  // (16.7 M voxels) before the insert is refused -- a sparser table is a speed choice, never a correctness one.
+  unsigned long long bucket_factor = ctx->diag.bucket_factor > 0 ? (unsigned long long)ctx->diag.bucket_factor : 6ull;
+  while (bucket_factor > 2 && (unsigned long long)num_voxels * bucket_factor > (1ull << 25)) bucket_factor--;
   const unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
-  if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;  // 32-bit byte offsets into the bucket table (4 GiB, ~11 M voxels)
+  if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
   const unsigned int nb = (unsigned int)nb64;
   VoxelBucket* buckets = nullptr;
   GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
@@ -277,6 +280,8 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   m->buckets = buckets;
   m->num_buckets = nb;
   m->num_voxels = num_voxels;
+  m->uid = next_uid();  // a plan built from the empty map (it could not have been: add() refuses maps without a table) never matches
+  ctx->mutation_epoch++;
   return GLIM_AMD_OK;
 }
 

@@ -108,6 +108,78 @@ class ShardedCostEvaluator:
             gathered[: send.shape[0]].copy_(send)
         return gathered
 
+    def profile_device(self, fset, poses, send, gathered, index_t, reps=5):
+        """Per-rank breakdown of one evaluation with HIP events on the current stream (outside any timed region): the fused kernels +
+        finalise of the owned factors, the all-gather, the index_select into factor order; and the wall time of the same evaluation with
+        the shard split in two halves whose exchanges are issued asynchronously, so that the gather of the first half (RCCL's stream)
+        overlaps the kernels of the second (our stream)."""
+        import torch
+        import torch.distributed as dist
+
+        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = np.zeros(3)
+        for _ in range(reps):
+            ev[0].record()
+            if self.hi > self.lo:
+                fset.linearize_device_async(poses[self.lo:self.hi], send.data_ptr(), 0)
+            ev[1].record()
+            if multi_rank:
+                dist.all_gather_into_tensor(gathered, send)
+            else:
+                gathered[: send.shape[0]].copy_(send)
+            ev[2].record()
+            blocks = gathered.index_select(0, index_t)  # noqa: F841
+            ev[3].record()
+            torch.cuda.synchronize()
+            acc += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])]
+        acc /= reps
+        return {"kernels_ms": float(acc[0]), "all_gather_ms": float(acc[1]), "index_select_ms": float(acc[2])}
+
+    # ---- two-halves form: the gather of the first half of every shard overlaps the kernels of the second half ----------------------------
+    def halves_layout(self):
+        """(max_rows, h, index): every rank's send buffer [max_rows x 29] is exchanged as rows [0, h) and rows [h, max_rows); the two
+        all-gathers land in gathered[: world * h] and gathered[world * h :]; row f of the assembled array is row index[f] of `gathered`."""
+        b = shard_bounds(self.costs, self.world_size)
+        max_rows = max(1, max(b[r + 1] - b[r] for r in range(self.world_size)))
+        h = (max_rows + 1) // 2
+        index = np.empty(self.n, dtype=np.int64)
+        for r in range(self.world_size):
+            k = np.arange(b[r + 1] - b[r])
+            index[b[r]:b[r + 1]] = np.where(k < h, r * h + k, self.world_size * h + r * (max_rows - h) + (k - h))
+        return max_rows, h, index
+
+    def halves_ranges(self):
+        """Factor ranges of this rank's two sets: ([lo, mid), [mid, hi))."""
+        _, h, _ = self.halves_layout()
+        mid = min(self.lo + h, self.hi)
+        return (self.lo, mid), (mid, self.hi)
+
+    def gather_device_halves(self, fset_a, fset_b, poses, send, gathered):
+        """`fset_a` / `fset_b` hold the factors of halves_ranges().  Set A is linearised and its rows handed to an asynchronous all-gather
+        (the collective's own stream waits for what is enqueued on the current stream so far); set B's kernels are enqueued right behind and
+        run while half A travels over xGMI; then half B is gathered.  Returns after both exchanges are ordered before the current stream."""
+        import torch.distributed as dist
+
+        max_rows, h, _ = self.halves_layout()
+        (lo, mid), (_, hi) = self.halves_ranges()
+        world = self.world_size
+        multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if mid > lo:
+            fset_a.linearize_device_async(poses[lo:mid], send.data_ptr(), 0)
+        w1 = dist.all_gather_into_tensor(gathered[: world * h], send[:h], async_op=True) if multi_rank else gathered[:h].copy_(send[:h])
+        if hi > mid:
+            fset_b.linearize_device_async(poses[mid:hi], send.data_ptr(), h)
+        if max_rows > h:
+            w2 = dist.all_gather_into_tensor(gathered[world * h:], send[h:], async_op=True) if multi_rank else gathered[world * h:].copy_(send[h:])
+        else:
+            w2 = None
+        if multi_rank:
+            w1.wait()
+            if w2 is not None:
+                w2.wait()
+        return gathered
+
     def evaluate_host(self, local_rows):
         """CPU/gloo form: local_rows is [(hi-lo) x 29]; returns the reduced [n x 29] array on every rank."""
         import torch

@@ -78,6 +78,14 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
 /* GLIM_AMD_ERR_STATE (and the context stays valid) while clouds, voxel maps, factor sets or search indices created from it are alive. */
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
 int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
+/* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
+ * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
+ * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
+ * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_finalize=0|1, pool=0|1
+ * (GLIM_AMD_DIAG only), multi_rccl=0|1, multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
+ * nothing changes.  get_diag prints the current state in the same syntax. */
+int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
+int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
 /* gtsam_points::cuda_device_names / cuda_mem_get_info (src/glim/util/debug.cpp:84, viewer/memory_monitor.cpp:39). */
 int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t* free_bytes, size_t* total_bytes, int* num_cus);
 
@@ -246,6 +254,12 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T_target
  * measured inside the library so that no binding overhead is included. */
 int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_per_call);
 
+/* GLIM's live call pattern (odometry_estimation_gpu.cpp:383-385; the optimisers' linearisation hook does clear -> add(graph) -> linearize per
+ * iteration): a FRESH factor set per linearisation -- create, add the n factors, synchronous linearize (poses T: n x 12), destroy -- `iters`
+ * times; microseconds per iteration, measured inside the library. */
+int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
+                                      const uint32_t* flags, const double* T_target_source, int iters, float* us_per_iteration);
+
 /* One Levenberg-Marquardt iteration as the optimisers drive it (sub_mapping.cpp:435-443, odometry_estimation_cpu.cpp:116-149): a synchronous
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
 int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
@@ -286,6 +300,14 @@ int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t
  *      global_mapping.cpp:322,448).  Fraction of source points that hit an occupied voxel of ANY target under its delta. */
 int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxelmap* const* targets, const double* T_target_source,
                      const glim_amd_cloud* source, double* overlap);
+/* num_queries overlap_gpu calls answered by ONE launch -- the keyframe loops of odometry_estimation_gpu.cpp:262-281 issue up to
+ * max_num_keyframes of them back to back.  Query q: num_targets[q] (map, delta) pairs, stored consecutively in `targets` /
+ * `T_target_source` (12 doubles each) in query order, against sources[q]; overlaps[q] receives the fraction.  At most 1024 queries. */
+int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
+                           const double* T_target_source, const glim_amd_cloud* const* sources, double* overlaps);
+/* timing aid: `iters` back-to-back glim_amd_overlap_batch calls with these arguments; microseconds per call, measured inside the library. */
+int glim_amd_overlap_profile(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
+                             const double* T_target_source, const glim_amd_cloud* const* sources, int iters, float* us_per_call);
 
 #ifdef __cplusplus
 }

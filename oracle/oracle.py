@@ -192,6 +192,36 @@ def lib():
     return _lib
 
 
+_fast = None
+
+
+def fast_lib():
+    """A second build of the SAME restatement for bench.py's `cpu_baseline` timing only: -O3 -march=native (SURVEY.md 8d "CPU baseline
+    timing"), compiled on the box it runs on into oracle/_fast/ (git-ignored).  The checker above keeps its bit-exact flags
+    (-O2 -ffp-contract=off -march=x86-64-v3); nothing is ever CHECKED against this build.  Returns None when gcc is unavailable."""
+    global _fast
+    if _fast is None:
+        out_dir = os.path.join(_HERE, "_fast")
+        path = os.path.join(out_dir, "libvgicp_oracle_native.so")
+        try:
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-fopenmp", "-fPIC", "-shared", os.path.join(_HERE, "vgicp_oracle.c"),
+                                   os.path.join(_HERE, "preprocess_oracle.c"), "-o", path, "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            L = C.CDLL(path)
+        except Exception:
+            return None
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+        L.orc_voxelmap_create.restype = vp
+        L.orc_voxelmap_create.argtypes = [C.c_double]
+        L.orc_voxelmap_destroy.argtypes = [vp]
+        L.orc_voxelmap_insert.argtypes = [vp, dp, dp, C.c_int]
+        L.orc_vgicp_linearize.restype = C.c_int
+        L.orc_vgicp_linearize.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int, C.POINTER(Linearized6), ip]
+        L.orc_max_threads.restype = C.c_int
+        _fast = L
+    return _fast
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

@@ -64,3 +64,12 @@ def small_pair(orc):
             "neighbors": nbrs,
         }
     return out
+
+
+@pytest.fixture(autouse=True)
+def _restore_diag_switches(request):
+    """Tests flip diagnostic switches of their (module-scoped) context with ctx.set_diag(...); every test leaves the defaults behind."""
+    yield
+    ctx = getattr(request.node, "funcargs", {}).get("ctx")
+    if ctx is not None and getattr(ctx, "_h", None):
+        ctx.set_diag("")

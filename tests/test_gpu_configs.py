@@ -252,11 +252,11 @@ def test_uploaded_plane_covariances_take_the_plane_kernel(api, ctx, orc, monkeyp
         check_factor(res[name], ref)
     # the plane-form stream (24 B per point) was built for it, not the general one (36 B per point)
     assert sg.memory_usage_gpu() - base == len(src) * 24
-    monkeypatch.setenv("GLIM_AMD_NO_PLANE", "1")
+    ctx.set_diag("plane=0")
     fset = api.NonlinearFactorSetGPU(ctx)
     fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
     gen = fset.linearize({0: np.eye(4), 1: delta})[0]
-    monkeypatch.delenv("GLIM_AMD_NO_PLANE")
+    ctx.set_diag("plane=1")
     assert gen["num_inliers"] == res["f64"]["num_inliers"]
     assert np.abs(gn_step(gen) - gn_step(res["f64"])).max() < 1e-5
     # a cloud whose covariances are NOT of that form stays general even though it has normals
@@ -352,3 +352,40 @@ def test_back_to_back_async_calls_keep_their_own_poses(api, ctx, orc, small_pair
     ctx.synchronize()
     for o in outs:
         hip.hipFree(o)
+
+
+def test_config3_at_its_own_size_sampled_pairs_match_the_oracle(api, orc):
+    """BASELINE configs[3] at the size bench.py times it: 256 merged submaps (merge_frames of 4 keyframes, 0.1 m), 1.0 m maps, ALL 32 640
+    pairs in one factor set.  64 pairs spread over the inlier-count distribution (the 16 least overlapping, the 16 most, 32 quantiles)
+    are linearised by the FP64 oracle on the downloaded clouds: inlier counts equal, damped Gauss-Newton step within 1e-4, correspondence
+    lists bit-exact on 8 of them -- the same check bench.py attaches to its `m2_global256` block (bench.sampled_pair_parity)."""
+    import bench
+    from glim_amd import multi, synth
+
+    ctx = api.Context(0, 1)
+    S = 256
+    submaps = bench.make_merged_submaps(api, ctx, S, 4, 40, 512)
+    clouds = [g for _, g in submaps]
+    poses = [T for T, _ in submaps]
+    vmaps = [api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(c) for c in clouds]
+    pairs = [(i, j) for i in range(S) for j in range(i + 1, S)]
+    deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
+    fset = api.NonlinearFactorSetGPU(ctx)
+    for i, j in pairs:
+        fset.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i], clouds[j]))
+    out = fset.linearize_poses(deltas)
+    records = np.stack([multi.compact_from_linearized(L) for L in out])
+    assert len(records) == 32640
+    par = bench.sampled_pair_parity(api, fset, range(len(pairs)), pairs, deltas, clouds, records)
+    print("configs[3] parity at full size:", par)
+    assert par["pairs_checked"] >= 64 and par["inlier_counts_equal"] and par["correspondences_bit_exact"]
+    assert par["correspondence_lists_compared"] >= 8 and par["gn_steps_compared"] >= 32
+    assert par["max_pose_delta_err"] < 1e-4
+    # the batch equals each factor evaluated on its own (a different plan: one chip-wide factor instead of a share of 32 640)
+    for k in (0, 12345, len(pairs) - 1):
+        i, j = pairs[k]
+        alone = api.NonlinearFactorSetGPU(ctx)
+        alone.add(api.IntegratedVGICPFactorGPU(i, j, vmaps[i], clouds[j]))
+        a = alone.linearize_poses(deltas[k:k + 1])[0]
+        assert a["num_inliers"] == out[k]["num_inliers"]
+        np.testing.assert_allclose(a["H_ss"], out[k]["H_ss"], rtol=2e-5, atol=1e-6 * np.abs(out[k]["H_ss"]).max())

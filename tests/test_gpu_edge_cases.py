@@ -54,9 +54,9 @@ def test_ragged_factor_set_sizes(api, ctx, orc, small_pair):
 
 @pytest.mark.parametrize("factor", ["1", "2"])
 def test_crowded_bucket_table_spills_stay_exact(api, ctx, orc, small_pair, monkeypatch, factor):
-    """GLIM_AMD_BUCKET_FACTOR=1 packs one key per two-way bucket on average: many keys spill to following buckets.  Lookups,
+    """diag bucket_factor=1 packs one key per two-way bucket on average: many keys spill to following buckets.  Lookups,
     map contents and the factor must stay exact (the probe compares full keys)."""
-    monkeypatch.setenv("GLIM_AMD_BUCKET_FACTOR", factor)
+    ctx.set_diag(f"bucket_factor={factor}")
     t, s = small_pair["target"], small_pair["source"]
     tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
     sg = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], ctx=ctx)
@@ -157,7 +157,7 @@ def test_far_from_origin_keeps_precision(api, ctx, orc, small_pair):
 
 
 def test_device_memory_pool_can_be_disabled(api, monkeypatch):
-    """GLIM_AMD_NO_POOL is read once per process; here we only check that repeated create/destroy cycles do not leak or crash."""
+    """The memory caches are a process-wide switch (GLIM_AMD_DIAG="pool=0"); here we only check that repeated create/destroy cycles do not leak or crash."""
     c2 = api.Context(0, 1)
     for n in (10, 1000, 100000):
         for _ in range(3):
@@ -212,3 +212,144 @@ def test_invalid_caller_input_is_an_error_code_not_a_fault(api, ctx, small_pair)
         api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g2)
     g2.close()
     other.close()
+
+
+# ---- plan cache, host-finalised single-factor call, batched overlap -----------------------------------------------------------------
+
+
+def _full_size_pair(api, ctx, rings=64, azimuths=512):
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(rings, azimuths)
+    poses = synth.arc_trajectory(2)
+    tgt, src = synth.scan(scene, poses[0], dirs, 0), synth.scan(scene, poses[1], dirs, 1)
+    tg, sg = api.PointCloudGPU.clone(tgt, ctx=ctx), api.PointCloudGPU.clone(src, ctx=ctx)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    return tgt, src, tg, sg, synth.relative_pose(poses[0], poses[1])
+
+
+def test_host_finalised_single_factor_call_has_the_device_finalises_bits(api, ctx, orc):
+    """The synchronous single-factor call sums the partial rows on the host as they arrive (one launch); diag host_finalize=0 takes the
+    fused kernel + device finalise + completion word.  Same summation order, same rotation arithmetic: identical bits, linearise and
+    error, unary and binary, a chip-wide factor (32 row groups) and a small one (8 row groups)."""
+    for rings, azimuths in ((64, 512), (16, 128)):
+        tgt, src, tg, sg, delta = _full_size_pair(api, ctx, rings, azimuths)
+        vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+        for target in (0, np.eye(4)):
+            f = api.IntegratedVGICPFactorGPU(target, 1, vm, sg)
+            values = {0: np.eye(4), 1: delta @ orc.se3_exp([0.002, -0.001, 0.003, 0.02, 0.01, -0.02])}
+            res = {}
+            for mode in ("host_finalize=1", "host_finalize=0", "host_finalize=0,poll=0"):
+                ctx.set_diag(mode)
+                fset = api.NonlinearFactorSetGPU(ctx)
+                fset.add(f)
+                res[mode] = (fset.linearize(values)[0], fset.error(values)[0])
+                res[mode + " again"] = (fset.linearize(values)[0], fset.error(values)[0])  # the arrival words of a re-used plan
+            ctx.set_diag("")
+            base = res["host_finalize=0"]
+            assert base[0]["num_inliers"] > 100
+            for mode, (L, e) in res.items():
+                assert L["num_inliers"] == base[0]["num_inliers"], mode
+                for k in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+                    np.testing.assert_array_equal(L[k], base[0][k], err_msg=f"{mode} {k}")
+                assert L["error"] == base[0]["error"] and e == base[1], mode
+
+
+def test_plan_cache_serves_fresh_sets_and_follows_object_identity(api, ctx, orc, small_pair):
+    """GLIM builds a fresh NonlinearFactorSetGPU per linearisation: sets with the same (map, cloud, flags) list share one cached plan and
+    give the same records as a set built with the cache off; destroying / rebuilding an object never resurrects a stale plan."""
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    clouds = [api.PointCloudGPU.clone(s["points"][k::3].astype(np.float64), s["covs"][k::3], ctx=ctx) for k in range(3)]
+    vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
+    factors = [api.IntegratedVGICPFactorGPU(0, 1 + k, vms[k % 2], clouds[k]) for k in range(3)]
+    values = {0: np.eye(4), 1: small_pair["delta"], 2: small_pair["delta"], 3: small_pair["delta"]}
+
+    def fresh():
+        fs = api.NonlinearFactorSetGPU(ctx)
+        for f in factors:
+            fs.add(f)
+        out = fs.linearize(values)
+        fs.close()
+        return out
+
+    ctx.set_diag("plan_cache=0")
+    want = fresh()
+    ctx.set_diag("")
+    for _ in range(4):  # the second and later iterations adopt the plan the first one parked
+        got = fresh()
+        for a, b in zip(got, want):
+            assert a["num_inliers"] == b["num_inliers"]
+            np.testing.assert_array_equal(a["H_ss"], b["H_ss"])
+            np.testing.assert_array_equal(a["b_s"], b["b_s"])
+    # clear() + add() on one set object, a different list in between
+    fs = api.NonlinearFactorSetGPU(ctx)
+    for rounds in range(3):
+        fs.clear()
+        for f in (factors if rounds != 1 else factors[:2]):
+            fs.add(f)
+        got = fs.linearize(values)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a["H_ss"], b["H_ss"])
+    # a new cloud / map at (possibly) the same address must not match the old plan: replace the second source by different points
+    clouds[1].close()
+    clouds[1] = api.PointCloudGPU.clone(s["points"][2::5].astype(np.float64), s["covs"][2::5], ctx=ctx)
+    factors[1] = api.IntegratedVGICPFactorGPU(0, 2, vms[1], clouds[1])
+    ref = orc.vgicp_linearize(orc.VoxelMap(1.0).insert(t["points"], t["covs"]), s["points"][2::5], s["covs"][2::5], small_pair["delta"])
+    got = fresh()[1]
+    assert got["num_inliers"] == ref["num_inliers"]
+    assert np.abs(gn(got) - gn(ref)).max() < 1e-4
+
+
+def test_reestimating_covariances_rebuilds_plans_that_streamed_the_old_ones(api, ctx, orc):
+    """A cloud uploaded with general covariances sits in a LIVE factor set (its plan holds the addresses of the 36 B/pt streams); then
+    glim_amd_cloud_estimate_covariances replaces the covariances (plane form, streams freed).  The next linearise of the same set must run
+    on the new data (it used to read freed memory with plane = 0)."""
+    tgt, src, tg, sg, delta = _full_size_pair(api, ctx, 32, 256)
+    _, cov_dev, _ = sg.download()
+    blur = 0.5 * (cov_dev + np.roll(cov_dev, 1, axis=0)).astype(np.float64)  # not of the plane form: the general kernel
+    up = api.PointCloudGPU.clone(src.astype(np.float64), blur, ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, up))
+    values = {0: np.eye(4), 1: delta}
+    first = fset.linearize(values)[0]
+    _, ct, _ = tg.download()
+    ref_map = orc.VoxelMap(0.5).insert(tgt, ct.astype(np.float64))
+    ref_blur = orc.vgicp_linearize(ref_map, src, blur.astype(np.float32).astype(np.float64), delta)
+    assert first["num_inliers"] == ref_blur["num_inliers"] and np.abs(gn(first) - gn(ref_blur)).max() < 1e-4
+    up.find_neighbors(10, download=False)
+    up.estimate_covariances(10)
+    second = fset.linearize(values)[0]  # same set object, nothing re-added
+    ref_plane = orc.vgicp_linearize(ref_map, src, cov_dev.astype(np.float64), delta)
+    assert second["num_inliers"] == ref_plane["num_inliers"]
+    assert np.abs(gn(second) - gn(ref_plane)).max() < 1e-4
+    assert abs(second["error"] - ref_plane["error"]) <= 3e-4 * abs(ref_plane["error"])
+
+
+def test_overlap_batch_equals_single_calls_and_oracle(api, ctx, orc, small_pair):
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    sg = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], ctx=ctx)
+    empty = api.PointCloudGPU.clone(np.zeros((0, 3), dtype=np.float32), ctx=ctx)
+    vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0, 2.0)]
+    refs = [orc.VoxelMap(r).insert(t["points"], t["covs"]) for r in (0.5, 1.0, 2.0)]
+    delta = small_pair["delta"]
+    far = np.eye(4)
+    far[:3, 3] = 1e4
+    shifted = delta @ orc.se3_exp([0, 0, 0.3, 2.0, 1.0, 0])
+    many = [vms[k % 3] for k in range(20)]  # more targets than fit the kernel arguments: the staged path
+    many_refs = [refs[k % 3] for k in range(20)]
+    many_T = [far] * 19 + [shifted]
+    queries = [([vms[0]], sg, [delta]), ([vms[0], vms[1]], sg, [far, shifted]), ([vms[2]], tg, [np.eye(4)]), ([vms[1]], empty, [delta]),
+               (many, sg, many_T), ([vms[0]], sg, [far])]
+    want = [orc.overlap(refs[0], s["points"], delta), orc.overlap([refs[0], refs[1]], s["points"], [far, shifted]), orc.overlap(refs[2], t["points"], np.eye(4)), 0.0,
+            orc.overlap(many_refs, s["points"], many_T), 0.0]
+    assert api.overlap_gpu_batch(queries, ctx=ctx) == want
+    assert api.overlap_gpu_batch(queries, ctx=ctx) == want  # counters were reset by the kernel
+    assert [api.overlap_gpu(q[0], q[1], q[2]) for q in queries] == want
+    assert api.overlap_gpu_batch(queries[:1], ctx=ctx) == want[:1]
+    assert api.overlap_gpu_batch([queries[4]], ctx=ctx) == [want[4]]

@@ -172,6 +172,25 @@ def _ragged_worker(rank, world, port, q):
             ev = multi.ShardedCostEvaluator(costs, rank, world)
             ok = ok and np.array_equal(ev.gather_host(rows[ev.lo:ev.hi]).numpy(), rows)
             ok = ok and np.array_equal(ev.evaluate_host(rows[ev.lo:ev.hi]).numpy(), rows)
+            # the two-halves form bench.py uses for N > 1 (gather of half A overlaps the kernels of half B): same method, host tensors, and
+            # stand-in sets that write their rows where the HIP finalise kernel would
+            import torch
+
+            max_rows, h, index = ev.halves_layout()
+            send = torch.zeros(max_rows, multi.COMPACT, dtype=torch.float64)
+            gathered = torch.zeros(world * max_rows, multi.COMPACT, dtype=torch.float64)
+
+            class FakeSet:
+                def __init__(self, lo):
+                    self.lo = lo
+
+                def linearize_device_async(self, poses, ptr, row_offset):
+                    assert ptr == send.data_ptr()
+                    send[row_offset:row_offset + len(poses)] = torch.as_tensor(rows[self.lo:self.lo + len(poses)])
+
+            (lo, mid), (_, hi) = ev.halves_ranges()
+            ev.gather_device_halves(FakeSet(lo), FakeSet(mid), rows, send, gathered)  # `poses` only supplies the slice lengths here
+            ok = ok and np.array_equal(gathered[torch.as_tensor(index)].numpy(), rows)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

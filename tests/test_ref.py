@@ -87,26 +87,124 @@ def test_restatement_equals_compiled_reference_on_random_inputs(orc, seed):
         np.testing.assert_array_equal(a, b)
 
 
+def degenerate_neighbourhood_cloud(seed=3):
+    """Points whose k-neighbourhoods include exactly collinear, exactly coplanar, exactly repeated and nearly isotropic sets -- the inputs on
+    which the smallest eigenvector is ill-defined -- next to ordinary noisy planes."""
+    rng = np.random.default_rng(seed)
+    n = 1500
+    line = np.c_[np.arange(n) * 0.01, np.zeros(n), np.zeros(n)]                       # exactly collinear (representable spacing aside)
+    plane = np.c_[rng.integers(-40, 40, (n, 2)) * 0.125, np.full(n, 2.0)]              # exactly coplanar, many exact ties
+    dup = np.repeat(rng.uniform(-1, 1, (n // 10, 3)) + [5, 5, 0], 10, axis=0)          # identical points
+    iso = rng.normal(0, 1e-3, (n, 3)) + [-6.0, 3.0, 1.0]                               # nearly isotropic blobs
+    noisy = np.c_[rng.uniform(-5, 5, (n, 2)), rng.normal(0, 0.01, n)] + [0, 20, 0]     # the ordinary case
+    return np.concatenate([line, plane, dup, iso, noisy]).astype(np.float32)
+
+
+def test_reference_covariance_is_a_function_of_its_normal_alone(orc, gold):
+    """The PLANE-regularised covariance the reference computes, V diag(1e-3, 1, 1) V^T with computeDirect's V
+    (cloud_covariance_estimation.cpp:181-196), equals I - 0.999 n n^T built from the reference's OWN normal to FP64 rounding on EVERY point --
+    ill-conditioned and degenerate neighbourhoods included -- because computeDirect's V is orthonormal to rounding in each of its branches.
+    This is what lets the HIP kernel (covariance.hip) and the plane-form factor stream carry the normal alone: no shortcut of the reference's
+    arithmetic is visible at FP32 storage precision (6e-8)."""
+    def check(covs, normals, what):
+        rebuilt = np.eye(3)[None] - 0.999 * normals[:, :, None] * normals[:, None, :]
+        err = np.abs(covs - rebuilt).max()
+        assert err < 1e-12, (what, err)
+        np.testing.assert_allclose(np.linalg.norm(normals, axis=1), 1.0, atol=1e-12, err_msg=what)
+
+    for k in (10, 5):
+        check(gold[f"covs_k{k}"], gold[f"normals_k{k}"], f"reference-generated fixture k={k}")
+    pts = degenerate_neighbourhood_cloud()
+    nb = orc.knn(pts, 10)
+    use_ref = orc.ref_lib() is not None  # the compiled reference where it exists (this container), its bit-equal restatement elsewhere
+    for k in (10, 5, 3):
+        nrm, cov = orc.covariances(pts, nb, k_neighbors=k, ref=use_ref)
+        check(cov, nrm, f"degenerate cloud k={k} ({'compiled reference' if use_ref else 'restatement'})")
+        if use_ref:
+            n2, c2 = orc.covariances(pts, nb, k_neighbors=k)
+            np.testing.assert_array_equal(nrm, n2)
+            np.testing.assert_array_equal(cov, c2)
+
+
+def covariance_report(points, neighbors, k, covs, normals, ref_c, ref_n):
+    """UNMASKED comparison of device covariances / normals with the reference's, plus the invariants that must hold on every point.
+    Returns (fraction of points whose covariance differs by more than 1e-5, the largest relative eigenvalue gap among them)."""
+    p = points.astype(np.float64)
+    nb = p[neighbors[:, :k]]
+    d = nb - nb.mean(1, keepdims=True)
+    sigma = np.einsum("nki,nkj->nij", d, d) / k
+    ev = np.linalg.eigvalsh(sigma)
+    scale = np.maximum(ev[:, 2], 1e-300)
+    gap = (ev[:, 1] - ev[:, 0]) / scale
+    n64, c64 = normals.astype(np.float64), covs.astype(np.float64)
+    # (i) unit normal, (ii) it faces the sensor (cloud_covariance_estimation.cpp:98-101), (iii) the stored covariance IS I - 0.999 n n^T
+    np.testing.assert_allclose(np.linalg.norm(n64, axis=1), 1.0, atol=2e-7)
+    assert np.all(np.einsum("ni,ni->n", p, n64) <= 1e-6 * np.linalg.norm(p, axis=1) + 1e-12)
+    np.testing.assert_allclose(c64, np.eye(3)[None] - 0.999 * n64[:, :, None] * n64[:, None, :], atol=3e-7)
+    # (iv) backward error: n is an eigenvector of the neighbourhood's covariance for its smallest eigenvalue as far as FP32 storage of n and
+    #      the closed-form solver allow -- the Rayleigh quotient sits at the bottom of the spectrum -- on EVERY point, however ill-conditioned
+    rq = np.einsum("ni,nij,nj->n", n64, sigma, n64)
+    assert np.all(rq - ev[:, 0] <= 1e-5 * scale + 1e-300), float(np.max((rq - ev[:, 0]) / scale))
+    # (v) forward error, no mask: the covariance matches the reference's within 1e-5 unless the two smallest eigenvalues coincide to within
+    #     the solver's own resolution -- there the reference's eigenvector itself is decided by rounding noise
+    bad = np.abs(c64 - ref_c).max(axis=(1, 2)) > 1e-5
+    flip = np.abs(n64 - ref_n).max(axis=1) > 1e-5
+    assert np.array_equal(bad | flip, flip | bad)
+    worst_gap = float(gap[bad | flip].max()) if np.any(bad | flip) else 0.0
+    return float(np.mean(bad | flip)), worst_gap
+
+
+def write_report(name, payload):
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        import json
+
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(payload, f, indent=1)
+
+
 @pytest.mark.gpu
 def test_hip_covariances_match_reference_generated_vectors(gold):
+    """Every point of the reference-generated fixture, no conditioning mask: the fraction of points beyond 1e-5 is reported (DESIGN.md
+    section 5) and must be explained by a vanishing eigenvalue gap; the invariants of covariance_report hold everywhere."""
     from glim_amd import api
 
     ctx = api.Context(0, 1)
     g = api.PointCloudGPU.clone(gold["points"], ctx=ctx)
+    report = {}
     for k in (10, 5):
         g.set_neighbors(gold["neighbors"])
         g.estimate_covariances(k)
         _, covs, normals = g.download()
-        ref_c, ref_n = gold[f"covs_k{k}"], gold[f"normals_k{k}"]
-        # smallest eigenvector well conditioned: compare covariance and normal; everywhere: the regularised spectrum
-        p = gold["points"].astype(np.float64)[gold["neighbors"][:, :k]]
-        d = p - p.mean(1, keepdims=True)
-        ev = np.linalg.eigvalsh(np.einsum("nki,nkj->nij", d, d) / k)
-        ok = (ev[:, 1] - ev[:, 0]) > 1e-3 * np.maximum(ev[:, 2], 1e-300)
-        assert ok.mean() > (0.9 if k == 10 else 0.5)  # 5 neighbours of a 24-ring scan are often collinear along the ring
-        np.testing.assert_allclose(covs[ok], ref_c[ok], rtol=0, atol=1e-5)
-        np.testing.assert_allclose(normals[ok], ref_n[ok], rtol=0, atol=1e-5)
+        frac, worst_gap = covariance_report(gold["points"], gold["neighbors"], k, covs, normals, gold[f"covs_k{k}"], gold[f"normals_k{k}"])
+        report[f"k{k}"] = {"points": int(len(covs)), "fraction_beyond_1e-5": frac, "largest_relative_gap_among_them": worst_gap}
+        print(f"covariance parity, reference-generated vectors, k={k}: fraction beyond 1e-5 = {frac:.2e}, largest relative eigenvalue gap among them = {worst_gap:.2e}")
+        assert frac <= 2e-3 and worst_gap < 1e-6, report
         np.testing.assert_allclose(np.linalg.eigvalsh(covs.astype(np.float64)), np.tile([1e-3, 1.0, 1.0], (len(covs), 1)), atol=2e-6)
+    write_report("covariance_parity_ref_vectors.json", report)
+
+
+@pytest.mark.gpu
+def test_hip_covariances_on_degenerate_neighbourhoods(orc):
+    """Exactly collinear / coplanar / repeated / nearly isotropic neighbourhoods: the invariants hold on every point, and wherever the device
+    and the reference disagree beyond 1e-5 the two smallest eigenvalues coincide (relative gap < 1e-6) -- the eigenvector's own indeterminacy."""
+    from glim_amd import api
+
+    ctx = api.Context(0, 1)
+    pts = degenerate_neighbourhood_cloud()
+    nb = orc.knn(pts, 10)
+    g = api.PointCloudGPU.clone(pts, ctx=ctx)
+    report = {}
+    for k in (10, 5, 3):
+        g.set_neighbors(nb)
+        g.estimate_covariances(k)
+        _, covs, normals = g.download()
+        rn, rc = orc.covariances(pts, nb, k_neighbors=k)
+        frac, worst_gap = covariance_report(pts, nb, k, covs, normals, rc, rn)
+        report[f"k{k}"] = {"points": int(len(pts)), "fraction_beyond_1e-5": frac, "largest_relative_gap_among_them": worst_gap}
+        print(f"covariance parity, degenerate neighbourhoods, k={k}: fraction beyond 1e-5 = {frac:.2e}, largest relative gap among them = {worst_gap:.2e}")
+        assert worst_gap < 1e-6, report
+    write_report("covariance_parity_degenerate.json", report)
 
 
 @pytest.mark.gpu
