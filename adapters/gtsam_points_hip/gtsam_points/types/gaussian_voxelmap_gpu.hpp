@@ -75,9 +75,17 @@ inline double overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets
   for (const auto& m : targets) t.push_back(device_map(m));
   return glim_amd::overlap_gpu(t, device_cloud(source), deltas);
 }
-// overlap_auto dispatches on the map type upstream; GLIM's GPU configurations only ever pass GPU maps to it (global_mapping.cpp:448)
+// The CPU overlap of the (CPU-only) gtsam_points install this tree is layered over -- upstream declares it in
+// gtsam_points/types/gaussian_voxelmap_cpu.hpp and libgtsam_points defines it; redeclared here so that overlap_auto can reach it without
+// pulling that header into every translation unit that includes this one.
+double overlap(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta);
+
+// overlap_auto dispatches on where the map lives, as upstream does: a GaussianVoxelMapGPU target takes the device path, anything else (a
+// libglim built with GTSAM_POINTS_USE_CUDA but run with enable_gpu = false creates GaussianVoxelMapCPU maps: global_mapping.cpp:275, and
+// reaches this call unconditionally at sub_mapping.cpp:253 and global_mapping.cpp:322,448) falls back to the CPU overlap.
 inline double overlap_auto(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta) {
-  return overlap_gpu(target, source, delta);
+  if (std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(target)) return overlap_gpu(target, source, delta);
+  return overlap(target, source, delta);
 }
 
 }  // namespace gtsam_points

@@ -140,6 +140,15 @@ class PointCloudGPU:
         return PointCloudGPU(h, ctx)
 
     @staticmethod
+    def clone_packed(points4, covs16=None, normals4=None, ctx=None):
+        """PointCloudGPU::clone of arrays that already have the reference's layout (n x Vector4d, n x column-major Matrix4d): nothing is
+        repacked on the Python side, so timing this call times the library."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(lib().glim_amd_cloud_create(ctx._h, len(points4), _dp(points4), _dp(covs16), _dp(normals4), C.byref(h)), "glim_amd_cloud_create")
+        return PointCloudGPU(h, ctx)
+
+    @staticmethod
     def clone_deskewed(points, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None, ctx=None):
         """CloudDeskewing::deskew (cloud_deskewing.cpp) fused with PointCloudGPU::clone: IMU-pose form when imu_times / imu_poses are
         given, constant-velocity form otherwise."""

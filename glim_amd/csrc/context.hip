@@ -36,7 +36,7 @@ const DiagKey kDiagKeys[] = {
   {"inline_pose", &Diag::inline_pose, nullptr, 0, 1},
   {"bucket_factor", &Diag::bucket_factor, nullptr, 0, 64},
   {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
-  {"host_finalize", &Diag::host_finalize, nullptr, 0, 1},
+  {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},

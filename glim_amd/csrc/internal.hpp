@@ -72,7 +72,7 @@ struct Diag {
   int inline_pose = 1;    // inline_pose=0|1                     pose of a single-factor set in the kernel arguments
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
-  int host_finalize = 1;  // host_finalize=0|1                   synchronous single-factor call: partial rows summed on the host as they arrive
+  int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
@@ -310,26 +310,23 @@ struct FactorPlan {
   int max_rows_per_factor = 0;    // most blocks (partial rows) any factor of the plan owns: picks the finalise kernel's width
   int plane_rows = 0, total_rows = 0;
   glim_amd::FactorDesc* d_descs = nullptr;
-  int2* d_blockmap = nullptr;     // total_rows x int2, then the rows[] index (int per block)
+  int2* d_blockmap = nullptr;     // total_rows x int2
   float* d_partials = nullptr;
   double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
   double* d_compact = nullptr;    // n x COMPACT
   // pinned pose staging: a ring, because an asynchronous call returns while its host-to-device copy may still be reading the slot
   static constexpr int POSE_RING = 4;
   double* h_poses = nullptr;      // POSE_RING x (2 x n x 12)
+  double* h_poses_dev = nullptr;  // device view of h_poses
   hipEvent_t pose_events[POSE_RING] = {nullptr, nullptr, nullptr, nullptr};
   bool pose_pending[POSE_RING] = {false, false, false, false};
   int pose_slot = 0;
   double* h_compact = nullptr;       // pinned, host-mapped
   double* h_compact_dev = nullptr;   // device view of h_compact (small sets: results land in host memory, no D2H copy)
-  int* d_done = nullptr;             // finalise-block arrival counter (polling fast path)
+  int* d_done = nullptr;             // finished factors of a launch (polling fast path)
   unsigned int* h_flag = nullptr;    // host-mapped completion word, written by the last finalise block
   unsigned int* h_flag_dev = nullptr;
   unsigned int poll_seq = 0;
-  // single-factor plans: host-mapped partial rows + one arrival word per row (the synchronous call sums the rows on the host while the
-  // blocks are still finishing: one launch, no finalise dispatch -- vgicp.hip run_sync)
-  float* h_rows = nullptr;           // total_rows x PARTIAL_STRIDE floats, then total_rows arrival words
-  float* h_rows_dev = nullptr;
   size_t cap_factors = 0, cap_blocks = 0;
   std::vector<glim_amd::FactorDesc> h_descs;
   hipStream_t last_stream = nullptr;  // stream of the last enqueue
@@ -349,6 +346,7 @@ struct glim_amd_factor_set {
   uint64_t seen_epoch = 0;       // ctx->mutation_epoch when the plan was last validated
   FactorPlan* plan = nullptr;    // owned while set; parked in ctx->plan_cache on clear / destroy
   glim_amd::InlineArgs inline_args{};  // single-factor sets: pose + descriptor ride in the kernel arguments
+  const double* poses_dev = nullptr;   // where this call's kernels read their poses (the plan's device array, or a host-mapped pinned slot)
 };
 
 namespace glim_amd {

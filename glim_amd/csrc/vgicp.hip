@@ -103,12 +103,10 @@ __device__ __forceinline__ PointIn load_point(const FactorDesc& d, unsigned int 
 // twice (per-block agent-scope release: 122 vs 80 us per 64 factors; write-through row stores: 149 vs 143 us per 128 factors, 22.9 vs
 // 18.8 us per synchronous single-factor call) and is gone: the second dispatch costs less than any in-kernel hand-off.
 struct FinalizeArgs {
-  const int* rows;           // per factor: the plan rows (blocks) that hold its partial sums, in chunk order
   double* out;               // compact records
   long long out_row_offset;
   int* done_counter;         // finished factors of this launch (polling fast path)
   unsigned int* host_flag;   // host-mapped completion word or null
-  unsigned int* row_flags;   // host-finalised single-factor call: one arrival word per partial row (host-mapped), else null
   unsigned int seq;
   int num_factors;
 };
@@ -156,37 +154,54 @@ __host__ __device__ inline void rotate_part(int part, const double* sum, const d
   }
 }
 
-// Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by all 32 * G threads of ONE block.  Thread (g, j),
-// g = tid / 32, j = tid % 32, sums rows g, g + G, g + 2 G, ... of value j; the G group sums are then added in group order.  The
-// order depends only on the plan, so results are bit-reproducible whichever block happens to run this.
-// G = 8 (256 threads) for factor sets, whose factors own a handful of rows each; G = 32 (1024 threads) when one factor is spread over
-// the whole chip (the synchronous single-factor call of the odometry: ~500 rows, now one batch of loads per thread instead of four).
-template <int G>
+// Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by the 256 threads of ONE block of the finalise kernel.  A
+// factor's rows are consecutive (row first_block + c belongs to its chunk c).  Thread t sums rows g, g + 32, g + 64, ... (g = t / 8) of the
+// four values 4 q .. 4 q + 3 (q = t % 8), as ONE batch of up to 16 independent 16-byte loads per thread and per 512 rows; the 32 group sums
+// are then added in group order.  The order depends only on the plan: results are bit-reproducible.
+// Finalising INSIDE the fused kernel (the block that finds all rows of its factor written sums them) was measured three times and is gone: per-block
+// agent-scope release + arrival count (round 2: 22.9 vs 18.8 us per synchronous single-factor call), and in round 3 with this very summation
+// code 25.1 us (fences) / 20.6 us (write-through rows, counted waits) against 17.5 us for the two dispatches, 38 / 29 against 27 us for the
+// odometry's 34-factor set (profiles/r03/probe/c2_*): several hundred blocks finishing together serialise on the arrival counter (~10 ns per
+// same-address atomic) for longer than the second dispatch costs.  So did summing the rows on the host as they arrive (35.9 us: the host
+// ping-pongs cache lines with the device's writes).
+constexpr int FIN_GROUPS = 32;
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
                                                 double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
-  const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
   const int first = d.first_block, nb = d.num_blocks;
-  // With one dependent (row id -> value) load pair per trip the trips of a thread are as many memory round trips (~23 us for a chip-wide
-  // factor: most of a synchronous single-factor call).  The loads of 16 trips are therefore issued together; the additions keep their order.
-  double s = 0.0;
+  // the pose is needed at the very end (rotate_part): fetched now, so that its latency hides behind the row loads
+  double Tl[12];
+  if (threadIdx.x < 4) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) Tl[i] = T[i];
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   constexpr int INFLIGHT = 16;
-  for (int c = g; c < nb; c += G * INFLIGHT) {
-    int r[INFLIGHT];
-    float v[INFLIGHT];
+  for (int c = g; c < nb; c += FIN_GROUPS * INFLIGHT) {
+    float4 v[INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) r[u] = fa.rows[first + min(c + G * u, nb - 1)];  // past the end: a valid row, value unused
-#pragma unroll
-    for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)r[u] * PARTIAL_STRIDE + j];
+    for (int u = 0; u < INFLIGHT; u++) {
+      const float* src = partials + (size_t)(first + min(c + FIN_GROUPS * u, nb - 1)) * PARTIAL_STRIDE + 4 * q;  // past the end: a valid row, value unused
+      v[u] = *reinterpret_cast<const float4*>(src);
+    }
 #pragma unroll
     for (int u = 0; u < INFLIGHT; u++)
-      if (c + G * u < nb) s += (double)v[u];
+      if (c + FIN_GROUPS * u < nb) {
+        s0 += (double)v[u].x;
+        s1 += (double)v[u].y;
+        s2 += (double)v[u].z;
+        s3 += (double)v[u].w;
+      }
   }
-  s_part[g][j] = s;
+  s_part[g][4 * q + 0] = s0;
+  s_part[g][4 * q + 1] = s1;
+  s_part[g][4 * q + 2] = s2;
+  s_part[g][4 * q + 3] = s3;
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < G; k++) t += s_part[k][threadIdx.x];
+    for (int k = 0; k < FIN_GROUPS; k++) t += s_part[k][threadIdx.x];
     s_sum[threadIdx.x] = t;
   }
   __syncthreads();
@@ -196,7 +211,7 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   if (t == 1) o[1] = s_sum[27];
   if (mode == MODE_LINEARIZE) {
     __shared__ double s_rot[32];
-    if (t < 4) rotate_part(t, s_sum, T, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
+    if (t < 4) rotate_part(t, s_sum, Tl, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
     __syncthreads();
     if (t < 21) o[2 + t] = s_rot[c_acc_of_upper[t]];
     if (t >= 21 && t < 24) o[2 + t] = s_rot[t];          // b_w = R^T sum u x q'
@@ -205,17 +220,18 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
     o[t] = 0.0;
   }
   if (fa.host_flag) {
-    // completion flag for the polling fast path: every finalising block makes its record visible system-wide, the one that
-    // completes the launch publishes `seq` into host-mapped memory (the host spins on it instead of a stream synchronise)
+    // completion word of the polling fast path: every finalising block waits until its record is visible system-wide (ONE fence), the one
+    // that completes the launch publishes `seq` into host-mapped memory (the host spins on it instead of a stream synchronise).  A
+    // single-factor launch has nobody to count.
     __threadfence_system();
     __syncthreads();
     if (t == 0) {
-      const int prev = atomicAdd(fa.done_counter, 1);
-      if (prev == fa.num_factors - 1) {
-        *fa.done_counter = 0;
-        __threadfence_system();
-        __hip_atomic_store(fa.host_flag, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      bool last = true;
+      if (fa.num_factors > 1) {
+        last = __hip_atomic_fetch_add(fa.done_counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == fa.num_factors - 1;
+        if (last) __hip_atomic_store(fa.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (last) __hip_atomic_store(fa.host_flag, fa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -231,79 +247,6 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: lives in SGPRs)
   float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
-
-// Opt-in variant (round-2 experiment, measured -1.5 % on the bench workload, kept out of the default build: DESIGN.md 4.1(d)): the point
-// transform in FP32 with an exactness guard instead of FP64.  Build with -DGLIM_AMD_K4_F32_TRANSFORM=1 (tools/ab_variant.sh).
-#ifndef GLIM_AMD_K4_F32_TRANSFORM
-#define GLIM_AMD_K4_F32_TRANSFORM 0
-#endif
-#if GLIM_AMD_K4_F32_TRANSFORM
-// FP32 image of the linearisation pose and of the voxel grid, plus the constants of the exactness guard below (wave-uniform).
-struct Pose32 {
-  float tx, ty, tz;  // translation
-  float inv_res, res;
-  float ke, ce;      // guard: E = ke * (|px| + |py| + |pz|) + ce,  ke = 2^-21 / res,  ce = ke * max |t|
-  float ecap;        // largest E for which the FP32 residual is accepted: 2^-14 m in voxel units
-};
-
-// FP64 transform of one point with the oracle's fma order, its voxel and its position inside the voxel relative to the centre.
-__device__ __forceinline__ void exact_cell(const double* __restrict__ T, double inv_res, float px, float py, float pz, int& cx, int& cy, int& cz, float& dx,
-                                           float& dy, float& dz, float& qx, float& qy, float& qz) {
-  double x, y, z;
-  transform_point_d(T, (double)px, (double)py, (double)pz, x, y, z);
-  const double tx = x * inv_res, ty = y * inv_res, tz = z * inv_res;
-  const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
-  cx = __double2int_rz(fx); cy = __double2int_rz(fy); cz = __double2int_rz(fz);  // out-of-range values saturate and fail the key range check
-  dx = (float)(tx - fx) - 0.5f; dy = (float)(ty - fy) - 0.5f; dz = (float)(tz - fz) - 0.5f;
-  qx = (float)x; qy = (float)y; qz = (float)z;
-}
-
-// q = R p + t, its voxel (cx, cy, cz), its position inside the voxel relative to the centre (dx, dy, dz in voxel units).
-//
-// The voxel coordinate must be the one the CPU factor gets from FP64 arithmetic (bit-exact correspondences are the parity contract), but FP64
-// and its conversions issue at half the FP32 rate on gfx950 (tools/ubench/valu_rate.hip: 2.4-2.5 vs 1.0-1.25 ticks per wave instruction).
-// So the transform runs in FP32 with a proof obligation attached: with R, t, 1/res rounded to FP32 and three fused multiply-adds per
-// axis, the FP32 voxel position t32 differs from the FP64 one by less than 6.1 * 2^-24 * (|px| + |py| + |pz| + |t|) / res (one rounding of
-// each input, one per fma, one for the product with 1/res; |R_ij| <= 1).  If t32 lies at least E = 8 * 2^-24 * (...) / res inside its unit
-// interval on all three axes, floor(t32) IS the FP64 coordinate (tests/test_fp32_guard.py checks the claim on the CPU, adversarial points
-// included).  Lanes closer than E to a voxel face (about 3e-4 of all points at 0.5 m voxels and 60 m range; also NaNs and coordinates
-// beyond 2^20 voxels) take the FP64 path, as a wave-uniform branch.  Residuals of FP32 lanes carry the FP32 transform's rounding
-// (<= 3.6e-7 of |p|_1 + |t|, like the reference's GPU kernels) instead of FP64's; the FP32 path is only taken where that stays below
-// 2^-14 m (|p|_1 + |t|_inf <= 128 m: every point of a sensor-centred scan); maps far from the origin keep the FP64 residual.
-__device__ __forceinline__ void locate_point(const double* __restrict__ Tl, double inv_res, const Pose32& P, const Rot32& R, float px, float py, float pz, int& cx,
-                                             int& cy, int& cz, float& dx, float& dy, float& dz, float& qx, float& qy, float& qz) {
-  qx = fmaf(R.r00, px, fmaf(R.r01, py, fmaf(R.r02, pz, P.tx)));
-  qy = fmaf(R.r10, px, fmaf(R.r11, py, fmaf(R.r12, pz, P.ty)));
-  qz = fmaf(R.r20, px, fmaf(R.r21, py, fmaf(R.r22, pz, P.tz)));
-  const float ux = qx * P.inv_res, uy = qy * P.inv_res, uz = qz * P.inv_res;
-  const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
-  cx = (int)fx; cy = (int)fy; cz = (int)fz;
-  dx = (ux - fx) - 0.5f; dy = (uy - fy) - 0.5f; dz = (uz - fz) - 0.5f;
-  const float E = fmaf(fabsf(px) + fabsf(py) + fabsf(pz), P.ke, P.ce);
-  const bool exact = (fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) <= 0.5f - E) && (E <= P.ecap);  // false for NaN
-  if (__any(!exact)) {
-    int ex, ey, ez;
-    float edx, edy, edz, eqx, eqy, eqz;
-    exact_cell(Tl, inv_res, px, py, pz, ex, ey, ez, edx, edy, edz, eqx, eqy, eqz);
-    if (!exact) {
-      cx = ex; cy = ey; cz = ez;
-      dx = edx; dy = edy; dz = edz;
-      qx = eqx; qy = eqy; qz = eqz;
-    }
-  }
-}
-
-__device__ __forceinline__ Pose32 make_pose32(const double* __restrict__ T, double res, double inv_res) {
-  Pose32 P;
-  P.tx = (float)T[3]; P.ty = (float)T[7]; P.tz = (float)T[11];
-  P.inv_res = (float)inv_res;
-  P.res = (float)res;
-  P.ke = 4.76837158203125e-7f * P.inv_res;  // 2^-21 / res
-  P.ce = P.ke * fmaxf(fabsf(P.tx), fmaxf(fabsf(P.ty), fabsf(P.tz))) * 1.0000002f;
-  P.ecap = 6.103515625e-5f * P.inv_res;  // 2^-14 m
-  return P;
-}
-#endif
 
 // What a point carries from the probe stage (trip t-1) to the algebra stage (trip t) of the pipelined loop.
 template <bool PLANE>
@@ -321,15 +264,9 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
                                                     const double* __restrict__ Te, const Rot32& R, bool validate, int last) {
   Probe<PLANE> o;
   const bool ok = in_trip && (i < d.n);
-#if GLIM_AMD_K4_F32_TRANSFORM
-  const Pose32 P32 = make_pose32(Tl, d.res, d.inv_res);  // wave-uniform, hoisted out of the loop by the compiler
-  int cx, cy, cz;
-  float dx32, dy32, dz32, qx, qy, qz;
-  locate_point(Tl, d.inv_res, P32, R, pt.p.x, pt.p.y, pt.p.z, cx, cy, cz, dx32, dy32, dz32, qx, qy, qz);
-  o.qp0 = qx - P32.tx;
-  o.qp1 = qy - P32.ty;
-  o.qp2 = qz - P32.tz;
-#else
+  // (An FP32 transform with an exactness guard -- FP32 q, floor accepted only when the point lies provably inside its voxel, FP64 fallback for
+  // the other 3e-4 of the lanes -- removes 33 half-rate instructions here; measured twice, -1.5 % on the plane-form kernel and -2 % on the
+  // VALU-bound 256-submap cost at the price of 1e-5 m in the residuals: not adopted, profiles/r03/probe/ab_fp32_transform_global256_and_m1.jsonl.)
   double qx, qy, qz;
   transform_point_d(Tl, (double)pt.p.x, (double)pt.p.y, (double)pt.p.z, qx, qy, qz);
   const double tx = qx * d.inv_res, ty = qy * d.inv_res, tz = qz * d.inv_res;
@@ -340,7 +277,6 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
   // in-voxel fraction for free
   const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
   const int cx = __double2int_rz(fx), cy = __double2int_rz(fy), cz = __double2int_rz(fz);
-#endif
   // out-of-range coordinates saturate in v_cvt_i32_f64 and fail the unsigned 21-bit range check
   const unsigned int ux = (unsigned int)(cx + KEY_OFFSET), uy = (unsigned int)(cy + KEY_OFFSET), uz = (unsigned int)(cz + KEY_OFFSET);
   bool keep = ok && (((ux | uy | uz) >> KEY_BITS) == 0u);
@@ -352,16 +288,10 @@ __device__ __forceinline__ Probe<PLANE> probe_point(const FactorDesc& d, const P
     o.qr1 = (float)(ey - ((double)cy + 0.5) * d.res);
     o.qr2 = (float)(ez - ((double)cz + 0.5) * d.res);
   } else {
-#if GLIM_AMD_K4_F32_TRANSFORM
-    o.qr0 = dx32 * P32.res;
-    o.qr1 = dy32 * P32.res;
-    o.qr2 = dz32 * P32.res;
-#else
     const float resf = (float)d.res;
     o.qr0 = ((float)(tx - fx) - 0.5f) * resf;
     o.qr1 = ((float)(ty - fy) - 0.5f) * resf;
     o.qr2 = ((float)(tz - fz) - 0.5f) * resf;
-#endif
   }
   if (PLANE) {
     // C_A = I - (1 - 1e-3) n n^T  =>  R C_A R^T = I - (1 - 1e-3) m m^T with m = R n
@@ -628,47 +558,34 @@ __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_
     if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
   }
   __syncthreads();
+  // a factor's partial rows are consecutive: row first_block + chunk (the finalisation reads them without an index table)
+  const size_t row = (size_t)(d.first_block + bm.y);
   if (threadIdx.x < PARTIAL_STRIDE) {
     const int j = threadIdx.x;
     float v = 0.f;
     const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
     if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
-    partials[(size_t)gblock * PARTIAL_STRIDE + j] = v;
-    if (INLINE && fa.row_flags) {
-      // host-finalised single-factor call: `partials` is host-mapped memory; this wavefront's row store is complete (release at system
-      // scope waits for the write acknowledgement) before the row's arrival word says so.  The host sums the rows as they arrive.
-      if (j == 0) __hip_atomic_store(fa.row_flags + gblock, fa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    partials[row * PARTIAL_STRIDE + j] = v;
   }
 }
 
-// Finalisation: one block of 32 * G threads per factor.
-template <int G>
-__global__ __launch_bounds__(32 * G) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
-                                                          int mode, const double* __restrict__ poses_lin, const InlineArgs ip) {
-  __shared__ double s_part[G][PARTIAL_STRIDE];
+// Finalisation: one 256-thread block per factor.
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
+                                                         int mode, const double* __restrict__ poses_lin, const InlineArgs ip) {
+  __shared__ double s_part[FIN_GROUPS][PARTIAL_STRIDE];
   __shared__ double s_sum[PARTIAL_STRIDE];
   const int f = blockIdx.x;
   const FactorDesc d = ip.valid ? ip.d : descs[f];
-  finalize_factor<G>(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
+  finalize_factor(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
 }
 
 __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
   const float4 p4 = d.pts[i];
-#if GLIM_AMD_K4_F32_TRANSFORM
-  // the same arithmetic as the fused kernels (locate_point), so what this entry reports is what they used
-  const Rot32 R32 = {(float)pose[0], (float)pose[1], (float)pose[2], (float)pose[4], (float)pose[5], (float)pose[6], (float)pose[8], (float)pose[9], (float)pose[10]};
-  const Pose32 P32 = make_pose32(pose, d.res, d.inv_res);
-  int cx, cy, cz;
-  float dx32, dy32, dz32, qx, qy, qz;
-  locate_point(pose, d.inv_res, P32, R32, p4.x, p4.y, p4.z, cx, cy, cz, dx32, dy32, dz32, qx, qy, qz);
-#else
   double qx, qy, qz;
   transform_point_d(pose, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
   const int cx = fast_floor_d(qx * d.inv_res), cy = fast_floor_d(qy * d.inv_res), cz = fast_floor_d(qz * d.inv_res);
-#endif
   bool hit = find_slot(d.buckets, d.num_buckets, pack_key(cx, cy, cz)) >= 0;
   if (hit && (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && d.normals) {
     const float4 nn = d.normals[i];
@@ -763,7 +680,7 @@ namespace glim_amd {
 namespace {
 
 constexpr size_t PLAN_CACHE_MAX = 16;    // idle plans kept per context
-constexpr int HOST_ROWS_MAX = 2048;      // most partial rows a host-finalised single-factor plan may have
+constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many factors: poses read by the kernels from host-mapped memory (96 B per factor over PCIe)
 
 void plan_free(FactorPlan* p) {
   if (!p) return;
@@ -778,7 +695,6 @@ void plan_free(FactorPlan* p) {
   if (p->h_poses) (void)pinned_free(p->h_poses);
   if (p->h_compact) (void)pinned_free(p->h_compact);
   if (p->h_flag) (void)pinned_free(p->h_flag);
-  if (p->h_rows) (void)pinned_free(p->h_rows);
   for (int i = 0; i < FactorPlan::POSE_RING; i++)
     if (p->pose_events[i]) (void)hipEventDestroy(p->pose_events[i]);
   delete p;
@@ -941,24 +857,19 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     }
     seg_rows[seg] = (int)(blockmap.size() - base);
   }
-  // rows[]: for each factor the plan rows that hold its partial sums, in chunk order
+  // a factor's partial rows are consecutive: row first_block + chunk, whatever block of the map computes the chunk
   long long total_blocks = 0;
   for (int f = 0; f < nf; f++) {
     plan->h_descs[f].first_block = (int)total_blocks;
     total_blocks += nblocks[f];
-  }
-  std::vector<int> rows((size_t)total_blocks);
-  for (size_t b = 0; b < blockmap.size(); b++) {
-    if (blockmap[b].x < 0) continue;
-    rows[(size_t)plan->h_descs[blockmap[b].x].first_block + blockmap[b].y] = (int)b;
   }
 
   plan->plane_rows = seg_rows[0];
   plan->total_rows = (int)blockmap.size();
   const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
   GA_HIP(pool_malloc(&plan->d_descs, nfa * sizeof(FactorDesc)));
-  GA_HIP(pool_malloc(&plan->d_blockmap, nba * sizeof(int2) + std::max<size_t>(1, rows.size()) * sizeof(int)));
-  GA_HIP(pool_malloc(&plan->d_partials, nba * PARTIAL_STRIDE * sizeof(float)));
+  GA_HIP(pool_malloc(&plan->d_blockmap, nba * sizeof(int2)));
+  GA_HIP(pool_malloc(&plan->d_partials, (size_t)std::max(1ll, total_blocks) * PARTIAL_STRIDE * sizeof(float)));
   GA_HIP(pool_malloc(&plan->d_poses, nfa * 24 * sizeof(double)));
   GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
   GA_HIP(pool_malloc(&plan->d_done, sizeof(int)));
@@ -974,29 +885,14 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     plan->h_flag = nullptr;
   }
   GA_HIP(pinned_malloc(&plan->h_poses, (size_t)FactorPlan::POSE_RING * nfa * 24 * sizeof(double)));
+  (void)host_device_view(plan->h_poses, &plan->h_poses_dev);
   GA_HIP(pinned_malloc(&plan->h_compact, nfa * COMPACT * sizeof(double)));
   (void)host_device_view(plan->h_compact, &plan->h_compact_dev);
-  if (nf == 1 && plan->total_rows <= HOST_ROWS_MAX) {
-    // single-factor plan: host-mapped partial rows + arrival words for the host-finalised synchronous call (run_sync)
-    const size_t bytes = (size_t)plan->total_rows * (PARTIAL_STRIDE * sizeof(float) + sizeof(unsigned int));
-    if (pinned_malloc(&plan->h_rows, bytes) == hipSuccess) {
-      memset(plan->h_rows, 0, bytes);
-      if (!host_device_view(plan->h_rows, &plan->h_rows_dev)) {
-        (void)pinned_free(plan->h_rows);
-        plan->h_rows = nullptr;
-      }
-    } else {
-      (void)hipGetLastError();
-      plan->h_rows = nullptr;
-    }
-  }
   plan->cap_factors = nfa;
   plan->cap_blocks = nba;
   if (nf > 0) {
     GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), (size_t)nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
     GA_HIP(hipMemcpyAsync(plan->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipMemcpyAsync(reinterpret_cast<char*>(plan->d_blockmap) + nba * sizeof(int2), rows.data(), rows.size() * sizeof(int),
-                          hipMemcpyHostToDevice, set->stream));
     GA_HIP(hipStreamSynchronize(set->stream));  // the staging vectors above die with this scope
   }
   plan->last_stream = set->stream;
@@ -1047,6 +943,7 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     set->plan = p;
   }
   set->inline_args.valid = 0;
+  set->poses_dev = set->plan->d_poses;
   if (set->entries.size() == 1) set->inline_args.d = set->plan->h_descs[0];
   set->dirty = false;
   set->seen_epoch = epoch;
@@ -1057,19 +954,13 @@ int factor_set_prepare(glim_amd_factor_set* set) {
 
 namespace {
 
-const int* rows_ptr(const FactorPlan* plan) {
-  return reinterpret_cast<const int*>(reinterpret_cast<const char*>(plan->d_blockmap) + plan->cap_blocks * sizeof(int2));
-}
-
 FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long long row_offset, bool poll) {
   const FactorPlan* plan = set->plan;
   FinalizeArgs fa;
-  fa.rows = rows_ptr(plan);
   fa.out = out;
   fa.out_row_offset = row_offset;
   fa.done_counter = plan->d_done;
   fa.host_flag = poll ? plan->h_flag_dev : nullptr;
-  fa.row_flags = nullptr;
   fa.seq = plan->poll_seq;
   fa.num_factors = (int)set->entries.size();
   return fa;
@@ -1078,8 +969,8 @@ FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long lon
 template <int MODE, bool FROZEN, bool INLINE>
 void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa, float* partials) {
   const FactorPlan* plan = set->plan;
-  const double* lin = plan->d_poses;
-  const double* ev = plan->d_poses + set->entries.size() * 12;
+  const double* lin = set->poses_dev;
+  const double* ev = set->poses_dev + set->entries.size() * 12;
   const int per_round = std::max(1, set->ctx->num_cus);
   if (plan->plane_rows > 0)
     vgicp_kernel<MODE, FROZEN, true, INLINE><<<plan->plane_rows, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, 0,
@@ -1104,11 +995,7 @@ void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const Finaliz
   set->plan->last_stream = set->stream;
 }
 
-// width of the device finalise (and of the host-side restatement of its summation order): 32 row groups when one factor is spread
-// over the whole chip, 8 for sets whose factors own a handful of rows each
-int finalize_groups(const FactorPlan* plan) { return plan->max_rows_per_factor > 128 ? 32 : 8; }
-
-// enqueue (no sync): poses already in d_poses / the inline arguments; writes compact records to `out` rows [row_offset, row_offset + n).
+// enqueue (no sync): poses already on the device / in the inline arguments; writes compact records to `out` rows [row_offset, row_offset + n).
 // Two or three launches: the fused kernel per plan segment + the FP64 finalise.
 int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll) {
   const int nf = (int)set->entries.size();
@@ -1116,10 +1003,7 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   FactorPlan* plan = set->plan;
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   launch_vgicp(set, mode, frozen, fa, plan->d_partials);
-  if (finalize_groups(plan) == 32)
-    finalize_kernel<32><<<nf, 1024, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, plan->d_poses, set->inline_args);
-  else
-    finalize_kernel<8><<<nf, 256, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, plan->d_poses, set->inline_args);
+  finalize_kernel<<<nf, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev, set->inline_args);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }
@@ -1145,6 +1029,12 @@ int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_
   double* h = plan->h_poses + (size_t)slot * plan->cap_factors * 24;
   memcpy(h, T_lin, nf * 12 * sizeof(double));
   if (T_eval) memcpy(h + nf * 12, T_eval, nf * 12 * sizeof(double));
+  if (!async_call && plan->h_poses_dev && nf <= HOST_POSES_MAX && set->ctx->diag.host_poses) {
+    // small synchronous set: the kernels read the poses straight from this pinned slot (the call returns only after they have run)
+    set->poses_dev = plan->h_poses_dev + (size_t)slot * plan->cap_factors * 24;
+    return GLIM_AMD_OK;
+  }
+  set->poses_dev = plan->d_poses;
   GA_HIP(hipMemcpyAsync(plan->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
   if (async_call) {
     if (!plan->pose_events[slot]) GA_HIP(hipEventCreateWithFlags(&plan->pose_events[slot], hipEventDisableTiming));
@@ -1175,61 +1065,18 @@ bool spin_until(const volatile unsigned int* word, unsigned int value) {
   }
 }
 
-// Host side of the host-finalised single-factor call: the fixed-order FP64 sum of finalize_factor<G> over the factor's partial rows, taken
-// as the rows ARRIVE in host-mapped memory (row c belongs to group c % G and the rows of a group are added in ascending order; the group
-// sums are then added in group order), followed by the shared rotate_part: the record has the bits the device finalise would produce.
-int host_finalize_rows(glim_amd_factor_set* set, int mode, unsigned int seq, double* o) {
-  const FactorPlan* plan = set->plan;
-  const int nb = plan->total_rows, G = finalize_groups(plan);
-  const float* rows = plan->h_rows;
-  const volatile unsigned int* flags = reinterpret_cast<const volatile unsigned int*>(plan->h_rows + (size_t)nb * PARTIAL_STRIDE);
-  double part[32][PARTIAL_STRIDE];
-  for (int g = 0; g < G; g++)
-    for (int j = 0; j < PARTIAL_STRIDE; j++) part[g][j] = 0.0;
-  for (int c = 0; c < nb; c++) {
-    if (flags[c] != seq && !spin_until(flags + c, seq)) {
-      // a block that has not reported after 200 ms: wait for the stream, then the row must be there
-      GA_HIP(hipStreamSynchronize(set->stream));
-      if (flags[c] != seq) return GLIM_AMD_ERR_STATE;
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const float* r = rows + (size_t)c * PARTIAL_STRIDE;
-    double* p = part[c % G];
-    for (int j = 0; j < PARTIAL_STRIDE; j++) p[j] += (double)r[j];
-  }
-  double sum[PARTIAL_STRIDE];
-  for (int j = 0; j < PARTIAL_STRIDE; j++) {
-    double t = 0.0;
-    for (int g = 0; g < G; g++) t += part[g][j];
-    sum[j] = t;
-  }
-  o[0] = sum[28];
-  o[1] = sum[27];
-  if (mode == MODE_LINEARIZE) {
-    static const int acc_of_upper[21] = {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20};  // == c_acc_of_upper
-    double rot[32];
-    for (int part_i = 0; part_i < 4; part_i++) rotate_part(part_i, sum, set->inline_args.m, rot);
-    for (int t = 0; t < 21; t++) o[2 + t] = rot[acc_of_upper[t]];
-    for (int t = 21; t < 24; t++) o[2 + t] = rot[t];
-    for (int t = 24; t < 27; t++) o[2 + t] = -rot[t];
-  } else {
-    for (int t = 2; t < COMPACT; t++) o[t] = 0.0;
-  }
-  return GLIM_AMD_OK;
-}
-
 // One synchronous evaluation (linearise or error) of the whole set: results in plan->h_compact when this returns.
-//  * single factor (the per-frame odometry call BASELINE configs[1] names): ONE launch.  Pose and descriptor ride in the kernel arguments,
-//    every block stores its partial row straight into host-mapped memory followed by the row's arrival word, and the host adds the rows up
-//    in the device finalise's order while the remaining blocks are still running -- no second dispatch, no atomics, no copies.
-//  * small sets: the finalise kernel writes the 232-byte records into host-mapped pinned memory and then publishes a sequence number
-//    there; the host spins on that word (sub-microsecond wake-up) instead of paying a stream-synchronise round trip.
+//  * small sets (<= 1024 factors, the per-frame odometry and sub-mapping cases): the records go straight into host-mapped pinned memory and
+//    the block that writes the last one publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of
+//    paying a stream-synchronise round trip.  A single factor takes its pose and descriptor through the kernel arguments: no upload at all.
+//    Other small sets leave their poses in host-mapped pinned memory and the kernels read them from there: no copy-engine transfer (and no
+//    wait for it) in front of the first kernel.
 //  * large sets: device records + one copy + stream synchronise.
 // The context mutex is held only while the work is enqueued, so factor sets of one context (different streams of its pool) overlap on
 // the device when driven from different host threads, like the reference's StreamTempBufferRoundRobin factors.
 int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval) {
   const size_t nf = set->entries.size();
-  bool poll = false, host_rows = false;
+  bool poll = false;
   unsigned int seq = 0;
   FactorPlan* plan = nullptr;
   {
@@ -1239,23 +1086,12 @@ int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const doub
     plan = set->plan;
     GA_TRY(upload_poses(set, T_lin, T_eval, false));
     const Diag& diag = set->ctx->diag;
-    host_rows = plan->h_rows && set->inline_args.valid && diag.host_finalize && diag.poll;
-    if (host_rows) {
-      seq = ++plan->poll_seq;
-      FinalizeArgs fa = finalize_args(set, nullptr, 0, false);
-      fa.row_flags = reinterpret_cast<unsigned int*>(plan->h_rows_dev + (size_t)plan->total_rows * PARTIAL_STRIDE);
-      fa.seq = seq;
-      launch_vgicp(set, mode, false, fa, plan->h_rows_dev);
-      GA_HIP(hipGetLastError());
-    } else {
-      const bool mapped = plan->h_compact_dev && nf <= 1024;
-      poll = mapped && plan->h_flag && diag.poll;
-      if (poll) seq = ++plan->poll_seq;
-      GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll));
-      if (!mapped) GA_HIP(hipMemcpyAsync(plan->h_compact, plan->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
-    }
+    const bool mapped = plan->h_compact_dev && nf <= 1024;
+    poll = mapped && plan->h_flag && diag.poll;
+    if (poll) seq = ++plan->poll_seq;
+    GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll));
+    if (!mapped) GA_HIP(hipMemcpyAsync(plan->h_compact, plan->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
   }
-  if (host_rows) return host_finalize_rows(set, mode, seq, plan->h_compact);
   if (!(poll && spin_until(plan->h_flag, seq))) GA_HIP(hipStreamSynchronize(set->stream));
   return GLIM_AMD_OK;
 }

@@ -81,7 +81,7 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
- * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_finalize=0|1, pool=0|1
+ * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, pool=0|1
  * (GLIM_AMD_DIAG only), multi_rccl=0|1, multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
  * nothing changes.  get_diag prints the current state in the same syntax. */
 int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
@@ -272,7 +272,7 @@ int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_tar
  * expanded on the host in the original factor order.  All calls are synchronous and must come from one host thread at a time. */
 typedef struct glim_amd_multi glim_amd_multi;
 /* devices: distinct HIP device ordinals.  A multi-device handle without a working RCCL is refused (GLIM_AMD_ERR_HIP) rather than
- * silently gathering over PCIe; a single device works either way (GLIM_AMD_MULTI_NO_RCCL=1 skips the collective there). */
+ * silently gathering over PCIe; a single device works either way (GLIM_AMD_DIAG="multi_rccl=0" skips the collective there). */
 int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out);
 int glim_amd_multi_destroy(glim_amd_multi* multi);
 int glim_amd_multi_info(const glim_amd_multi* multi, int32_t* num_devices, int32_t* uses_rccl, int64_t* num_factors);

@@ -425,5 +425,32 @@ inline double overlap_gpu(const std::vector<GaussianVoxelMapGPU::ConstPtr>& targ
 inline double overlap_auto(const GaussianVoxelMapGPU::ConstPtr& target, const PointCloudGPU::ConstPtr& source, const Isometry3d& delta) {
   return overlap_gpu(target, source, delta);
 }
+// Extension (no upstream counterpart): many overlap_gpu calls answered by ONE launch -- the keyframe elimination loop of
+// odometry_estimation_gpu.cpp:262-281 issues 43 of them back to back for 15 keyframes.  queries[q] = (targets, source, deltas).
+struct OverlapQuery {
+  std::vector<GaussianVoxelMapGPU::ConstPtr> targets;
+  PointCloudGPU::ConstPtr source;
+  std::vector<Isometry3d> deltas;
+};
+inline std::vector<double> overlap_gpu_batch(const std::vector<OverlapQuery>& queries) {
+  std::vector<double> out(queries.size(), 0.0);
+  if (queries.empty()) return out;
+  std::vector<int32_t> num_targets;
+  std::vector<const glim_amd_voxelmap*> maps;
+  std::vector<const glim_amd_cloud*> sources;
+  std::vector<double> T;
+  for (const auto& q : queries) {
+    if (q.targets.empty() || q.targets.size() != q.deltas.size() || !q.source) throw std::runtime_error("overlap_gpu_batch: targets/deltas mismatch");
+    num_targets.push_back((int32_t)q.targets.size());
+    sources.push_back(q.source->handle());
+    for (std::size_t i = 0; i < q.targets.size(); i++) {
+      maps.push_back(q.targets[i]->handle());
+      T.insert(T.end(), q.deltas[i].m.begin(), q.deltas[i].m.end());
+    }
+  }
+  check(glim_amd_overlap_batch(queries[0].source->context()->context(), (int32_t)queries.size(), num_targets.data(), maps.data(), T.data(), sources.data(), out.data()),
+        "overlap_gpu_batch");
+  return out;
+}
 
 }  // namespace glim_amd

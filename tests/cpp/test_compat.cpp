@@ -150,6 +150,9 @@ int main() {
       REQUIRE(overlap_gpu(maps[0], fb, far) == 0.0);
       REQUIRE(std::fabs(overlap_gpu({maps[0], maps[1]}, fb, {far, delta}) - overlap_gpu(maps[1], fb, delta)) < 1e-12);
       REQUIRE(std::fabs(factors[0]->inlier_fraction() - ov) < 1e-12);
+      // the batched form answers the same queries in one launch
+      const std::vector<double> batch = overlap_gpu_batch({{{maps[0]}, fb, {delta}}, {{maps[0]}, fb, {far}}, {{maps[0], maps[1]}, fb, {far, delta}}});
+      REQUIRE(batch.size() == 3 && batch[0] == ov && batch[1] == 0.0 && batch[2] == overlap_gpu(maps[1], fb, delta));
     }
     orc_voxelmap_destroy(om);
   }

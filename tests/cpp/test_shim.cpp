@@ -45,6 +45,18 @@ PointCloudCPU::Ptr PointCloudCPU::clone(const PointCloud& frame) {
   out->covs = out->covs_storage.empty() ? nullptr : out->covs_storage.data();
   return out;
 }
+// libgtsam_points' CPU overlap (declared by gaussian_voxelmap_gpu.hpp for overlap_auto's fallback): a recording stand-in
+static int g_cpu_overlap_calls = 0;
+double overlap(const GaussianVoxelMap::ConstPtr&, const PointCloud::ConstPtr&, const Eigen::Isometry3d&) {
+  g_cpu_overlap_calls++;
+  return 0.25;
+}
+// a voxel map that does not live on the device (GaussianVoxelMapCPU in a real build)
+struct HostOnlyMap : public GaussianVoxelMap {
+  double voxel_resolution() const override { return 1.0; }
+  void insert(const PointCloud&) override {}
+  void save_compact(const std::string&) const override {}
+};
 }  // namespace gtsam_points
 
 static gtsam_points::PointCloudCPU::Ptr make_frame(int n, double ox, double oy, double yaw, unsigned seed) {
@@ -162,7 +174,11 @@ int main() {
   const double ov_multi = gtsam_points::overlap_gpu(keyframes_, frame1, deltas, *stream);
   const double ov_single = gtsam_points::overlap_gpu(voxelmaps[1], frame1, delta, *stream);
   REQUIRE(ov_multi >= ov_single && ov_single > 0.5 && ov_multi <= 1.0);
-  REQUIRE(gtsam_points::overlap_auto(voxelmaps[1], frame1, delta) == ov_single);
+  REQUIRE(gtsam_points::overlap_auto(voxelmaps[1], frame1, delta) == ov_single && gtsam_points::g_cpu_overlap_calls == 0);
+  // a map that is NOT on the device (enable_gpu = false: global_mapping.cpp:275 builds GaussianVoxelMapCPU): overlap_auto falls back to the
+  // CPU overlap of libgtsam_points, as upstream's does (sub_mapping.cpp:253, global_mapping.cpp:322,448), instead of throwing
+  const gtsam_points::GaussianVoxelMap::ConstPtr host_map = std::make_shared<gtsam_points::HostOnlyMap>();
+  REQUIRE(gtsam_points::overlap_auto(host_map, frame1, delta) == 0.25 && gtsam_points::g_cpu_overlap_calls == 1);
   // src/glim/util/debug.cpp:84 and src/glim/viewer/memory_monitor.cpp:39: device names and memory figures through the same headers
   const std::vector<std::string> devices = gtsam_points::cuda_device_names();
   REQUIRE(!devices.empty() && !devices[0].empty());

@@ -231,31 +231,37 @@ def _full_size_pair(api, ctx, rings=64, azimuths=512):
     return tgt, src, tg, sg, synth.relative_pose(poses[0], poses[1])
 
 
-def test_host_finalised_single_factor_call_has_the_device_finalises_bits(api, ctx, orc):
-    """The synchronous single-factor call sums the partial rows on the host as they arrive (one launch); diag host_finalize=0 takes the
-    fused kernel + device finalise + completion word.  Same summation order, same rotation arithmetic: identical bits, linearise and
-    error, unary and binary, a chip-wide factor (32 row groups) and a small one (8 row groups)."""
-    for rings, azimuths in ((64, 512), (16, 128)):
+def test_synchronous_call_variants_give_identical_bits(api, ctx, orc):
+    """The fast paths of the synchronous call -- pose + descriptor in the kernel arguments (single factor), poses read from host-mapped memory
+    (small sets), completion word instead of a stream synchronise -- against the plain path with each of them switched off: identical bits,
+    linearise and error, unary and binary, a chip-wide single factor, a small single factor and a 34-factor set shaped like the odometry's,
+    repeated (a re-used plan, a re-used pose slot)."""
+    for rings, azimuths, copies in ((64, 512, 1), (16, 128, 1), (16, 256, 34)):
         tgt, src, tg, sg, delta = _full_size_pair(api, ctx, rings, azimuths)
-        vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+        vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
         for target in (0, np.eye(4)):
-            f = api.IntegratedVGICPFactorGPU(target, 1, vm, sg)
-            values = {0: np.eye(4), 1: delta @ orc.se3_exp([0.002, -0.001, 0.003, 0.02, 0.01, -0.02])}
+            factors = [api.IntegratedVGICPFactorGPU(target, 1 + k, vms[k % 2], sg) for k in range(copies)]
             res = {}
-            for mode in ("host_finalize=1", "host_finalize=0", "host_finalize=0,poll=0"):
+            for mode in ("", "poll=0", "host_poses=0", "inline_pose=0", "inline_pose=0,host_poses=0,poll=0"):
                 ctx.set_diag(mode)
                 fset = api.NonlinearFactorSetGPU(ctx)
-                fset.add(f)
-                res[mode] = (fset.linearize(values)[0], fset.error(values)[0])
-                res[mode + " again"] = (fset.linearize(values)[0], fset.error(values)[0])  # the arrival words of a re-used plan
+                for f in factors:
+                    fset.add(f)
+                for rep in range(5):
+                    values = {0: np.eye(4)}
+                    for k in range(copies):
+                        values[1 + k] = delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + 0.05 * rep))
+                    res[(mode, rep)] = (fset.linearize(values), fset.error(values))
             ctx.set_diag("")
-            base = res["host_finalize=0"]
-            assert base[0]["num_inliers"] > 100
-            for mode, (L, e) in res.items():
-                assert L["num_inliers"] == base[0]["num_inliers"], mode
-                for k in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
-                    np.testing.assert_array_equal(L[k], base[0][k], err_msg=f"{mode} {k}")
-                assert L["error"] == base[0]["error"] and e == base[1], mode
+            assert res[("", 0)][0][0]["num_inliers"] > 100
+            for (mode, rep), (Ls, es) in res.items():
+                base = res[("inline_pose=0,host_poses=0,poll=0", rep)]
+                for k, (L, B) in enumerate(zip(Ls, base[0])):
+                    assert L["num_inliers"] == B["num_inliers"], mode
+                    for key in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+                        np.testing.assert_array_equal(L[key], B[key], err_msg=f"{mode} rep {rep} factor {k} {key}")
+                    assert L["error"] == B["error"], mode
+                assert list(es) == list(base[1]), mode
 
 
 def test_plan_cache_serves_fresh_sets_and_follows_object_identity(api, ctx, orc, small_pair):
