@@ -99,6 +99,19 @@ int diag_print(const Diag& d, char* buf, size_t len) {
   return GLIM_AMD_OK;
 }
 
+hipError_t read_back_sync(::glim_amd_ctx* ctx, hipStream_t st, void* dst_host, const void* src_device, size_t bytes) {
+  constexpr size_t SCRATCH = 1024;
+  if (bytes > SCRATCH || (!ctx->pinned_scratch && pinned_malloc(&ctx->pinned_scratch, SCRATCH) != hipSuccess)) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, st);  // pageable fallback
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
+  hipError_t e = hipMemcpyAsync(ctx->pinned_scratch, src_device, bytes, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) memcpy(dst_host, ctx->pinned_scratch, bytes);
+  return e;
+}
+
 const Diag& process_diag() {
   static const Diag d = [] {
     Diag x;
@@ -201,6 +214,7 @@ int glim_amd_ctx_destroy(glim_amd_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto s : ctx->streams) (void)hipStreamSynchronize(s);
   ctx_release_factor_resources(ctx);
+  if (ctx->pinned_scratch) (void)pinned_free(ctx->pinned_scratch);
   if (ctx->owns_streams)
     for (auto s : ctx->streams) (void)hipStreamDestroy(s);
   if (--g_live_contexts == 0) pool_trim(ctx->device);  // last context gone: give the cached device memory back

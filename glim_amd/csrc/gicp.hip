@@ -475,8 +475,7 @@ int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspond
     GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
     gi_key_kernel<<<blocks, 256, 0, st>>>(n, target->pts, 1.0 / h, vkey.as<u64>(), bb.as<int>());
     GA_HIP(hipGetLastError());
-    GA_HIP(hipMemcpyAsync(h_bb, bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));
     if (pass == 1 || h_bb[0] > h_bb[3]) break;
     const double ex = (h_bb[3] - h_bb[0] + 1) * h, ey = (h_bb[4] - h_bb[1] + 1) * h, ez = (h_bb[5] - h_bb[2] + 1) * h;
     const double area = ex * ey + ey * ez + ex * ez;

@@ -84,6 +84,11 @@ const Diag& process_diag();                        // GLIM_AMD_DIAG, parsed once
 int diag_parse(Diag& d, const char* key_values);   // GLIM_AMD_OK or GLIM_AMD_ERR_INVALID (unknown key / bad value); d untouched on error
 int diag_print(const Diag& d, char* buf, size_t len);
 
+// Small device -> host read-back (counters, bounding boxes: <= 1 KiB) followed by a synchronise of `st`.  A device-to-host copy into pageable
+// memory (a stack variable) is staged by the runtime and blocks the caller for ~20 us; through the context's pinned scratch it is one DMA
+// packet.  Caller holds ctx->mu.
+hipError_t read_back_sync(::glim_amd_ctx* ctx, hipStream_t st, void* dst_host, const void* src_device, size_t bytes);
+
 // stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
 size_t radix_sort_scratch_bytes(int n);
 hipError_t radix_sort_pairs(hipStream_t st, int n, int bits, unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
@@ -201,6 +206,7 @@ struct glim_amd_ctx {
   unsigned int* ov_host = nullptr;            // pinned: [0] completion word, [1 + q] hits of query q
   unsigned int* ov_host_dev = nullptr;
   unsigned int ov_seq = 0;
+  void* pinned_scratch = nullptr;  // 1 KiB of pinned host memory for small read-backs (read_back_sync; guarded by mu)
   void quiesce() {
     if (async_pending.exchange(false))
       for (auto s : streams) (void)hipStreamSynchronize(s);

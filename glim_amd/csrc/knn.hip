@@ -263,14 +263,13 @@ struct GridBuffers {
   unsigned int T = 0;
 };
 
-int build_grid(hipStream_t st, int n, const float4* pts, double h, GridBuffers& g, int* h_stats) {
+int build_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, double h, GridBuffers& g, int* h_stats) {
   GA_HIP(hipMemsetAsync(g.keys.p, 0xff, (size_t)g.T * sizeof(unsigned long long), st));
   GA_HIP(hipMemsetAsync(g.counts.p, 0, (size_t)g.T * sizeof(int), st));
   GA_HIP(hipMemsetAsync(g.stats.p, 0, 4 * sizeof(int), st));
   grid_insert_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, 1.0 / h, (unsigned long long*)g.keys.p, g.T - 1, (int*)g.counts.p, (int*)g.slot_of.p,
                                                       (int*)g.stats.p);
-  GA_HIP(hipMemcpyAsync(h_stats, g.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_stats, g.stats.p, 4 * sizeof(int)));
   return GLIM_AMD_OK;
 }
 
@@ -291,8 +290,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, (int*)bb.p);
   int h_bb[6];
-  GA_HIP(hipMemcpyAsync(h_bb, bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));
   double ext[3];
   for (int a = 0; a < 3; a++) ext[a] = std::max(1e-6, (double)unordered(h_bb[3 + a]) - (double)unordered(h_bb[a]));
   const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
@@ -328,7 +326,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   int num_todo = 0;
   bool first = true;
   for (int level = 0; level < 16; level++) {
-    GA_TRY(build_grid(st, n, pts, h, g, h_stats));
+    GA_TRY(build_grid(ctx, st, n, pts, h, g, h_stats));
     if (h_stats[1] != 0) {  // a coordinate fell outside the key range at this cell size: coarsen
       if (h > 1e9) return GLIM_AMD_ERR_RANGE;
       h *= 4.0;
@@ -340,8 +338,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
     DISPATCH_K(launch_grid, st, n, (const float4*)g.sorted.p, h, (const unsigned long long*)g.keys.p, g.T - 1, (const int*)g.starts.p,
                (const int*)g.counts.p, k, out, next, (int*)g.stats.p, pts, first ? (const int*)nullptr : todo, num_todo, last ? MAX_RING : level_ring);
     GA_HIP(hipGetLastError());
-    GA_HIP(hipMemcpyAsync(h_stats, g.stats.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(read_back_sync(ctx, st, h_stats, g.stats.p, 4 * sizeof(int)));
     first = false;
     num_todo = h_stats[2];
     if (num_todo == 0) return GLIM_AMD_OK;
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(256) void half_box_kernel(int n, int C, const float
 }
 
 int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out, unsigned int* rank) {
-  DeviceTemp bb, ka, kb, va, vb, hist, sorted, box, stats;
+  DeviceTemp bb, ka, kb, va, vb, hist, sorted, box, stats, box32;  // (all returned to the pool after the synchronise at the end)
   const int C = (n + CHUNK - 1) / CHUNK;
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   GA_HIP(pool_malloc(&ka.p, (size_t)n * sizeof(unsigned long long)));
@@ -496,8 +493,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, bb.as<int>());
   int h_bb[6];
-  GA_HIP(hipMemcpyAsync(h_bb, bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));
   float lo[3], ext = 0.f;
   for (int a = 0; a < 3; a++) {
     lo[a] = unordered(h_bb[a]);
@@ -532,12 +528,10 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   if (k > 0 && !(ext < 1e18f)) {
     DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
   } else if (k > 0 && pair_lanes) {
-    DeviceTemp box32;
     GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
     half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
     knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select);
     GA_HIP(hipGetLastError());
-    GA_HIP(hipStreamSynchronize(st));  // box32 goes back to the pool at the end of this scope
   } else if (k > 0) {
     knn_launch_chunks(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), select);  // k == 0: ordering only
   }
@@ -551,8 +545,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
     }
   }
   int h_stats[4];
-  GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats)));
   return h_stats[1] != 0 ? GLIM_AMD_ERR_RANGE : GLIM_AMD_OK;
 }
 

@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict
 // tests/test_knn_model.py); 131 072-pt scan 0.46 -> 0.36 ms, 307 104-pt depth frame 0.72 -> 0.60 ms with the group boxes and the packed
 // mask pass (profiles/r02/probe/knn_select_groupbox_ab.txt, BENCH_r02 `staged`).
 //
+// The launch lasts as long as its slowest wavefront (a sparse chunk next to a dense patch streams 2-3 x the average number of candidate
+// chunks).  Measured in round 3 and NOT adopted: handing the chunks whose grown box meets the most chunk boxes to the pair-lane kernel (two
+// wavefronts of half the queries each) -- exact at every threshold, but 0.54-0.64 ms against 0.34 ms for a 131 072-pt scan: the split
+// machinery alone costs 0.05 ms and a pair-lane wavefront of a heavy chunk is not much shorter than the 64-query one, the lock-step steps
+// last as long as their slowest lane either way (profiles/r03/probe/knn_heavy_split_*.txt); 10 instead of 13 Hilbert bits per axis (one sort
+// pass less, worse chunks: 0.41 ms).
 // Measured against this kernel and NOT adopted (profiles/r02/probe/knn_chunk_variants_ab.txt; all bit-identical): candidates read with
 // v_readlane instead of LDS (-1 %); branch-free insertion (K compares + selects, or min / max on the distances) instead of the early-exit
 // bubble, one or two candidates per round (+17 ... +28 %); loads issued one step ahead of their use (+4 %); an all-FP64 mask pass (+8 %).

@@ -477,7 +477,7 @@ struct SortBuffers {
 
 // Stage A (downsampling) on the raw device arrays.  Random grid: fills `sel` (n ints, 1 = survives) and leaves P/T/I = the raw
 // arrays; voxel grid: writes the averaged arrays (avgP/avgT/avgI, *m entries).
-int downsample_random(hipStream_t st, int n, const double4* p4, const u64* ckey, int vbits, double rate, u64 seed, SortBuffers& sb, int* counters,
+int downsample_random(glim_amd_ctx* ctx, hipStream_t st, int n, const double4* p4, const u64* ckey, int vbits, double rate, u64 seed, SortBuffers& sb, int* counters,
                       int* h_counters, int* sel) {
   u64* ks = nullptr;
   u32* vs = nullptr;
@@ -496,8 +496,7 @@ int downsample_random(hipStream_t st, int n, const double4* p4, const u64* ckey,
   pp_count_voxels_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, ks, invalid, counters);
   pp_select_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, rate, ks, vs, invalid, counters, sel);
   GA_HIP(hipGetLastError());
-  GA_HIP(hipMemcpyAsync(h_counters, counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_counters, counters, 4 * sizeof(int)));
   const long long max_num_points = (long long)((double)n * rate * 1.2);
   if ((long long)h_counters[2] > max_num_points) {
     pp_cap_key_kernel<<<grid_for(n), 256, 0, st>>>(n, seed, sel, sb.ka.as<u64>());
@@ -508,7 +507,7 @@ int downsample_random(hipStream_t st, int n, const double4* p4, const u64* ckey,
   return GLIM_AMD_OK;
 }
 
-int downsample_voxelgrid(hipStream_t st, int n, const double4* p4, const double* times, const double* inten, const u64* ckey, int vbits, int block_size,
+int downsample_voxelgrid(glim_amd_ctx* ctx, hipStream_t st, int n, const double4* p4, const double* times, const double* inten, const u64* ckey, int vbits, int block_size,
                          SortBuffers& sb, int* counters, int* h_counters, DeviceTemp& avgP, DeviceTemp& avgT, DeviceTemp& avgI, int* m_out) {
   u64* ks = nullptr;
   u32* vs = nullptr;
@@ -521,8 +520,7 @@ int downsample_voxelgrid(hipStream_t st, int n, const double4* p4, const double*
   GA_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int), st));
   pp_head_flag_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, ks, 1ull << vbits, block_size, heads.as<int>(), counters + 1);
   GA_HIP(exclusive_scan_int(st, heads.as<int>(), (unsigned int)n + 1, tiles.as<int>(), seg.as<int>()));
-  GA_HIP(hipMemcpyAsync(h_counters, seg.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_counters, seg.as<int>() + n, sizeof(int)));
   const int m = h_counters[0];
   *m_out = m;
   const size_t mm = (size_t)(m > 0 ? m : 1);
@@ -619,8 +617,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
         pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
         GA_HIP(hipGetLastError());
-        GA_HIP(hipMemcpyAsync(h_bb, d_bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
-        GA_HIP(hipStreamSynchronize(st));
+        GA_HIP(read_back_sync(ctx, st, h_bb, d_bb.p, sizeof(h_bb)));
         int bx = 0, by = 0, bz = 0;
         if (h_bb[0] <= h_bb[3]) {
           bx = bits_for(h_bb[3] - h_bb[0]);
@@ -634,10 +631,10 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         GA_HIP(hipGetLastError());
         if (random) {
           GA_HIP(pool_malloc(&d_sel.p, (size_t)n * sizeof(int)));
-          GA_TRY(downsample_random(st, n, P, d_ckey.as<u64>(), vbits, rate, prm->seed, sb, d_counters.as<int>(), h_counters, d_sel.as<int>()));
+          GA_TRY(downsample_random(ctx, st, n, P, d_ckey.as<u64>(), vbits, rate, prm->seed, sb, d_counters.as<int>(), h_counters, d_sel.as<int>()));
           sel = d_sel.as<int>();
         } else {
-          GA_TRY(downsample_voxelgrid(st, n, P, T, I, d_ckey.as<u64>(), vbits, prm->voxelgrid_block_size, sb, d_counters.as<int>(), h_counters, avgP,
+          GA_TRY(downsample_voxelgrid(ctx, st, n, P, T, I, d_ckey.as<u64>(), vbits, prm->voxelgrid_block_size, sb, d_counters.as<int>(), h_counters, avgP,
                                       avgT, avgI, &m));
           P = avgP.as<double4>();
           T = avgT.as<double>();
@@ -667,8 +664,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         GA_HIP(exclusive_scan_int(st, flags.as<int>(), (unsigned int)m + 1, tiles.as<int>(), pos.as<int>()));
         pp_compact_time_kernel<<<grid_for(m), 256, 0, st>>>(m, flags.as<int>(), pos.as<int>(), T, sb.ka.as<u64>(), sb.va.as<u32>());
         GA_HIP(hipGetLastError());
-        GA_HIP(hipMemcpyAsync(h_counters, pos.as<int>() + m, sizeof(int), hipMemcpyDeviceToHost, st));
-        GA_HIP(hipStreamSynchronize(st));
+        GA_HIP(read_back_sync(ctx, st, h_counters, pos.as<int>() + m, sizeof(int)));
         f = h_counters[0];
         u64* ks = nullptr;
         GA_HIP(radix_sort_pairs(st, f, 64, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), false, sb.hist.as<int>(), &ks, &order));
@@ -707,8 +703,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
     pp_compact_index_kernel<<<grid_for(f), 256, 0, st>>>(f, flags.as<int>(), pos.as<int>(), idx.as<u32>());
     GA_HIP(hipGetLastError());
     int kept = 0;
-    GA_HIP(hipMemcpyAsync(&kept, pos.as<int>() + f, sizeof(int), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(read_back_sync(ctx, st, &kept, pos.as<int>() + f, sizeof(int)));
     CloudGuard filtered;
     GA_TRY(alloc_frame_cloud(ctx, kept, has_int, &filtered.c));
     if (kept > 0) {
@@ -788,8 +783,7 @@ int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* p
     GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
     pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, P.as<double4>(), 1.0 / resolution, d_vkey.as<u64>(), d_bb.as<int>());
     GA_HIP(hipGetLastError());
-    GA_HIP(hipMemcpyAsync(h_bb, d_bb.p, sizeof(h_bb), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(read_back_sync(ctx, st, h_bb, d_bb.p, sizeof(h_bb)));
     int bx = 0, by = 0, bz = 0;
     if (h_bb[0] <= h_bb[3]) {
       bx = bits_for(h_bb[3] - h_bb[0]);
@@ -809,8 +803,7 @@ int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* p
     GA_HIP(hipMemsetAsync(d_nvalid.p, 0, sizeof(int), st));
     pp_head_flag_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, ks, 1ull << vbits, block_size, heads.as<int>(), d_nvalid.as<int>());
     GA_HIP(exclusive_scan_int(st, heads.as<int>(), (unsigned int)n + 1, tiles.as<int>(), seg.as<int>()));
-    GA_HIP(hipMemcpyAsync(&m, seg.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    GA_HIP(hipStreamSynchronize(st));
+    GA_HIP(read_back_sync(ctx, st, &m, seg.as<int>() + n, sizeof(int)));
     GA_HIP(pool_malloc(&avgP.p, (size_t)std::max(m, 1) * sizeof(double4)));
     GA_HIP(pool_malloc(&avgC.p, (size_t)std::max(m, 1) * 6 * sizeof(double)));
     if (m > 0) {

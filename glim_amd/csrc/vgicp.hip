@@ -754,12 +754,17 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   glim_amd_ctx* ctx = set->ctx;
   const Diag& diag = ctx->diag;
   const bool allow_plane = diag.plane != 0;
-  // Grid sizing: the plane-form and the general factors are separate launches (segments); each aims for ONE resident set of blocks
-  // (num_cus x waves per SIMD of that kernel variant) with equal work each, so every lane reduces its 28 accumulators exactly once; each
-  // factor gets blocks in proportion to its points.  (Finer grids were measured level: 1280 blocks 142.7 us, 2560 142.6, 5120 138.6,
-  // 10240 142.9 per 128 factors.)
+  // Grid sizing: the plane-form and the general factors are separate launches (segments); each aims for a WHOLE NUMBER of resident sets of
+  // blocks (num_cus x waves per SIMD of that kernel variant) with equal work each, and for at most PPT_MAX points per thread; each factor
+  // gets blocks in proportion to its points.  One resident set where that keeps a thread below 2 PPT_MAX points (every lane then reduces its
+  // 28 accumulators exactly once: two rounds of 26-point threads cost the 128-factor launch 3 % against one round of 51-point threads);
+  // otherwise shorter blocks in k >= 3 full rounds: a block that walks a whole 62 k-pt submap (243 points per
+  // thread) made the 256-submap cost 12.2 ms against 10.9 ms at 32 points per thread, and the 380-factor sub-mapping bundle 0.24 against
+  // 0.21 ms, while a grid that is NOT a multiple of the resident set (2048 or 4096 blocks for 1280 slots) costs the 128-factor launch 13 %
+  // in a half-empty last round (profiles/r03/probe/ppt_sweep.txt).
+  constexpr long long PPT_MAX = 32;
   long long seg_points[2] = {0, 0};
-  const long long seg_target[2] = {(long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_PLANE, (long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_GENERAL};
+  long long seg_target[2] = {(long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_PLANE, (long long)std::max(1, ctx->num_cus) * GLIM_AMD_MINW_GENERAL};
   const int forced_ppt = diag.ppt;
 
   plan->built_plane = diag.plane;
@@ -800,6 +805,10 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     d.res = e.target->resolution;
     d.flags = e.flags;
     seg_points[d.plane ? 0 : 1] += d.n;
+  }
+  for (int seg = 0; seg < 2; seg++) {
+    const long long resident = seg_target[seg], fine = (seg_points[seg] + BLOCK * PPT_MAX - 1) / (BLOCK * PPT_MAX);
+    if (fine > 2 * resident) seg_target[seg] = ((fine + resident - 1) / resident) * resident;  // (up to two rounds' worth of points: one round of longer blocks)
   }
   for (int f = 0; f < nf; f++) {
     FactorDesc& d = plan->h_descs[f];

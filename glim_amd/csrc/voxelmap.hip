@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void insert_keys_kernel(int n, const float4* _
   }
 }
 
+// Small clouds (the odometry's 10 000-point frames): the keys go straight into the FINAL table, sized from the number of points instead of the
+// number of voxels (2 buckets per point hold 4 keys per point, and a cloud has at most one voxel per point), so the build needs no count
+// of the distinct keys before it can allocate: one host synchronise per map instead of two, four kernels instead of six.
+// stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
+__global__ __launch_bounds__(256) void insert_keys_direct_kernel(int n, const float4* __restrict__ pts, double inv_res, VoxelBucket* __restrict__ buckets,
+                                                                 unsigned int num_buckets, unsigned long long* __restrict__ pkeys, int* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long key = EMPTY_KEY;
+  if (i < n) {
+    const float4 p = pts[i];
+    key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
+    pkeys[i] = key;
+    if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
+  }
+  unsigned long long group;
+  if (!wave_group_by_key(key, key != EMPTY_KEY, group)) return;  // one CAS chain per distinct key of the wavefront
+  unsigned int b = bucket_of(key, num_buckets);
+  for (;;) {
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
+      if (prev == EMPTY_KEY) {
+        atomicAdd(&stats[0], 1);
+        return;
+      }
+      if (prev == key) return;
+    }
+    b = (b + 1 == num_buckets) ? 0u : b + 1;
+  }
+}
+
 // Re-insert the distinct keys into the final bucket table: way 0, then way 1, then the next bucket.
 __global__ __launch_bounds__(256) void move_keys_kernel(const unsigned long long* __restrict__ tkeys, unsigned int tsize,
                                                         VoxelBucket* __restrict__ buckets, unsigned int num_buckets) {
@@ -231,6 +262,42 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   const int n = (int)cloud->n;
 
   DeviceTemp tkeys, pkeys, stats, acc;
+  constexpr int DIRECT_MAX_POINTS = 32768;
+  if (n > 0 && n <= DIRECT_MAX_POINTS && ctx->diag.bucket_factor == 0) {
+    // small cloud: table sized from the points, keys inserted directly, ONE synchronise (insert_keys_direct_kernel)
+    const unsigned int nb = (unsigned int)std::max(16, 2 * n);  // 4 ways per point: the load factor stays below 1/2 whatever the cloud
+    VoxelBucket* buckets = nullptr;
+    GA_HIP(pool_malloc(&pkeys.p, (size_t)n * sizeof(unsigned long long)));
+    GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
+    GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
+    GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
+    hipError_t e = hipMemsetAsync(stats.p, 0, 2 * sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long), st);
+    int h_stats[2] = {0, 0};
+    if (e == hipSuccess) {
+      init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
+      insert_keys_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, m->inv_resolution, buckets, nb, (unsigned long long*)pkeys.p, (int*)stats.p);
+      accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets, nb, (long long*)acc.p);
+      finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats));
+    if (e != hipSuccess) {
+      set_hip_error(e, "voxelmap_insert");
+      (void)pool_free(buckets);
+      return GLIM_AMD_ERR_HIP;
+    }
+    if (h_stats[1] != 0) {
+      (void)pool_free(buckets);
+      return GLIM_AMD_ERR_RANGE;
+    }
+    m->buckets = buckets;
+    m->num_buckets = nb;
+    m->num_voxels = h_stats[0];
+    m->uid = next_uid();
+    ctx->mutation_epoch++;
+    return GLIM_AMD_OK;
+  }
   const unsigned int tsize0 = next_pow2((unsigned long long)(n > 32 ? n : 32) * 2);
   GA_HIP(pool_malloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
   GA_HIP(pool_malloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
@@ -244,8 +311,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     GA_HIP(hipGetLastError());
   }
   int h_stats[2] = {0, 0};
-  GA_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
-  GA_HIP(hipStreamSynchronize(st));
+  GA_HIP(read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats)));
   if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
 
   const int num_voxels = h_stats[0];

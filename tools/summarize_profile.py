@@ -7,6 +7,9 @@ usage: python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01 [facto
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_id  # noqa: E402  (identity of the factor kernel these counters were measured on; bench.py checks it)
+
 src, dst = sys.argv[1], sys.argv[2]
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 # optional 4th / 5th / 6th argument: workload tag (traffic file suffix + the tag bench.py looks up), stream bytes per point, points per launch
@@ -89,7 +92,7 @@ if dom:
             "workload": (f"odometry128k (bench.py default, F={F}), plane-form source clouds" if TAG == "odometry128k"
                          else f"{TAG} (bench.py --workload {TAG}, {F} factors per launch, {STREAM_BPP:.0f} B/pt stream)"),
             "kernel": dom["kernel"][dom["kernel"].find("vgicp_kernel"):].split("(")[0],
-            "kernel_avg_us_rocprof": dom["avg_us"],
+            "kernel_avg_us_rocprof": dom["avg_us"], "kernel_source_id": kernel_source_id(),
             "source": "rocprofv3 --pmc passes of tools/profile.sh (FETCH_SIZE; WRITE_SIZE; TCC_EA0_RDREQ_{32,64,128}B_sum), averages over the launches of the dominant kernel",
             "fetch_size_kb_raw": fetch_kb, "write_size_kb_raw": write_kb,
             "rdreq_32B": r32, "rdreq_64B": r64, "rdreq_128B": r128,
