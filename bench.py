@@ -781,7 +781,21 @@ def run_global256(args, D, api, ctx, extra_only=False):
     own = float(sum(36 * n + 64 * v for n, v in zip(n_pts, n_vox)))
     roof["frac_own_bytes"] = own / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     roof["note"] = ("the pairs of one rank share 256 clouds / maps (0.6 GB): most re-reads are served by the 256 MiB Infinity Cache and L2, so "
-                    "fractions above 1 are cache bandwidth, not HBM")
+                    "fractions above 1 are cache bandwidth, not HBM -- the bound of this workload is vector-ALU issue, `valu_issue_floor`")
+    # The bound that applies here: issue ticks of the general kernel's per-point instruction mix (tools/isa_stats.py: 171 FP32, 36 FP64,
+    # 51 integer, 15 compare / select vector instructions) at the measured issue costs of tools/ubench/valu_rate.hip (profiles/r02/probe/valu_rate.txt:
+    # 1.15 / 2.43 / 2.0 / 3.0 ticks per wave instruction; one tick = one full-rate FP32 instruction = 2 cycles), 1024 SIMDs at 2.4 GHz.  Trips of a
+    # wavefront without any correspondence skip ~60 % of their instructions; their share is not known per run, so the floor is given for none of
+    # them skipped and for the 16.6 % measured on this workload's pair sample (profiles/r02/probe/miss_model.txt).
+    ticks = 171 * 1.15 + 36 * 2.43 + 51 * 2.0 + 15 * 3.0
+    pts_per_s = 64.0 * 1024.0 / (ticks * 2.0 / 2.4e9)
+    visits = float(sum(n_pts))
+    roof["valu_issue_floor"] = {
+        "ticks_per_point_trip": ticks, "chip_points_per_s": pts_per_s, "point_visits": visits,
+        "floor_ms_no_trip_skipped": visits / pts_per_s * 1e3,
+        "floor_ms_16.6pct_trips_skip_60pct": visits * (1.0 - 0.166 * 0.6) / pts_per_s * 1e3,
+        "frac_of_floor": (visits * (1.0 - 0.166 * 0.6) / pts_per_s * 1e3) / roof["kernel_ms"],
+    }
     parity = sampled_pair_parity(api, fset, ev.owned(), pairs, deltas, clouds, host) if not args.no_cpu_baseline else None
     per_rank = None
     if D.collective:

@@ -1,7 +1,7 @@
 """tools/knn_model.py is the CPU model of the Hilbert-chunk kNN kernel that design decisions of glim_amd/csrc/knn_chunks.hip were priced with (it reproduces
 the kernel's per-wavefront work counters exactly, profiles/r02/probe/knn_model_results.txt).  Two things are pinned here, on the CPU:
-the model answers exactly like the oracle, and so does its step-by-step emulation of the per-lane threshold selection that knn_chunks.hip stages behind
--DGLIM_AMD_KNN_SELECT -- on the distributions the GPU tests use for the kernel itself (ties everywhere, duplicates, far offset, two scales, fewer
+the model answers exactly like the oracle, and so does its step-by-step emulation of the per-lane threshold selection of the chunk kernels
+(knn_chunks.hip / knn_pairs.hip, the shipped path for k <= 10) -- on the distributions the GPU tests use for the kernel itself (ties everywhere, duplicates, far offset, two scales, fewer
 points than a chunk)."""
 import os
 import sys

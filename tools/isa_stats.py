@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static look at a kernel's hot loop (no GPU needed): compiles a .hip file to gfx950 assembly and prints, for every kernel whose
 mangled name contains the given substring, the VGPR / SGPR counts and the instruction mix of its longest loop.
-  python tools/isa_stats.py glim_amd/csrc/vgicp.hip vgicp_kernelILi0ELb0ELb1ELb0E v_rcp_f32 [extra hipcc flags, e.g. -DGLIM_AMD_K4_F32_TRANSFORM=1]
+  python tools/isa_stats.py glim_amd/csrc/vgicp.hip vgicp_kernelILi0ELb0ELb1ELb0E v_rcp_f32 [extra hipcc flags]
 """
 import collections
 import re

@@ -1,5 +1,5 @@
 """CPU model of the Hilbert-chunk kNN kernel (glim_amd/csrc/knn_chunks.hip, knn_chunk_kernel): reproduces the per-wavefront work counters the
-kernel dumps with GLIM_AMD_KNN_DEBUG -- chunks scanned ("tiles") and lock-step insertion rounds -- for a given cloud, so that changes of
+kernel dumps with the diagnostic switch knn_debug=<file> (GLIM_AMD_DIAG) -- chunks scanned ("tiles") and lock-step insertion rounds -- for a given cloud, so that changes of
 the visiting order / seeding can be evaluated without a GPU (the counters explain 83 % of the wavefront times: tools/knn_debug.py).
 Not part of the product and not an oracle: a design tool.
 
@@ -162,7 +162,7 @@ def run(pts, order="index", seeds=K + 2, verbose=False, seed_mode="wrap", levels
                     done |= take
                 m = best_m
             if select_bits is not None and m.sum(axis=1).max() > select_bits[1]:
-                # the -DGLIM_AMD_KNN_SELECT code of knn_chunks.hip, step by step: bisection over FP32 bit patterns (select_bits[0] steps, 16 octaves below the
+                # the SELECT code of knn_chunks.hip, step by step: bisection over FP32 bit patterns (select_bits[0] steps, 16 octaves below the
                 # bound), counting list entries (FP64) and accepted candidates (FP32); candidates beyond keep = t * 1.000002f + 1e-37f are dropped
                 f32 = np.float32
                 run.selections[c] += 1
@@ -316,7 +316,7 @@ def main():
                ("index", {"levels": (1, 0.8, 0.6, 0.4, 0.2, 0.1, 0.03, 0.003), "level_scans": 1000}),
                ("index", {"bands": (1, 0.5, 0.25, 0.06), "level_scans": 1000}),                          # banded pops
                ("index", {"heavy": (16, 2.5)}),                                                          # cooperative merge of heavy lanes
-               ("index", {"select_bits": (8, 6)}),                                                      # the -DGLIM_AMD_KNN_SELECT code, emulated step by step
+               ("index", {"select_bits": (8, 6)}),                                                      # the SELECT code of knn_chunks.hip, emulated step by step
                ("index", {"select_bits": (8, 12)}),
                ("index", {"select_bits": (5, 6)}),
                ("index", {"select_slack": 0.04, "level_scans": 3}),                                      # bisection to 4 % in the first three scans only

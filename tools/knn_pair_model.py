@@ -1,6 +1,6 @@
 """CPU model of the pair-lane kNN kernel (glim_amd/csrc/knn_pairs.hip): 32 queries per wavefront, two lanes per query with separate top-k lists over
 disjoint candidates and a shared pruning bound, lists merged at the end.  Like tools/knn_model.py it follows the kernel step by step and counts the
-lock-step insertion rounds; it exists to check, without a GPU, that the staged per-lane threshold selection (GLIM_AMD_KNN_SELECT) leaves the merged
+lock-step insertion rounds; it exists to check, without a GPU, that the per-lane threshold selection of the chunk kernels leaves the merged
 lists exact in THIS kernel too (a lane selects over its own list only) and to price it.  A design tool, not an oracle.
 
   python tools/knn_pair_model.py        # 65 536-pt scan: rounds with / without the selection, lists compared with the exhaustive answer

@@ -1,21 +1,21 @@
 #!/bin/bash
-# Everything profiles/<tag>/ is built from, in one gpurun call (run from the repo root on the GPU box):   tools/round_evidence.sh r02_final
+# Everything profiles/<tag>/ is built from, in one gpurun call (run from the repo root on the GPU box):   tools/round_evidence.sh r03
 #  1. the -m gpu test-suite                      2. tools/profile.sh: rocprofv3 kernel trace + stats, then the separate PMC passes, of the default bench
 #  3. the default bench line (with cpu_baseline and m2_global256) and the other workloads; tools/batch_sweep.py
 #  4. PMC passes of the global256 workload (general kernel)
 # The raw rocprofv3 output is summarised HERE (tools/summarize_profile.py) and deleted: gpurun copies at most 64 MiB back.
-TAG=${1:-r02_final}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/evidence_$TAG
 mkdir -p $OUT
 cd $REPO
-(timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > $OUT/gputest.log
+(timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v '^$' | tail -15) > $OUT/gputest.log
 timeout 500 bash $REPO/tools/profile.sh $TAG > $OUT/profile.log 2>&1 < /dev/null
 cd $REPO
 python tools/summarize_profile.py gpurun_out/prof_$TAG $OUT 128 > $OUT/summarize.log 2>&1
 rm -rf gpurun_out/prof_$TAG
 timeout 250 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null
-for w in submap20 global256 rgbd300k frontend128k; do
+for w in odometry_frame submap20 global256 rgbd300k frontend128k; do
   timeout 300 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err < /dev/null
 done
 timeout 200 python tools/batch_sweep.py > $OUT/batch_sweep.json 2> $OUT/batch_sweep.err < /dev/null
@@ -24,6 +24,12 @@ if [ -z "$SKIP_GLOBAL256_PMC" ]; then
   cd $REPO
   mkdir -p $OUT/global256
   python tools/summarize_profile.py gpurun_out/prof_${TAG}_g $OUT/global256 32640 global256 36 2029810471 >> $OUT/summarize.log 2>&1
+  # the kernel trace of the whole-frame pipelines (kNN, covariance, voxel map, preprocessing kernels): per-kernel durations only
+  cd /tmp && export TMPDIR=/tmp
+  PYTHONPATH=$REPO timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG}_frame -- python $REPO/tools/knn_time.py > $OUT/knn_time.txt 2>&1
+  cd $REPO
+  cp $(find gpurun_out/prof_${TAG}_frame -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_frame_pipeline.csv 2>/dev/null
+  rm -rf gpurun_out/prof_${TAG}_frame
   rm -rf gpurun_out/prof_${TAG}_g
 fi
 du -sh $REPO/gpurun_out
