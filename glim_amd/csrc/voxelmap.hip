@@ -39,18 +39,30 @@ __global__ __launch_bounds__(256) void init_buckets_kernel(VoxelBucket* __restri
   reinterpret_cast<uint4*>(buckets)[i] = v;
 }
 
-// Runs of equal keys inside a wavefront.  Consecutive points of a scan (ring order, or the order a merge left them in) mostly fall into the
-// same voxel, so the lanes of a wavefront form a handful of RUNS of equal keys; a key that comes back later in the wavefront simply forms a
-// second run.  `head`: first lane of its run; returns the lane index of the run's first lane.  (The election of one leader per DISTINCT key
-// of round 2 cost a wave-uniform loop trip per key and, for the sums, one trip per member of the largest group; runs need neither:
-// accumulate 25.8 -> ? us, insert_keys 16.8 -> ? us for a 131 072-pt scan.)
-__device__ __forceinline__ int wave_run_start(unsigned long long key, bool& head) {
+// Wavefront-level grouping of equal keys: consecutive points of a scan usually fall into the same voxel, and 64 lanes hammering
+// one table word with atomics serialise in the L2.  Every distinct key of the wavefront elects ONE leader lane; `group` is the
+// ballot of the lanes sharing this lane's key.  The loop is wave-uniform (one trip per distinct key, ~10 on LiDAR scans).
+// (Round 3 measured the alternative -- RUNS of equal keys reduced with a six-step segmented scan, one set of atomics per run -- slower:
+// accumulate 27 -> 43 us at 131 072 points: a key that comes back later in the wavefront costs a second set of ten 64-bit atomics, and the
+// scan's 114 cross-lane moves are paid whatever the run lengths.)
+__device__ __forceinline__ bool wave_group_by_key(unsigned long long key, bool valid, unsigned long long& group) {
   const int lane = threadIdx.x & 63;
-  const unsigned int plo = __shfl_up((unsigned int)key, 1, 64), phi = __shfl_up((unsigned int)(key >> 32), 1, 64);
-  head = lane == 0 || (((unsigned long long)phi << 32) | plo) != key;
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-  return 63 - __builtin_clzll(below);  // lane 0 is always a head: `below` is never 0
+  unsigned long long remaining = __ballot(valid);
+  bool leader = false;
+  group = 0ull;
+  while (remaining) {
+    const int l = __ffsll((long long)remaining) - 1;
+    const unsigned int klo = __shfl((unsigned int)key, l, 64), khi = __shfl((unsigned int)(key >> 32), l, 64);
+    const unsigned long long kl = ((unsigned long long)khi << 32) | klo;
+    const bool mine = valid && key == kl;
+    const unsigned long long same = __ballot(mine);
+    if (mine) {
+      group = same;
+      leader = (lane == l);
+    }
+    remaining &= ~same;
+  }
+  return leader;
 }
 
 // stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
@@ -65,9 +77,8 @@ __global__ __launch_bounds__(256) void insert_keys_kernel(int n, const float4* _
     pkeys[i] = key;
     if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
   }
-  bool head;
-  (void)wave_run_start(key, head);
-  if (!head || key == EMPTY_KEY) return;  // one CAS chain per run of equal keys of the wavefront
+  unsigned long long group;
+  if (!wave_group_by_key(key, key != EMPTY_KEY, group)) return;  // one CAS chain per distinct key of the wavefront
   unsigned int s = hash_key(key) & tmask;
   for (;;) {
     const unsigned long long prev = atomicCAS(&tkeys[s], EMPTY_KEY, key);
@@ -94,9 +105,8 @@ __global__ __launch_bounds__(256) void insert_keys_direct_kernel(int n, const fl
     pkeys[i] = key;
     if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
   }
-  bool head;
-  (void)wave_run_start(key, head);
-  if (!head || key == EMPTY_KEY) return;  // one CAS chain per run of equal keys of the wavefront
+  unsigned long long group;
+  if (!wave_group_by_key(key, key != EMPTY_KEY, group)) return;  // one CAS chain per distinct key of the wavefront
   unsigned int b = bucket_of(key, num_buckets);
   for (;;) {
 #pragma unroll
@@ -127,13 +137,14 @@ __global__ __launch_bounds__(256) void move_keys_kernel(const unsigned long long
   }
 }
 
-__device__ __forceinline__ long long shfl_up_ll(long long v, int off) {
-  const unsigned int lo = __shfl_up((unsigned int)v, off, 64), hi = __shfl_up((unsigned int)((unsigned long long)v >> 32), off, 64);
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+  const unsigned int lo = __shfl((unsigned int)v, src, 64), hi = __shfl((unsigned int)((unsigned long long)v >> 32), src, 64);
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// Every point contributes 9 fixed-point sums + a count to its voxel.  Lanes of a run of equal keys are summed in registers first and only
-// the run's last lane touches memory: ~10 runs x 10 atomics per wavefront instead of 64 x 10.
+// Every point contributes 9 fixed-point sums + a count to its voxel.  Lanes of a wavefront that share a voxel are summed in
+// registers first (integer adds: order-free, so still bit-reproducible) and only the group leader touches memory: ~10 leaders x 10
+// atomics per wavefront instead of 64 x 10.
 __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
                                                          const float2* __restrict__ covB, const unsigned long long* __restrict__ pkeys,
                                                          const VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
@@ -156,32 +167,27 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
     v[7] = __double2ll_rn((double)b.x * COV_SCALE);
     v[8] = __double2ll_rn((double)b.y * COV_SCALE);
   }
-  // segmented inclusive scan over the runs of equal keys (six shuffle steps whatever the run lengths; integer adds: order-free, so the
-  // sums stay bit-reproducible), then the LAST lane of every run adds the run's sums to its voxel: one set of 10 atomics per run
-  bool head;
-  const int start = wave_run_start(key, head);
-  const int lane = threadIdx.x & 63;
-  int cnt = 1;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const bool take = lane - off >= start;
+  unsigned long long group;
+  const bool leader = wave_group_by_key(key, key != EMPTY_KEY, group);
+  // leaders gather their group's values member by member (every lane takes part in the shuffles; trips = largest group)
+  long long sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rest = leader ? group : 0ull;
+  while (__ballot(rest != 0ull)) {
+    const int src = rest ? (__ffsll((long long)rest) - 1) : 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      const long long t = shfl_up_ll(v[j], off);
-      if (take) v[j] += t;
+      const long long t = shfl_ll(v[j], src);
+      if (rest) sum[j] += t;
     }
-    const int c = __shfl_up(cnt, off, 64);
-    if (take) cnt += c;
+    rest &= rest - 1ull;
   }
-  const unsigned int nlo = __shfl_down((unsigned int)key, 1, 64), nhi = __shfl_down((unsigned int)(key >> 32), 1, 64);
-  const bool tail = lane == 63 || (((unsigned long long)nhi << 32) | nlo) != key;
-  if (!tail || key == EMPTY_KEY) return;
+  if (!leader) return;
   const int s = find_slot(buckets, num_buckets, key);
   if (s < 0) return;
   long long* dst = acc + (size_t)s * ACC_STRIDE;
 #pragma unroll
-  for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)v[j]);
-  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)cnt);
+  for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)sum[j]);
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
 }
 
 // one thread per (bucket, way)
