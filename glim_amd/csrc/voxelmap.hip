@@ -4,6 +4,7 @@
 // src/glim/mapping/global_mapping.cpp:265-266,747-748.  Statistic per voxel = mean of member means and mean of member
 // covariances, voxel identity = integer coordinate fast_floor(p * (1/resolution)).
 //
+// A second insert() into the same map adds to its voxels (the CPU voxel map's semantics; "incremental insert" below).
 // Build (all on the context stream):
 //   1. insert_keys   : every point CASes its packed 64-bit coordinate key into an over-sized scratch table (2N slots,
 //                      never full) and the distinct keys are counted                        -> V
@@ -190,6 +191,52 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
   atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
 }
 
+// ---- incremental insert (a second insert() into a map: GaussianVoxelMapCPU semantics, gtsam_points GaussianVoxel::add re-opens a finalised voxel
+// with mean *= n, cov *= n before accumulating -- SURVEY.md App. B.4; GLIM's GPU callers insert once per map, the CPU odometry inserts per frame,
+// odometry_estimation_cpu.cpp:66-67,189).  The map is rebuilt: the keys of the old voxels and of the new cloud go into one scratch table (counts
+// the voxels of the union), the old voxels are re-opened into the new table's fixed-point accumulators, then the new points accumulate as usual.
+// one thread per (old bucket, way): the key of every old voxel into the scratch table
+__global__ __launch_bounds__(256) void reinsert_old_keys_kernel(const VoxelBucket* __restrict__ old, unsigned int old_buckets, unsigned long long* __restrict__ tkeys,
+                                                                unsigned int tmask, int* __restrict__ stats) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * old_buckets) return;
+  const unsigned long long key = old[i >> 1].key[i & 1];
+  if (key == EMPTY_KEY) return;
+  unsigned int s = hash_key(key) & tmask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&tkeys[s], EMPTY_KEY, key);
+    if (prev == EMPTY_KEY) {
+      atomicAdd(&stats[0], 1);
+      return;
+    }
+    if (prev == key) return;
+    s = (s + 1) & tmask;
+  }
+}
+
+// one thread per (old bucket, way): count x (mean, covariance) of the old voxel, as fixed-point sums, into its slot of the new table
+__global__ __launch_bounds__(256) void reopen_old_voxels_kernel(const VoxelBucket* __restrict__ old, unsigned int old_buckets, double res,
+                                                                const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, long long* __restrict__ acc) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * old_buckets) return;
+  const unsigned long long key = old[i >> 1].key[i & 1];
+  if (key == EMPTY_KEY) return;
+  const float* r = old[i >> 1].rec[i & 1];
+  const long long cnt = (long long)__float_as_int(r[9]);
+  int cx, cy, cz;
+  unpack_key(key, cx, cy, cz);
+  const double c = (double)cnt;
+  const int s = find_slot(buckets, num_buckets, key);
+  if (s < 0) return;
+  long long* dst = acc + (size_t)s * ACC_STRIDE;
+  const double m[3] = {(double)r[0] + ((double)cx + 0.5) * res, (double)r[1] + ((double)cy + 0.5) * res, (double)r[2] + ((double)cz + 0.5) * res};
+#pragma unroll
+  for (int j = 0; j < 3; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)__double2ll_rn(m[j] * c * MEAN_SCALE));
+#pragma unroll
+  for (int j = 0; j < 6; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + 3 + j), (unsigned long long)__double2ll_rn((double)r[3 + j] * c * COV_SCALE));
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)cnt);
+}
+
 // one thread per (bucket, way)
 __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
                                                        const long long* __restrict__ acc, double res) {
@@ -256,7 +303,6 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) {
   if (!m || !cloud || cloud->ctx != m->ctx) return GLIM_AMD_ERR_INVALID;
   if (!cloud->has_covs) return GLIM_AMD_ERR_STATE;
-  if (m->buckets) return GLIM_AMD_ERR_UNSUPPORTED;  // GLIM's GPU path builds each map with a single insert()
   if (cloud->n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;
   glim_amd_ctx* ctx = m->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
@@ -266,7 +312,10 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
 
   DeviceTemp tkeys, pkeys, stats, acc;
   constexpr int DIRECT_MAX_POINTS = 32768;
-  if (n > 0 && n <= DIRECT_MAX_POINTS && ctx->diag.bucket_factor == 0) {
+  VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
+  const unsigned int old_buckets = old ? m->num_buckets : 0u;
+  if (old) ctx->quiesce();  // asynchronous factor launches may still be reading the table that is about to be replaced
+  if (!old && n > 0 && n <= DIRECT_MAX_POINTS && ctx->diag.bucket_factor == 0) {
     // small cloud: table sized from the points, keys inserted directly, ONE synchronise (insert_keys_direct_kernel)
     const unsigned int nb = (unsigned int)std::max(16, 2 * n);  // 4 ways per point: the load factor stays below 1/2 whatever the cloud
     VoxelBucket* buckets = nullptr;
@@ -301,7 +350,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     ctx->mutation_epoch++;
     return GLIM_AMD_OK;
   }
-  const unsigned int tsize0 = next_pow2((unsigned long long)(n > 32 ? n : 32) * 2);
+  const unsigned int tsize0 = next_pow2((unsigned long long)std::max<long long>(32, (long long)n + (old ? (long long)m->num_voxels : 0ll)) * 2);
   GA_HIP(pool_malloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
   GA_HIP(pool_malloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
   GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
@@ -313,9 +362,13 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
                                                          (unsigned long long*)pkeys.p, (int*)stats.p);
     GA_HIP(hipGetLastError());
   }
+  if (old) {
+    reinsert_old_keys_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, (unsigned long long*)tkeys.p, tsize0 - 1, (int*)stats.p);
+    GA_HIP(hipGetLastError());
+  }
   int h_stats[2] = {0, 0};
   GA_HIP(read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats)));
-  if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;
+  if (h_stats[1] != 0) return GLIM_AMD_ERR_RANGE;  // (the map is unchanged)
 
   const int num_voxels = h_stats[0];
   // buckets per voxel (default 6: x-adjacent voxel pairs share a bucket -- device_math.hpp GLIM_AMD_PAIR_SHIFT -- so about 0.1 pairs per
@@ -334,6 +387,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (e == hipSuccess) {
     init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
     move_keys_kernel<<<(tsize0 + 255) / 256, 256, 0, st>>>((const unsigned long long*)tkeys.p, tsize0, buckets, nb);
+    if (old) reopen_old_voxels_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, m->resolution, buckets, nb, (long long*)acc.p);
     if (n > 0)
       accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets,
                                                           nb, (long long*)acc.p);
@@ -346,10 +400,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     (void)pool_free(buckets);
     return GLIM_AMD_ERR_HIP;
   }
+  if (old) (void)pool_free(old);
   m->buckets = buckets;
   m->num_buckets = nb;
   m->num_voxels = num_voxels;
-  m->uid = next_uid();  // a plan built from the empty map (it could not have been: add() refuses maps without a table) never matches
+  m->uid = next_uid();  // plans built from the previous table are rebuilt (factor_set_prepare)
   ctx->mutation_epoch++;
   return GLIM_AMD_OK;
 }

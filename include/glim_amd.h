@@ -208,7 +208,9 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* cloud, int k_neighbors);
  * compatibility and ignored: this build is lossless (every point is inserted). */
 int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int init_num_buckets, int max_bucket_scan_count,
                              double target_points_drop_rate, glim_amd_voxelmap** out);
-/* one-shot build from a cloud that has covariances.  Voxel = mean of member means, mean of member covariances. */
+/* build from a cloud that has covariances.  Voxel = mean of member means, mean of member covariances.  A second insert into the same map
+ * adds its points to the voxels already there (GaussianVoxelMapCPU semantics: odometry_estimation_cpu.cpp:66-67,189); the map is rebuilt, so
+ * GLIM's GPU callers, which insert once per map, pay nothing for it. */
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* vmap, const glim_amd_cloud* cloud);
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* vmap);
 /* VoxelMapInfo (standard_viewer_mem.cpp:76-77): num_voxels, num_buckets, resolution, device bytes. */

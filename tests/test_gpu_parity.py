@@ -124,6 +124,47 @@ def test_voxelmap_matches_oracle(api, ctx, orc, small_pair, res):
     np.testing.assert_array_equal(C2[o2], gC[order_g])
 
 
+@pytest.mark.parametrize("res", [0.25, 1.0])
+def test_voxelmap_incremental_insert_matches_oracle(api, ctx, orc, small_pair, res):
+    """A second and third insert() into the same map add to the voxels already there (GaussianVoxelMapCPU semantics: a finalised voxel is re-opened
+    with mean *= n, cov *= n; odometry_estimation_cpu.cpp:66-67,189): coordinate sets and member counts equal the oracle's after every insert, the
+    statistics agree to FP32 storage accuracy, a factor against the grown map matches the oracle's, and a live factor set follows the new table."""
+    t, s = small_pair["target"], small_pair["source"]
+    shifted = s["points"] + np.array([0.3, -0.2, 0.1], dtype=np.float32)  # overlapping clouds: old voxels grow, new ones appear
+    parts = [(t["points"], t["covs"]), (shifted, s["covs"]), (t["points"][::3] + np.float32(7.0), t["covs"][::3])]
+    vm = api.GaussianVoxelMapGPU(res, ctx=ctx)
+    ref = orc.VoxelMap(res)
+    sg = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], ctx=ctx)
+    fset = None
+    for k, (p, c) in enumerate(parts):
+        vm.insert(api.PointCloudGPU.clone(p.astype(np.float64), c, ctx=ctx))
+        ref.insert(p, c)
+        assert vm.voxelmap_info()["num_voxels"] == ref.num_voxels()
+        gc, gn, gm, gC = vm.voxels()
+        rc, rn, rm, rC = ref.voxels()
+        og, orr = np.lexsort(gc.T[::-1]), np.lexsort(rc.T[::-1])
+        np.testing.assert_array_equal(gc[og], rc[orr])
+        np.testing.assert_array_equal(gn[og], rn[orr])
+        assert gn.sum() == sum(len(q[0]) for q in parts[: k + 1])
+        # the first insert is exact to FP32 storage; a re-opened voxel starts from its FP32 mean / covariance (what the map stores)
+        np.testing.assert_allclose(gm[og], rm[orr], rtol=1e-6, atol=2e-7 * (k + 1))
+        np.testing.assert_allclose(gC[og], rC[orr], rtol=1e-6, atol=2e-7 * (k + 1))
+        if fset is None:
+            fset = api.NonlinearFactorSetGPU(ctx)
+            fset.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg))
+        got = fset.linearize({1: small_pair["delta"]})[0]  # the SAME set object: its plan must follow the rebuilt table
+        want = orc.vgicp_linearize(ref, s["points"], s["covs"], small_pair["delta"])
+        assert got["num_inliers"] == want["num_inliers"]
+        assert np.abs(gn_step(got) - gn_step(want)).max() < POSE_TOL
+    # an empty cloud changes nothing
+    before = vm.voxels()
+    vm.insert(api.PointCloudGPU.clone(np.zeros((0, 3)), np.zeros((0, 3, 3)), ctx=ctx))
+    after = vm.voxels()
+    o0, o1 = np.lexsort(before[0].T[::-1]), np.lexsort(after[0].T[::-1])
+    np.testing.assert_array_equal(before[0][o0], after[0][o1])
+    np.testing.assert_array_equal(before[1][o0], after[1][o1])
+
+
 def test_voxelmap_negative_coordinates_and_range_error(api, ctx):
     pts = np.array([[-0.1, -0.1, -0.1], [-0.9, -0.2, -0.3], [0.1, 0.1, 0.1], [-1.0, 0.0, 0.0]], dtype=np.float64)
     covs = np.tile(np.eye(3), (4, 1, 1))
