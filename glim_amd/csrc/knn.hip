@@ -10,8 +10,8 @@
 //   * curve-ordered chunks (default, knn_curve): Hilbert sort, 64-point chunks with boxes, one wavefront per chunk streaming the
 //     candidate chunks through LDS (knn_chunks.hip, knn_pairs.hip); adapts to the local density by construction.  0.36 ms for a
 //     131 072-point LiDAR scan, 0.60 ms for a 307 104-point depth frame on MI355X.
-//   * hashed uniform grid (clouds below 24 576 points; diag knn_path=grid, knn_grid): counting sort into cells, ring walk per query with
-//     exactness bound and coarser retry levels: 0.85 / 1.11 ms at the two sizes above; also the cross-check of the chunk path.
+//   * hashed uniform grid (diag knn_path=grid, knn_grid): counting sort into cells, ring walk per query with exactness bound and coarser
+//     retry levels: 0.85 / 1.11 ms at the two sizes above, up to 5 ms on small clouds of uneven density; the cross-check of the chunk path.
 //   * exhaustive: LDS-tiled scan of every point (tiny clouds, and the grid path's last resort).
 #include <algorithm>
 #include <cmath>
@@ -592,9 +592,11 @@ int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_o
     DISPATCH_K(launch_brute, st, n, c->pts, k, c->neighbors, (const int*)nullptr, n);
     GA_HIP(hipGetLastError());
   } else {
-    // below ~24k points the chunk kernel's 47-odd blocks leave most of the chip idle and its sort passes are pure latency: the grid
-    // path is 0.09 ms faster on a 12 000-point preprocessed scan, level at 42k-58k points, 1.4-1.7x slower from 131k points up
-    const bool grid = diag.knn_path == KNN_PATH_GRID || (n < 24576 && diag.knn_path != KNN_PATH_CHUNKS);
+    // The Hilbert-chunk path answers every cloud above the exhaustive kernel's range.  The hashed grid (first implementation) is kept as an
+    // independent cross-check (diag knn_path=grid): on an evenly sampled 12 000-point scan it used to be 0.09 ms faster than the chunk path, but
+    // on clouds of uneven density its coarser retry levels explode -- a random 10 000 ... 32 768-point subset of a 131 072-pt scan takes it
+    // 0.5 ... 5.5 ms against 0.20 ... 0.48 ms for the chunks (tools/knn_small_time.py, profiles/r03/probe/knn_small_clouds.txt).
+    const bool grid = diag.knn_path == KNN_PATH_GRID;
     if (grid) GA_TRY(knn_grid(ctx, st, n, c->pts, k, c->neighbors));
     else {
       // the Hilbert rank of every point is kept: estimate_covariances writes the factor's plane-form stream in that order
