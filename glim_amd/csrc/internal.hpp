@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/glim_amd.h"
@@ -206,6 +207,7 @@ struct glim_amd_ctx {
   unsigned int* ov_host = nullptr;            // pinned: [0] completion word, [1 + q] hits of query q
   unsigned int* ov_host_dev = nullptr;
   unsigned int ov_seq = 0;
+  std::vector<std::pair<int, double>> voxel_ratio_hints;  // (resolution class, voxels per point of the last map built there): voxelmap.hip
   void* pinned_scratch = nullptr;  // 1 KiB of pinned host memory for small read-backs (read_back_sync; guarded by mu)
   void quiesce() {
     if (async_pending.exchange(false))

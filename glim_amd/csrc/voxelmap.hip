@@ -13,6 +13,7 @@
 //                      addition is associative, so the sums (and the map) are bit-reproducible whatever the atomic order
 //   4. finalise      : sums / count in FP64, stored as FP32 in the bucket (keys + statistics share one 128-byte line)
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -267,6 +268,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__
   r[11] = 0.f;
 }
 
+// voxels-per-point ratio of the last map built at a resolution class (sizes the direct build of the next one)
+void remember_voxel_ratio(glim_amd_ctx* ctx, int res_class, double ratio) {
+  for (auto& h : ctx->voxel_ratio_hints)
+    if (h.first == res_class) {
+      h.second = ratio;
+      return;
+    }
+  if (ctx->voxel_ratio_hints.size() >= 32) ctx->voxel_ratio_hints.erase(ctx->voxel_ratio_hints.begin());
+  ctx->voxel_ratio_hints.emplace_back(res_class, ratio);
+}
+
+// table sizes in 8 steps per octave: the maps of consecutive frames (whose voxel counts differ by a few per cent) get tables of the SAME
+// size, so that the memory pool hands the previous frame's blocks back instead of missing on a slightly larger request
+unsigned long long round_buckets(unsigned long long nb) {
+  if (nb <= 64) return nb;
+  unsigned long long step = 1;
+  while ((step << 4) <= nb) step <<= 1;  // step = 2^(floor(log2 nb) - 3)
+  return std::min<unsigned long long>(((nb + step - 1) / step) * step, 1ull << 25);
+}
+
 unsigned int next_pow2(unsigned long long v) {
   unsigned long long p = 1;
   while (p < v) p <<= 1;
@@ -315,9 +336,22 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
   if (old) ctx->quiesce();  // asynchronous factor launches may still be reading the table that is about to be replaced
-  if (!old && n > 0 && n <= DIRECT_MAX_POINTS && ctx->diag.bucket_factor == 0) {
-    // small cloud: table sized from the points, keys inserted directly, ONE synchronise (insert_keys_direct_kernel)
-    const unsigned int nb = (unsigned int)std::max(16, 2 * n);  // 4 ways per point: the load factor stays below 1/2 whatever the cloud
+  // Direct build (keys straight into the final table, ONE synchronise: insert_keys_direct_kernel) needs the table size before the voxels are
+  // counted.  Small clouds: 2 buckets per point (4 ways per point: load factor below 1/2 whatever the cloud).  Larger clouds: 6 buckets per
+  // EXPECTED voxel, from the voxels-per-point ratio of the last map this context built at (about) this resolution -- consecutive frames of a
+  // stream have the same density -- and never fewer than N / 2 buckets, which hold one key per point: the table cannot overflow whatever the
+  // estimate, a poor one only costs longer probe chains until the next map corrects it.  The first map at a resolution takes the counting path.
+  const int res_class = (int)lround(8.0 * log2(m->resolution));  // resolutions within ~9 % share a class
+  double expected_ratio = 0.0;
+  for (const auto& h : ctx->voxel_ratio_hints)
+    if (h.first == res_class) expected_ratio = h.second;
+  const bool direct_small = n > 0 && n <= DIRECT_MAX_POINTS;
+  const bool direct_large = n > DIRECT_MAX_POINTS && expected_ratio > 0.0;
+  if (!old && (direct_small || direct_large) && ctx->diag.bucket_factor == 0) {
+    const unsigned long long want = direct_small ? 2ull * (unsigned long long)n
+                                                 : std::max<unsigned long long>((unsigned long long)n / 2 + 1, (unsigned long long)(6.0 * expected_ratio * (double)n));
+    if (want > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
+    const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, want));
     VoxelBucket* buckets = nullptr;
     GA_HIP(pool_malloc(&pkeys.p, (size_t)n * sizeof(unsigned long long)));
     GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
@@ -348,6 +382,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     m->num_voxels = h_stats[0];
     m->uid = next_uid();
     ctx->mutation_epoch++;
+    remember_voxel_ratio(ctx, res_class, (double)h_stats[0] / (double)n);
     return GLIM_AMD_OK;
   }
   const unsigned int tsize0 = next_pow2((unsigned long long)std::max<long long>(32, (long long)n + (old ? (long long)m->num_voxels : 0ll)) * 2);
@@ -377,8 +412,9 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   // (16.7 M voxels) before the insert is refused -- a sparser table is a speed choice, never a correctness one.
   unsigned long long bucket_factor = ctx->diag.bucket_factor > 0 ? (unsigned long long)ctx->diag.bucket_factor : 6ull;
   while (bucket_factor > 2 && (unsigned long long)num_voxels * bucket_factor > (1ull << 25)) bucket_factor--;
-  const unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
+  unsigned long long nb64 = std::max<unsigned long long>(16, (unsigned long long)num_voxels * bucket_factor);
   if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
+  if (ctx->diag.bucket_factor == 0) nb64 = round_buckets(nb64);
   const unsigned int nb = (unsigned int)nb64;
   VoxelBucket* buckets = nullptr;
   GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
@@ -401,6 +437,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     return GLIM_AMD_ERR_HIP;
   }
   if (old) (void)pool_free(old);
+  else if (n > 0) remember_voxel_ratio(ctx, res_class, (double)num_voxels / (double)n);
   m->buckets = buckets;
   m->num_buckets = nb;
   m->num_voxels = num_voxels;
