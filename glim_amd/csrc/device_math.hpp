@@ -153,4 +153,10 @@ __device__ __forceinline__ int block_reduce_i(int v, int* s_tmp) {
   return v;
 }
 
+// Reset of a bounding-box accumulator (3 minima, 3 maxima as order-preserving ints) on the device: copying six ints from a stack array is a
+// staged, blocking host-to-device transfer (~10 us), a one-wave kernel is an ordinary asynchronous launch.
+static __global__ void init_bbox_kernel(int* __restrict__ bb) {
+  if (threadIdx.x < 6) bb[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (int)0x80000000;
+}
+
 }  // namespace glim_amd

@@ -464,7 +464,6 @@ int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspond
   GA_HIP(pool_malloc(&va.p, nn * sizeof(u32)));
   GA_HIP(pool_malloc(&vb.p, nn * sizeof(u32)));
   GA_HIP(pool_malloc(&hist.p, radix_sort_scratch_bytes(n)));
-  const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   const int blocks = std::max(1, std::min((n + 2047) / 2048, 128));
   int h_bb[6];
   // pass 1 with a provisional cell edge to learn the extent, then the edge that gives ~3 points per occupied cell of a surface-like
@@ -472,7 +471,7 @@ int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspond
   const double R = max_correspondence_distance_hint > 0.0 ? max_correspondence_distance_hint : 1.0;
   double h = R;
   for (int pass = 0; pass < 2; pass++) {
-    GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+    init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
     gi_key_kernel<<<blocks, 256, 0, st>>>(n, target->pts, 1.0 / h, vkey.as<u64>(), bb.as<int>());
     GA_HIP(hipGetLastError());
     GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));

@@ -337,6 +337,8 @@ struct FactorPlan {
   unsigned int poll_seq = 0;
   size_t cap_factors = 0, cap_blocks = 0;
   std::vector<glim_amd::FactorDesc> h_descs;
+  std::vector<int2> h_blockmap;
+  bool uploaded = false;              // d_descs / d_blockmap hold h_descs / h_blockmap (single-factor plans upload on first non-inline launch)
   hipStream_t last_stream = nullptr;  // stream of the last enqueue
   bool maybe_busy = false;            // an asynchronous enqueue may still be running on last_stream
 };

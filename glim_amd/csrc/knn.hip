@@ -286,8 +286,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   DeviceTemp bb, unresolved_a, unresolved_b;
   GridBuffers g;
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
-  const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-  GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+  init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, (int*)bb.p);
   int h_bb[6];
   GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));
@@ -488,8 +487,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(pool_malloc(&sorted.p, (size_t)C * CHUNK * sizeof(float4)));
   GA_HIP(pool_malloc(&box.p, ((size_t)C + (size_t)(C + CHUNK - 1) / CHUNK) * 6 * sizeof(float)));  // chunk boxes, then the boxes of the groups of 64 chunks
   GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
-  const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-  GA_HIP(hipMemcpyAsync(bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+  init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
   GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, bb.as<int>());
   int h_bb[6];

@@ -612,9 +612,8 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       DeviceTemp avgP, avgT, avgI;
       int m = n;
       if (!sample_all) {
-        const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
         int h_bb[6];
-        GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+        init_bbox_kernel<<<1, 64, 0, st>>>(d_bb.as<int>());
         pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
         GA_HIP(hipGetLastError());
         GA_HIP(read_back_sync(ctx, st, h_bb, d_bb.p, sizeof(h_bb)));
@@ -778,9 +777,8 @@ int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* p
     GA_HIP(pool_malloc(&d_vkey.p, (size_t)n * sizeof(u64)));
     GA_HIP(pool_malloc(&d_bb.p, 6 * sizeof(int)));
     GA_HIP(pool_malloc(&d_nvalid.p, sizeof(int)));
-    const int init_bb[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     int h_bb[6];
-    GA_HIP(hipMemcpyAsync(d_bb.p, init_bb, sizeof(init_bb), hipMemcpyHostToDevice, st));
+    init_bbox_kernel<<<1, 64, 0, st>>>(d_bb.as<int>());
     pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, P.as<double4>(), 1.0 / resolution, d_vkey.as<u64>(), d_bb.as<int>());
     GA_HIP(hipGetLastError());
     GA_HIP(read_back_sync(ctx, st, h_bb, d_bb.p, sizeof(h_bb)));

@@ -749,6 +749,17 @@ namespace {
 // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"); when a segment holds enough factors,
 // all chunks of one factor are given rows of one residue class so that the factor's voxel table stays in a single XCD's 4 MiB L2.
 // This is a speed-only choice: any placement is correct.
+int plan_upload(glim_amd_factor_set* set, FactorPlan* plan) {
+  if (plan->uploaded) return GLIM_AMD_OK;
+  const size_t nf = plan->h_descs.size();
+  if (nf > 0) {
+    GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
+    GA_HIP(hipMemcpyAsync(plan->d_blockmap, plan->h_blockmap.data(), plan->h_blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
+  }
+  plan->uploaded = true;
+  return GLIM_AMD_OK;
+}
+
 int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   const int nf = (int)set->entries.size();
   glim_amd_ctx* ctx = set->ctx;
@@ -899,11 +910,12 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   (void)host_device_view(plan->h_compact, &plan->h_compact_dev);
   plan->cap_factors = nfa;
   plan->cap_blocks = nba;
-  if (nf > 0) {
-    GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), (size_t)nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipMemcpyAsync(plan->d_blockmap, blockmap.data(), blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipStreamSynchronize(set->stream));  // the staging vectors above die with this scope
-  }
+  plan->h_blockmap = std::move(blockmap);
+  plan->uploaded = false;
+  // Descriptors and block map go to the device when a launch first needs them THERE (plan_upload): a single-factor set linearised
+  // synchronously takes both through the kernel arguments, so the per-frame "new cloud, new map, one factor" pattern of the odometry front
+  // end builds its plan without a single transfer.  The host copies live in the plan, so no synchronise is needed either way.
+  if (nf > 1) GA_TRY(plan_upload(set, plan));
   plan->last_stream = set->stream;
   plan->maybe_busy = false;
   return GLIM_AMD_OK;
@@ -1010,6 +1022,7 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
   FactorPlan* plan = set->plan;
+  if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));  // (the inline kernels read pose and descriptor from their arguments)
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   launch_vgicp(set, mode, frozen, fa, plan->d_partials);
   finalize_kernel<<<nf, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev, set->inline_args);
@@ -1356,6 +1369,7 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   GA_HIP(hipStreamSynchronize(set->stream));
   float ms = 0.f;
   GA_HIP(hipEventRecord(e0, set->stream));
+  if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));
   const FinalizeArgs fa_prof = finalize_args(set, plan->d_compact, 0, false);
   for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof, plan->d_partials);
   GA_HIP(hipEventRecord(e1, set->stream));
