@@ -76,6 +76,11 @@ __global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __
 // PointCloudGPU::clone(frame) therefore qualifies for the 24 B/pt factor kernel.)  Tolerance: C and n are each rounded to FP32
 // independently (<= 6e-8 per coefficient), n n^T then differs by <= 1.3e-7 per entry; 4e-7 leaves margin and is far below any covariance a
 // merged / averaged cloud would show (those differ from the form by 1e-3 or more).
+__device__ __forceinline__ bool off_plane_form(float c00, float c01, float c02, float c11, float c12, float c22, float nx, float ny, float nz) {
+  const float w = 0.999f, tol = 4e-7f;
+  return !(fabsf(c00 - (1.f - w * nx * nx)) <= tol && fabsf(c01 + w * nx * ny) <= tol && fabsf(c02 + w * nx * nz) <= tol &&
+           fabsf(c11 - (1.f - w * ny * ny)) <= tol && fabsf(c12 + w * ny * nz) <= tol && fabsf(c22 - (1.f - w * nz * nz)) <= tol);
+}
 __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4* __restrict__ covA, const float2* __restrict__ covB,
                                                          const float4* __restrict__ nrm, unsigned int* __restrict__ violations) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,11 +89,100 @@ __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4
     const float4 a = covA[i];
     const float2 b = covB[i];
     const float4 v = nrm[i];
-    const float w = 0.999f, tol = 4e-7f;
-    bad = !(fabsf(a.x - (1.f - w * v.x * v.x)) <= tol && fabsf(a.y + w * v.x * v.y) <= tol && fabsf(a.z + w * v.x * v.z) <= tol &&
-            fabsf(a.w - (1.f - w * v.y * v.y)) <= tol && fabsf(b.x + w * v.y * v.z) <= tol && fabsf(b.y - (1.f - w * v.z * v.z)) <= tol);
+    bad = off_plane_form(a.x, a.y, a.z, a.w, b.x, b.y, v.x, v.y, v.z);
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(violations, 1u);
+}
+
+// Small clouds (the odometry front end clones one 10 000-point frame per scan, odometry_estimation_gpu.cpp:96).  The general path -- three
+// pageable host-to-device copies of the reference layouts (192 B per point), the pack kernel, the plane-form kernel and their two
+// synchronisations -- costs 140 us there, most of it fixed.  Here the host converts straight into the FP32 device layout (56 B per point, the
+// same round-to-nearest casts as pack_f64_kernel) in a pinned, device-mapped staging block, and ONE kernel pulls the block over PCIe into the
+// cloud's arrays and evaluates the plane-form predicate on the way (violations land in a word of the same block): one launch, one
+// synchronise, 79 us.  Above HOST_PACK_MAX_POINTS the runtime's pageable copy path (43 GB/s measured at 25 MB) beats a single host thread.
+constexpr int64_t HOST_PACK_MAX_POINTS = 32768;
+__global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __restrict__ s_pts, const float4* __restrict__ s_covA,
+                                                      const float2* __restrict__ s_covB, const float4* __restrict__ s_nrm, float4* __restrict__ pts,
+                                                      float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm,
+                                                      unsigned int* __restrict__ host_violations) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    pts[i] = s_pts[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), v = a;
+    float2 b = make_float2(0.f, 0.f);
+    if (s_covA) {
+      covA[i] = a = s_covA[i];
+      covB[i] = b = s_covB[i];
+    }
+    if (s_nrm) nrm[i] = v = s_nrm[i];
+    bad = s_covA && s_nrm && off_plane_form(a.x, a.y, a.z, a.w, b.x, b.y, v.x, v.y, v.z);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_violations, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// host half: the reference layouts (Vector4d, column-major Matrix4d) -> the FP32 sections of the staging block
+void host_pack_f64(int64_t n, const double* points4, const double* covs16, const double* normals4, float* pts, float* covA, float* covB, float* nrm) {
+  for (int64_t i = 0; i < n; i++) {
+    const double* p = points4 + 4 * i;
+    pts[4 * i + 0] = (float)p[0];
+    pts[4 * i + 1] = (float)p[1];
+    pts[4 * i + 2] = (float)p[2];
+    pts[4 * i + 3] = 1.0f;
+  }
+  if (covs16)
+    for (int64_t i = 0; i < n; i++) {
+      const double* c = covs16 + 16 * i;  // column-major 4x4: (r,c) at c*4 + r
+      covA[4 * i + 0] = (float)c[0];
+      covA[4 * i + 1] = (float)c[4];
+      covA[4 * i + 2] = (float)c[8];
+      covA[4 * i + 3] = (float)c[5];
+      covB[2 * i + 0] = (float)c[9];
+      covB[2 * i + 1] = (float)c[10];
+    }
+  if (normals4)
+    for (int64_t i = 0; i < n; i++) {
+      const double* v = normals4 + 4 * i;
+      nrm[4 * i + 0] = (float)v[0];
+      nrm[4 * i + 1] = (float)v[1];
+      nrm[4 * i + 2] = (float)v[2];
+      nrm[4 * i + 3] = 0.0f;
+    }
+}
+
+// upload of a small cloud through the pinned staging block; GLIM_AMD_ERR_UNSUPPORTED: no device view of pinned memory here (caller takes the general path)
+int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4) {
+  const int64_t n = c->n;
+  float* stage = nullptr;
+  if (pinned_malloc(&stage, (size_t)n * 14 * sizeof(float) + 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return GLIM_AMD_ERR_UNSUPPORTED;
+  }
+  float* dev = nullptr;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), stage, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)pinned_free(stage);
+    return GLIM_AMD_ERR_UNSUPPORTED;
+  }
+  // sections: pts [0, 4n), covA [4n, 8n), nrm [8n, 12n), covB [12n, 14n) -- the float4 sections first, so that every section is 16-byte
+  // aligned -- then the violation word of the plane-form test
+  host_pack_f64(n, points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
+  volatile unsigned int* violations = reinterpret_cast<unsigned int*>(stage + 14 * n);
+  *violations = 0u;
+  hipStream_t s = ctx->stream();
+  unstage_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((int)n, reinterpret_cast<const float4*>(dev), covs16 ? reinterpret_cast<const float4*>(dev + 4 * n) : nullptr,
+                                                        reinterpret_cast<const float2*>(dev + 12 * n), normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr,
+                                                        c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  const bool plane = covs16 && normals4 && *violations == 0u;
+  (void)pinned_free(stage);
+  if (e != hipSuccess) {
+    set_hip_error(e, "cloud_create small upload");
+    return GLIM_AMD_ERR_HIP;
+  }
+  c->plane_form = plane;
+  return GLIM_AMD_OK;
 }
 
 // factor streams in the Hilbert order of the cloud (rank == null: arrival order)
@@ -196,6 +290,17 @@ int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
   GA_HIP(hipSetDevice(ctx->device));
   glim_amd_cloud* c = nullptr;
   GA_TRY(alloc_cloud(ctx, n, covs16 != nullptr, normals4 != nullptr, &c));
+  if (n > 0 && n <= HOST_PACK_MAX_POINTS && ctx->diag.host_pack) {
+    const int rc = create_small_f64(ctx, c, points4, covs16, normals4);
+    if (rc == GLIM_AMD_OK) {
+      *out = c;
+      return GLIM_AMD_OK;
+    }
+    if (rc != GLIM_AMD_ERR_UNSUPPORTED) {
+      glim_amd_cloud_destroy(c);
+      return rc;
+    }
+  }
   if (n > 0) {
     hipStream_t s = ctx->stream();
     DeviceTemp dp, dc, dn;

@@ -37,6 +37,7 @@ const DiagKey kDiagKeys[] = {
   {"bucket_factor", &Diag::bucket_factor, nullptr, 0, 64},
   {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
+  {"host_pack", &Diag::host_pack, nullptr, 0, 1},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},
@@ -97,6 +98,24 @@ int diag_print(const Diag& d, char* buf, size_t len) {
   if (!buf || len < s.size() + 1) return GLIM_AMD_ERR_INVALID;
   memcpy(buf, s.c_str(), s.size() + 1);
   return GLIM_AMD_OK;
+}
+
+// the context's 1 KiB pinned scratch block as the host sees it and as kernels see it (mapped); false: not available here
+bool pinned_scratch_views(::glim_amd_ctx* ctx, void** host, void** device) {
+  constexpr size_t SCRATCH = 1024;
+  if (!ctx->pinned_scratch && pinned_malloc(&ctx->pinned_scratch, SCRATCH) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->pinned_scratch = nullptr;
+    return false;
+  }
+  if (!ctx->pinned_scratch_dev && hipHostGetDevicePointer(&ctx->pinned_scratch_dev, ctx->pinned_scratch, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->pinned_scratch_dev = nullptr;
+    return false;
+  }
+  *host = ctx->pinned_scratch;
+  *device = ctx->pinned_scratch_dev;
+  return true;
 }
 
 hipError_t read_back_sync(::glim_amd_ctx* ctx, hipStream_t st, void* dst_host, const void* src_device, size_t bytes) {

@@ -74,6 +74,7 @@ struct Diag {
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
+  int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
@@ -89,6 +90,7 @@ int diag_print(const Diag& d, char* buf, size_t len);
 // memory (a stack variable) is staged by the runtime and blocks the caller for ~20 us; through the context's pinned scratch it is one DMA
 // packet.  Caller holds ctx->mu.
 hipError_t read_back_sync(::glim_amd_ctx* ctx, hipStream_t st, void* dst_host, const void* src_device, size_t bytes);
+bool pinned_scratch_views(::glim_amd_ctx* ctx, void** host, void** device);  // the same block as kernels address it (mapped); caller holds ctx->mu
 
 // stable LSD radix sort of (u64 key, u32 value) pairs (sort.hip)
 size_t radix_sort_scratch_bytes(int n);
@@ -209,6 +211,7 @@ struct glim_amd_ctx {
   unsigned int ov_seq = 0;
   std::vector<std::pair<int, double>> voxel_ratio_hints;  // (resolution class, voxels per point of the last map built there): voxelmap.hip
   void* pinned_scratch = nullptr;  // 1 KiB of pinned host memory for small read-backs (read_back_sync; guarded by mu)
+  void* pinned_scratch_dev = nullptr;  // its device view (kernels that hand a few words to the host themselves)
   void quiesce() {
     if (async_pending.exchange(false))
       for (auto s : streams) (void)hipStreamSynchronize(s);

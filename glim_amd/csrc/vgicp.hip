@@ -579,6 +579,57 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const FactorDesc* __res
   finalize_factor(d, f, partials, fa, mode, s_part, s_sum, ip.valid ? ip.m : poses_lin + 12 * (size_t)f);
 }
 
+// Finalisation of a large set of short factors (configs[3]: 32 640 factors of ~8 rows): one WAVEFRONT per factor, four per block, no block
+// barrier.  One 256-thread block per factor is latency-bound there (two barriers, a 32-deep LDS sum and the serial rotation per block, sixteen
+// resident rounds: 145 us per evaluation).  Lane j < 32 adds value j of the factor's rows in row order -- exactly the order finalize_factor's
+// group sums give a factor of at most FIN_GROUPS rows, so both kernels produce the same bits; lanes 0..3 then rotate as there.
+constexpr int FIN_WAVES = BLOCK / 64;
+constexpr int FIN_SHORT_MIN_FACTORS = 2048;
+__global__ __launch_bounds__(BLOCK) void finalize_short_kernel(const FactorDesc* __restrict__ descs, const float* __restrict__ partials, const FinalizeArgs fa,
+                                                               int mode, const double* __restrict__ poses_lin) {
+  __shared__ double s_sum[FIN_WAVES][PARTIAL_STRIDE];
+  __shared__ double s_rot[FIN_WAVES][32];
+  const int wave = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const int f = blockIdx.x * FIN_WAVES + wave;
+  if (f >= fa.num_factors) return;
+  const int first = descs[f].first_block, nb = descs[f].num_blocks;  // nb <= FIN_GROUPS (launch site)
+  double Tl[12];
+  if (t < 4) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) Tl[i] = poses_lin[12 * (size_t)f + i];
+  }
+  if (t < PARTIAL_STRIDE) {
+    double sum = 0.0;
+    constexpr int INFLIGHT = 8;
+    for (int c = 0; c < nb; c += INFLIGHT) {
+      float v[INFLIGHT];
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++) v[u] = partials[(size_t)(first + min(c + u, nb - 1)) * PARTIAL_STRIDE + t];
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++)
+        if (c + u < nb) sum += (double)v[u];
+    }
+    s_sum[wave][t] = sum;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
+  if (t == 0) o[0] = s_sum[wave][28];
+  if (t == 1) o[1] = s_sum[wave][27];
+  if (mode == MODE_LINEARIZE) {
+    if (t < 4) rotate_part(t, s_sum[wave], Tl, s_rot[wave]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t < 21) o[2 + t] = s_rot[wave][c_acc_of_upper[t]];
+    if (t >= 21 && t < 24) o[2 + t] = s_rot[wave][t];
+    if (t >= 24 && t < 27) o[2 + t] = -s_rot[wave][t];
+  } else if (t >= 2 && t < COMPACT) {
+    o[t] = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void correspondence_kernel(FactorDesc d, const double* __restrict__ pose, int32_t* __restrict__ corr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.n) return;
@@ -1025,7 +1076,11 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));  // (the inline kernels read pose and descriptor from their arguments)
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   launch_vgicp(set, mode, frozen, fa, plan->d_partials);
-  finalize_kernel<<<nf, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev, set->inline_args);
+  // more factors than one resident round of per-factor blocks, all of them short: a wavefront per factor (same bits)
+  if (nf > FIN_SHORT_MIN_FACTORS && plan->max_rows_per_factor <= FIN_GROUPS && !fa.host_flag && !set->inline_args.valid)
+    finalize_short_kernel<<<(nf + FIN_WAVES - 1) / FIN_WAVES, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev);
+  else
+    finalize_kernel<<<nf, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev, set->inline_args);
   GA_HIP(hipGetLastError());
   return GLIM_AMD_OK;
 }

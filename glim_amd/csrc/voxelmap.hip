@@ -41,6 +41,20 @@ __global__ __launch_bounds__(256) void init_buckets_kernel(VoxelBucket* __restri
   reinterpret_cast<uint4*>(buckets)[i] = v;
 }
 
+// direct build: buckets initialised, accumulators and the two counters zeroed by ONE launch instead of a kernel and two memsets
+// (acc16: the accumulator table as 16-byte words, 10 per bucket against the bucket's own 8)
+__global__ __launch_bounds__(256) void init_tables_kernel(VoxelBucket* __restrict__ buckets, unsigned int n, uint4* __restrict__ acc16, size_t acc_words,
+                                                          int* __restrict__ stats) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) stats[0] = stats[1] = 0;
+  if (i < (size_t)n * 8) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((i & 7) == 0) v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // key[0] = key[1] = EMPTY_KEY
+    reinterpret_cast<uint4*>(buckets)[i] = v;
+  }
+  if (i < acc_words) acc16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Wavefront-level grouping of equal keys: consecutive points of a scan usually fall into the same voxel, and 64 lanes hammering
 // one table word with atomics serialise in the L2.  Every distinct key of the wavefront elects ONE leader lane; `group` is the
 // ballot of the lanes sharing this lane's key.  The loop is wave-uniform (one trip per distinct key, ~10 on LiDAR scans).
@@ -239,9 +253,16 @@ __global__ __launch_bounds__(256) void reopen_old_voxels_kernel(const VoxelBucke
 }
 
 // one thread per (bucket, way)
+// stats / host_stats (direct build): the voxel count and the range flag of the key insertion, handed to the host through mapped pinned
+// memory by this last launch -- the call then needs a stream synchronise only, no device-to-host copy
 __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
-                                                       const long long* __restrict__ acc, double res) {
+                                                       const long long* __restrict__ acc, double res, const int* __restrict__ stats,
+                                                       int* __restrict__ host_stats) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && host_stats) {
+    host_stats[0] = stats[0];
+    host_stats[1] = stats[1];
+  }
   if (i >= 2 * num_buckets) return;
   const unsigned int b = i >> 1, w = i & 1;
   const unsigned long long key = buckets[b].key[w];
@@ -357,17 +378,24 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
     GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
     GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
-    hipError_t e = hipMemsetAsync(stats.p, 0, 2 * sizeof(int), st);
-    if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long), st);
+    // four launches and one synchronise: tables, keys, sums, records (the last one also hands the counters to the host)
+    static_assert((2 * ACC_STRIDE * sizeof(long long)) % sizeof(uint4) == 0, "accumulators are cleared in 16-byte words");
+    const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
+    int *h_view = nullptr, *d_view = nullptr;
+    const bool mapped = pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view));
     int h_stats[2] = {0, 0};
-    if (e == hipSuccess) {
-      init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
-      insert_keys_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, m->inv_resolution, buckets, nb, (unsigned long long*)pkeys.p, (int*)stats.p);
-      accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets, nb, (long long*)acc.p);
-      finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution);
-      e = hipGetLastError();
+    init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
+    insert_keys_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, m->inv_resolution, buckets, nb, (unsigned long long*)pkeys.p, (int*)stats.p);
+    accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets, nb, (long long*)acc.p);
+    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && mapped) {
+      e = hipStreamSynchronize(st);
+      h_stats[0] = h_view[0];
+      h_stats[1] = h_view[1];
+    } else if (e == hipSuccess) {
+      e = read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats));
     }
-    if (e == hipSuccess) e = read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats));
     if (e != hipSuccess) {
       set_hip_error(e, "voxelmap_insert");
       (void)pool_free(buckets);
@@ -427,7 +455,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (n > 0)
       accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets,
                                                           nb, (long long*)acc.p);
-    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution);
+    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, nullptr, nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);

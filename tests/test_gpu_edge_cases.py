@@ -264,6 +264,42 @@ def test_synchronous_call_variants_give_identical_bits(api, ctx, orc):
                 assert list(es) == list(base[1]), mode
 
 
+def test_wave_per_factor_finalise_gives_the_block_finalise_bits(api, ctx, orc, small_pair):
+    """Sets of more than 2 048 short factors (configs[3]'s 32 640 pairs) are finalised by one wavefront per factor instead of one block per
+    factor: the records must carry the same bits as the same factors evaluated in sets small enough for the block kernel (points per thread
+    pinned, so that both plans cut every factor into the same rows)."""
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    clouds = [api.PointCloudGPU.clone(s["points"][k::3].astype(np.float64), s["covs"][k::3], ctx=ctx) for k in range(3)]
+    vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
+    nf = 2100
+    factors = [api.IntegratedVGICPFactorGPU(0, 1 + k, vms[k % 2], clouds[k % 3]) for k in range(nf)]
+    values = {0: np.eye(4)}
+    for k in range(nf):
+        values[1 + k] = small_pair["delta"] @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.01 * k))
+    ctx.set_diag("ppt=2")
+
+    def run(lo, hi):
+        fs = api.NonlinearFactorSetGPU(ctx)
+        for f in factors[lo:hi]:
+            fs.add(f)
+        out = fs.linearize(values), fs.error(values)
+        fs.close()
+        return out
+
+    big = run(0, nf)
+    parts = [run(lo, min(nf, lo + 700)) for lo in range(0, nf, 700)]
+    ctx.set_diag("")
+    want_L = [L for part in parts for L in part[0]]
+    want_e = [e for part in parts for e in part[1]]
+    assert len(want_L) == nf and sum(L["num_inliers"] for L in want_L) > 100 * nf
+    for k, (a, b) in enumerate(zip(big[0], want_L)):
+        assert a["num_inliers"] == b["num_inliers"] and a["error"] == b["error"], k
+        for key in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"factor {k} {key}")
+    assert list(big[1]) == want_e
+
+
 def test_plan_cache_serves_fresh_sets_and_follows_object_identity(api, ctx, orc, small_pair):
     """GLIM builds a fresh NonlinearFactorSetGPU per linearisation: sets with the same (map, cloud, flags) list share one cached plan and
     give the same records as a set built with the cache off; destroying / rebuilding an object never resurrects a stale plan."""

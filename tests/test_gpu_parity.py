@@ -82,6 +82,36 @@ def test_cloud_roundtrip_f64_and_f32_layouts(api, ctx, small_pair):
     assert g64.memory_usage_gpu() == len(s["points"]) * (16 + 24 + 16)
 
 
+def test_small_cloud_host_pack_equals_the_device_pack(api, ctx, orc, small_pair):
+    """Clouds of up to 32 768 points are converted to the device layout on the host and pulled over by one kernel (host_pack=1, the default);
+    the general path uploads the FP64 arrays and packs on the device.  Same arrays, same plane-form decision (a factor over either cloud runs
+    the same kernel and gives the same bits) -- for plane-form covariances and for general ones."""
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    general = s["covs"][:, :3, :3] + 0.01 * np.eye(3)[None]
+    for covs in (s["covs"], general):
+        out = {}
+        for mode in ("host_pack=1", "host_pack=0"):
+            ctx.set_diag(mode)
+            g = api.PointCloudGPU.clone(s["points"].astype(np.float64), covs, s["normals"], ctx=ctx)
+            ctx.set_diag("")
+            fset = api.NonlinearFactorSetGPU(ctx)
+            fset.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, g))
+            out[mode] = (g.download(), fset.linearize({1: small_pair["delta"]})[0])
+        (a, La), (b, Lb) = out["host_pack=1"], out["host_pack=0"]
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        assert La["num_inliers"] == Lb["num_inliers"] > 100 and La["error"] == Lb["error"]
+        np.testing.assert_array_equal(La["H_ss"], Lb["H_ss"])
+        np.testing.assert_array_equal(La["b_s"], Lb["b_s"])
+    # without covariances / normals
+    ctx.set_diag("host_pack=1")
+    bare = api.PointCloudGPU.clone(s["points"].astype(np.float64), ctx=ctx)
+    ctx.set_diag("")
+    np.testing.assert_array_equal(bare.download(covs=False, normals=False)[0], s["points"])
+
+
 def test_empty_cloud_and_empty_set(api, ctx, small_pair):
     e = api.PointCloudGPU.clone(np.zeros((0, 3)), np.zeros((0, 3, 3)), ctx=ctx)
     assert e.size() == 0
