@@ -107,37 +107,6 @@ __global__ __launch_bounds__(256) void insert_keys_kernel(int n, const float4* _
   }
 }
 
-// Small clouds (the odometry's 10 000-point frames): the keys go straight into the FINAL table, sized from the number of points instead of the
-// number of voxels (2 buckets per point hold 4 keys per point, and a cloud has at most one voxel per point), so the build needs no count
-// of the distinct keys before it can allocate: one host synchronise per map instead of two, four kernels instead of six.
-// stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
-__global__ __launch_bounds__(256) void insert_keys_direct_kernel(int n, const float4* __restrict__ pts, double inv_res, VoxelBucket* __restrict__ buckets,
-                                                                 unsigned int num_buckets, unsigned long long* __restrict__ pkeys, int* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long key = EMPTY_KEY;
-  if (i < n) {
-    const float4 p = pts[i];
-    key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
-    pkeys[i] = key;
-    if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
-  }
-  unsigned long long group;
-  if (!wave_group_by_key(key, key != EMPTY_KEY, group)) return;  // one CAS chain per distinct key of the wavefront
-  unsigned int b = bucket_of(key, num_buckets);
-  for (;;) {
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-      const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
-      if (prev == EMPTY_KEY) {
-        atomicAdd(&stats[0], 1);
-        return;
-      }
-      if (prev == key) return;
-    }
-    b = (b + 1 == num_buckets) ? 0u : b + 1;
-  }
-}
-
 // Re-insert the distinct keys into the final bucket table: way 0, then way 1, then the next bucket.
 __global__ __launch_bounds__(256) void move_keys_kernel(const unsigned long long* __restrict__ tkeys, unsigned int tsize,
                                                         VoxelBucket* __restrict__ buckets, unsigned int num_buckets) {
@@ -201,6 +170,65 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
   const int s = find_slot(buckets, num_buckets, key);
   if (s < 0) return;
   long long* dst = acc + (size_t)s * ACC_STRIDE;
+#pragma unroll
+  for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)sum[j]);
+  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
+}
+
+// Direct build (fresh maps whose table size is known before the voxels are counted, glim_amd_voxelmap_insert): the keys go straight into the
+// FINAL table, and in the same pass the leader of every key group of a wavefront adds its group's sums to the accumulators of the slot it has
+// just claimed or found -- a slot is usable from the moment its key is in place, no matter which wavefront put it there.  One grouping pass
+// instead of two, no per-point key array, one host synchronise per map instead of two, three launches instead of six.
+// stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
+__global__ __launch_bounds__(256) void build_direct_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
+                                                           const float2* __restrict__ covB, double inv_res, VoxelBucket* __restrict__ buckets,
+                                                           unsigned int num_buckets, long long* __restrict__ acc, int* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long key = EMPTY_KEY;
+  long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < n) {
+    const float4 p = pts[i];
+    const float4 a = covA[i];
+    const float2 b = covB[i];
+    key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
+    if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
+    v[0] = __double2ll_rn((double)p.x * MEAN_SCALE);
+    v[1] = __double2ll_rn((double)p.y * MEAN_SCALE);
+    v[2] = __double2ll_rn((double)p.z * MEAN_SCALE);
+    v[3] = __double2ll_rn((double)a.x * COV_SCALE);
+    v[4] = __double2ll_rn((double)a.y * COV_SCALE);
+    v[5] = __double2ll_rn((double)a.z * COV_SCALE);
+    v[6] = __double2ll_rn((double)a.w * COV_SCALE);
+    v[7] = __double2ll_rn((double)b.x * COV_SCALE);
+    v[8] = __double2ll_rn((double)b.y * COV_SCALE);
+  }
+  unsigned long long group;
+  const bool leader = wave_group_by_key(key, key != EMPTY_KEY, group);
+  long long sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rest = leader ? group : 0ull;
+  while (__ballot(rest != 0ull)) {
+    const int src = rest ? (__ffsll((long long)rest) - 1) : 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const long long t = shfl_ll(v[j], src);
+      if (rest) sum[j] += t;
+    }
+    rest &= rest - 1ull;
+  }
+  if (!leader) return;
+  unsigned int b = bucket_of(key, num_buckets);
+  int slot = -1;
+  while (slot < 0) {
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      if (slot >= 0) continue;
+      const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
+      if (prev == EMPTY_KEY) atomicAdd(&stats[0], 1);
+      if (prev == EMPTY_KEY || prev == key) slot = (int)(2u * b + (unsigned int)w);
+    }
+    b = (b + 1 == num_buckets) ? 0u : b + 1;
+  }
+  long long* dst = acc + (size_t)slot * ACC_STRIDE;
 #pragma unroll
   for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)sum[j]);
   atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
@@ -357,7 +385,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
   if (old) ctx->quiesce();  // asynchronous factor launches may still be reading the table that is about to be replaced
-  // Direct build (keys straight into the final table, ONE synchronise: insert_keys_direct_kernel) needs the table size before the voxels are
+  // Direct build (keys straight into the final table, ONE synchronise: build_direct_kernel) needs the table size before the voxels are
   // counted.  Small clouds: 2 buckets per point (4 ways per point: load factor below 1/2 whatever the cloud).  Larger clouds: 6 buckets per
   // EXPECTED voxel, from the voxels-per-point ratio of the last map this context built at (about) this resolution -- consecutive frames of a
   // stream have the same density -- and never fewer than N / 2 buckets, which hold one key per point: the table cannot overflow whatever the
@@ -374,19 +402,17 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (want > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
     const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, want));
     VoxelBucket* buckets = nullptr;
-    GA_HIP(pool_malloc(&pkeys.p, (size_t)n * sizeof(unsigned long long)));
     GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
     GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
     GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
-    // four launches and one synchronise: tables, keys, sums, records (the last one also hands the counters to the host)
+    // three launches and one synchronise: tables, keys + sums, records (the last one also hands the counters to the host)
     static_assert((2 * ACC_STRIDE * sizeof(long long)) % sizeof(uint4) == 0, "accumulators are cleared in 16-byte words");
     const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
     int *h_view = nullptr, *d_view = nullptr;
     const bool mapped = pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view));
     int h_stats[2] = {0, 0};
     init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
-    insert_keys_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, m->inv_resolution, buckets, nb, (unsigned long long*)pkeys.p, (int*)stats.p);
-    accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets, nb, (long long*)acc.p);
+    build_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, m->inv_resolution, buckets, nb, (long long*)acc.p, (int*)stats.p);
     finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && mapped) {
