@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void bbox_kernel(int n, const float4* __restri
       atomicMax(&bb[3 + a], hi[a]);
     }
 }
-float unordered(int i) {
+__host__ __device__ inline float unordered(int i) {
   const int j = i >= 0 ? i : i ^ 0x7fffffff;
   float f;
   memcpy(&f, &j, sizeof(f));
@@ -374,11 +374,18 @@ __device__ __forceinline__ unsigned long long spread3(unsigned int v) {  // 21 b
   return x;
 }
 
-// stats[1] counts points with a non-finite coordinate (an error, as in the grid path)
-__global__ __launch_bounds__(256) void curve_key_kernel(int n, const float4* __restrict__ pts, float lox, float loy, float loz, float scale, unsigned int qmax, int bits,
+// stats[1] counts points with a non-finite coordinate (an error, as in the grid path).  The bounding box (bbox_kernel's ordered ints) is read
+// HERE, not by the host: one synchronise per kNN call instead of two.  stats[2] is the guard word of the chunk kernels: 1 = the box is not
+// finite, 2 = the cloud spans 1e18 m or more (the FP32 mask passes need finite FP32 squared distances: the exhaustive FP64 kernel answers).
+__global__ __launch_bounds__(256) void curve_key_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ bb, unsigned int qmax, int bits,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ stats) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const float lox = unordered(bb[0]), loy = unordered(bb[1]), loz = unordered(bb[2]);
+  const float ext = fmaxf(fmaxf(unordered(bb[3]) - lox, unordered(bb[4]) - loy), unordered(bb[5]) - loz);
+  const bool finite_box = ext >= 0.f && isfinite(ext) && isfinite(lox) && isfinite(loy) && isfinite(loz);
+  if (i == 0 && !(finite_box && ext < 1e18f)) stats[2] = finite_box ? 2 : 1;
   if (i >= n) return;
+  const float scale = (finite_box && ext > 0.f) ? (float)qmax / ext : 0.f;
   const float4 p = pts[i];
   if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
     atomicAdd(&stats[1], 1);
@@ -490,18 +497,9 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
   GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, bb.as<int>());
-  int h_bb[6];
-  GA_HIP(read_back_sync(ctx, st, h_bb, bb.p, sizeof(h_bb)));
-  float lo[3], ext = 0.f;
-  for (int a = 0; a < 3; a++) {
-    lo[a] = unordered(h_bb[a]);
-    ext = std::max(ext, unordered(h_bb[3 + a]) - lo[a]);
-  }
-  if (!(ext >= 0.f) || !std::isfinite(ext) || !std::isfinite(lo[0]) || !std::isfinite(lo[1]) || !std::isfinite(lo[2])) return GLIM_AMD_ERR_RANGE;
   const int bits = n < 32768 ? 8 : 13;  // per axis: 24-bit keys / 3 sort passes for small clouds, 39 bits / 5 passes otherwise; the order only affects speed
   const unsigned int qmax = (1u << bits) - 1u;
-  const float scale = ext > 0.f ? (float)qmax / ext : 0.f;
-  curve_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, lo[0], lo[1], lo[2], scale, qmax, bits, ka.as<unsigned long long>(), stats.as<int>());
+  curve_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, pts, bb.as<int>(), qmax, bits, ka.as<unsigned long long>(), stats.as<int>());
   unsigned long long* ks = nullptr;
   unsigned int* order = nullptr;
   GA_HIP(radix_sort_pairs(st, n, 3 * bits, ka.as<unsigned long long>(), va.as<unsigned int>(), kb.as<unsigned long long>(), vb.as<unsigned int>(), true,
@@ -523,15 +521,14 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // answered by the exhaustive FP64 kernel instead.
   const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
   const bool pair_lanes = !dbg.p && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
-  if (k > 0 && !(ext < 1e18f)) {
-    DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
-  } else if (k > 0 && pair_lanes) {
+  const int* guard = stats.as<int>() + 2;
+  if (k > 0 && pair_lanes) {
     GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
     half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
-    knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select);
+    knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select, guard);
     GA_HIP(hipGetLastError());
   } else if (k > 0) {
-    knn_launch_chunks(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), select);  // k == 0: ordering only
+    knn_launch_chunks(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, dbg.as<int>(), select, guard);  // k == 0: ordering only
   }
   GA_HIP(hipGetLastError());
   if (dbg.p) {
@@ -544,7 +541,13 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   }
   int h_stats[4];
   GA_HIP(read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats)));
-  return h_stats[1] != 0 ? GLIM_AMD_ERR_RANGE : GLIM_AMD_OK;
+  if (h_stats[1] != 0 || h_stats[2] == 1) return GLIM_AMD_ERR_RANGE;
+  if (h_stats[2] == 2 && k > 0) {  // astronomic extent: the chunk kernels stood down
+    DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);
+    GA_HIP(hipGetLastError());
+    GA_HIP(hipStreamSynchronize(st));
+  }
+  return GLIM_AMD_OK;
 }
 
 }  // namespace

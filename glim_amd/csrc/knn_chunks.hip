@@ -68,12 +68,13 @@ __global__ __launch_bounds__(256) void group_box_kernel(int C, float* __restrict
 // bubble, one or two candidates per round (+17 ... +28 %); loads issued one step ahead of their use (+4 %); an all-FP64 mask pass (+8 %).
 template <int K, bool SELECT>
 __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const float4* __restrict__ sorted, const float* __restrict__ box, int k,
-                                                        int32_t* __restrict__ out, int* __restrict__ dbg) {
+                                                        int32_t* __restrict__ out, int* __restrict__ dbg, const int* __restrict__ guard) {
   __shared__ __attribute__((aligned(8))) float s_px[4][CHUNK], s_py[4][CHUNK], s_pz[4][CHUNK];
   __shared__ int s_pi[4][CHUNK];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + w;
   if (c >= C) return;  // whole wavefront
+  if (*guard != 0) return;  // the cloud's extent is not finite or beyond the FP32 mask's range (knn.hip: curve_key_kernel): the caller answers otherwise
   const float4 q4 = sorted[c * CHUNK + lane];
   const int self = __float_as_int(q4.w);
   const bool live = self >= 0;
@@ -269,23 +270,23 @@ __global__ __launch_bounds__(256) void knn_chunk_kernel(int n, int C, const floa
 }
 
 template <int K>
-void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool select) {
+void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, int* dbg, bool select, const int* guard) {
   if constexpr (K <= 10) {  // the selection keeps 64 distances in registers next to the list: beyond k = 10 it spills
     if (select) {
-      knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+      knn_chunk_kernel<K, true><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg, guard);
       return;
     }
   }
-  knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg);
+  knn_chunk_kernel<K, false><<<(C + 3) / 4, 256, 0, st>>>(n, C, sorted, box, k, out, dbg, guard);
 }
 
 }  // namespace
 
 namespace glim_amd {
 
-void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select) {
+void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select, const int* guard) {
   group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box);
-  DISPATCH_K(launch_chunks, st, n, C, sorted, box, k, out, dbg, select);
+  DISPATCH_K(launch_chunks, st, n, C, sorted, box, k, out, dbg, select, guard);
 }
 
 }  // namespace glim_amd

@@ -10,9 +10,10 @@
 namespace glim_amd {
 // 64-query chunk kernel over the Hilbert-ordered points (`sorted`, C chunks of 64 with boxes `box`, which also has room for the boxes of the
 // groups of 64 chunks: this call fills them first).  dbg: optional per-wavefront counters.  select: see knn_chunks.hip.
-void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select);
+// guard: one device int, non-zero = do nothing (the caller found the cloud's extent unusable for the FP32 mask pass)
+void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select, const int* guard);
 // pair-lane kernel over 32-point half chunks (C32 of them, boxes `box32`); k <= 16
-void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select);
+void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select, const int* guard);
 }  // namespace glim_amd
 
 namespace {

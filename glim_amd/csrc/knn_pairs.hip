@@ -19,11 +19,12 @@ namespace {
 // before it is offered to the list, which applies the exact (distance, index) test.  Results are bit-identical to the other implementations.
 template <int K, bool SELECT>
 __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point chunks */, const float4* __restrict__ sorted, const float* __restrict__ box,
-                                                       int k, int32_t* __restrict__ out) {
+                                                       int k, int32_t* __restrict__ out, const int* __restrict__ guard) {
   __shared__ float4 s_pt[4][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, ql = lane & 31;
   const int c = blockIdx.x * 4 + w;
   if (c >= C) return;  // whole wavefront
+  if (*guard != 0) return;  // see knn_chunk_kernel
   const float4 q4 = sorted[c * QCH + ql];
   const int self = __float_as_int(q4.w);
   const bool live = self >= 0;
@@ -210,22 +211,22 @@ __global__ __launch_bounds__(256) void knn_pair_kernel(int n, int C /* 32-point 
 }
 
 template <int K>
-void launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select) {
+void launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select, const int* guard) {
   if constexpr (K <= 10) {
     if (select) {
-      knn_pair_kernel<K, true><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
+      knn_pair_kernel<K, true><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out, guard);
       return;
     }
   }
-  knn_pair_kernel<K, false><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out);
+  knn_pair_kernel<K, false><<<(C32 + 3) / 4, 256, 0, st>>>(n, C32, sorted, box32, k, out, guard);
 }
 
 }  // namespace
 
 namespace glim_amd {
 
-void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select) {
-  DISPATCH_K16(launch_pairs, st, n, C32, sorted, box32, k, out, select);
+void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select, const int* guard) {
+  DISPATCH_K16(launch_pairs, st, n, C32, sorted, box32, k, out, select, guard);
 }
 
 }  // namespace glim_amd

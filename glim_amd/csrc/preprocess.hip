@@ -600,6 +600,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       SortBuffers sb;
       GA_TRY(sb.alloc(n));
       int h_counters[4] = {0, 0, 0, 0};
+      double* h_times_stage = nullptr;
 
       // ---- downsampling (cloud_preprocessor.cpp:103-109) ----
       const double rate = prm->downsample_target > 0 ? (double)prm->downsample_target / (double)n : prm->downsample_rate;
@@ -673,8 +674,19 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       if (f > 0) {
         pp_gather_out_kernel<<<grid_for(f), 256, 0, st>>>(f, order, P, T, I, prm->global_shutter, c->pts, c->pts64, c->times, c->intensities);
         GA_HIP(hipGetLastError());
+        // no outlier removal behind this: the host copy of the time stamps rides on this scope's synchronise (pinned staging: a
+        // device-to-host copy into pageable memory is staged by the runtime and costs a second round trip)
+        if (!prm->enable_outlier_removal && pinned_malloc(&h_times_stage, (size_t)f * sizeof(double)) == hipSuccess)
+          GA_HIP(hipMemcpyAsync(h_times_stage, c->times, (size_t)f * sizeof(double), hipMemcpyDeviceToHost, st));
+        else
+          (void)hipGetLastError();
       }
-      GA_HIP(hipStreamSynchronize(st));  // scratch of this scope is released below
+      const hipError_t se = hipStreamSynchronize(st);  // scratch of this scope is released below
+      if (h_times_stage) {
+        if (se == hipSuccess) c->h_times.assign(h_times_stage, h_times_stage + f);
+        (void)pinned_free(h_times_stage);
+      }
+      GA_HIP(se);
     }
   }
 
@@ -717,7 +729,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
   // ---- host copy of the time stamps (deskewing builds its time table from them) + kNN for the covariances (:183-184) ----
   {
     glim_amd_cloud* c = result.c;
-    if (c->n > 0) {
+    if (c->n > 0 && c->h_times.size() != (size_t)c->n) {
       std::lock_guard<std::mutex> lock(ctx->mu);
       GA_HIP(hipSetDevice(ctx->device));
       c->h_times.resize((size_t)c->n);
