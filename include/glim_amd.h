@@ -81,8 +81,8 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
- * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, pool=0|1
- * (GLIM_AMD_DIAG only), multi_rccl=0|1, multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
+ * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
+ * pool=0|1 (GLIM_AMD_DIAG only), multi_rccl=0|1, multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
  * nothing changes.  get_diag prints the current state in the same syntax. */
 int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
 int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
