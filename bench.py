@@ -473,21 +473,34 @@ def run_odometry_frame(args, D, api, ctx):
         n4 = np.zeros((nn, 4))
         n4[:, :3] = n32
         reps = 30
-        t_clone = t_maps = 0.0
+        t_clone = t_maps = t_first = t_second = 0.0
         for _ in range(reps):
             t0 = time.perf_counter()
             g = api.PointCloudGPU.clone_packed(p4, c16, n4, ctx=ctx)
             t1 = time.perf_counter()
             ms = [api.GaussianVoxelMapGPU(rr, ctx=ctx).insert(g) for rr in levels]
             t2 = time.perf_counter()
+            # the first factor that uses the new cloud as its source builds the cloud's factor streams (Hilbert rank + stream kernel): a
+            # per-frame cost that the steady-state linearisation figures above do not contain.  Timed as first use minus second use.
+            one = api.NonlinearFactorSetGPU(ctx)
+            one.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vmaps[0][0], g))
+            one.linearize({1: np.eye(4)})
+            t3 = time.perf_counter()
+            one.linearize({1: np.eye(4)})
+            t4 = time.perf_counter()
             t_clone += t1 - t0
             t_maps += t2 - t1
+            t_first += t3 - t2
+            t_second += t4 - t3
+            one.close()
             for m in ms:
                 m.close()
             g.close()
         r["create_frame_us"] = {"clone_upload_pack": t_clone / reps * 1e6, "two_voxelmap_inserts": t_maps / reps * 1e6,
+                                "factor_streams_on_first_use": max(0.0, (t_first - t_second) / reps * 1e6),
                                 "upload_bytes": int(p4.nbytes + c16.nbytes + n4.nbytes), "note": "pageable host arrays, as GLIM hands them over"}
-        frame_us = r["create_frame_us"]["clone_upload_pack"] + r["create_frame_us"]["two_voxelmap_inserts"] + ITERS * r["fresh_set_linearize_us"] + r["overlap_15_targets_us"]
+        frame_us = (r["create_frame_us"]["clone_upload_pack"] + r["create_frame_us"]["two_voxelmap_inserts"] + r["create_frame_us"]["factor_streams_on_first_use"]
+                    + ITERS * r["fresh_set_linearize_us"] + r["overlap_15_targets_us"])
         r["frame_us"] = {"optimiser_iterations": ITERS, "ordinary_frame": frame_us, "new_keyframe_frame": frame_us + r["keyframe_elimination_loop_separate_calls_us"],
                          "new_keyframe_frame_batched_loop": frame_us + r["keyframe_elimination_loop_one_batch_us"]}
         # parity of this configuration (surface validation ON has no CPU counterpart: checked against the same factors with it OFF <= inliers)

@@ -192,8 +192,9 @@ void build_deskew_table(int64_t n, const double* times, const double* T_imu_lida
 
 // device: (upload the raw points unless they are already resident,) entry indices and the table; transform + pack.
 // Caller holds ctx->mu.
+// carry: a preprocessed cloud whose neighbour lists the result takes over (copied on the device before the one synchronise of this call), or null
 int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const double* d_points4, const std::vector<int>& entry, const std::vector<Pose>& TT,
-               glim_amd_cloud** out) {
+               const glim_amd_cloud* carry, glim_amd_cloud** out) {
   glim_amd_cloud* c = new glim_amd_cloud();
   c->ctx = ctx;
   c->n = n;
@@ -205,21 +206,40 @@ int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const doub
   }
   if (n > 0) {
     hipStream_t s = ctx->stream();
-    DeviceTemp dp, de, dt;
+    DeviceTemp dp;
     if (!d_points4) {
       e = pool_malloc(&dp.p, (size_t)n * 4 * sizeof(double));
       if (e == hipSuccess) e = hipMemcpyAsync(dp.p, h_points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
       d_points4 = (const double*)dp.p;
     }
-    if (e == hipSuccess) e = pool_malloc(&de.p, (size_t)n * sizeof(int));
-    if (e == hipSuccess) e = pool_malloc(&dt.p, TT.size() * sizeof(Pose));
-    if (e == hipSuccess) e = hipMemcpyAsync(de.p, entry.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(dt.p, TT.data(), TT.size() * sizeof(Pose), hipMemcpyHostToDevice, s);
+    // table and per-point entries travel in ONE pinned block (two pageable copies are staged by the runtime one after the other)
+    const size_t entry_bytes = ((size_t)n * sizeof(int) + 63) & ~(size_t)63, table_bytes = TT.size() * sizeof(Pose);
+    char* stage = nullptr;
+    DeviceTemp dev;
+    if (e == hipSuccess) e = pool_malloc(&dev.p, entry_bytes + table_bytes);
+    if (e == hipSuccess) e = pinned_malloc(&stage, entry_bytes + table_bytes);
     if (e == hipSuccess) {
-      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, d_points4, (const int*)de.p, (const double*)dt.p, c->pts);
+      memcpy(stage, entry.data(), (size_t)n * sizeof(int));
+      memcpy(stage + entry_bytes, TT.data(), table_bytes);
+      e = hipMemcpyAsync(dev.p, stage, entry_bytes + table_bytes, hipMemcpyHostToDevice, s);
+    }
+    if (e == hipSuccess) {
+      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, d_points4, (const int*)dev.p, (const double*)((const char*)dev.p + entry_bytes), c->pts);
       e = hipGetLastError();
     }
+    if (e == hipSuccess && carry && carry->neighbors) {
+      e = pool_malloc(&c->neighbors, (size_t)n * carry->k * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(c->neighbors, carry->neighbors, (size_t)n * carry->k * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) c->k = carry->k;
+    }
+    if (e == hipSuccess && carry && carry->curve_rank) {
+      // ... and so is the Hilbert rank of the raw points (motion correction moves a point by centimetres; the order only affects the speed of
+      // the factor kernel's voxel look-ups): estimate_covariances does not have to sort the cloud a second time
+      e = pool_malloc(&c->curve_rank, (size_t)n * sizeof(unsigned int));
+      if (e == hipSuccess) e = hipMemcpyAsync(c->curve_rank, carry->curve_rank, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (stage) (void)pinned_free(stage);
     if (e != hipSuccess) {
       set_hip_error(e, "cloud deskew");
       glim_amd_cloud_destroy(c);
@@ -246,7 +266,7 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
   build_deskew_table(n, times, T_imu_lidar12, n_imu, imu_times, imu_poses12, stamp, linear_vel3, angular_vel3, entry, TT);
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
-  return run_deskew(ctx, n, points4, nullptr, entry, TT, out);
+  return run_deskew(ctx, n, points4, nullptr, entry, TT, nullptr, out);
 }
 
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
@@ -263,18 +283,8 @@ int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   glim_amd_cloud* c = nullptr;
-  GA_TRY(run_deskew(ctx, n, nullptr, reinterpret_cast<const double*>(pre->pts64), entry, TT, &c));
-  if (pre->neighbors && n > 0) {  // the neighbour lists found on the raw scan are carried over (odometry_estimation_imu.cpp:320)
-    hipError_t e = pool_malloc(&c->neighbors, (size_t)n * pre->k * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(c->neighbors, pre->neighbors, (size_t)n * pre->k * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
-    if (e != hipSuccess) {
-      set_hip_error(e, "cloud_deskew(neighbors)");
-      glim_amd_cloud_destroy(c);
-      return GLIM_AMD_ERR_HIP;
-    }
-    c->k = pre->k;
-  }
+  // (the neighbour lists found on the raw scan are carried over: odometry_estimation_imu.cpp:320)
+  GA_TRY(run_deskew(ctx, n, nullptr, reinterpret_cast<const double*>(pre->pts64), entry, TT, pre, &c));
   *out = c;
   return GLIM_AMD_OK;
 }

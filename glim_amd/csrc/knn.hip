@@ -555,9 +555,12 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
 namespace glim_amd {
 
 // Hilbert rank of every point of a cloud that has none yet (clouds whose neighbours came from the host or from the grid path).
-// Caller holds ctx->mu.  Tiny clouds and clouds with non-finite points simply stay in arrival order.
+// Caller holds ctx->mu.  Clouds with non-finite points simply stay in arrival order, and so do clouds below 32 768 points: sorting a cloud
+// ONLY for its rank costs 70 us at 10 000 points, which GLIM's odometry would pay for every frame (the frame arrives with CPU covariances,
+// so no kNN runs here whose by-product the rank would be) to gain 0.5 us per 34-factor linearisation
+// (`bench.py --workload odometry_frame`, create_frame_us.factor_streams_on_first_use: 115 -> 44 us).
 int cloud_curve_rank(glim_amd_cloud* c, hipStream_t st) {
-  if (c->curve_rank || c->n < 4096 || c->n > (int64_t)(1 << 28) || !c->ctx->diag.curve_order) return GLIM_AMD_OK;
+  if (c->curve_rank || c->n < 32768 || c->n > (int64_t)(1 << 28) || !c->ctx->diag.curve_order) return GLIM_AMD_OK;
   GA_HIP(pool_malloc(&c->curve_rank, (size_t)c->n * sizeof(unsigned int)));
   const int rc = knn_curve(c->ctx, st, (int)c->n, c->pts, 0, nullptr, c->curve_rank);
   if (rc != GLIM_AMD_OK) {
