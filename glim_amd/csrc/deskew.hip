@@ -239,6 +239,7 @@ int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const doub
       if (e == hipSuccess) e = hipMemcpyAsync(c->curve_rank, carry->curve_rank, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    else (void)hipStreamSynchronize(s);  // (an upload that did get enqueued must not outlive its staging block)
     if (stage) (void)pinned_free(stage);
     if (e != hipSuccess) {
       set_hip_error(e, "cloud deskew");
