@@ -586,6 +586,26 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, name):
     np.testing.assert_array_equal(g.find_neighbors(10), ref)
 
 
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_knn_refuses_non_finite_points_and_the_context_survives(api, ctx, orc, bad):
+    """A non-finite coordinate is an error (GLIM_AMD_ERR_RANGE), found on the device: the bounding box never travels to the host, the chunk
+    kernels stand down behind their guard word.  The next call on the same context answers as usual."""
+    from glim_amd._lib import GlimAmdError
+
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-20, 20, (6000, 3)).astype(np.float32)
+    ref = orc.knn(pts.astype(np.float64), 10, method="brute")
+    broken = pts.copy()
+    broken[1234, 1] = bad
+    for variant in ("wave64", "pair"):
+        ctx.set_diag(f"knn_path=chunks,knn_kernel={variant}")
+        with pytest.raises(GlimAmdError) as err:
+            api.PointCloudGPU.clone(broken, ctx=ctx).find_neighbors(10)
+        assert err.value.code == -4
+        np.testing.assert_array_equal(api.PointCloudGPU.clone(pts, ctx=ctx).find_neighbors(10), ref)
+    ctx.set_diag("")
+
+
 def test_knn_threshold_selection_is_exact(api, ctx, orc):
     """The per-lane threshold selection of the chunk kernels (knn_chunks.hip; the default for k <= 10) must leave every neighbour list
     bit-identical: both kernels (64 queries per wavefront / pair lanes), k = 10 and k = 5 (the two list sizes it is instantiated for), with the
