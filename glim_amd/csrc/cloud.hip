@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4
 // synchronisations -- costs 140 us there, most of it fixed.  Here the host converts straight into the FP32 device layout (56 B per point, the
 // same round-to-nearest casts as pack_f64_kernel) in a pinned, device-mapped staging block, and ONE kernel pulls the block over PCIe into the
 // cloud's arrays and evaluates the plane-form predicate on the way (violations land in a word of the same block): one launch, one
-// synchronise, 79 us.  Above HOST_PACK_MAX_POINTS the runtime's pageable copy path (43 GB/s measured at 25 MB) beats a single host thread.
+// synchronise, 58 us (odometry_frame bench).  Above HOST_PACK_MAX_POINTS the runtime's pageable copy path (43 GB/s measured at 25 MB) beats a single host thread.
 constexpr int64_t HOST_PACK_MAX_POINTS = 32768;
 __global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __restrict__ s_pts, const float4* __restrict__ s_covA,
                                                       const float2* __restrict__ s_covB, const float4* __restrict__ s_nrm, float4* __restrict__ pts,
