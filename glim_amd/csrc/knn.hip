@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void curve_key_kernel(int n, const float4* __r
 // one wavefront per chunk: points in curve order (xyz + original index, index -1 and +inf coordinates past the end) and the chunk boxes
 __global__ __launch_bounds__(256) void curve_gather_kernel(int n, int C, const float4* __restrict__ pts, const unsigned int* __restrict__ order,
                                                            float4* __restrict__ sorted, float* __restrict__ box /* [C][6] */,
-                                                           unsigned int* __restrict__ rank) {
+                                                           float* __restrict__ box32 /* [2 C][6] or null */, unsigned int* __restrict__ rank) {
   const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (c >= C) return;
   const int s = c * CHUNK + lane;
@@ -441,13 +441,28 @@ __global__ __launch_bounds__(256) void curve_gather_kernel(int n, int C, const f
   }
   sorted[s] = q;
   float lo[3] = {q.x, q.y, q.z}, hi[3] = {s < n ? q.x : -inf, s < n ? q.y : -inf, s < n ? q.z : -inf};
+  // xor offsets <= 16 stay inside a 32-lane half: the boxes of the two 32-point half chunks (the pair-lane kNN kernel works on those,
+  // box32[2 c + half]) fall out of the same butterfly, one step before the chunk's own box
 #pragma unroll
   for (int a = 0; a < 3; a++)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 16; off >= 1; off >>= 1) {
       lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
       hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
     }
+  if (box32 && (lane & 31) == 0) {
+    const int h = 2 * c + (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      box32[6 * h + a] = lo[a];
+      box32[6 * h + 3 + a] = hi[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = fminf(lo[a], __shfl_xor(lo[a], 32, 64));
+    hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 32, 64));
+  }
   if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -457,29 +472,10 @@ __global__ __launch_bounds__(256) void curve_gather_kernel(int n, int C, const f
   }
 }
 
-// the same boxes per 32-point half chunk (the pair-lane kNN kernel works on 32-point chunks): box32[2 c + half]
-__global__ __launch_bounds__(256) void half_box_kernel(int n, int C, const float4* __restrict__ sorted, float* __restrict__ box32 /* [2 C][6] */) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (c >= C) return;
-  const int s = c * CHUNK + lane;
-  const float inf = __int_as_float(0x7f800000);
-  const float4 q = sorted[s];
-  float lo[3] = {q.x, q.y, q.z}, hi[3] = {s < n ? q.x : -inf, s < n ? q.y : -inf, s < n ? q.z : -inf};
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {  // xor offsets <= 16 stay inside a 32-lane half
-      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
-      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
-    }
-  if ((lane & 31) == 0) {
-    const int h = 2 * c + (lane >> 5);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      box32[6 * h + a] = lo[a];
-      box32[6 * h + 3 + a] = hi[a];
-    }
-  }
+// bounding-box accumulator (init_bbox_kernel's values) and the four status words of a kNN call, in one launch
+__global__ void knn_scratch_init_kernel(int* __restrict__ bb, int* __restrict__ stats) {
+  if (threadIdx.x < 6) bb[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (int)0x80000000;
+  if (threadIdx.x < 4) stats[threadIdx.x] = 0;
 }
 
 int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out, unsigned int* rank) {
@@ -494,8 +490,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(pool_malloc(&sorted.p, (size_t)C * CHUNK * sizeof(float4)));
   GA_HIP(pool_malloc(&box.p, ((size_t)C + (size_t)(C + CHUNK - 1) / CHUNK) * 6 * sizeof(float)));  // chunk boxes, then the boxes of the groups of 64 chunks
   GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
-  init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
-  GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
+  knn_scratch_init_kernel<<<1, 64, 0, st>>>(bb.as<int>(), stats.as<int>());
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, bb.as<int>());
   const int bits = n < 32768 ? 8 : 13;  // per axis: 24-bit keys / 3 sort passes for small clouds, 39 bits / 5 passes otherwise; the order only affects speed
   const unsigned int qmax = (1u << bits) - 1u;
@@ -504,10 +499,12 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   unsigned int* order = nullptr;
   GA_HIP(radix_sort_pairs(st, n, 3 * bits, ka.as<unsigned long long>(), va.as<unsigned int>(), kb.as<unsigned long long>(), vb.as<unsigned int>(), true,
                           hist.as<int>(), &ks, &order));
-  curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), rank);
   DeviceTemp dbg;
   const Diag& diag = ctx->diag;
   if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
+  const bool pair_lanes = !dbg.p && k > 0 && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
+  if (pair_lanes) GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
+  curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), box32.as<float>(), rank);
   // Which of the two chunk kernels: both are tail-bound -- the launch lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt
   // scan: mean wavefront 157 us, kernel 266 us; 41 % VALU utilisation) -- and the pair-lane kernel shortens the average wavefront by only ~18 %
   // for ~20-34 % more instructions (the lock-step insertion loop costs max-over-lanes rounds either way).  It wins where the 64-query kernel
@@ -520,11 +517,8 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   // The FP32 mask passes of both chunk kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than 1e18 m is
   // answered by the exhaustive FP64 kernel instead.
   const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
-  const bool pair_lanes = !dbg.p && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
   const int* guard = stats.as<int>() + 2;
-  if (k > 0 && pair_lanes) {
-    GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
-    half_box_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, sorted.as<float4>(), box32.as<float>());
+  if (pair_lanes) {
     knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select, guard);
     GA_HIP(hipGetLastError());
   } else if (k > 0) {
