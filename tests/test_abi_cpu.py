@@ -116,3 +116,18 @@ def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "glim_amd ABI version" in out.stdout
+
+
+def test_committed_traffic_files_were_measured_on_the_current_factor_kernel():
+    """bench.py quotes `roofline.traffic` from the committed PMC passes (the counters need rocprofv3 runs of their own); the files carry the
+    hash of the factor kernel's sources, and the newest one per workload must be the hash of the sources in the tree -- editing vgicp.hip /
+    device_math.hpp / internal.hpp / the Makefile without re-running tools/round_evidence.sh fails here, not silently on the bench line."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for tag in ("odometry128k", "global256"):
+        got = bench.measured_traffic(tag)
+        assert got is not None, tag
+        assert got[2], f"{got[1]} was measured on another version of the factor kernel ({tag})"
