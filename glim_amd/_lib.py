@@ -91,11 +91,11 @@ SYMBOLS = {
     "glim_amd_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
     "glim_amd_cloud_create": (_i, [_vp, _i64, _dp, _dp, _dp, _pp]),
     "glim_amd_cloud_create_f32": (_i, [_vp, _i64, _fp, _fp, _fp, _pp]),
-    "glim_amd_cloud_create_deskewed": (_i, [_vp, _i64, _dp, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_cloud_create_deskewed": (_i, [_vp, _i64, _dp, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _i32, _pp]),
     "glim_amd_preprocess_default_params": (_i, [C.POINTER(PreprocessParams)]),
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
-    "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _pp]),
+    "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _i32, _pp]),
     "glim_amd_cloud_save_compact": (_i, [_vp, C.c_char_p]),
     "glim_amd_cloud_load_compact": (_i, [_vp, C.c_char_p, _pp]),
     "glim_amd_nn_index_create": (_i, [_vp, _d, _pp]),

@@ -149,9 +149,11 @@ class PointCloudGPU:
         return PointCloudGPU(h, ctx)
 
     @staticmethod
-    def clone_deskewed(points, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None, ctx=None):
+    def clone_deskewed(points, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None, ctx=None,
+                       to_imu_frame=False):
         """CloudDeskewing::deskew (cloud_deskewing.cpp) fused with PointCloudGPU::clone: IMU-pose form when imu_times / imu_poses are
-        given, constant-velocity form otherwise."""
+        given, constant-velocity form otherwise.  to_imu_frame: also apply `pt = T_imu_lidar * pt` (odometry_estimation_imu.cpp:314-316),
+        the step both reference callers take before estimating covariances."""
         ctx = ctx or default_context()
         points = np.asarray(points, dtype=np.float64)
         n = points.shape[0]
@@ -169,7 +171,7 @@ class PointCloudGPU:
         av = None if angular_vel is None else np.ascontiguousarray(angular_vel, dtype=np.float64)
         h = C.c_void_p()
         check(lib().glim_amd_cloud_create_deskewed(ctx._h, n, _dp(p4), _dp(t), _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av),
-                                                   C.byref(h)), "glim_amd_cloud_create_deskewed")
+                                                   int(bool(to_imu_frame)), C.byref(h)), "glim_amd_cloud_create_deskewed")
         return PointCloudGPU(h, ctx)
 
     @staticmethod
@@ -222,8 +224,15 @@ class PointCloudGPU:
         check(lib().glim_amd_cloud_download_merged(self._h, _dp(p4), _dp(c16)), "glim_amd_cloud_download_merged")
         return p4[:, :3].copy(), np.transpose(c16.reshape(n, 4, 4)[:, :3, :3], (0, 2, 1)).copy()
 
-    def deskew(self, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None):
-        """CloudDeskewing::deskew of a preprocessed cloud that is already on the device; the raw-scan neighbours are carried over."""
+    def download_points64(self):
+        """The exact FP64 points a preprocessed / deskewed / merged cloud keeps next to its FP32 image (N x 3)."""
+        p4 = np.zeros((self.size(), 4))
+        check(lib().glim_amd_cloud_download_frame(self._h, _dp(p4), None, None, None), "glim_amd_cloud_download_frame")
+        return p4[:, :3].copy()
+
+    def deskew(self, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=None, angular_vel=None, to_imu_frame=False):
+        """CloudDeskewing::deskew of a preprocessed cloud that is already on the device; the raw-scan neighbours are carried over.
+        to_imu_frame: followed by `pt = T_imu_lidar * pt` (odometry_estimation_imu.cpp:314-316, sub_mapping.cpp:368-370)."""
         Til = pose12(T_imu_lidar)
         it = ip = None
         n_imu = 0
@@ -234,7 +243,8 @@ class PointCloudGPU:
         lv = None if linear_vel is None else np.ascontiguousarray(linear_vel, dtype=np.float64)
         av = None if angular_vel is None else np.ascontiguousarray(angular_vel, dtype=np.float64)
         h = C.c_void_p()
-        check(lib().glim_amd_cloud_deskew(self._h, _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av), C.byref(h)), "glim_amd_cloud_deskew")
+        check(lib().glim_amd_cloud_deskew(self._h, _dp(Til), n_imu, _dp(it), _dp(ip), float(stamp), _dp(lv), _dp(av), int(bool(to_imu_frame)), C.byref(h)),
+              "glim_amd_cloud_deskew")
         g = PointCloudGPU(h, self.ctx)
         g._k = getattr(self, "_k", 0)
         return g

@@ -54,7 +54,7 @@ __device__ __forceinline__ V3 extract_kernel(const V3& c0, const V3& c1, const V
 // eigenvector of the smallest eigenvalue of the symmetric matrix (m00 m01 m02 m11 m12 m22), computeDirect semantics.
 __device__ V3 smallest_eigenvector(double m00, double m01, double m02, double m11, double m12, double m22) {
   const double eps = 2.220446049250313e-16;
-  const double shift = (m00 + m11 + m22) / 3.0;
+  const double shift = (m00 + (m11 + m22)) / 3.0;  // Eigen's trace(): a0 + (a1 + a2)
   m00 -= shift; m11 -= shift; m22 -= shift;
   double scale = fmax(fmax(fabs(m00), fabs(m11)), fmax(fabs(m22), fmax(fabs(m01), fmax(fabs(m02), fabs(m12)))));
   if (scale > 0.0) {
@@ -96,7 +96,12 @@ __device__ V3 smallest_eigenvector(double m00, double m01, double m02, double m1
   return extract_kernel(k0, k1, k2, rep);
 }
 
-__global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __restrict__ pts, const int32_t* __restrict__ nbrs, int k_corr,
+// FP64_POINTS: the cloud keeps the exact FP64 points its FP32 image was rounded from (preprocessed, deskewed and merged clouds: pts64) and
+// the sums are taken over THOSE, as the reference estimates from the FP64 deskewed points (odometry_estimation_imu.cpp:320,
+// sub_mapping.cpp:374); a cloud uploaded through PointCloudGPU::clone is an FP32 object in the reference too and is read as such.
+template <bool FP64_POINTS>
+__global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __restrict__ pts, const double4* __restrict__ pts64,
+                                                         const int32_t* __restrict__ nbrs, int k_corr,
                                                          int k_nbr, float4* __restrict__ covA, float2* __restrict__ covB,
                                                          float4* __restrict__ normals, float4* __restrict__ pn4, float2* __restrict__ n2,
                                                          const unsigned int* __restrict__ rank) {
@@ -105,8 +110,14 @@ __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __
   double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
   const int32_t* row = nbrs + (size_t)k_corr * i;
   for (int j = 0; j < k_nbr; j++) {
-    const float4 p = pts[row[j]];
-    const double x = p.x, y = p.y, z = p.z;
+    double x, y, z;
+    if (FP64_POINTS) {
+      const double4 p = pts64[row[j]];
+      x = p.x; y = p.y; z = p.z;
+    } else {
+      const float4 p = pts[row[j]];
+      x = p.x; y = p.y; z = p.z;
+    }
     sx += x; sy += y; sz += z;
     sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
   }
@@ -122,7 +133,12 @@ __global__ __launch_bounds__(256) void covariance_kernel(int n, const float4* __
   covA[i] = make_float4((float)(1.0 - w * e.x * e.x), (float)(-w * e.x * e.y), (float)(-w * e.x * e.z), (float)(1.0 - w * e.y * e.y));
   covB[i] = make_float2((float)(-w * e.y * e.z), (float)(1.0 - w * e.z * e.z));
   const float4 p = pts[i];
-  if ((double)p.x * e.x + (double)p.y * e.y + (double)p.z * e.z > 0.0) {
+  double px = p.x, py = p.y, pz = p.z;
+  if (FP64_POINTS) {
+    const double4 q = pts64[i];
+    px = q.x; py = q.y; pz = q.z;
+  }
+  if (px * e.x + py * e.y + pz * e.z > 0.0) {  // :98-101  points[i].dot(normal) > 0 -> flip
     e.x = -e.x; e.y = -e.y; e.z = -e.z;
   }
   normals[i] = make_float4((float)e.x, (float)e.y, (float)e.z, 0.0f);
@@ -162,7 +178,12 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (c->n > 0) {
     const int n = (int)c->n;
     GA_TRY(cloud_curve_rank(c, ctx->stream()));
-    covariance_kernel<<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals, c->pn4, c->n2, c->curve_rank);
+    if (c->pts64)
+      covariance_kernel<true><<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->pts64, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals,
+                                                                          c->pn4, c->n2, c->curve_rank);
+    else
+      covariance_kernel<false><<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, nullptr, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals,
+                                                                           c->pn4, c->n2, c->curve_rank);
     GA_HIP(hipGetLastError());
     GA_HIP(hipStreamSynchronize(ctx->stream()));
   }

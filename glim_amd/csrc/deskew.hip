@@ -1,8 +1,10 @@
 // deskew.hip -- motion-undistortion of a scan fused with the device upload.
 // Replaces glim::CloudDeskewing::deskew (src/glim/common/cloud_deskewing.cpp:11-53 constant velocity, :55-133 IMU poses) as
 // called between preprocessing and covariance estimation (src/glim/odometry/odometry_estimation_imu.cpp:313-316,
-// src/glim/mapping/sub_mapping.cpp:356-372) followed by PointCloudGPU::clone: one kernel reads the raw Vector4d points and
-// writes the deskewed FP32 SoA cloud, so the deskewed FP64 copy never exists on the host.
+// src/glim/mapping/sub_mapping.cpp:356-372), fused with the step both callers take next -- every deskewed point moved into the IMU frame,
+// `pt = T_imu_lidar * pt` (odometry_estimation_imu.cpp:314-316, sub_mapping.cpp:368-370) -- and with PointCloudGPU::clone: one kernel reads
+// the raw Vector4d points and writes the deskewed cloud (exact FP64 points for the covariance kernel + their FP32 image for the factor path),
+// so the deskewed FP64 copy never exists on the host.
 //
 // The reference quantises time into a table (a new entry whenever a point is more than 0.1 ms after the last entry, :24-36,
 // :72-84) and computes ONE rigid transform T_lidar0_lidar1 per entry; every point is moved by the transform of its entry.
@@ -76,7 +78,7 @@ void quat_from_rot(const Pose& T, double* q) {
   double m[3][3];
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) m[r][c] = T.m[4 * r + c];
-  double t = m[0][0] + m[1][1] + m[2][2];
+  double t = m[0][0] + (m[1][1] + m[2][2]);  // Eigen's trace(): a0 + (a1 + a2)
   if (t > 0.0) {
     t = std::sqrt(t + 1.0);
     q[3] = 0.5 * t;
@@ -124,18 +126,31 @@ void quat_to_rot(const double* q, double* R) {
   R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
 }
 
-// one thread per point: q = T[entry(i)] p  in FP64, packed to the FP32 SoA cloud
+// Eigen::Isometry3d * Eigen::Vector4d as the oracle states it: three 4-term sums with separate roundings (no FMA contraction), w copied
+__device__ __forceinline__ double4 apply_pose(const double* __restrict__ T, const double4 p) {
+  double4 q;
+  q.x = dadd(dadd(dadd(dmul(T[0], p.x), dmul(T[1], p.y)), dmul(T[2], p.z)), dmul(T[3], p.w));
+  q.y = dadd(dadd(dadd(dmul(T[4], p.x), dmul(T[5], p.y)), dmul(T[6], p.z)), dmul(T[7], p.w));
+  q.z = dadd(dadd(dadd(dmul(T[8], p.x), dmul(T[9], p.y)), dmul(T[10], p.z)), dmul(T[11], p.w));
+  q.w = p.w;
+  return q;
+}
+
+// one thread per point: q = T[entry(i)] p in FP64 (cloud_deskewing.cpp:47-51, :127-130) and -- IMU_FRAME -- q = T_imu_lidar q as a SECOND
+// FP64 product with its own roundings, which is what both callers do to every deskewed point before they estimate covariances
+// (odometry_estimation_imu.cpp:314-316 `pt = T_imu_lidar * pt`, sub_mapping.cpp:368-370).  The exact FP64 result is kept (pts64: the
+// covariance kernel reads it, as the reference estimates from the FP64 deskewed points, :320 / :374) next to its FP32 image for the factor path.
+template <bool IMU_FRAME>
 __global__ __launch_bounds__(256) void deskew_pack_kernel(int64_t n, const double* __restrict__ points4, const int* __restrict__ entry,
-                                                          const double* __restrict__ table, float4* __restrict__ pts) {
+                                                          const double* __restrict__ table, const double* __restrict__ T_imu_lidar,
+                                                          float4* __restrict__ pts, double4* __restrict__ pts64) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double4 p = reinterpret_cast<const double4*>(points4)[i];
-  const double* T = table + 12 * (size_t)entry[i];
-  // the oracle's expression with separate roundings (no FMA contraction): bit-identical FP64 result before the FP32 pack
-  const double x = dadd(dadd(dadd(dmul(T[0], p.x), dmul(T[1], p.y)), dmul(T[2], p.z)), dmul(T[3], p.w));
-  const double y = dadd(dadd(dadd(dmul(T[4], p.x), dmul(T[5], p.y)), dmul(T[6], p.z)), dmul(T[7], p.w));
-  const double z = dadd(dadd(dadd(dmul(T[8], p.x), dmul(T[9], p.y)), dmul(T[10], p.z)), dmul(T[11], p.w));
-  pts[i] = make_float4((float)x, (float)y, (float)z, 1.0f);
+  double4 q = apply_pose(table + 12 * (size_t)entry[i], p);
+  if (IMU_FRAME) q = apply_pose(T_imu_lidar, q);
+  pts64[i] = q;
+  pts[i] = make_float4((float)q.x, (float)q.y, (float)q.z, 1.0f);
 }
 
 // host: time table + one transform per entry (cloud_deskewing.cpp:22-45 / :70-124)
@@ -193,12 +208,14 @@ void build_deskew_table(int64_t n, const double* times, const double* T_imu_lida
 // device: (upload the raw points unless they are already resident,) entry indices and the table; transform + pack.
 // Caller holds ctx->mu.
 // carry: a preprocessed cloud whose neighbour lists the result takes over (copied on the device before the one synchronise of this call), or null
+// imu_frame: 12 doubles (T_imu_lidar) to move the deskewed points on into the IMU frame, or null to leave them in the LiDAR frame
 int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const double* d_points4, const std::vector<int>& entry, const std::vector<Pose>& TT,
-               const glim_amd_cloud* carry, glim_amd_cloud** out) {
+               const double* imu_frame, const glim_amd_cloud* carry, glim_amd_cloud** out) {
   glim_amd_cloud* c = new glim_amd_cloud();
   c->ctx = ctx;
   c->n = n;
   hipError_t e = pool_malloc(&c->pts, (size_t)(n > 0 ? n : 1) * sizeof(float4));
+  if (e == hipSuccess) e = pool_malloc(&c->pts64, (size_t)(n > 0 ? n : 1) * sizeof(double4));
   if (e != hipSuccess) {
     set_hip_error(e, "pool_malloc(deskewed cloud)");
     delete c;
@@ -212,19 +229,23 @@ int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const doub
       if (e == hipSuccess) e = hipMemcpyAsync(dp.p, h_points4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, s);
       d_points4 = (const double*)dp.p;
     }
-    // table and per-point entries travel in ONE pinned block (two pageable copies are staged by the runtime one after the other)
-    const size_t entry_bytes = ((size_t)n * sizeof(int) + 63) & ~(size_t)63, table_bytes = TT.size() * sizeof(Pose);
+    // table (+ the extrinsic) and per-point entries travel in ONE pinned block (two pageable copies are staged by the runtime one after the other)
+    const size_t entry_bytes = ((size_t)n * sizeof(int) + 63) & ~(size_t)63, table_bytes = (TT.size() + 1) * sizeof(Pose);
     char* stage = nullptr;
     DeviceTemp dev;
     if (e == hipSuccess) e = pool_malloc(&dev.p, entry_bytes + table_bytes);
     if (e == hipSuccess) e = pinned_malloc(&stage, entry_bytes + table_bytes);
     if (e == hipSuccess) {
       memcpy(stage, entry.data(), (size_t)n * sizeof(int));
-      memcpy(stage + entry_bytes, TT.data(), table_bytes);
+      memcpy(stage + entry_bytes, TT.data(), TT.size() * sizeof(Pose));
+      if (imu_frame) memcpy(stage + entry_bytes + TT.size() * sizeof(Pose), imu_frame, sizeof(Pose));
       e = hipMemcpyAsync(dev.p, stage, entry_bytes + table_bytes, hipMemcpyHostToDevice, s);
     }
     if (e == hipSuccess) {
-      deskew_pack_kernel<<<(unsigned int)((n + 255) / 256), 256, 0, s>>>(n, d_points4, (const int*)dev.p, (const double*)((const char*)dev.p + entry_bytes), c->pts);
+      const double* d_table = (const double*)((const char*)dev.p + entry_bytes);
+      const unsigned int grid = (unsigned int)((n + 255) / 256);
+      if (imu_frame) deskew_pack_kernel<true><<<grid, 256, 0, s>>>(n, d_points4, (const int*)dev.p, d_table, d_table + 12 * TT.size(), c->pts, c->pts64);
+      else deskew_pack_kernel<false><<<grid, 256, 0, s>>>(n, d_points4, (const int*)dev.p, d_table, nullptr, c->pts, c->pts64);
       e = hipGetLastError();
     }
     if (e == hipSuccess && carry && carry->neighbors) {
@@ -257,7 +278,7 @@ extern "C" {
 
 int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
                                    int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
-                                   const double* angular_vel3, glim_amd_cloud** out) {
+                                   const double* angular_vel3, int32_t to_imu_frame, glim_amd_cloud** out) {
   if (!ctx || !out || n < 0 || !T_imu_lidar12 || (n > 0 && (!points4 || !times))) return GLIM_AMD_ERR_INVALID;
   if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
   *out = nullptr;
@@ -267,11 +288,11 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
   build_deskew_table(n, times, T_imu_lidar12, n_imu, imu_times, imu_poses12, stamp, linear_vel3, angular_vel3, entry, TT);
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
-  return run_deskew(ctx, n, points4, nullptr, entry, TT, nullptr, out);
+  return run_deskew(ctx, n, points4, nullptr, entry, TT, to_imu_frame ? T_imu_lidar12 : nullptr, nullptr, out);
 }
 
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
-                          double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out) {
+                          double stamp, const double* linear_vel3, const double* angular_vel3, int32_t to_imu_frame, glim_amd_cloud** out) {
   if (!pre || !out || !T_imu_lidar12) return GLIM_AMD_ERR_INVALID;
   if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
   *out = nullptr;
@@ -285,7 +306,7 @@ int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12
   GA_HIP(hipSetDevice(ctx->device));
   glim_amd_cloud* c = nullptr;
   // (the neighbour lists found on the raw scan are carried over: odometry_estimation_imu.cpp:320)
-  GA_TRY(run_deskew(ctx, n, nullptr, reinterpret_cast<const double*>(pre->pts64), entry, TT, pre, &c));
+  GA_TRY(run_deskew(ctx, n, nullptr, reinterpret_cast<const double*>(pre->pts64), entry, TT, to_imu_frame ? T_imu_lidar12 : nullptr, pre, &c));
   *out = c;
   return GLIM_AMD_OK;
 }

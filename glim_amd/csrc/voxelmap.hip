@@ -396,10 +396,12 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (h.first == res_class) expected_ratio = h.second;
   const bool direct_small = n > 0 && n <= DIRECT_MAX_POINTS;
   const bool direct_large = n > DIRECT_MAX_POINTS && expected_ratio > 0.0;
-  if (!old && (direct_small || direct_large) && ctx->diag.bucket_factor == 0) {
+  // (`do { ... } while (0)`: a direct build that turns out unsuitable -- table request beyond the 2^25-bucket addressing limit, or a table that
+  //  came out too full because the density hint was stale -- `break`s out and the counting path below builds the map instead)
+  if (!old && (direct_small || direct_large) && ctx->diag.bucket_factor == 0) do {
     const unsigned long long want = direct_small ? 2ull * (unsigned long long)n
                                                  : std::max<unsigned long long>((unsigned long long)n / 2 + 1, (unsigned long long)(6.0 * expected_ratio * (double)n));
-    if (want > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
+    if (want > (1ull << 25)) break;  // the counting path sizes the table from the voxels actually present (few voxels of a huge cloud still fit)
     const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, want));
     VoxelBucket* buckets = nullptr;
     GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
@@ -431,14 +433,25 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       (void)pool_free(buckets);
       return GLIM_AMD_ERR_RANGE;
     }
+    remember_voxel_ratio(ctx, res_class, (double)h_stats[0] / (double)n);
+    // A stale hint (the previous map at this resolution was dense, this cloud is sparse -- e.g. already downsampled at about the voxel size)
+    // leaves the floor of N / 2 buckets, one way per point, 80-100 % full: lookups stay correct but every miss walks hundreds of buckets, for
+    // the whole life of the map.  Above 0.35 keys per way the table is rebuilt by the counting path (6 buckets per voxel actually present).
+    if (direct_large && (double)h_stats[0] > 0.35 * 2.0 * (double)nb) {
+      (void)pool_free(buckets);
+      (void)pool_free(stats.p);
+      stats.p = nullptr;
+      (void)pool_free(acc.p);
+      acc.p = nullptr;
+      break;
+    }
     m->buckets = buckets;
     m->num_buckets = nb;
     m->num_voxels = h_stats[0];
     m->uid = next_uid();
     ctx->mutation_epoch++;
-    remember_voxel_ratio(ctx, res_class, (double)h_stats[0] / (double)n);
     return GLIM_AMD_OK;
-  }
+  } while (0);
   const unsigned int tsize0 = next_pow2((unsigned long long)std::max<long long>(32, (long long)n + (old ? (long long)m->num_voxels : 0ll)) * 2);
   GA_HIP(pool_malloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
   GA_HIP(pool_malloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));

@@ -115,10 +115,17 @@ int glim_amd_cloud_load_compact(glim_amd_ctx* ctx, const char* dir, glim_amd_clo
  * velocity: n_imu == 0, linear_vel3 / angular_vel3, NULL = zero) and :55-133 (IMU poses: imu_times[n_imu], imu_poses12[n_imu x 12]
  * = T_world_imu row-major 3x4, `stamp` = scan start time), as called at src/glim/odometry/odometry_estimation_imu.cpp:313-316.
  * points4: n x Vector4d, times: n per-point offsets from the scan start (as the preprocessor leaves them: ascending), T_imu_lidar12:
- * extrinsic.  The result is a device cloud of the deskewed points (no covariances yet). */
+ * extrinsic.
+ * to_imu_frame != 0 fuses the step BOTH reference callers take next: every deskewed point is moved into the IMU frame,
+ * `pt = T_imu_lidar * pt` (odometry_estimation_imu.cpp:314-316; sub_mapping.cpp:368-370 with T_lidar_imu.inverse()), as a second FP64
+ * product with its own roundings, BEFORE the covariances are estimated (:320 / :374) -- so normals face the IMU-frame origin
+ * (cloud_covariance_estimation.cpp:98-101) and every voxel map / factor built from the cloud lives in the IMU frame, as in GLIM.
+ * to_imu_frame == 0 returns exactly CloudDeskewing::deskew's value (LiDAR frame).
+ * The result is a device cloud of the deskewed points -- the exact FP64 values (what glim_amd_cloud_estimate_covariances reads and
+ * glim_amd_cloud_download_frame returns) and their FP32 image for the factor path; no covariances yet. */
 int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
                                    int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
-                                   const double* angular_vel3, glim_amd_cloud** out);
+                                   const double* angular_vel3, int32_t to_imu_frame, glim_amd_cloud** out);
 
 /* ---- scan preprocessing on device: CloudPreprocessor::preprocess_impl,
  * src/glim/preprocess/cloud_preprocessor.cpp:92-188 -- downsampling (gtsam_points::randomgrid_sampling / voxelgrid_sampling,
@@ -150,11 +157,12 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n, const double* points4, con
 /* PreprocessedFrame fields of a preprocessed cloud back on the host; any pointer may be NULL.  points4 n x 4 (w = 1), times n,
  * intensities n (GLIM_AMD_ERR_STATE if the scan had none), neighbors n x k. */
 int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, double* times, double* intensities, int32_t* neighbors);
-/* CloudDeskewing::deskew applied to a preprocessed cloud that is already on the device (same arguments as
- * glim_amd_cloud_create_deskewed).  The new cloud shares nothing with `pre`; the neighbour lists found on the raw scan are
- * carried over, as the reference does (odometry_estimation_imu.cpp:313-320: deskew, then covariances from raw_frame->neighbors). */
+/* CloudDeskewing::deskew (+ the IMU-frame step when to_imu_frame != 0) applied to a preprocessed cloud that is already on the device
+ * (same arguments as glim_amd_cloud_create_deskewed).  The new cloud shares nothing with `pre`; the neighbour lists found on the raw scan
+ * are carried over, as the reference does (odometry_estimation_imu.cpp:313-320: deskew, IMU frame, then covariances from raw_frame->neighbors). */
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
-                          const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, glim_amd_cloud** out);
+                          const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, int32_t to_imu_frame,
+                          glim_amd_cloud** out);
 /* ---- GICP factor on device: gtsam_points::IntegratedGICPFactor -- nearest-neighbour correspondences instead
  * of a voxel lookup -- as constructed at src/glim/mapping/sub_mapping.cpp:202 (between factors, one linearize, :203),
  * src/glim/mapping/global_mapping.cpp:400-402 (set_max_correspondence_distance(0.5), 10 LM iterations) and

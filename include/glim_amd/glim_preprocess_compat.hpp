@@ -5,8 +5,9 @@
 //
 //   glim_amd::CloudPreprocessor preprocessor(params);                       // glim_ros / offline tools construct it from the config
 //   auto frame = preprocessor.preprocess(raw_points);                        // PreprocessedFrame: times, points, intensities, neighbors
-//   auto deskewed = deskewing.deskew(frame, T_imu_lidar, imu_times, imu_poses, raw->stamp);   // odometry_estimation_imu.cpp:313
-//   deskewed->estimate_covariances(k);                                      // :320  (neighbours of the raw scan, carried over)
+//   auto deskewed = deskewing.deskew(frame, T_imu_lidar, imu_times, imu_poses, raw->stamp, CloudDeskewing::Frame::IMU);
+//                                                                            // odometry_estimation_imu.cpp:313-316: deskew + `pt = T_imu_lidar * pt`
+//   deskewed->estimate_covariances(k);                                      // :320  (neighbours of the raw scan, carried over; FP64 points)
 //
 // Differences from the reference, all on purpose:
 //   * the preprocessed cloud also stays on the device (PreprocessedFrame::gpu), so deskewing, covariance estimation, the voxel map
@@ -151,21 +152,31 @@ private:
 
 // glim::CloudDeskewing (cloud_deskewing.hpp:11-54): both forms, applied to the device-resident preprocessed frame; the result is
 // the deskewed device cloud with the raw scan's neighbour lists, ready for estimate_covariances() (odometry_estimation_imu.cpp:313-320).
+//
+// `out` (no default: the call site has to say it): which frame the result is expressed in.  CloudDeskewing::deskew itself returns LiDAR-frame
+// points (Frame::LIDAR), and BOTH of its callers move every point into the IMU frame right away -- `for (auto& pt : deskewed) pt =
+// T_imu_lidar * pt;` (odometry_estimation_imu.cpp:314-316, sub_mapping.cpp:368-370) -- BEFORE they estimate covariances: Frame::IMU fuses that
+// loop into the deskewing kernel as a second FP64 product, and is what a port of those two call sites must pass (the result is a device
+// cloud, so the host loop cannot run on it afterwards; with Frame::LIDAR the normals would face the LiDAR origin and every map / factor built
+// from the cloud would live in the LiDAR frame).
 class CloudDeskewing {
 public:
-  PointCloudGPU::Ptr deskew(const PreprocessedFrame& frame, const Isometry3d& T_imu_lidar, const Vector3d& linear_vel, const Vector3d& angular_vel) const {
+  enum class Frame { LIDAR = 0, IMU = 1 };
+  PointCloudGPU::Ptr deskew(const PreprocessedFrame& frame, const Isometry3d& T_imu_lidar, const Vector3d& linear_vel, const Vector3d& angular_vel,
+                            Frame out) const {
     glim_amd_cloud* h = nullptr;
-    check(glim_amd_cloud_deskew(frame.gpu->handle(), T_imu_lidar.m.data(), 0, nullptr, nullptr, 0.0, linear_vel.data(), angular_vel.data(), &h),
+    check(glim_amd_cloud_deskew(frame.gpu->handle(), T_imu_lidar.m.data(), 0, nullptr, nullptr, 0.0, linear_vel.data(), angular_vel.data(),
+                                out == Frame::IMU ? 1 : 0, &h),
           "CloudDeskewing::deskew");
     return adopt_cloud(h, frame.gpu->context());
   }
   PointCloudGPU::Ptr deskew(const PreprocessedFrame& frame, const Isometry3d& T_imu_lidar, const std::vector<double>& imu_times,
-                            const std::vector<Isometry3d>& imu_poses, double stamp) const {
+                            const std::vector<Isometry3d>& imu_poses, double stamp, Frame out) const {
     std::vector<double> poses(12 * imu_poses.size());
     for (std::size_t i = 0; i < imu_poses.size(); i++) std::memcpy(&poses[12 * i], imu_poses[i].m.data(), 12 * sizeof(double));
     glim_amd_cloud* h = nullptr;
     check(glim_amd_cloud_deskew(frame.gpu->handle(), T_imu_lidar.m.data(), (std::int32_t)imu_times.size(), imu_times.data(), poses.data(), stamp, nullptr,
-                                nullptr, &h),
+                                nullptr, out == Frame::IMU ? 1 : 0, &h),
           "CloudDeskewing::deskew");
     return adopt_cloud(h, frame.gpu->context());
   }

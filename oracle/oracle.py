@@ -52,6 +52,9 @@ def ref_lib():
         L.ref_covariance_estimate.argtypes = [dp, C.c_int, ip, C.c_int, C.c_int, dp, dp, C.c_int]
         L.ref_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
         L.ref_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
+        if hasattr(L, "ref_frontend"):
+            L.ref_frontend.restype = C.c_int
+            L.ref_frontend.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, dp, dp, C.c_int, ip, C.c_int, C.c_int, dp, dp, dp, C.c_int]
         if hasattr(L, "ref_preprocess"):
             L.ref_preprocess.restype = C.c_int
             L.ref_preprocess.argtypes = [dp, dp, dp, C.c_int, C.POINTER(PreprocessParams), dp, dp, dp, ip, dp, C.c_int]
@@ -160,6 +163,8 @@ def lib():
         L.orc_gn_align.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int, C.c_double, C.c_int, dp]
         L.orc_deskew_constvel.restype = C.c_int
         L.orc_deskew_constvel.argtypes = [dp, dp, dp, dp, dp, C.c_int, dp]
+        L.orc_transform_points.restype = C.c_int
+        L.orc_transform_points.argtypes = [dp, dp, C.c_int, dp]
         L.orc_deskew_imu.restype = C.c_int
         L.orc_deskew_imu.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp, dp, C.c_int, dp]
         pp = C.POINTER(PreprocessParams)
@@ -411,6 +416,48 @@ def vgicp_linearize(vmap, src_xyz, src_covs33, delta, num_threads=0, want_corr=F
     return out
 
 
+def vgicp_linearize_sv(vmap, src_xyz, src_covs33, src_normals, delta, force=None, num_threads=0, want_corr=False):
+    """orc_vgicp_linearize_sv: the factor with surface validation ON (predicate of DESIGN.md 4.8, FP64; upstream unverified).  Returns the
+    linearisation dict plus `s` (the per-point predicate value (R n) . q; a point is dropped when s > 0) and, on request, `corr`."""
+    p4, c16 = points4(src_xyz), covs16(src_covs33)
+    n4 = np.zeros_like(p4)
+    n4[:, :3] = np.asarray(src_normals, dtype=np.float64)
+    n = p4.shape[0]
+    L = Linearized6()
+    corr = np.zeros((n, 4), dtype=np.int32) if want_corr else None
+    s = np.zeros(n)
+    f = None if force is None else np.ascontiguousarray(force, dtype=np.int8)
+    fn = lib().orc_vgicp_linearize_sv
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int8),
+                   C.c_int, C.POINTER(Linearized6), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    rc = fn(vmap._h, _dp(p4), _dp(c16), _dp(n4), n, _dp(pose12(delta)), f.ctypes.data_as(C.POINTER(C.c_int8)) if f is not None else None, num_threads,
+            C.byref(L), _ip(corr) if want_corr else None, _dp(s))
+    if rc != 0:
+        raise ValueError("orc_vgicp_linearize_sv failed")
+    out = _lin_to_dict(L)
+    out["s"] = s
+    if want_corr:
+        out["corr"] = corr
+    return out
+
+
+def vgicp_error_frozen_sv(vmap, src_xyz, src_covs33, src_normals, delta_lin, delta_eval, force=None, num_threads=0):
+    """error at delta_eval over the correspondences (voxel hit AND surface validation) frozen at delta_lin; returns (error, inliers)."""
+    p4, c16 = points4(src_xyz), covs16(src_covs33)
+    n4 = np.zeros_like(p4)
+    n4[:, :3] = np.asarray(src_normals, dtype=np.float64)
+    f = None if force is None else np.ascontiguousarray(force, dtype=np.int8)
+    fn = lib().orc_vgicp_error_frozen_sv
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                   C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_int64)]
+    ninl = C.c_int64()
+    e = fn(vmap._h, _dp(p4), _dp(c16), _dp(n4), p4.shape[0], _dp(pose12(delta_lin)), _dp(pose12(delta_eval)),
+           f.ctypes.data_as(C.POINTER(C.c_int8)) if f is not None else None, num_threads, C.byref(ninl))
+    return float(e), int(ninl.value)
+
+
 def vgicp_error(vmap, src_xyz, src_covs33, delta, num_threads=0, delta_lin=None):
     p4 = points4(src_xyz)
     c16 = covs16(src_covs33)
@@ -472,6 +519,44 @@ def deskew(points_xyz, times, T_imu_lidar, imu_times=None, imu_poses=None, stamp
         lv, av = _f64(linear_vel, (3,)), _f64(angular_vel, (3,))
         f_cv(_dp(Til), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _dp(out))
     return out[:, :3].copy()
+
+
+def transform_points(T, points_xyz):
+    """`pt = T * pt` for every point (Isometry3d * Vector4d): the IMU-frame step after deskewing (odometry_estimation_imu.cpp:314-316)."""
+    p4 = points4(points_xyz)
+    out = np.zeros_like(p4)
+    lib().orc_transform_points(_dp(pose12(T)), _dp(p4), p4.shape[0], _dp(out))
+    return out[:, :3].copy()
+
+
+def frontend(points_xyz, times, neighbors, T_imu_lidar, imu_times=None, imu_poses=None, stamp=0.0, linear_vel=(0, 0, 0), angular_vel=(0, 0, 0),
+             to_imu_frame=True, ref=False, num_threads=0):
+    """The chain between preprocessing and create_frame (odometry_estimation_imu.cpp:313-320): deskew -> pt = T_imu_lidar * pt -> covariance
+    estimation from the RAW scan's neighbours, on FP64 points throughout.  Returns (points N x 3, normals N x 3, covs N x 3 x 3).
+    ref=True: the three steps on the reference's own compiled objects (oracle/_ref `ref_frontend`); otherwise the restatement's functions."""
+    nb = np.ascontiguousarray(neighbors, dtype=np.int32)
+    n, k = nb.shape
+    if ref:
+        p4 = points4(points_xyz)
+        t = _f64(times, (n,))
+        op, on, oc = np.zeros((n, 4)), np.zeros((n, 4)), np.zeros((n, 16))
+        if imu_times is not None and len(imu_times) > 0:
+            it = _f64(imu_times, (-1,))
+            ip = np.ascontiguousarray(np.stack([pose12(P) for P in imu_poses]))
+            n_imu, lv, av = len(it), np.zeros(3), np.zeros(3)
+        else:
+            it, ip, n_imu = np.zeros(1), np.zeros((1, 12)), -1
+            lv, av = _f64(linear_vel, (3,)), _f64(angular_vel, (3,))
+        rc = ref_lib().ref_frontend(_dp(pose12(T_imu_lidar)), _dp(it), _dp(ip), n_imu, float(stamp), _dp(lv), _dp(av), _dp(t), _dp(p4), n, _ip(nb), k,
+                                    int(bool(to_imu_frame)), _dp(op), _dp(on), _dp(oc), int(num_threads))
+        if rc != 0:
+            raise ValueError("ref_frontend failed")
+        return op[:, :3].copy(), on[:, :3].copy(), covs33(oc)
+    d = deskew(points_xyz, times, T_imu_lidar, imu_times=imu_times, imu_poses=imu_poses, stamp=stamp, linear_vel=linear_vel, angular_vel=angular_vel)
+    if to_imu_frame:
+        d = transform_points(T_imu_lidar, d)
+    normals, covs = covariances(d, nb, num_threads=num_threads)
+    return d, normals, covs
 
 
 # ---- scan preprocessing (SURVEY.md 8f rank 1) ----------------------------------------------------------

@@ -72,4 +72,43 @@ int ref_deskew_imu(const double* T_imu_lidar12, const double* imu_times, const d
   return 0;
 }
 
+// The per-scan front end between preprocessing and create_frame, as OdometryEstimationIMU::insert_frame runs it
+// (src/glim/odometry/odometry_estimation_imu.cpp:313-320), on the reference's own objects:
+//     auto deskewed = deskewing->deskew(T_imu_lidar, pred_imu_times, pred_imu_poses, raw_frame->stamp, raw_frame->times, raw_frame->points);
+//     for (auto& pt : deskewed) { pt = T_imu_lidar * pt; }
+//     covariance_estimation->estimate(deskewed, raw_frame->neighbors, deskewed_normals, deskewed_covs);
+// (sub_mapping.cpp:364-374 is the same chain with T_lidar_imu.inverse().)  n_imu < 0 selects the constant-velocity form of deskew().
+// to_imu_frame == 0 skips the middle line (what a LiDAR-frame cloud would give; for the tests that show the difference).
+int ref_frontend(const double* T_imu_lidar12, const double* imu_times, const double* imu_poses12, int n_imu, double stamp, const double* linear_vel3,
+                 const double* angular_vel3, const double* times, const double* pts4, int n, const int32_t* nbrs, int k, int to_imu_frame,
+                 double* out_points4, double* out_normals4, double* out_covs16, int num_threads) {
+  if (n <= 0) return 0;
+  glim::CloudDeskewing deskewing;
+  const Eigen::Isometry3d T_imu_lidar = pose_from12(T_imu_lidar12);
+  const std::vector<double> t(times, times + n);
+  std::vector<Eigen::Vector4d> deskewed;
+  if (n_imu < 0) {
+    deskewed = deskewing.deskew(T_imu_lidar, Eigen::Vector3d(linear_vel3[0], linear_vel3[1], linear_vel3[2]),
+                                Eigen::Vector3d(angular_vel3[0], angular_vel3[1], angular_vel3[2]), t, points_from4(pts4, n));
+  } else {
+    const std::vector<double> it(imu_times, imu_times + n_imu);
+    std::vector<Eigen::Isometry3d> poses;
+    for (int i = 0; i < n_imu; i++) poses.push_back(pose_from12(imu_poses12 + 12 * (size_t)i));
+    deskewed = deskewing.deskew(T_imu_lidar, it, poses, stamp, t, points_from4(pts4, n));
+  }
+  if (to_imu_frame)
+    for (auto& pt : deskewed) {
+      pt = T_imu_lidar * pt;
+    }
+  const std::vector<int> neighbors(nbrs, nbrs + (size_t)n * k);
+  std::vector<Eigen::Vector4d> normals;
+  std::vector<Eigen::Matrix4d> covs;
+  glim::CloudCovarianceEstimation est(num_threads > 0 ? num_threads : 1);
+  est.estimate(deskewed, neighbors, normals, covs);  // the 4-argument overload: k = neighbors.size() / points.size()
+  points_to4(deskewed, out_points4);
+  points_to4(normals, out_normals4);
+  for (int i = 0; i < n; i++) std::memcpy(out_covs16 + 16 * (size_t)i, covs[(size_t)i].data(), 16 * sizeof(double));
+  return 0;
+}
+
 }  // extern "C"

@@ -337,7 +337,7 @@ void orc_eigen3_direct(const double* m9, double* evals, double* evecs /* column-
   /* lower-triangular view mirrored (selfadjointView<Lower>) */
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) sm[r][c] = (r >= c) ? m9[3 * r + c] : m9[3 * c + r];
-  const double shift = (sm[0][0] + sm[1][1] + sm[2][2]) / 3.0;
+  const double shift = (sm[0][0] + (sm[1][1] + sm[2][2])) / 3.0; /* mat.trace(): Eigen's unrolled scalar reduction of 3 terms is a0 + (a1 + a2) */
   for (int i = 0; i < 3; i++) sm[i][i] -= shift;
   double scale = 0.0;
   for (int r = 0; r < 3; r++)
@@ -695,9 +695,22 @@ static void acc_add(acc_t* dst, const acc_t* src) {
   dst->inliers += src->inliers;
 }
 
+/* Surface validation of IntegratedVGICPFactorGPU::set_enable_surface_validation(true) (src/glim/odometry/odometry_estimation_gpu.cpp:145,162).
+ * (!) The upstream predicate lives in gtsam_points (not in /root/reference) and is UNVERIFIED; this oracle states the one DESIGN.md section 4.8
+ * documents, in FP64: a correspondence is dropped when the transformed source normal faces away from the target-frame origin,
+ *     s_i = (R n_i) . q_i > 0,   q_i = delta p_i,  R = delta's rotation,
+ * (the covariance estimator orients n so that p . n <= 0, cloud_covariance_estimation.cpp:98-101).  `force` (optional, n entries) overrides
+ * the decision per point: 0 reject, 1 accept, anything else = the predicate -- so a test can hand the FP32 device's decisions for the few
+ * points whose |s| is below FP32 resolution and still compare sums.  s_out (optional): s_i of every point. */
+typedef struct {
+  const double* normals4;
+  const int8_t* force;
+  double* s_out;
+} sv_args;
+
 /* shared driver: correspondences at T_lin, residuals at T_eval */
-static void vgicp_run(const orc_voxelmap* map, const double* pts, const double* covs, int n, const double* T_lin,
-                      const double* T_eval, int num_threads, int need_H, acc_t* total, int32_t* corr) {
+static void vgicp_run_sv(const orc_voxelmap* map, const double* pts, const double* covs, int n, const double* T_lin,
+                         const double* T_eval, int num_threads, int need_H, acc_t* total, int32_t* corr, const sv_args* sv) {
   num_threads = clamp_threads(num_threads);
   acc_t* parts = (acc_t*)calloc((size_t)num_threads, sizeof(acc_t));
 #pragma omp parallel num_threads(num_threads)
@@ -714,7 +727,17 @@ static void vgicp_run(const orc_voxelmap* map, const double* pts, const double* 
       orc_transform_point(T_lin, p, q_lin);
       int32_t c[3];
       orc_voxel_coord(q_lin, map->inv_resolution, c);
-      const int v = orc_voxelmap_lookup(map, c);
+      int v = orc_voxelmap_lookup(map, c);
+      if (sv) {
+        const double* nn = sv->normals4 + 4 * (size_t)i;
+        double rn[3];
+        for (int r = 0; r < 3; r++) rn[r] = (T_lin[4 * r + 0] * nn[0] + T_lin[4 * r + 1] * nn[1]) + T_lin[4 * r + 2] * nn[2];
+        const double s = (rn[0] * q_lin[0] + rn[1] * q_lin[1]) + rn[2] * q_lin[2];
+        if (sv->s_out) sv->s_out[i] = s;
+        int reject = s > 0.0;
+        if (sv->force && (sv->force[i] == 0 || sv->force[i] == 1)) reject = !sv->force[i];
+        if (reject) v = -1;
+      }
       if (corr) {
         corr[4 * (size_t)i + 0] = c[0];
         corr[4 * (size_t)i + 1] = c[1];
@@ -739,6 +762,40 @@ static void vgicp_run(const orc_voxelmap* map, const double* pts, const double* 
   memset(total, 0, sizeof(*total));
   for (int t = 0; t < num_threads; t++) acc_add(total, &parts[t]);
   free(parts);
+}
+
+static void vgicp_run(const orc_voxelmap* map, const double* pts, const double* covs, int n, const double* T_lin,
+                      const double* T_eval, int num_threads, int need_H, acc_t* total, int32_t* corr) {
+  vgicp_run_sv(map, pts, covs, n, T_lin, T_eval, num_threads, need_H, total, corr, NULL);
+}
+
+static void acc_to_out(const acc_t* total, orc_linearized6* out) {
+  out->num_inliers = total->inliers;
+  out->error = ORC_ERROR_SCALE * total->err;
+  memcpy(out->H_tt, total->H_tt, sizeof(total->H_tt));
+  memcpy(out->H_ss, total->H_ss, sizeof(total->H_ss));
+  memcpy(out->H_ts, total->H_ts, sizeof(total->H_ts));
+  memcpy(out->b_t, total->b_t, sizeof(total->b_t));
+  memcpy(out->b_s, total->b_s, sizeof(total->b_s));
+}
+
+int orc_vgicp_linearize_sv(const orc_voxelmap* target, const double* pts, const double* covs, const double* normals4, int n, const double* delta,
+                           const int8_t* force, int num_threads, orc_linearized6* out, int32_t* corr, double* s_out) {
+  if (!target || !out || !normals4) return -1;
+  const sv_args sv = {normals4, force, s_out};
+  acc_t total;
+  vgicp_run_sv(target, pts, covs, n, delta, delta, num_threads, 1, &total, corr, &sv);
+  acc_to_out(&total, out);
+  return 0;
+}
+
+double orc_vgicp_error_frozen_sv(const orc_voxelmap* target, const double* pts, const double* covs, const double* normals4, int n,
+                                 const double* delta_lin, const double* delta_eval, const int8_t* force, int num_threads, int64_t* num_inliers) {
+  const sv_args sv = {normals4, force, NULL};
+  acc_t total;
+  vgicp_run_sv(target, pts, covs, n, delta_lin, delta_eval, num_threads, 0, &total, NULL, &sv);
+  if (num_inliers) *num_inliers = total.inliers;
+  return ORC_ERROR_SCALE * total.err;
 }
 
 int orc_vgicp_linearize(const orc_voxelmap* target, const double* pts, const double* covs, int n, const double* delta,
@@ -945,7 +1002,7 @@ static void quat_from_rot(const double* T12, double* q /* x y z w */) {
   double m[3][3];
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) m[r][c] = T12[4 * r + c];
-  double t = m[0][0] + m[1][1] + m[2][2];
+  double t = m[0][0] + (m[1][1] + m[2][2]); /* mat.trace(), see orc_eigen3_direct */
   if (t > 0.0) {
     t = sqrt(t + 1.0);
     q[3] = 0.5 * t;
@@ -1117,5 +1174,12 @@ int orc_deskew_imu(const double* T_imu_lidar, const double* imu_times, const dou
   free(TT);
   free(table);
   free(idx);
+  return 0;
+}
+
+/* `pt = T_imu_lidar * pt` for every deskewed point (src/glim/odometry/odometry_estimation_imu.cpp:314-316, src/glim/mapping/sub_mapping.cpp:368-370):
+ * Eigen::Isometry3d * Eigen::Vector4d, the same product CloudDeskewing::deskew applies (apply_pose). */
+int orc_transform_points(const double* T12, const double* points4, int n, double* out4) {
+  for (int i = 0; i < n; i++) apply_pose(T12, points4 + 4 * (size_t)i, out4 + 4 * (size_t)i);
   return 0;
 }

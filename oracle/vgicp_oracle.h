@@ -115,6 +115,14 @@ double orc_vgicp_error(const orc_voxelmap* target, const double* src_points4, co
 double orc_vgicp_error_frozen(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, int n,
                               const double* delta_lin12, const double* delta_eval12, int num_threads, int64_t* num_inliers);
 
+/* The same with surface validation (IntegratedVGICPFactorGPU::set_enable_surface_validation(true), odometry_estimation_gpu.cpp:145,162):
+ * a correspondence is dropped when s_i = (R n_i) . (delta p_i) > 0 -- the predicate DESIGN.md 4.8 documents; the upstream one is in
+ * gtsam_points and UNVERIFIED.  normals4: n x 4.  force (optional, n): 0 reject / 1 accept / other = predicate.  s_out (optional, n): s_i. */
+int orc_vgicp_linearize_sv(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, const double* src_normals4, int n,
+                           const double* delta12, const int8_t* force, int num_threads, orc_linearized6* out, int32_t* corr, double* s_out);
+double orc_vgicp_error_frozen_sv(const orc_voxelmap* target, const double* src_points4, const double* src_covs16, const double* src_normals4, int n,
+                                 const double* delta_lin12, const double* delta_eval12, const int8_t* force, int num_threads, int64_t* num_inliers);
+
 /* overlap (row a8): fraction of source points whose transformed position hits an occupied voxel; the
  * multi-target form counts a point once if any (map_j, delta_j) matches
  * (src/glim/odometry/odometry_estimation_gpu.cpp:224-231). */
@@ -138,6 +146,10 @@ int orc_deskew_constvel(const double* T_imu_lidar12, const double* linear_vel3, 
                         const double* points4, int n, double* out4);
 int orc_deskew_imu(const double* T_imu_lidar12, const double* imu_times, const double* imu_poses12, int n_imu, double stamp,
                    const double* times, const double* points4, int n, double* out4);
+
+/* the step both callers of deskew() take next, before covariance estimation: pt = T_imu_lidar * pt
+ * (src/glim/odometry/odometry_estimation_imu.cpp:314-316, src/glim/mapping/sub_mapping.cpp:368-370).  In place is allowed. */
+int orc_transform_points(const double* T12, const double* points4, int n, double* out4);
 
 /* ---- GICP factor  gtsam_points::IntegratedGICPFactor: sub_mapping.cpp:202, global_mapping.cpp:400,
  * global_mapping_pose_graph.cpp:393.  Nearest target point within max_correspondence_distance (exact, ties to the smaller

@@ -241,13 +241,19 @@ int main() {
     const Isometry3d T_imu_lidar = pose2d(0.1, -0.05, 0.02);
     const Vector3d lv{{3.0, -1.0, 0.2}}, av{{0.05, -0.1, 0.8}};
     CloudDeskewing deskewing;
-    auto deskewed = deskewing.deskew(*frame, T_imu_lidar, lv, av);
+    // default: deskew() + the `pt = T_imu_lidar * pt` loop of both reference callers (odometry_estimation_imu.cpp:314-316), fused
+    auto deskewed = deskewing.deskew(*frame, T_imu_lidar, lv, av, CloudDeskewing::Frame::IMU);
     REQUIRE((int)deskewed->size() == m);
-    std::vector<double> ref_d(4 * (size_t)m);
+    std::vector<double> ref_d(4 * (size_t)m), ref_imu(4 * (size_t)m);
     orc_deskew_constvel(T_imu_lidar.m.data(), lv.data(), av.data(), ref_t.data(), ref_p.data(), m, ref_d.data());
+    orc_transform_points(T_imu_lidar.m.data(), ref_d.data(), m, ref_imu.data());
     const std::vector<float> got_d = deskewed->download_points();
     for (int i = 0; i < m; i++)
-      for (int a = 0; a < 3; a++) REQUIRE(std::fabs((double)got_d[3 * (size_t)i + a] - ref_d[4 * (size_t)i + a]) <= 1e-6 * (1.0 + std::fabs(ref_d[4 * (size_t)i + a])));
+      for (int a = 0; a < 3; a++) REQUIRE(got_d[3 * (size_t)i + a] == (float)ref_imu[4 * (size_t)i + a]);
+    // Frame::LIDAR: the bare CloudDeskewing::deskew value
+    const std::vector<float> got_l = deskewing.deskew(*frame, T_imu_lidar, lv, av, CloudDeskewing::Frame::LIDAR)->download_points();
+    for (int i = 0; i < m; i++)
+      for (int a = 0; a < 3; a++) REQUIRE(got_l[3 * (size_t)i + a] == (float)ref_d[4 * (size_t)i + a]);
     deskewed->estimate_covariances(10);
     auto vm = std::make_shared<GaussianVoxelMapGPU>(0.5);
     vm->insert(*deskewed);

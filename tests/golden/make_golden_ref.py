@@ -3,7 +3,8 @@
 /root/reference/src/glim/common/cloud_covariance_estimation.cpp and cloud_deskewing.cpp compiled unmodified (oracle/Makefile target `ref`;
 stand-in Eigen / GTSAM headers under oracle/ref_standin/, see there for what that does and does not pin).
 
-This is the reference pin of SURVEY.md 8a row a2 (covariance + normal) and 8f rank 2 (deskewing): the restatement in oracle/vgicp_oracle.c and
+This is the reference pin of SURVEY.md 8a row a2 (covariance + normal) and 8f rank 2 (deskewing, and the composed chain
+deskew -> IMU frame -> covariance of odometry_estimation_imu.cpp:313-320 through oracle/ref_shim.cpp `ref_frontend`): the restatement in oracle/vgicp_oracle.c and
 the HIP kernels are tested against these vectors (tests/test_ref.py).  It can only be regenerated where /root/reference exists:
     python tests/golden/make_golden_ref.py
 """
@@ -52,6 +53,13 @@ def compute(orc, inp, ref):
     out["deskew_constvel_still"] = orc.deskew(p, t, Til, linear_vel=[0.5, 0, 0], angular_vel=[0, 0, 0], ref=ref)  # theta^2 <= eps branch of Expmap
     out["deskew_imu"] = orc.deskew(p, t, Til, imu_times=inp["imu_times"], imu_poses=list(inp["imu_poses"]), stamp=STAMP, ref=ref)
     out["deskew_imu_short_track"] = orc.deskew(p, t, Til, imu_times=inp["imu_times"][:2], imu_poses=list(inp["imu_poses"][:2]), stamp=STAMP, ref=ref)
+    # the composed chain between preprocessing and create_frame (odometry_estimation_imu.cpp:313-320): deskew -> pt = T_imu_lidar * pt ->
+    # covariances from the raw scan's neighbours, all on FP64 points; the LiDAR-frame variant (middle step skipped) shows what the step changes
+    for name, kw in (("frontend_imu", dict(imu_times=inp["imu_times"], imu_poses=list(inp["imu_poses"]), stamp=STAMP)),
+                     ("frontend_constvel", dict(linear_vel=LINEAR_VEL, angular_vel=ANGULAR_VEL))):
+        for frame in ("imuframe", "lidarframe"):
+            pts, nrm, cov = orc.frontend(p, t, inp["neighbors"], Til, to_imu_frame=(frame == "imuframe"), ref=ref, **kw)
+            out[f"{name}.{frame}.points"], out[f"{name}.{frame}.normals"], out[f"{name}.{frame}.covs"] = pts, nrm, cov
     return out
 
 

@@ -395,3 +395,36 @@ def test_overlap_batch_equals_single_calls_and_oracle(api, ctx, orc, small_pair)
     assert [api.overlap_gpu(q[0], q[1], q[2]) for q in queries] == want
     assert api.overlap_gpu_batch(queries[:1], ctx=ctx) == want[:1]
     assert api.overlap_gpu_batch([queries[4]], ctx=ctx) == [want[4]]
+
+
+def test_stale_density_hint_does_not_leave_an_overfull_table(api, orc):
+    """the direct build of a > 32 768-point cloud sizes its table from the voxels-per-point ratio of the PREVIOUS map at that resolution.
+    A dense scan (ratio ~0.1) followed by a cloud that was already downsampled at about the voxel size (ratio ~1) would leave the floor table of
+    N / 2 two-way buckets 100 % full for the whole life of the map; the build must notice and fall back to the counting path (6 buckets per voxel
+    present).  Contents stay exact either way."""
+    ctx = api.Context(0, 1)
+    rng = np.random.default_rng(9)
+    res = 0.5
+    # dense: 65 536 points inside a 10 m cube -> ~8000 voxels (ratio 0.12)
+    dense = rng.uniform(-5, 5, size=(65536, 3)).astype(np.float32)
+    cov = np.tile((np.eye(3) * 1e-2).astype(np.float32), (65536, 1, 1))
+    dg = api.PointCloudGPU.clone(dense, cov, ctx=ctx)
+    api.GaussianVoxelMapGPU(res, ctx=ctx).insert(dg)                      # first map at this resolution: counting path, leaves the hint
+    hinted = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(dg).voxelmap_info()  # direct build with a good hint
+    assert hinted["num_voxels"] <= 0.35 * 2 * hinted["num_buckets"]
+    # sparse: one point per voxel on a 40^3 lattice (64 000 points, ratio 1.0) at the same resolution
+    g = np.stack(np.meshgrid(*[np.arange(40)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    sparse = ((g + 0.5) * res + rng.uniform(-0.2, 0.2, size=g.shape)).astype(np.float32)
+    cov2 = np.tile((np.eye(3) * 1e-2).astype(np.float32), (len(sparse), 1, 1))
+    sg = api.PointCloudGPU.clone(sparse, cov2, ctx=ctx)
+    vm = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(sg)
+    info = vm.voxelmap_info()
+    assert info["num_voxels"] == 64000
+    assert info["num_voxels"] <= 0.35 * 2 * info["num_buckets"], info   # without the check: 64 000 keys in 32 768 two-way buckets
+    ref = orc.VoxelMap(res).insert(sparse, cov2.astype(np.float64))
+    assert ref.num_voxels() == 64000
+    coords, counts, means, covs = vm.voxels()
+    assert len(np.unique(coords, axis=0)) == 64000 and np.all(counts == 1)
+    # and the next sparse map builds directly with the corrected hint
+    again = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(sg).voxelmap_info()
+    assert again["num_voxels"] == 64000 and again["num_voxels"] <= 0.35 * 2 * again["num_buckets"]

@@ -1,0 +1,194 @@
+"""Surface validation ON -- the configuration OdometryEstimationGPU actually runs (set_enable_surface_validation(true) on every factor,
+src/glim/odometry/odometry_estimation_gpu.cpp:145,162) -- against an independent FP64 statement of the predicate in the oracle
+(oracle/vgicp_oracle.c orc_vgicp_linearize_sv): accept mask, inliers, H, b, error and the Gauss-Newton step, at configs[1]'s size and on the
+34-factor set of the live odometry pattern.
+
+The upstream predicate lives in koide3/gtsam_points (not in /root/reference): UNVERIFIED.  What is pinned here is that the HIP kernels compute
+the predicate DESIGN.md 4.8 documents -- drop a correspondence when (R n_i) . (delta p_i) > 0 -- exactly as the FP64 oracle does, on every
+point whose predicate value is above FP32 resolution; the number of points below it is printed (and their device decisions are handed to the
+oracle, so the sums are still compared on identical correspondence sets).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4
+# |s| <= BOUNDARY * |q|: the FP32 evaluation of s = (R n) . q (unit n, |q| metres) carries ~4 roundings of 6e-8 relative to |q|
+BOUNDARY = 1e-6
+
+
+@pytest.fixture(scope="module")
+def api():
+    from glim_amd import api as _api
+
+    assert _api.device_count() >= 1, "these tests need a GPU and must not fall back"
+    return _api
+
+
+@pytest.fixture(scope="module")
+def ctx(api):
+    return api.Context(0, 2)
+
+
+def gn_step(L, lam=0.0):
+    return np.linalg.solve(L["H_ss"] + lam * np.eye(6), -L["b_s"])
+
+
+def compare(got, ref, binary, what):
+    assert got["num_inliers"] == ref["num_inliers"], what
+    np.testing.assert_allclose(got["error"], ref["error"], rtol=2e-4, err_msg=what)
+    scale = np.abs(ref["H_ss"]).max()
+    np.testing.assert_allclose(got["H_ss"], ref["H_ss"], rtol=0, atol=2e-4 * scale, err_msg=what)
+    np.testing.assert_allclose(got["b_s"], ref["b_s"], rtol=0, atol=2e-4 * np.abs(ref["b_s"]).max() + 1e-6 * scale, err_msg=what)
+    if binary:
+        np.testing.assert_allclose(got["H_tt"], ref["H_tt"], rtol=0, atol=2e-4 * np.abs(ref["H_tt"]).max(), err_msg=what)
+        np.testing.assert_allclose(got["H_ts"], ref["H_ts"], rtol=0, atol=2e-4 * np.abs(ref["H_ts"]).max(), err_msg=what)
+        np.testing.assert_allclose(got["b_t"], ref["b_t"], rtol=0, atol=2e-4 * np.abs(ref["b_t"]).max() + 1e-6 * scale, err_msg=what)
+    lam = 1e-6 * np.trace(ref["H_ss"]) / 6
+    worst = 0.0
+    for l in (0.0, lam):
+        worst = max(worst, float(np.abs(gn_step(got, l) - gn_step(ref, l)).max()))
+    assert worst < POSE_TOL, (what, worst)
+    return worst
+
+
+def validated_reference(orc, fset, index, ref_map, src, covs, normals, delta):
+    """Oracle linearisation with validation ON for factor `index` of `fset`: the device's accept mask must equal the oracle's FP64 predicate on
+    every point outside the FP32-resolution boundary; boundary points take the device's decision.  Returns (reference, #boundary, #rejected)."""
+    corr = fset.correspondences(index, delta)
+    dev_hit = corr[:, 3] > 0
+    first = orc.vgicp_linearize_sv(ref_map, src, covs, normals, delta, want_corr=True)
+    np.testing.assert_array_equal(corr[:, :3], first["corr"][:, :3])  # voxel coordinates: bit-exact, validation or not
+    q = src.astype(np.float64) @ delta[:3, :3].T + delta[:3, 3]
+    boundary = np.abs(first["s"]) <= BOUNDARY * np.linalg.norm(q, axis=1)
+    orc_hit = first["corr"][:, 3] >= 0
+    np.testing.assert_array_equal(dev_hit[~boundary], orc_hit[~boundary])
+    plain_hit = orc.vgicp_linearize(ref_map, src, covs, delta, want_corr=True)["corr"][:, 3] >= 0
+    rejected = int((plain_hit & ~orc_hit).sum())
+    first["force"] = None
+    if not boundary.any():
+        return first, 0, rejected
+    force = np.full(len(src), -1, dtype=np.int8)
+    # a boundary point is accepted by the predicate iff the device kept it (the voxel lookup itself is exact on both sides)
+    force[boundary] = np.where(plain_hit[boundary], dev_hit[boundary], 1).astype(np.int8)
+    again = orc.vgicp_linearize_sv(ref_map, src, covs, normals, delta, force=force)
+    again["force"] = force
+    return again, int(boundary.sum()), rejected
+
+
+def test_config1_full_size_scan_with_surface_validation(api, ctx, orc):
+    """configs[1] (131 072 points, 0.5 m voxels), unary and binary, plane-form and general kernel, validation ON."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(128, 1024)
+    poses = synth.arc_trajectory(2)
+    tgt, src = synth.scan(scene, poses[0], dirs, 0), synth.scan(scene, poses[1], dirs, 1)
+    assert len(src) == 131072
+    delta = synth.relative_pose(poses[0], poses[1])
+    tg, sg = api.PointCloudGPU.clone(tgt, ctx=ctx), api.PointCloudGPU.clone(src, ctx=ctx)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    _, ct, _ = tg.download()
+    _, cs, ns = sg.download()
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    ref_map = orc.VoxelMap(0.5).insert(tgt, ct.astype(np.float64))
+    cs64, ns64 = cs.astype(np.float64), ns.astype(np.float64)
+    report = {}
+    for mode in ("plane", "general"):
+        ctx.set_diag("plane=1" if mode == "plane" else "plane=0")
+        for binary in (False, True):
+            f = api.IntegratedVGICPFactorGPU(0 if binary else np.eye(4), 1, vm, sg)
+            f.set_enable_surface_validation(True)
+            fset = api.NonlinearFactorSetGPU(ctx)
+            fset.add(f)
+            values = {0: np.eye(4), 1: delta}
+            got = fset.linearize(values)[0]
+            ref, n_boundary, n_rejected = validated_reference(orc, fset, 0, ref_map, src, cs64, ns64, delta)
+            worst = compare(got, ref, binary, (mode, binary))
+            assert n_rejected > 0  # the predicate does something on this scan pair
+            # error() with the GPU factor's frozen-correspondence semantics (LM's trial step) sums over the same validated set
+            moved = delta @ orc.se3_exp([1e-3, -2e-3, 1e-3, 0.01, -0.02, 0.01])
+            e_got = fset.error({0: np.eye(4), 1: moved}, values_lin=values)[0]
+            e_ref, inl_ref = orc.vgicp_error_frozen_sv(ref_map, src, cs64, ns64, delta, moved, force=ref["force"])
+            assert int(fset.last_error_inliers[0]) == inl_ref == ref["num_inliers"]
+            np.testing.assert_allclose(e_got, e_ref, rtol=2e-4)
+            report[f"{mode}.{'binary' if binary else 'unary'}"] = {
+                "points": int(len(src)), "inliers": int(got["num_inliers"]), "rejected_by_validation": n_rejected,
+                "points_within_fp32_resolution_of_the_boundary": n_boundary, "gn_step_err": worst}
+    ctx.set_diag("")
+    print("surface validation ON, configs[1]:", report)
+    _write("surface_validation_config1.json", report)
+
+
+def test_odometry_34_factor_set_with_surface_validation(api, ctx, orc):
+    """The live odometry pattern (odometry_estimation_gpu.cpp:128-206): (2 window + 15 keyframes) x 2 levels = 34 factors on 10 000-pt frames,
+    validation ON for every factor, linearised as ONE fresh set; every factor against the oracle."""
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    K, WIN, LEVELS = 15, 2, 2
+    dirs = synth.lidar_directions(128, 1024)
+    poses = synth.arc_trajectory(K + WIN + 1, step=0.4, yaw_step_deg=1.5)
+    rng = np.random.default_rng(3)
+    frames, host = [], []
+    for i, T in enumerate(poses):
+        pts = synth.scan(scene, T, dirs, 500 + i)
+        pts = pts[np.sort(rng.choice(len(pts), 10000, replace=False))]
+        g = api.PointCloudGPU.clone(pts, ctx=ctx)
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+        frames.append(g)
+        host.append(pts)
+    res0 = api.adaptive_voxel_resolution(api.median_distance(host[-1]), 0.25, 0.5, 5.0, 20.0)
+    levels = [res0 * 2.0 ** lv for lv in range(LEVELS)]
+    vmaps = [[api.GaussianVoxelMapGPU(r, ctx=ctx).insert(g) for r in levels] for g in frames[:-1]]
+    cur, cur_pose = frames[-1], poses[-1] @ orc.se3_exp([2e-3, -1e-3, 3e-3, 0.03, -0.02, 0.01])  # the optimiser's current (not converged) estimate
+    _, cs, ns = cur.download()
+    cs64, ns64 = cs.astype(np.float64), ns.astype(np.float64)
+    src = host[-1]
+    fset = api.NonlinearFactorSetGPU(ctx)
+    spec = []
+    for t in list(range(len(frames) - 1 - WIN, len(frames) - 1)) + list(range(K)):
+        binary = t >= len(frames) - 1 - WIN
+        for lv in range(LEVELS):
+            f = api.IntegratedVGICPFactorGPU(t if binary else poses[t], 99, vmaps[t][lv], cur)
+            f.set_enable_surface_validation(True)
+            fset.add(f)
+            spec.append((t, lv, binary))
+    assert len(spec) == 34
+    values = {t: poses[t] for t in range(len(poses) - 1)}
+    values[99] = cur_pose
+    out = fset.linearize(values)
+    ref_maps = {}
+    worst, n_boundary_total, n_rejected_total = 0.0, 0, 0
+    for k, (t, lv, binary) in enumerate(spec):
+        if (t, lv) not in ref_maps:
+            ct = frames[t].download(normals=False)[1].astype(np.float64)
+            ref_maps[(t, lv)] = orc.VoxelMap(levels[lv]).insert(host[t], ct)
+        delta = synth.relative_pose(poses[t], cur_pose)
+        ref, n_boundary, n_rejected = validated_reference(orc, fset, k, ref_maps[(t, lv)], src, cs64, ns64, delta)
+        if ref["num_inliers"] >= 100:
+            worst = max(worst, compare(out[k], ref, binary, spec[k]))
+        else:
+            assert out[k]["num_inliers"] == ref["num_inliers"]
+        n_boundary_total += n_boundary
+        n_rejected_total += n_rejected
+    report = {"factors": len(spec), "points_per_frame": int(cur.size()), "voxel_resolutions_m": [round(x, 3) for x in levels],
+              "rejected_by_validation_total": n_rejected_total, "points_within_fp32_resolution_of_the_boundary_total": n_boundary_total,
+              "max_gn_step_err": worst}
+    print("surface validation ON, 34-factor odometry set:", report)
+    _write("surface_validation_odometry34.json", report)
+    assert n_rejected_total > 0
+
+
+def _write(name, payload):
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(payload, f, indent=1)

@@ -432,3 +432,43 @@ def test_median_distance_and_adaptive_resolution(orc, small_pair):
         assert orc.adaptive_resolution(dm, 0.25, 0.5, 4.0, 12.0) == pytest.approx(want)
         assert api.adaptive_voxel_resolution(dm, 0.25, 0.5, 4.0, 12.0) == pytest.approx(want)
     assert orc.median_distance(np.zeros((0, 3))) == 0.0 and api.median_distance(np.zeros((0, 3))) == 0.0
+
+
+def test_vgicp_surface_validation_leg(orc, small_pair):
+    """orc_vgicp_linearize_sv: the predicate of DESIGN.md 4.8 in FP64 -- drop a correspondence when (R n) . (delta p) > 0.  Pinned here by its
+    own definition only (the upstream predicate is in gtsam_points: unverified): sensor-facing normals at the identity change nothing, flipped
+    normals drop everything, the sums equal the plain factor restricted to the accepted subset, `force` overrides per point."""
+    t, s = small_pair["target"], small_pair["source"]
+    vm = orc.VoxelMap(0.5).insert(t["points"], t["covs"])
+    src, covs, nrm = s["points"], s["covs"], s["normals"]
+    I = np.eye(4)
+    plain = orc.vgicp_linearize(vm, src, covs, I, want_corr=True)
+    sv = orc.vgicp_linearize_sv(vm, src, covs, nrm, I, want_corr=True)
+    # the estimator orients normals towards the sensor, p . n <= 0 (cloud_covariance_estimation.cpp:98-101); the fixture stores them rounded to
+    # FP32, which can lift a grazing point's product to +1e-7 at most
+    assert np.all(sv["s"] <= 1e-6 * np.linalg.norm(src, axis=1))
+    assert sv["num_inliers"] == int(np.sum((plain["corr"][:, 3] >= 0) & ~(sv["s"] > 0.0))) >= plain["num_inliers"] - 3
+    flipped = orc.vgicp_linearize_sv(vm, src, covs, -nrm, I)
+    assert flipped["num_inliers"] == int(np.sum((plain["corr"][:, 3] >= 0) & (sv["s"] >= 0.0))) <= 3
+    # a real relative pose: a strict subset survives, and the sums are those of the plain factor over the accepted points alone
+    delta = small_pair["delta"]  # (thin structures seen from both sides, grazing ground returns)
+    plain = orc.vgicp_linearize(vm, src, covs, delta, want_corr=True)
+    sv = orc.vgicp_linearize_sv(vm, src, covs, nrm, delta, want_corr=True)
+    q = src.astype(np.float64) @ delta[:3, :3].T + delta[:3, 3]
+    s_np = np.einsum("ni,ni->n", nrm @ delta[:3, :3].T, q)
+    np.testing.assert_allclose(sv["s"], s_np, atol=1e-12)
+    keep = (plain["corr"][:, 3] >= 0) & ~(sv["s"] > 0.0)
+    np.testing.assert_array_equal(sv["corr"][:, 3] >= 0, keep)
+    assert 0 < sv["num_inliers"] == int(keep.sum()) < plain["num_inliers"]
+    subset = orc.vgicp_linearize(vm, src[keep], covs[keep], delta)
+    assert subset["num_inliers"] == sv["num_inliers"]
+    np.testing.assert_allclose(sv["H_ss"], subset["H_ss"], rtol=1e-12)
+    np.testing.assert_allclose(sv["b_s"], subset["b_s"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(sv["error"], subset["error"], rtol=1e-12)
+    # force: accept everything == the plain factor; reject everything == empty
+    everything = orc.vgicp_linearize_sv(vm, src, covs, nrm, delta, force=np.ones(len(src), dtype=np.int8))
+    assert everything["num_inliers"] == plain["num_inliers"]
+    nothing = orc.vgicp_linearize_sv(vm, src, covs, nrm, delta, force=np.zeros(len(src), dtype=np.int8))
+    assert nothing["num_inliers"] == 0 and not np.any(nothing["H_ss"])
+    e, inl = orc.vgicp_error_frozen_sv(vm, src, covs, nrm, delta, delta)
+    assert inl == sv["num_inliers"] and abs(e - sv["error"]) <= 1e-12 * abs(sv["error"])
