@@ -19,6 +19,9 @@
 
 using namespace glim_amd;
 
+// every FP64 expression of the host-side table below is evaluated with separate roundings, like the oracle (-ffp-contract=off)
+#pragma clang fp contract(off)
+
 namespace {
 
 struct Pose {
@@ -42,33 +45,45 @@ Pose inverse(const Pose& A) {
   return I;
 }
 
-// gtsam::Pose3::Expmap([omega; v])
+// gtsam::Pose3::Expmap([omega; v]) as GTSAM 4.2 evaluates it (cloud_deskewing.cpp:43), in the operation order of the oracle's restatement
+// (oracle/vgicp_oracle.c pose3_expmap_gtsam, itself bit-equal to the compiled reference over the stand-in Pose3.h): R = I + sin(theta) K +
+// (1 - cos(theta)) K^2, K = hat(omega) / theta, 1 - cos(theta) = 2 sin^2(theta / 2); t = (omega x v - R (omega x v) + omega (omega . v)) / theta^2.
+// The table has to carry the oracle's BITS: the deskewed FP64 points are compared bit for bit (tests/test_ref.py).
 Pose se3_exp(const double* xi) {
-  const double wx = xi[0], wy = xi[1], wz = xi[2];
-  const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
-  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-  double W2[9];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-  double a, b, c;
-  if (th < 1e-8) {
-    a = 1.0 - th2 / 6.0;
-    b = 0.5 - th2 / 24.0;
-    c = 1.0 / 6.0 - th2 / 120.0;
+  const double eps = 2.220446049250313e-16;
+  const double w[3] = {xi[0], xi[1], xi[2]}, v[3] = {xi[3], xi[4], xi[5]};
+  const double theta2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  double R[9];
+  if (theta2 <= eps) {
+    for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
   } else {
-    a = std::sin(th) / th;
-    b = (1.0 - std::cos(th)) / th2;
-    c = (th - std::sin(th)) / (th2 * th);
+    const double theta = std::sqrt(theta2);
+    const double sin_theta = std::sin(theta);
+    const double s2 = std::sin(theta / 2.0);
+    const double one_minus_cos = 2.0 * s2 * s2;
+    double K[9], KK[9];
+    for (int i = 0; i < 9; i++) K[i] = W[i] / theta;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = (K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c]) + K[3 * r + 2] * K[6 + c];
+    for (int i = 0; i < 9; i++) R[i] = (((i % 4 == 0) ? 1.0 : 0.0) + K[i] * sin_theta) + KK[i] * one_minus_cos;
+  }
+  double t[3];
+  if (theta2 > eps) {
+    const double wv = (w[0] * v[0] + w[1] * v[1]) + w[2] * v[2];
+    const double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    double Rc[3];
+    for (int r = 0; r < 3; r++) Rc[r] = (R[3 * r] * c[0] + R[3 * r + 1] * c[1]) + R[3 * r + 2] * c[2];
+    for (int r = 0; r < 3; r++) t[r] = ((c[r] - Rc[r]) + w[r] * wv) / theta2;
+  } else {
+    t[0] = v[0]; t[1] = v[1]; t[2] = v[2];
   }
   Pose T;
   for (int r = 0; r < 3; r++) {
-    double V[3];
-    for (int cc = 0; cc < 3; cc++) {
-      const double I = (r == cc) ? 1.0 : 0.0;
-      T.m[4 * r + cc] = I + a * W[3 * r + cc] + b * W2[3 * r + cc];
-      V[cc] = I + b * W[3 * r + cc] + c * W2[3 * r + cc];
-    }
-    T.m[4 * r + 3] = V[0] * xi[3] + V[1] * xi[4] + V[2] * xi[5];
+    T.m[4 * r + 0] = R[3 * r + 0];
+    T.m[4 * r + 1] = R[3 * r + 1];
+    T.m[4 * r + 2] = R[3 * r + 2];
+    T.m[4 * r + 3] = t[r];
   }
   return T;
 }
@@ -289,6 +304,23 @@ int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* p
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   return run_deskew(ctx, n, points4, nullptr, entry, TT, to_imu_frame ? T_imu_lidar12 : nullptr, nullptr, out);
+}
+
+int glim_amd_debug_deskew_table(int64_t n, const double* times, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
+                                double stamp, const double* linear_vel3, const double* angular_vel3, int32_t* entry_out, double* table12_out, int32_t table_cap,
+                                int32_t* table_size) {
+  if (n < 0 || !T_imu_lidar12 || (n > 0 && !times) || !table_size) return GLIM_AMD_ERR_INVALID;
+  if (n_imu < 0 || (n_imu > 0 && (!imu_times || !imu_poses12))) return GLIM_AMD_ERR_INVALID;
+  std::vector<int> entry;
+  std::vector<Pose> TT;
+  build_deskew_table(n, times, T_imu_lidar12, n_imu, imu_times, imu_poses12, stamp, linear_vel3, angular_vel3, entry, TT);
+  *table_size = (int32_t)TT.size();
+  if (entry_out) memcpy(entry_out, entry.data(), (size_t)n * sizeof(int32_t));
+  if (table12_out) {
+    if ((int32_t)TT.size() > table_cap) return GLIM_AMD_ERR_INVALID;
+    memcpy(table12_out, TT.data(), TT.size() * sizeof(Pose));
+  }
+  return GLIM_AMD_OK;
 }
 
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,

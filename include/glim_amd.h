@@ -163,6 +163,12 @@ int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, 
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
                           const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, int32_t to_imu_frame,
                           glim_amd_cloud** out);
+/* parity / debug only (host arithmetic, no device needed): the time table CloudDeskewing::deskew builds (cloud_deskewing.cpp:22-45 / :70-124) --
+ * entry_out[i] = table entry of point i (n, may be NULL), table12_out = one row-major 3x4 T_lidar0_lidar1 per entry (table_cap entries, may
+ * be NULL), *table_size = number of entries.  The deskewing kernels gather from exactly this table. */
+int glim_amd_debug_deskew_table(int64_t n, const double* times, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
+                                double stamp, const double* linear_vel3, const double* angular_vel3, int32_t* entry_out, double* table12_out, int32_t table_cap,
+                                int32_t* table_size);
 /* ---- GICP factor on device: gtsam_points::IntegratedGICPFactor -- nearest-neighbour correspondences instead
  * of a voxel lookup -- as constructed at src/glim/mapping/sub_mapping.cpp:202 (between factors, one linearize, :203),
  * src/glim/mapping/global_mapping.cpp:400-402 (set_max_correspondence_distance(0.5), 10 LM iterations) and

@@ -119,3 +119,50 @@ def test_hip_deskew_matches_oracle(orc, form):
     assert api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(g).voxelmap_info()["num_voxels"] > 100
     empty = api.PointCloudGPU.clone_deskewed(np.zeros((0, 3)), np.zeros(0), Til, ctx=ctx)
     assert empty.size() == 0
+
+
+@pytest.mark.parametrize("form", ["constvel", "constvel_still", "imu", "imu_short"])
+def test_library_deskew_table_reproduces_the_oracle_bit_for_bit(orc, form):
+    """Host logic of glim_amd/csrc/deskew.hip (no device needed): the time table and the per-entry transforms the deskewing kernel gathers from,
+    applied here with numpy in the kernel's operation order (three 4-term sums, separate roundings), give the oracle's -- hence the compiled
+    reference's (tests/test_ref.py) -- FP64 deskewed points bit for bit, and so does the IMU-frame step on top."""
+    import ctypes as C
+
+    from glim_amd import _lib
+
+    rng = np.random.default_rng(12)
+    n = 5000
+    pts = rng.uniform(-40, 40, (n, 3)).astype(np.float32).astype(np.float64)
+    times = np.sort(rng.uniform(0, 0.1, n))
+    times[200:260] = times[200]
+    Til = orc.se3_exp([0.3, -0.2, 0.4, 0.5, -0.3, 1.2])
+    it = 100.0 + np.sort(rng.uniform(-0.05, 0.15, 9))
+    ip = [orc.se3_exp(rng.normal(size=6))]
+    for _ in it[1:]:
+        ip.append(ip[-1] @ orc.se3_exp(rng.normal(size=6) * 0.05))
+    kw = {"constvel": dict(linear_vel=[4.0, -2.0, 0.3], angular_vel=[0.1, -0.2, 1.5]), "constvel_still": dict(linear_vel=[0.5, 0, 0], angular_vel=[0, 0, 0]),
+          "imu": dict(imu_times=it, imu_poses=ip, stamp=100.0), "imu_short": dict(imu_times=it[:1], imu_poses=ip[:1], stamp=100.0)}[form]
+    want = orc.deskew(pts, times, Til, **kw)
+    L = _lib.lib()
+    dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+    T12 = np.ascontiguousarray(Til[:3, :4].reshape(12))
+    if "imu_times" in kw:
+        imu_t = np.ascontiguousarray(kw["imu_times"], dtype=np.float64)
+        imu_p = np.ascontiguousarray(np.stack([P[:3, :4].reshape(12) for P in kw["imu_poses"]]))
+        n_imu, lv, av = len(imu_t), None, None
+    else:
+        imu_t = imu_p = None
+        n_imu, lv, av = 0, np.array(kw["linear_vel"], dtype=np.float64), np.array(kw["angular_vel"], dtype=np.float64)
+    entry = np.zeros(n, dtype=np.int32)
+    table = np.zeros((n, 12))
+    size = C.c_int32()
+    rc = L.glim_amd_debug_deskew_table(n, dp(times), dp(T12), n_imu, dp(imu_t), dp(imu_p), float(kw.get("stamp", 0.0)), dp(lv), dp(av),
+                                       entry.ctypes.data_as(C.POINTER(C.c_int32)), dp(table), n, C.byref(size))
+    assert rc == 0 and 0 < size.value <= n
+
+    def apply(T, p):  # Isometry3d * Vector4d in the kernel's order
+        return np.stack([((T[:, 4 * r] * p[:, 0] + T[:, 4 * r + 1] * p[:, 1]) + T[:, 4 * r + 2] * p[:, 2]) + T[:, 4 * r + 3] * 1.0 for r in range(3)], axis=1)
+
+    got = apply(table[entry], pts)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(apply(np.tile(T12, (n, 1)), got), orc.transform_points(Til, want))
