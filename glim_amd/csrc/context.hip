@@ -38,6 +38,7 @@ const DiagKey kDiagKeys[] = {
   {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
+  {"fuse", &Diag::fuse, nullptr, 0, 1},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},

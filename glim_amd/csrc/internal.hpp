@@ -74,6 +74,7 @@ struct Diag {
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
+  int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
@@ -323,6 +324,10 @@ struct FactorPlan {
   glim_amd::FactorDesc* d_descs = nullptr;
   int2* d_blockmap = nullptr;     // total_rows x int2
   float* d_partials = nullptr;
+  char* d_rows16 = nullptr;       // tagged partial rows of the single-dispatch synchronous form (vgicp.hip TAG_ROW_BYTES per row), or null
+  int* d_finmap = nullptr;        // factor ids the trailing blocks of each segment's single-dispatch launch finalise (plane-form segment first)
+  int fin_count[2] = {0, 0};
+  std::vector<int> h_finmap;
   double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
   double* d_compact = nullptr;    // n x COMPACT
   // pinned pose staging: a ring, because an asynchronous call returns while its host-to-device copy may still be reading the slot

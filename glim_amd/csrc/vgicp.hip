@@ -109,7 +109,23 @@ struct FinalizeArgs {
   unsigned int* host_flag;   // host-mapped completion word or null
   unsigned int seq;
   int num_factors;
+  // single-dispatch form (vgicp_kernel<..., FUSED>): tagged partial rows and, per launch segment, the factors its trailing blocks finalise
+  char* rows16;              // TAG_ROW_BYTES per plan row
+  const int* finmap;         // factor ids, plane-form segment first (null for a single-factor set: factor 0)
 };
+
+// ---- tagged rows: the hand-off of the single-dispatch synchronous call --------------------------------------------------------------
+// A block's partial row travels to the block that finalises its factor INSIDE the launch as ten self-validating 16-byte granules
+// {v[3p], v[3p+1], v[3p+2], tag}, p = 0..9, tag = the call's sequence number: ONE write-through (sc1) dwordx4 store per granule -- it
+// leaves the writing XCD's L2 at once and is performed as a unit -- and sc1 loads on the reading side, which are served past the reader's L1
+// and its XCD's L2 copy (MI355X_MICROARCH.md "inter-workgroup visibility": the granule form needs no fence, no flag and no counter).  A
+// granule whose tag is not this call's has not arrived yet; the reader just looks again.  No atomics: the three in-kernel finalisations of
+// round 3 serialised ~500 arrivals of a chip-wide factor on one counter (~10 ns per same-address atomic = 5 us).
+constexpr int TAG_PIECES = 10;
+constexpr int TAG_ROW_BYTES = TAG_PIECES * 16;
+constexpr unsigned int AUX_SC1 = 16u;                    // cache policy of the raw buffer intrinsics: agent-coherent (write-through / L2-bypass)
+constexpr unsigned int AUX_SC1_VOLATILE = 16u | (1u << 31);  // ... and not to be hoisted out of / merged across the polling loop
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 // The last step of a linearisation, shared by the device finalise kernel and by the host-finalised single-factor call so that both give
 // the same bits: the kernel accumulated H' = sum J'^T M J' and b' = sum J'^T M r for J' = [hat(R p) | -I] in the target frame; with
@@ -165,6 +181,7 @@ __host__ __device__ inline void rotate_part(int part, const double* sum, const d
 // same-address atomic) for longer than the second dispatch costs.  So did summing the rows on the host as they arrive (35.9 us: the host
 // ping-pongs cache lines with the device's writes).
 constexpr int FIN_GROUPS = 32;
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double (&Tl)[12]);
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
                                                 double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
   const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
@@ -197,6 +214,12 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
   s_part[g][4 * q + 1] = s1;
   s_part[g][4 * q + 2] = s2;
   s_part[g][4 * q + 3] = s3;
+  finalize_tail(f, fa, mode, s_part, s_sum, Tl);
+}
+
+// Second half of a factor's finalisation, shared by the finalise kernel and by the finalising blocks of the single-dispatch kernel (same
+// bits): the 32 group sums of s_part added in group order, the four R^T B R rotations, the record, the completion word.
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double (&Tl)[12]) {
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
     double t = 0.0;
@@ -234,6 +257,60 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
       if (last) __hip_atomic_store(fa.host_flag, fa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// Finalising block of the single-dispatch kernel: the same fixed-order FP64 sum as finalize_factor -- value j of the factor's rows c = g, g + 32,
+// g + 64, ... added in that order into group sum g, the 32 group sums then added in group order (finalize_tail) -- taken over the tagged
+// rows as they arrive.  (group, piece) pair k = 10 g + p is handled by thread k, pairs 256..319 by threads 0..63 in a second round.  A
+// thread re-reads the <= 16 granules of a round until every tag is this call's; then it adds them.  The spin is bounded (~1 s): a row that
+// never arrives (cannot happen: the writing blocks wait for nothing) ends in a NaN record instead of a hung device.
+__device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum,
+                                               const double* __restrict__ T) {
+  const int first = d.first_block, nb = d.num_blocks;
+  double Tl[12];
+  if (threadIdx.x < 4) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) Tl[i] = T[i];
+  }
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rows16 + (size_t)first * TAG_ROW_BYTES, 0, nb * TAG_ROW_BYTES, 0x00020000);
+  const int seq = (int)fa.seq;
+  bool lost = false;
+  constexpr int INFLIGHT = 16;
+  for (int k = threadIdx.x; k < FIN_GROUPS * TAG_PIECES; k += BLOCK) {
+    const int g = k / TAG_PIECES, p = k - g * TAG_PIECES;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int c = g; c < nb; c += FIN_GROUPS * INFLIGHT) {
+      v4i_t v[INFLIGHT];
+      for (unsigned int spins = 0;; spins++) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; u++) {
+          const int row = min(c + FIN_GROUPS * u, nb - 1);  // past the end: a valid row, value unused
+          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * TAG_ROW_BYTES + p * 16, 0, AUX_SC1_VOLATILE);
+          ok = ok && v[u].w == seq;
+        }
+        if (ok) break;
+        if (spins > (1u << 20)) {
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++)
+        if (c + FIN_GROUPS * u < nb) {
+          s0 += (double)__int_as_float(v[u].x);
+          s1 += (double)__int_as_float(v[u].y);
+          s2 += (double)__int_as_float(v[u].z);
+        }
+    }
+    if (lost) s0 = s1 = s2 = __builtin_nan("");
+    s_part[g][3 * p + 0] = s0;
+    s_part[g][3 * p + 1] = s1;
+    s_part[g][3 * p + 2] = s2;
+  }
+  if (threadIdx.x < FIN_GROUPS) s_part[threadIdx.x][30] = s_part[threadIdx.x][31] = 0.0;
+  finalize_tail(f, fa, mode, s_part, s_sum, Tl);
 }
 
 // resident waves per SIMD the register allocation aims for: the plane-form kernel fits 96 VGPRs (5 waves), the general one needs 99 (4 waves)
@@ -490,12 +567,26 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane runs the algebra (a lane
 // without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  block_offset: first plan row of
 // this launch's segment; blocks_per_round: blocks the device takes per dispatch round (its CUs), for the priority phase.
-template <int MODE, bool FROZEN, bool PLANE, bool INLINE>
-__global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
+// FUSED: the single-dispatch form of a small synchronous set.  The launch carries `fin_blocks` extra blocks behind the segment's rows; block
+// seg_rows + i finalises factor finmap[fin_offset + i] (fused_finalize) while the row blocks publish their partial rows as tagged granules
+// instead of plain rows: no second dispatch, no kernel boundary, no arrival counter.
+// (FUSED variants serve small latency-bound sets that never fill the chip: they take the general kernel's 128-register budget, which keeps
+//  the finalising branch's sixteen 16-byte loads in flight out of scratch.)
+template <int MODE, bool FROZEN, bool PLANE, bool INLINE, bool FUSED>
+__global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
                                                           float* __restrict__ partials, const InlineArgs ip, const FinalizeArgs fa, int block_offset,
-                                                          int blocks_per_round) {
-  __shared__ float s_red[4][PARTIAL_STRIDE];
+                                                          int blocks_per_round, int seg_rows, int fin_offset) {
+  // one LDS object: the row blocks use the first 512 bytes (s_red), a finalising block all of it (s_part, s_sum)
+  __shared__ double s_lds[FUSED ? (FIN_GROUPS + 1) * PARTIAL_STRIDE : (4 * PARTIAL_STRIDE * (int)sizeof(float)) / (int)sizeof(double)];
+  float (*s_red)[PARTIAL_STRIDE] = reinterpret_cast<float (*)[PARTIAL_STRIDE]>(s_lds);
+  if (FUSED && (int)blockIdx.x >= seg_rows) {
+    const int ff = INLINE ? 0 : fa.finmap[fin_offset + ((int)blockIdx.x - seg_rows)];
+    const FactorDesc fd = INLINE ? ip.d : descs[ff];
+    fused_finalize(fd, ff, fa, MODE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE,
+                   INLINE ? ip.m : poses_lin + 12 * (size_t)ff);
+    return;
+  }
   const int gblock = block_offset + (int)blockIdx.x;  // row of this block in the plan (the plane-form and the general segment are separate launches)
   // INLINE (single-factor sets): pose and descriptor are read from the kernel arguments (scalar loads from the kernarg segment), the block
   // map is the identity -- no dependent blockmap -> descriptor load chain in front of the first stream load
@@ -560,6 +651,22 @@ __global__ __launch_bounds__(BLOCK, PLANE ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_
   __syncthreads();
   // a factor's partial rows are consecutive: row first_block + chunk (the finalisation reads them without an index table)
   const size_t row = (size_t)(d.first_block + bm.y);
+  if (FUSED) {
+    // tagged granules (see TAG_PIECES): thread p < 10 publishes values 3p .. 3p + 2 and this call's tag with ONE write-through 16-byte store
+    if (threadIdx.x < TAG_PIECES) {
+      float v[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int j = 3 * (int)threadIdx.x + k;
+        const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
+        v[k] = live ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.f;
+      }
+      const v4i_t piece = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), (int)fa.seq};
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rows16 + row * TAG_ROW_BYTES, 0, TAG_ROW_BYTES, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(piece, rsrc, (int)threadIdx.x * 16, 0, AUX_SC1);
+    }
+    return;
+  }
   if (threadIdx.x < PARTIAL_STRIDE) {
     const int j = threadIdx.x;
     float v = 0.f;
@@ -731,6 +838,7 @@ namespace glim_amd {
 namespace {
 
 constexpr size_t PLAN_CACHE_MAX = 16;    // idle plans kept per context
+constexpr int FUSED_MAX_FACTORS = 1024, FUSED_MAX_ROWS = 16384;  // sets that may take the single-dispatch form (2.6 MB of tagged rows at most)
 constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many factors: poses read by the kernels from host-mapped memory (96 B per factor over PCIe)
 
 void plan_free(FactorPlan* p) {
@@ -740,6 +848,8 @@ void plan_free(FactorPlan* p) {
   if (p->d_descs) (void)pool_free(p->d_descs);
   if (p->d_blockmap) (void)pool_free(p->d_blockmap);
   if (p->d_partials) (void)pool_free(p->d_partials);
+  if (p->d_rows16) (void)pool_free(p->d_rows16);
+  if (p->d_finmap) (void)pool_free(p->d_finmap);
   if (p->d_poses) (void)pool_free(p->d_poses);
   if (p->d_compact) (void)pool_free(p->d_compact);
   if (p->d_done) (void)pool_free(p->d_done);
@@ -806,6 +916,7 @@ int plan_upload(glim_amd_factor_set* set, FactorPlan* plan) {
   if (nf > 0) {
     GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
     GA_HIP(hipMemcpyAsync(plan->d_blockmap, plan->h_blockmap.data(), plan->h_blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
+    if (plan->d_finmap) GA_HIP(hipMemcpyAsync(plan->d_finmap, plan->h_finmap.data(), plan->h_finmap.size() * sizeof(int), hipMemcpyHostToDevice, set->stream));
   }
   plan->uploaded = true;
   return GLIM_AMD_OK;
@@ -832,6 +943,7 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   plan->built_plane = diag.plane;
   plan->built_ppt = diag.ppt;
   plan->h_descs.assign(nf, FactorDesc());
+  plan->h_finmap.clear();
   std::vector<int> nblocks(nf);
   for (int f = 0; f < nf; f++) {
     const auto& e = set->entries[f];
@@ -927,6 +1039,9 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
         for (size_t j = 0; j < per_xcd[x].size(); j++) blockmap[base + j * 8 + x] = per_xcd[x][j];
     }
     seg_rows[seg] = (int)(blockmap.size() - base);
+    // the factors the trailing blocks of this segment's single-dispatch launch finalise, in plan order
+    plan->fin_count[seg] = (int)fs.size();
+    for (int f : fs) plan->h_finmap.push_back(f);
   }
   // a factor's partial rows are consecutive: row first_block + chunk, whatever block of the map computes the chunk
   long long total_blocks = 0;
@@ -945,6 +1060,12 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
   GA_HIP(pool_malloc(&plan->d_done, sizeof(int)));
   GA_HIP(hipMemsetAsync(plan->d_done, 0, sizeof(int), set->stream));
+  // single-dispatch form (small synchronous sets only): tagged rows, every tag 0 = "no call yet" (sequence numbers start at 1)
+  if (nf >= 1 && nf <= FUSED_MAX_FACTORS && total_blocks <= FUSED_MAX_ROWS) {
+    GA_HIP(pool_malloc(&plan->d_rows16, (size_t)total_blocks * TAG_ROW_BYTES));
+    GA_HIP(hipMemsetAsync(plan->d_rows16, 0, (size_t)total_blocks * TAG_ROW_BYTES, set->stream));
+    GA_HIP(pool_malloc(&plan->d_finmap, (size_t)nf * sizeof(int)));
+  }
   if (pinned_malloc(&plan->h_flag, 64) == hipSuccess) {
     *plan->h_flag = 0;
     if (!host_device_view(plan->h_flag, &plan->h_flag_dev)) {
@@ -1035,35 +1156,45 @@ FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long lon
   fa.host_flag = poll ? plan->h_flag_dev : nullptr;
   fa.seq = plan->poll_seq;
   fa.num_factors = (int)set->entries.size();
+  fa.rows16 = plan->d_rows16;
+  fa.finmap = plan->d_finmap;
   return fa;
 }
 
-template <int MODE, bool FROZEN, bool INLINE>
+template <int MODE, bool FROZEN, bool INLINE, bool FUSED>
 void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa, float* partials) {
   const FactorPlan* plan = set->plan;
   const double* lin = set->poses_dev;
   const double* ev = set->poses_dev + set->entries.size() * 12;
   const int per_round = std::max(1, set->ctx->num_cus);
-  if (plan->plane_rows > 0)
-    vgicp_kernel<MODE, FROZEN, true, INLINE><<<plan->plane_rows, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, 0,
-                                                                                        per_round);
-  if (plan->total_rows > plan->plane_rows)
-    vgicp_kernel<MODE, FROZEN, false, INLINE><<<plan->total_rows - plan->plane_rows, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials,
-                                                                                                              set->inline_args, fa, plan->plane_rows, per_round);
+  const int rows0 = plan->plane_rows, rows1 = plan->total_rows - plan->plane_rows;
+  const int fin0 = FUSED ? plan->fin_count[0] : 0, fin1 = FUSED ? plan->fin_count[1] : 0;
+  if (rows0 > 0)
+    vgicp_kernel<MODE, FROZEN, true, INLINE, FUSED><<<rows0 + fin0, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, 0,
+                                                                                            per_round, rows0, 0);
+  if (rows1 > 0)
+    vgicp_kernel<MODE, FROZEN, false, INLINE, FUSED><<<rows1 + fin1, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa,
+                                                                                             rows0, per_round, rows1, fin0);
 }
 
-// the fused kernel(s) alone (no finalisation); partials: the plan's device rows, or the host-mapped rows of a host-finalised call
-void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const FinalizeArgs& fa, float* partials) {
+// the factor kernel(s); partials: the plan's device rows.  fused: the single-dispatch form (tagged rows, finalising blocks inside the launch)
+void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const FinalizeArgs& fa, float* partials, bool fused) {
   const bool inl = set->inline_args.valid != 0;
+#define GA_LAUNCH(MODE, FROZEN, INL)                                           \
+  do {                                                                         \
+    if (fused) launch_segments<MODE, FROZEN, INL, true>(set, fa, partials);    \
+    else launch_segments<MODE, FROZEN, INL, false>(set, fa, partials);         \
+  } while (0)
   if (mode == MODE_LINEARIZE) {
-    if (inl) launch_segments<MODE_LINEARIZE, false, true>(set, fa, partials);
-    else launch_segments<MODE_LINEARIZE, false, false>(set, fa, partials);
+    if (inl) GA_LAUNCH(MODE_LINEARIZE, false, true);
+    else GA_LAUNCH(MODE_LINEARIZE, false, false);
   } else if (frozen) {
-    launch_segments<MODE_ERROR, true, false>(set, fa, partials);
+    GA_LAUNCH(MODE_ERROR, true, false);
   } else {
-    if (inl) launch_segments<MODE_ERROR, false, true>(set, fa, partials);
-    else launch_segments<MODE_ERROR, false, false>(set, fa, partials);
+    if (inl) GA_LAUNCH(MODE_ERROR, false, true);
+    else GA_LAUNCH(MODE_ERROR, false, false);
   }
+#undef GA_LAUNCH
   set->plan->last_stream = set->stream;
 }
 
@@ -1075,7 +1206,13 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   FactorPlan* plan = set->plan;
   if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));  // (the inline kernels read pose and descriptor from their arguments)
   const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
-  launch_vgicp(set, mode, frozen, fa, plan->d_partials);
+  // small synchronous sets whose completion the host polls: ONE dispatch per segment, the factors are finalised inside it
+  const bool fused = poll && plan->d_rows16 && set->ctx->diag.fuse;
+  launch_vgicp(set, mode, frozen, fa, plan->d_partials, fused);
+  if (fused) {
+    GA_HIP(hipGetLastError());
+    return GLIM_AMD_OK;
+  }
   // more factors than one resident round of per-factor blocks, all of them short: a wavefront per factor (same bits)
   if (nf > FIN_SHORT_MIN_FACTORS && plan->max_rows_per_factor <= FIN_GROUPS && !fa.host_flag && !set->inline_args.valid)
     finalize_short_kernel<<<(nf + FIN_WAVES - 1) / FIN_WAVES, BLOCK, 0, set->stream>>>(plan->d_descs, plan->d_partials, fa, mode, set->poses_dev);
@@ -1426,7 +1563,7 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T, int i
   GA_HIP(hipEventRecord(e0, set->stream));
   if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));
   const FinalizeArgs fa_prof = finalize_args(set, plan->d_compact, 0, false);
-  for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof, plan->d_partials);
+  for (int i = 0; i < iters; i++) launch_vgicp(set, MODE_LINEARIZE, false, fa_prof, plan->d_partials, false);
   GA_HIP(hipEventRecord(e1, set->stream));
   GA_HIP(hipEventSynchronize(e1));
   GA_HIP(hipEventElapsedTime(&ms, e0, e1));

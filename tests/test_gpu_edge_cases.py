@@ -242,7 +242,7 @@ def test_synchronous_call_variants_give_identical_bits(api, ctx, orc):
         for target in (0, np.eye(4)):
             factors = [api.IntegratedVGICPFactorGPU(target, 1 + k, vms[k % 2], sg) for k in range(copies)]
             res = {}
-            for mode in ("", "poll=0", "host_poses=0", "inline_pose=0", "inline_pose=0,host_poses=0,poll=0"):
+            for mode in ("", "fuse=0", "poll=0", "host_poses=0", "inline_pose=0", "fuse=0,inline_pose=0", "inline_pose=0,host_poses=0,poll=0"):
                 ctx.set_diag(mode)
                 fset = api.NonlinearFactorSetGPU(ctx)
                 for f in factors:
@@ -262,6 +262,53 @@ def test_synchronous_call_variants_give_identical_bits(api, ctx, orc):
                         np.testing.assert_array_equal(L[key], B[key], err_msg=f"{mode} rep {rep} factor {k} {key}")
                     assert L["error"] == B["error"], mode
                 assert list(es) == list(base[1]), mode
+
+
+def test_single_dispatch_form_under_repetition_and_mixed_segments(api, ctx, orc, small_pair):
+    """The single-dispatch synchronous form (tagged partial rows handed to finalising blocks inside the launch, vgicp.hip FUSED) re-uses its rows call
+    after call: 400 back-to-back calls alternating between two poses must return, every time, exactly the record of THAT pose as the two-dispatch
+    form (fuse=0) computes it -- a stale row or a stale tag would surface as the other pose's bits.  Chip-wide single factor, the odometry's
+    34-factor shape, and a set that mixes plane-form and general (merged-submap-like) sources, i.e. two launch segments with their own finalisers."""
+    t, s = small_pair["target"], small_pair["source"]
+    tgt, src, tg, sg, delta = _full_size_pair(api, ctx, 128, 1024)
+    vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
+    general = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"] * 1.5, ctx=ctx)  # not plane-form: 36 B/pt kernel
+    small_t = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    small_vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(small_t)
+    cases = {
+        "single": [api.IntegratedVGICPFactorGPU(0, 1, vms[0], sg)],
+        "set34": [api.IntegratedVGICPFactorGPU(0 if k < 4 else np.eye(4), 1 + k, vms[k % 2], sg) for k in range(34)],
+        "mixed": [api.IntegratedVGICPFactorGPU(0, 1 + k, small_vm if k % 3 == 0 else vms[k % 2], general if k % 3 == 0 else sg) for k in range(7)],
+    }
+    for name, factors in cases.items():
+        poses = []
+        for which in (0, 1):
+            values = {0: np.eye(4)}
+            for k in range(len(factors)):
+                d = small_pair["delta"] if (name == "mixed" and k % 3 == 0) else delta
+                values[1 + k] = d @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + 3.0 * which))
+            poses.append(values)
+        ctx.set_diag("fuse=0")
+        ref_set = api.NonlinearFactorSetGPU(ctx)
+        for f in factors:
+            ref_set.add(f)
+        want = [(ref_set.linearize(v), ref_set.error(v)) for v in poses]
+        ctx.set_diag("")
+        fset = api.NonlinearFactorSetGPU(ctx)
+        for f in factors:
+            fset.add(f)
+        assert want[0][0][0]["num_inliers"] > 100 and want[0][0][0]["H_ss"][0, 0] != want[1][0][0]["H_ss"][0, 0]
+        for rep in range(400):
+            which = (rep * 7 // 3) % 2
+            Ls = fset.linearize(poses[which])
+            es = fset.error(poses[which]) if rep % 5 == 0 else None
+            for k, (L, B) in enumerate(zip(Ls, want[which][0])):
+                assert L["num_inliers"] == B["num_inliers"], (name, rep, k)
+                for key in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+                    np.testing.assert_array_equal(L[key], B[key], err_msg=f"{name} rep {rep} factor {k} {key}")
+                assert L["error"] == B["error"], (name, rep, k)
+            if es is not None:
+                assert list(es) == list(want[which][1]), (name, rep)
 
 
 def test_wave_per_factor_finalise_gives_the_block_finalise_bits(api, ctx, orc, small_pair):
