@@ -74,6 +74,8 @@ struct Diag {
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
+  int resident = 1;       // resident=0|1                       repeated synchronous linearisations of a small set go through a resident kernel (no launch per call)
+  int resident_idle_us = 2000;  // resident_idle_us=<n>         the resident kernel leaves after this long without a request
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
@@ -327,6 +329,8 @@ struct FactorPlan {
   char* d_rows16 = nullptr;       // tagged partial rows of the single-dispatch synchronous form (vgicp.hip TAG_ROW_BYTES per row), or null
   int* d_finmap = nullptr;        // factor ids the trailing blocks of each segment's single-dispatch launch finalise (plane-form segment first)
   int fin_count[2] = {0, 0};
+  char* h_rec16 = nullptr;        // single-dispatch form: the records as host-mapped 16-byte granules {value, sequence number}, COMPACT per factor
+  char* h_rec16_dev = nullptr;
   std::vector<int> h_finmap;
   double* d_poses = nullptr;      // 2 x n x 12 (lin, eval)
   double* d_compact = nullptr;    // n x COMPACT
@@ -344,6 +348,7 @@ struct FactorPlan {
   unsigned int* h_flag_dev = nullptr;
   unsigned int poll_seq = 0;
   size_t cap_factors = 0, cap_blocks = 0;
+  int sync_linearize_calls = 0;      // synchronous linearisations this plan has served (a resident session starts after a few)
   std::vector<glim_amd::FactorDesc> h_descs;
   std::vector<int2> h_blockmap;
   bool uploaded = false;              // d_descs / d_blockmap hold h_descs / h_blockmap (single-factor plans upload on first non-inline launch)

@@ -111,6 +111,7 @@ struct FinalizeArgs {
   int num_factors;
   // single-dispatch form (vgicp_kernel<..., FUSED>): tagged partial rows and, per launch segment, the factors its trailing blocks finalise
   char* rows16;              // TAG_ROW_BYTES per plan row
+  char* rec16;               // host-mapped record granules (COMPACT x 16 B per factor) of the single-dispatch form, or null
   const int* finmap;         // factor ids, plane-form segment first (null for a single-factor set: factor 0)
 };
 
@@ -229,19 +230,29 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
   }
   __syncthreads();
   const int t = threadIdx.x;
-  double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
-  if (t == 0) o[0] = s_sum[28];
-  if (t == 1) o[1] = s_sum[27];
+  __shared__ double s_rot[32];
   if (mode == MODE_LINEARIZE) {
-    __shared__ double s_rot[32];
     if (t < 4) rotate_part(t, s_sum, Tl, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
     __syncthreads();
-    if (t < 21) o[2 + t] = s_rot[c_acc_of_upper[t]];
-    if (t >= 21 && t < 24) o[2 + t] = s_rot[t];          // b_w = R^T sum u x q'
-    if (t >= 24 && t < 27) o[2 + t] = -s_rot[t];         // b_v = -R^T sum u
-  } else if (t >= 2 && t < COMPACT) {
-    o[t] = 0.0;
   }
+  // slot t of the compact record: [count, error, 21 upper-triangular H_ss entries, b_w = R^T sum u x q', b_v = -R^T sum u]
+  double value = 0.0;
+  if (t == 0) value = s_sum[28];
+  else if (t == 1) value = s_sum[27];
+  else if (mode == MODE_LINEARIZE && t < COMPACT) value = t < 23 ? s_rot[c_acc_of_upper[t - 2]] : (t < 26 ? s_rot[t - 2] : -s_rot[t - 2]);
+  if (fa.rec16) {
+    // Single-dispatch form: the record goes to host-mapped memory as 29 self-validating 16-byte granules {value, sequence number}, one
+    // store each -- a PCIe write lands as a unit, so a granule whose tag is this call's carries this call's value.  The host polls the
+    // tags: no system fence (~1 us of write acknowledgements), no arrival counter, no completion word.
+    if (t < COMPACT) {
+      const long long bits = __double_as_longlong(value);
+      const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)fa.seq, 0};
+      *reinterpret_cast<__attribute__((address_space(1))) v4i_t*>(reinterpret_cast<uintptr_t>(fa.rec16 + ((size_t)f * COMPACT + t) * 16)) = g;
+    }
+    return;
+  }
+  double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
+  if (t < COMPACT) o[t] = value;
   if (fa.host_flag) {
     // completion word of the polling fast path: every finalising block waits until its record is visible system-wide (ONE fence), the one
     // that completes the launch publishes `seq` into host-mapped memory (the host spins on it instead of a stream synchronise).  A
@@ -560,13 +571,90 @@ __device__ __forceinline__ void rotate_priority(int step) {
   }
 }
 
+// One (factor, chunk) row of a plan, computed by the 256 threads of a block: its lanes walk the factor's points in 256-point hands dealt
+// round robin to the factor's blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane
+// runs the algebra (a lane without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  On return
+// (after a block barrier) s_red[w][j] holds wavefront w's sum of accumulator j, s_red[w][28] its inlier count.
+template <int MODE, bool FROZEN, bool PLANE>
+__device__ __forceinline__ void compute_row(const FactorDesc& d, const double* __restrict__ Tl, const double* __restrict__ Te, int chunk, int prio_phase,
+                                            float (*s_red)[PARTIAL_STRIDE]) {
+  // rotation of the linearisation pose in FP32 (R[r][c])
+  // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
+  const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
+  const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
+  const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
+  const Rot32 R = {R00, R01, R02, R10, R11, R12, R20, R21, R22};
+  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.sn != nullptr);
+  const int last = d.n - 1;
+
+  float acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; j++) acc[j] = 0.f;
+  int wave_inliers = 0;  // wave-uniform count (scalar registers)
+
+  const int ppt = d.ppt;
+  // Points of a factor are dealt to its blocks in 256-point hands, round robin: trip t of block (chunk) c covers points
+  // [(t * num_blocks + c) * 256, +256).  Contiguous chunks (block c = points [c * ppt * 256, +ppt * 256)) left the launch TAIL-bound: in
+  // Hilbert order a chunk is one region of the scan, and a region of sparse far-range points touches several times more bucket lines per
+  // point than a dense near-range one -- per-block time stamps (tools/k4_timing.py) showed equal-sized blocks of ONE resident set taking
+  // 75 ... 159 us (median 114), the kernel lasting as long as the slowest.  Dealt round robin every block sees the same mix.
+  const int stride = d.num_blocks * BLOCK;
+  const int base = chunk * BLOCK + threadIdx.x;
+  if (d.n > 0) {
+    // Software pipeline over the points of this lane (pipe_trip above): the key gather of a point is issued one trip before its algebra.
+    // (Issuing it two trips ahead buys little: loads return in order, so the record gather of the trip in between would wait for it.)
+    PipeCtx<PLANE> pc = {d, Tl, Te, R, base, stride, ppt, last, validate};
+    PointIn nxt = load_point<PLANE>(d, (unsigned int)min(base, last));
+    Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base, ppt > 0, Tl, Te, R, validate, last);
+    nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
+    for (int it = 0; it < ppt; it++) {
+      rotate_priority(it + prio_phase);
+      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers);
+    }
+  }
+
+  // ---- block reduction: DPP wave sums -> LDS ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE == MODE_LINEARIZE) {
+#pragma unroll
+    for (int j = 0; j < NACC; j++) {
+      const float v = wave_sum_to_lane63(acc[j]);
+      if (lane == 63) s_red[wave][j] = v;
+    }
+  } else {
+    const float v = wave_sum_to_lane63(acc[27]);
+    if (lane == 63) s_red[wave][27] = v;
+  }
+  {
+    if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
+  }
+  __syncthreads();
+}
+
+// value j of the block's partial row from the four wavefront sums (the same expression wherever a row is published: same bits)
+template <int MODE>
+__device__ __forceinline__ float row_value(const float (*s_red)[PARTIAL_STRIDE], int j) {
+  const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
+  return live ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.f;
+}
+
+// tagged granules (see TAG_PIECES): thread p < 10 publishes values 3p .. 3p + 2 and the call's tag with ONE write-through 16-byte store
+template <int MODE>
+__device__ __forceinline__ void publish_row_tagged(const float (*s_red)[PARTIAL_STRIDE], char* rows16, size_t row, unsigned int tag) {
+  if (threadIdx.x < TAG_PIECES) {
+    const int j = 3 * (int)threadIdx.x;
+    const v4i_t piece = {__float_as_int(row_value<MODE>(s_red, j)), __float_as_int(row_value<MODE>(s_red, j + 1)), __float_as_int(row_value<MODE>(s_red, j + 2)),
+                         (int)tag};
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rows16 + row * TAG_ROW_BYTES, 0, TAG_ROW_BYTES, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(piece, rsrc, (int)threadIdx.x * 16, 0, AUX_SC1);
+  }
+}
+
 // The fused factor kernel.  MODE: linearise (28 sums) or error only.  FROZEN: residual at a separate evaluation pose with correspondences
 // and Mahalanobis matrices frozen at the linearisation pose.  PLANE: plane-form source stream (24 B/pt) or general (36 B/pt).  INLINE: the
 // pose and the descriptor of a single-factor set arrive in the kernel arguments (block b is chunk b of factor 0).
-// One block = one (factor, chunk) row of the plan; its lanes walk the factor's points in 256-point hands dealt round robin to the factor's
-// blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane runs the algebra (a lane
-// without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  block_offset: first plan row of
-// this launch's segment; blocks_per_round: blocks the device takes per dispatch round (its CUs), for the priority phase.
+// One block = one (factor, chunk) row of the plan (compute_row).  block_offset: first plan row of this launch's segment; blocks_per_round:
+// blocks the device takes per dispatch round (its CUs), for the priority phase.
 // FUSED: the single-dispatch form of a small synchronous set.  The launch carries `fin_blocks` extra blocks behind the segment's rows; block
 // seg_rows + i finalises factor finmap[fin_offset + i] (fused_finalize) while the row blocks publish their partial rows as tagged granules
 // instead of plain rows: no second dispatch, no kernel boundary, no arrival counter.
@@ -596,83 +684,173 @@ __global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GL
   const FactorDesc d = INLINE ? ip.d : descs[f];
   const double* Tl = INLINE ? ip.m : poses_lin + 12 * (size_t)f;
   const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
-
-  // rotation of the linearisation pose in FP32 (R[r][c])
-  // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
-  const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
-  const float R10 = (float)Tl[4], R11 = (float)Tl[5], R12 = (float)Tl[6];
-  const float R20 = (float)Tl[8], R21 = (float)Tl[9], R22 = (float)Tl[10];
-  const Rot32 R = {R00, R01, R02, R10, R11, R12, R20, R21, R22};
-  const bool validate = (d.flags & GLIM_AMD_FACTOR_SURFACE_VALIDATION) && (PLANE || d.sn != nullptr);
-  const int last = d.n - 1;
-
-  float acc[NACC];
-#pragma unroll
-  for (int j = 0; j < NACC; j++) acc[j] = 0.f;
-  int wave_inliers = 0;  // wave-uniform count (scalar registers)
-
-  const int ppt = d.ppt;
-  // Points of a factor are dealt to its blocks in 256-point hands, round robin: trip t of block (chunk) c covers points
-  // [(t * num_blocks + c) * 256, +256).  Contiguous chunks (block c = points [c * ppt * 256, +ppt * 256)) left the launch TAIL-bound: in
-  // Hilbert order a chunk is one region of the scan, and a region of sparse far-range points touches several times more bucket lines per
-  // point than a dense near-range one -- per-block time stamps (tools/k4_timing.py) showed equal-sized blocks of ONE resident set taking
-  // 75 ... 159 us (median 114), the kernel lasting as long as the slowest.  Dealt round robin every block sees the same mix.
-  const int stride = d.num_blocks * BLOCK;
-  const int base = bm.y * BLOCK + threadIdx.x;
-  if (d.n > 0) {
-    // Software pipeline over the points of this lane (pipe_trip above): the key gather of a point is issued one trip before its algebra.
-    // (Issuing it two trips ahead buys little: loads return in order, so the record gather of the trip in between would wait for it.)
-    PipeCtx<PLANE> pc = {d, Tl, Te, R, base, stride, ppt, last, validate};
-    PointIn nxt = load_point<PLANE>(d, (unsigned int)min(base, last));
-    Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base, ppt > 0, Tl, Te, R, validate, last);
-    nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
-    const int prio_phase = gblock / blocks_per_round;  // which of the CU's resident blocks this one is (dispatch is round robin over the CUs)
-    for (int it = 0; it < ppt; it++) {
-      rotate_priority(it + prio_phase);
-      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers);
-    }
-  }
-
-  // ---- block reduction: DPP wave sums -> LDS -> one partial row ----
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (MODE == MODE_LINEARIZE) {
-#pragma unroll
-    for (int j = 0; j < NACC; j++) {
-      const float v = wave_sum_to_lane63(acc[j]);
-      if (lane == 63) s_red[wave][j] = v;
-    }
-  } else {
-    const float v = wave_sum_to_lane63(acc[27]);
-    if (lane == 63) s_red[wave][27] = v;
-  }
-  {
-    if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
-  }
-  __syncthreads();
+  // prio_phase: which of the CU's resident blocks this one is (dispatch is round robin over the CUs)
+  compute_row<MODE, FROZEN, PLANE>(d, Tl, Te, bm.y, gblock / blocks_per_round, s_red);
   // a factor's partial rows are consecutive: row first_block + chunk (the finalisation reads them without an index table)
   const size_t row = (size_t)(d.first_block + bm.y);
   if (FUSED) {
-    // tagged granules (see TAG_PIECES): thread p < 10 publishes values 3p .. 3p + 2 and this call's tag with ONE write-through 16-byte store
-    if (threadIdx.x < TAG_PIECES) {
-      float v[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int j = 3 * (int)threadIdx.x + k;
-        const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
-        v[k] = live ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.f;
-      }
-      const v4i_t piece = {__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), (int)fa.seq};
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rows16 + row * TAG_ROW_BYTES, 0, TAG_ROW_BYTES, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(piece, rsrc, (int)threadIdx.x * 16, 0, AUX_SC1);
-    }
+    publish_row_tagged<MODE>(s_red, fa.rows16, row, fa.seq);
     return;
   }
-  if (threadIdx.x < PARTIAL_STRIDE) {
-    const int j = threadIdx.x;
-    float v = 0.f;
-    const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
-    if (live) v = (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]);
-    partials[row * PARTIAL_STRIDE + j] = v;
+  if (threadIdx.x < PARTIAL_STRIDE) partials[row * PARTIAL_STRIDE + threadIdx.x] = row_value<MODE>(s_red, (int)threadIdx.x);
+}
+
+// ---- resident form of the synchronous call --------------------------------------------------------------------------------------------
+// A kernel that STAYS on the device between calls and takes its requests through host-mapped memory: no launch on the request path at all
+// (tools/ubench/sync_floor.hip on this box: launch -> trivial kernel -> host-mapped word -> host wake-up 6.2 us; request word -> resident
+// leader -> 512 worker blocks -> 512 granules back -> completion word 3.3 us).  For GLIM's odometry, which linearises the same small factor
+// list again and again (odometry_estimation_gpu.cpp:383-385, once per optimiser iteration).
+//   blocks 0 .. workers-1                 compute plan rows b, b + workers, ... (compute_row) and publish them as tagged granules
+//   blocks workers .. workers + nf - 1    finalise one factor each (fused_finalize: same bits as every other form); block `workers` also LEADS:
+//                                         it polls the request word in host memory, reads the poses the host left beside it and re-publishes
+//                                         them in device memory as {double, tag} granules -- which is also the "go" signal for everyone else
+// Tags of a resident session have bit 31 set (the launch-per-call forms count from 1), 0xffffffff = exit.  The leader exits on its own after
+// `idle_polls` empty polls (a few milliseconds), so a device-wide synchronise elsewhere in the process can never wait for long, and every
+// other wait is bounded as well: a session that loses its leader dies instead of hanging the device.
+struct ResidentArgs {
+  const FactorDesc* descs;
+  const int2* blockmap;
+  const int* finmap;
+  int total_rows, num_factors, workers, blocks_per_round;
+  char* rows16;                    // tagged partial rows (the plan's)
+  char* rec16;                     // host-mapped record granules (the plan's)
+  char* pose16;                    // device: num_factors x 12 pose granules {double, tag, 0}
+  const double* h_poses;           // host-mapped: num_factors x 12 doubles, complete before the host writes the request tag
+  unsigned int* mail;              // host-mapped: [0] request tag (host writes), [16] alive (1 while the kernel serves, 0 once it has left)
+  unsigned int first_tag;          // the last tag served before this launch
+  unsigned int idle_polls;         // leader: empty polls before it leaves
+};
+constexpr unsigned int RES_EXIT = 0xffffffffu;
+
+// wave 0, lanes 0..11: wait for the 12 pose granules of factor f.  exact != 0: until their tag is `exact`; otherwise until it is a session tag
+// different from `last`.  Returns the tag through s_tag (RES_EXIT when the session ends or the wait gives up) and the pose through s_pose.
+__device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigned int last, unsigned int exact, double* s_pose, unsigned int* s_tag) {
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x < 12 ? (int)threadIdx.x : 0;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16 + (size_t)f * 12 * 16, 0, 12 * 16, 0x00020000);
+    v4i_t g;
+    unsigned int tag = RES_EXIT;
+    const unsigned int limit = ra.idle_polls * 64u + (1u << 16);
+    for (unsigned int spins = 0; spins < limit; spins++) {
+      g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, 0, AUX_SC1_VOLATILE);
+      const unsigned int t = (unsigned int)g.z;
+      const bool mine = exact ? (t == exact || t == RES_EXIT) : ((t & 0x80000000u) != 0u && t != last);
+      // every lane must see the SAME new tag (the leader writes the 12 granules of a factor with one store instruction, but they travel separately)
+      const unsigned int t0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+      if (__all(mine && t == t0)) {
+        tag = t0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (threadIdx.x < 12) s_pose[threadIdx.x] = __longlong_as_double(((long long)(unsigned int)g.y << 32) | (long long)(unsigned int)g.x);
+    if (threadIdx.x == 0) *s_tag = tag;
+  }
+  __syncthreads();
+}
+
+// (3 waves per SIMD = 3 blocks per CU = 768 resident blocks: a session holds at most 2 x CUs workers + 64 finalisers)
+__global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs ra) {
+  __shared__ double s_lds[(FIN_GROUPS + 1) * PARTIAL_STRIDE];
+  __shared__ double s_pose[12];
+  __shared__ unsigned int s_tag;
+  float (*s_red)[PARTIAL_STRIDE] = reinterpret_cast<float (*)[PARTIAL_STRIDE]>(s_lds);
+  const int b = (int)blockIdx.x;
+  const bool finaliser = b >= ra.workers, leader = b == ra.workers;
+  unsigned int last = ra.first_tag;
+  // the first real row of a worker decides which factor's pose granules it watches between requests (a worker that owns only padding rows of
+  // an XCD-aware map watches factor 0: it still has to see the session end)
+  int first_row = -1;
+  if (!finaliser)
+    for (int r = b; r < ra.total_rows && first_row < 0; r += ra.workers)
+      if (ra.blockmap[r].x >= 0) first_row = r;
+  for (;;) {
+    if (leader) {
+      // ---- wait for a request in host memory; re-publish the poses (device granules) or the end of the session
+      if (threadIdx.x == 0) {
+        unsigned int req = last;
+        for (unsigned int idle = 0;; idle++) {
+          req = __hip_atomic_load(ra.mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (req != last) break;
+          if (idle >= ra.idle_polls) {
+            req = RES_EXIT;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        s_tag = req;
+      }
+      __syncthreads();
+      const unsigned int req = s_tag;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.num_factors * 12 * 16, 0x00020000);
+      for (int i = threadIdx.x; i < ra.num_factors * 12; i += BLOCK) {
+        long long bits = 0;
+        if (req != RES_EXIT) bits = __double_as_longlong(__hip_atomic_load(ra.h_poses + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)req, 0};
+        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, i * 16, 0, AUX_SC1);
+      }
+      if (req == RES_EXIT) {
+        if (threadIdx.x == 0) __hip_atomic_store(ra.mail + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __syncthreads();
+    }
+    if (finaliser) {
+      const int f = ra.finmap ? ra.finmap[b - ra.workers] : 0;
+      wait_pose(ra, f, last, leader ? s_tag : 0u, s_pose, &s_tag);
+      const unsigned int tag = s_tag;
+      if (tag == RES_EXIT) return;
+      FinalizeArgs fa;
+      fa.out = nullptr;
+      fa.out_row_offset = 0;
+      fa.done_counter = nullptr;
+      fa.host_flag = nullptr;
+      fa.seq = tag;
+      fa.num_factors = ra.num_factors;
+      fa.rows16 = ra.rows16;
+      fa.rec16 = ra.rec16;
+      fa.finmap = ra.finmap;
+      const FactorDesc d = ra.descs[f];
+      fused_finalize(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose);
+      __syncthreads();
+      last = tag;
+      continue;
+    }
+    // ---- worker: its rows of this request
+    if (first_row < 0) {
+      wait_pose(ra, 0, last, 0u, s_pose, &s_tag);  // nothing to compute: this block only follows the session
+      if (s_tag == RES_EXIT) return;
+      last = s_tag;
+      __syncthreads();
+      continue;
+    }
+    unsigned int tag = 0;
+    int have = -1;  // factor whose pose Tl holds
+    double Tl[12];
+    for (int r = first_row; r < ra.total_rows; r += ra.workers) {
+      const int2 bm = ra.blockmap[r];
+      if (bm.x < 0) continue;
+      if (bm.x != have) {
+        wait_pose(ra, bm.x, last, tag, s_pose, &s_tag);
+        if (s_tag == RES_EXIT) return;
+        tag = s_tag;
+        have = bm.x;
+        // the pose as wave-uniform scalars (the launch-per-call kernels read theirs from the kernel arguments / a uniform address)
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          const long long bits = __double_as_longlong(s_pose[i]);
+          const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(bits & 0xffffffffll));
+          const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(bits >> 32));
+          Tl[i] = __longlong_as_double(((long long)hi << 32) | (long long)lo);
+        }
+      }
+      const FactorDesc d = ra.descs[bm.x];
+      if (d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red);
+      else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red);
+      publish_row_tagged<MODE_LINEARIZE>(s_red, ra.rows16, (size_t)(d.first_block + bm.y), tag);
+      __syncthreads();  // s_red and s_pose are reused by the next row
+    }
+    last = tag;
   }
 }
 
@@ -835,6 +1013,8 @@ void hat3(const double* a, double* H) {
 // -----------------------------------------------------------------------------------------------------------------
 namespace glim_amd {
 
+void resident_release(glim_amd_ctx* ctx, FactorPlan* plan);  // ends the resident session (below) of this context / plan, if any
+
 namespace {
 
 constexpr size_t PLAN_CACHE_MAX = 16;    // idle plans kept per context
@@ -843,6 +1023,7 @@ constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many fac
 
 void plan_free(FactorPlan* p) {
   if (!p) return;
+  resident_release(nullptr, p);  // a resident session that serves this plan ends first
   // nothing enqueued earlier (asynchronous entry points included) may still be using the buffers that go back to the pool
   if (p->maybe_busy && p->last_stream) (void)hipStreamSynchronize(p->last_stream);
   if (p->d_descs) (void)pool_free(p->d_descs);
@@ -856,6 +1037,7 @@ void plan_free(FactorPlan* p) {
   if (p->h_poses) (void)pinned_free(p->h_poses);
   if (p->h_compact) (void)pinned_free(p->h_compact);
   if (p->h_flag) (void)pinned_free(p->h_flag);
+  if (p->h_rec16) (void)pinned_free(p->h_rec16);
   for (int i = 0; i < FactorPlan::POSE_RING; i++)
     if (p->pose_events[i]) (void)hipEventDestroy(p->pose_events[i]);
   delete p;
@@ -875,6 +1057,7 @@ bool host_device_view(T* host, T** dev) {
 }  // namespace
 
 void ctx_release_factor_resources(glim_amd_ctx* ctx) {
+  resident_release(ctx, nullptr);
   for (FactorPlan* p : ctx->plan_cache) plan_free(p);
   ctx->plan_cache.clear();
   if (ctx->ov_counters) (void)pool_free(ctx->ov_counters);
@@ -1065,6 +1248,17 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     GA_HIP(pool_malloc(&plan->d_rows16, (size_t)total_blocks * TAG_ROW_BYTES));
     GA_HIP(hipMemsetAsync(plan->d_rows16, 0, (size_t)total_blocks * TAG_ROW_BYTES, set->stream));
     GA_HIP(pool_malloc(&plan->d_finmap, (size_t)nf * sizeof(int)));
+    const size_t rec_bytes = (size_t)nf * COMPACT * 16;
+    if (pinned_malloc(&plan->h_rec16, rec_bytes) == hipSuccess) {
+      memset(plan->h_rec16, 0, rec_bytes);
+      if (!host_device_view(plan->h_rec16, &plan->h_rec16_dev)) {
+        (void)pinned_free(plan->h_rec16);
+        plan->h_rec16 = nullptr;
+      }
+    } else {
+      (void)hipGetLastError();
+      plan->h_rec16 = nullptr;
+    }
   }
   if (pinned_malloc(&plan->h_flag, 64) == hipSuccess) {
     *plan->h_flag = 0;
@@ -1157,6 +1351,7 @@ FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long lon
   fa.seq = plan->poll_seq;
   fa.num_factors = (int)set->entries.size();
   fa.rows16 = plan->d_rows16;
+  fa.rec16 = nullptr;
   fa.finmap = plan->d_finmap;
   return fa;
 }
@@ -1198,6 +1393,49 @@ void launch_vgicp(glim_amd_factor_set* set, int mode, bool frozen, const Finaliz
   set->plan->last_stream = set->stream;
 }
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#endif
+}
+
+bool use_single_dispatch(const glim_amd_factor_set* set, bool poll) {
+  const FactorPlan* plan = set->plan;
+  return poll && plan->d_rows16 && plan->h_rec16_dev && set->ctx->diag.fuse;
+}
+
+// host side of the single-dispatch form's completion: wait until every record granule carries this call's sequence number, then unpack the
+// values into plan->h_compact (where every consumer of a synchronous call reads them).  false after ~200 ms.
+// alive (optional): a word the producer clears when it leaves without serving (resident session): the wait ends early then.
+bool collect_tagged_records(FactorPlan* plan, size_t nf, unsigned int seq, const volatile unsigned int* alive = nullptr) {
+  const volatile unsigned long long* g = reinterpret_cast<const volatile unsigned long long*>(plan->h_rec16);
+  const size_t n = nf * COMPACT;
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t i = 0;
+  for (unsigned long spins = 0; i < n;) {
+    if ((unsigned int)g[2 * i + 1] == seq) {
+      i++;
+      continue;
+    }
+    cpu_relax();
+    ++spins;
+    if (alive && (spins & 0x3f) == 0x3f && *alive == 0) {
+      // the session has ended; its last stores may still be in flight: look once more after a moment, then report
+      for (int k = 0; k < 2000; k++) cpu_relax();
+      while (i < n && (unsigned int)g[2 * i + 1] == seq) i++;
+      if (i < n) return false;
+      break;
+    }
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(plan->h_compact);
+  for (size_t k = 0; k < n; k++) out[k] = g[2 * k];
+  return true;
+}
+
 // enqueue (no sync): poses already on the device / in the inline arguments; writes compact records to `out` rows [row_offset, row_offset + n).
 // Two or three launches: the fused kernel per plan segment + the FP64 finalise.
 int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll) {
@@ -1205,9 +1443,10 @@ int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long l
   if (nf == 0) return GLIM_AMD_OK;
   FactorPlan* plan = set->plan;
   if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));  // (the inline kernels read pose and descriptor from their arguments)
-  const FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
+  FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   // small synchronous sets whose completion the host polls: ONE dispatch per segment, the factors are finalised inside it
-  const bool fused = poll && plan->d_rows16 && set->ctx->diag.fuse;
+  const bool fused = use_single_dispatch(set, poll);
+  if (fused) fa.rec16 = plan->h_rec16_dev;
   launch_vgicp(set, mode, frozen, fa, plan->d_partials, fused);
   if (fused) {
     GA_HIP(hipGetLastError());
@@ -1258,14 +1497,6 @@ int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_
   return GLIM_AMD_OK;
 }
 
-inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-  __builtin_ia32_pause();
-#elif defined(__aarch64__)
-  asm volatile("yield" ::: "memory");
-#endif
-}
-
 // spin until *word == value (acquire); false after ~200 ms
 bool spin_until(const volatile unsigned int* word, unsigned int value) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -1279,6 +1510,178 @@ bool spin_until(const volatile unsigned int* word, unsigned int value) {
   }
 }
 
+// ---- resident sessions (host side; kernel: resident_kernel) ------------------------------------------------------------------------------
+// ONE session per device, process-wide: a resident kernel spins on wave slots, and two of them that each wait for blocks the other keeps
+// from becoming resident would only get going again when one idles out.  A plan is served through the session after RESIDENT_WARMUP
+// launch-per-call linearisations (a set that is linearised once or twice never starts one); it takes the session over from another plan
+// only when that one has not been asked for RESIDENT_TAKEOVER_US.
+constexpr int RESIDENT_MAX_FACTORS = 64, RESIDENT_WARMUP = 3;
+constexpr long long RESIDENT_TAKEOVER_US = 1000;
+struct ResidentSession {
+  std::mutex mu;
+  FactorPlan* plan = nullptr;
+  glim_amd_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  unsigned int *h_mail = nullptr, *h_mail_dev = nullptr;  // [0] request tag, [16] alive
+  double *h_poses = nullptr, *h_poses_dev = nullptr;      // RESIDENT_MAX_FACTORS x 12
+  char* d_pose16 = nullptr;
+  unsigned int counter = 0, last_tag = 0;
+  bool launched = false;
+  std::atomic<bool> busy{false};
+  std::chrono::steady_clock::time_point last_use;
+  unsigned long long launches = 0, requests = 0;
+};
+ResidentSession g_resident[16];
+
+unsigned int next_session_tag(ResidentSession& S) {
+  S.counter = (S.counter >= 0x7ffffff0u) ? 1u : S.counter + 1u;
+  return 0x80000000u | S.counter;
+}
+
+// S.mu held.  Ends the resident kernel (if any) and waits for it.
+void resident_stop(ResidentSession& S) {
+  if (!S.launched) return;
+  if (S.h_mail) {
+    reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = RES_EXIT;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+  }
+  (void)hipStreamSynchronize(S.stream);
+  S.launched = false;
+  S.plan = nullptr;
+  S.ctx = nullptr;
+}
+
+// S.mu and the context mutex held, device current.  (Re)starts the resident kernel for `plan`; it will serve the first request tag != S.last_tag.
+int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* plan) {
+  glim_amd_ctx* ctx = set->ctx;
+  if (!S.stream) GA_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  if (!S.h_mail) {
+    GA_HIP(pinned_malloc(&S.h_mail, 256));
+    memset(S.h_mail, 0, 256);
+    if (!host_device_view(S.h_mail, &S.h_mail_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
+    GA_HIP(pinned_malloc(&S.h_poses, (size_t)RESIDENT_MAX_FACTORS * 12 * sizeof(double)));
+    if (!host_device_view(S.h_poses, &S.h_poses_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
+    GA_HIP(pool_malloc(&S.d_pose16, (size_t)RESIDENT_MAX_FACTORS * 12 * 16));
+  }
+  // descriptors, block map and finaliser map have to be on the device (a single-factor plan may never have uploaded them), and complete
+  // before the session's stream reads them
+  if (!plan->uploaded) {
+    GA_TRY(plan_upload(set, plan));
+    GA_HIP(hipStreamSynchronize(set->stream));
+  }
+  const int nf = (int)set->entries.size();
+  volatile unsigned int* mail = S.h_mail;
+  mail[0] = S.last_tag;  // (a pending request overwrites this right after the launch)
+  mail[16] = 1u;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  GA_HIP(hipMemsetAsync(S.d_pose16, 0, (size_t)RESIDENT_MAX_FACTORS * 12 * 16, S.stream));  // stale granules (an earlier session's exit tags) must not be read as news
+  ResidentArgs ra;
+  ra.descs = plan->d_descs;
+  ra.blockmap = plan->d_blockmap;
+  ra.finmap = plan->d_finmap;
+  ra.total_rows = plan->total_rows;
+  ra.num_factors = nf;
+  ra.workers = std::min(plan->total_rows, 2 * std::max(1, ctx->num_cus));
+  ra.blocks_per_round = std::max(1, ctx->num_cus);
+  ra.rows16 = plan->d_rows16;
+  ra.rec16 = plan->h_rec16_dev;
+  ra.pose16 = S.d_pose16;
+  ra.h_poses = S.h_poses_dev;
+  ra.mail = S.h_mail_dev;
+  ra.first_tag = S.last_tag;
+  // one empty poll of the request word is one PCIe read (~1.2 us) plus a short sleep
+  ra.idle_polls = (unsigned int)std::max(100, ctx->diag.resident_idle_us * 2 / 3);
+  resident_kernel<<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
+  GA_HIP(hipGetLastError());
+  S.launched = true;
+  S.plan = plan;
+  S.ctx = ctx;
+  S.launches++;
+  return GLIM_AMD_OK;
+}
+
+// The synchronous linearisation of a small set through the device's resident session.  Returns GLIM_AMD_OK (records in plan->h_compact),
+// GLIM_AMD_ERR_UNSUPPORTED when this call should take the launch-per-call path instead, or an error.
+int run_resident(glim_amd_factor_set* set, const double* T_lin) {
+  glim_amd_ctx* ctx = set->ctx;
+  if (ctx->device < 0 || ctx->device >= 16) return GLIM_AMD_ERR_UNSUPPORTED;
+  ResidentSession& S = g_resident[ctx->device];
+  const size_t nf = set->entries.size();
+  FactorPlan* plan = nullptr;
+  unsigned int tag = 0;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GA_HIP(hipSetDevice(ctx->device));
+    GA_TRY(factor_set_prepare(set));
+    plan = set->plan;
+    const Diag& diag = ctx->diag;
+    if (!diag.resident || !diag.fuse || !diag.poll || !plan->d_rows16 || !plan->h_rec16_dev || nf > (size_t)RESIDENT_MAX_FACTORS) return GLIM_AMD_ERR_UNSUPPORTED;
+    if (++plan->sync_linearize_calls <= RESIDENT_WARMUP) return GLIM_AMD_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> slock(S.mu);
+    if (S.busy.load()) return GLIM_AMD_ERR_UNSUPPORTED;  // another thread's request is in flight
+    const auto now = std::chrono::steady_clock::now();
+    if (S.launched && S.plan != plan) {
+      if (std::chrono::duration_cast<std::chrono::microseconds>(now - S.last_use).count() < RESIDENT_TAKEOVER_US) return GLIM_AMD_ERR_UNSUPPORTED;
+      resident_stop(S);
+    }
+    if (S.launched && reinterpret_cast<volatile unsigned int*>(S.h_mail)[16] == 0u) {
+      (void)hipStreamSynchronize(S.stream);  // it has idled out
+      S.launched = false;
+    }
+    if (!S.launched) {
+      const int rc = resident_launch(S, set, plan);
+      if (rc != GLIM_AMD_OK) return rc == GLIM_AMD_ERR_UNSUPPORTED ? rc : rc;
+    }
+    memcpy(S.h_poses, T_lin, nf * 12 * sizeof(double));
+    std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
+    tag = next_session_tag(S);
+    reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = tag;
+    S.busy.store(true);
+    S.last_use = now;
+    S.requests++;
+  }
+  bool ok = collect_tagged_records(plan, nf, tag, reinterpret_cast<volatile unsigned int*>(S.h_mail) + 16);
+  if (!ok) {
+    // the kernel left (idle time-out racing with this request) or is stuck: make sure it is gone, start a fresh one, which finds the pending
+    // request in the mailbox
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::mutex> slock(S.mu);
+    (void)hipSetDevice(ctx->device);
+    reinterpret_cast<volatile unsigned int*>(S.h_mail)[16] = 0u;
+    (void)hipStreamSynchronize(S.stream);
+    S.launched = false;
+    int rc = resident_launch(S, set, plan);
+    if (rc == GLIM_AMD_OK) {
+      reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = tag;
+      ok = collect_tagged_records(plan, nf, tag, nullptr);
+    }
+    if (!ok) {
+      resident_stop(S);
+      S.busy.store(false);
+      return GLIM_AMD_ERR_STATE;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> slock(S.mu);
+    S.last_tag = tag;
+    S.busy.store(false);
+  }
+  return GLIM_AMD_OK;
+}
+
+}  // namespace
+
+namespace glim_amd {
+void resident_release(glim_amd_ctx* ctx, FactorPlan* plan) {
+  for (ResidentSession& S : g_resident) {
+    std::lock_guard<std::mutex> slock(S.mu);
+    if (S.launched && ((plan && S.plan == plan) || (ctx && S.ctx == ctx))) resident_stop(S);
+  }
+}
+}  // namespace glim_amd
+
+namespace {
+
 // One synchronous evaluation (linearise or error) of the whole set: results in plan->h_compact when this returns.
 //  * small sets (<= 1024 factors, the per-frame odometry and sub-mapping cases): the records go straight into host-mapped pinned memory and
 //    the block that writes the last one publishes a sequence number there; the host spins on that word (sub-microsecond wake-up) instead of
@@ -1290,7 +1693,11 @@ bool spin_until(const volatile unsigned int* word, unsigned int value) {
 // the device when driven from different host threads, like the reference's StreamTempBufferRoundRobin factors.
 int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval) {
   const size_t nf = set->entries.size();
-  bool poll = false;
+  if (mode == MODE_LINEARIZE && !T_eval && nf <= (size_t)RESIDENT_MAX_FACTORS && set->ctx->diag.resident) {
+    const int rc = run_resident(set, T_lin);
+    if (rc != GLIM_AMD_ERR_UNSUPPORTED) return rc;
+  }
+  bool poll = false, fused = false;
   unsigned int seq = 0;
   FactorPlan* plan = nullptr;
   {
@@ -1303,8 +1710,15 @@ int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const doub
     const bool mapped = plan->h_compact_dev && nf <= 1024;
     poll = mapped && plan->h_flag && diag.poll;
     if (poll) seq = ++plan->poll_seq;
+    fused = use_single_dispatch(set, poll);
     GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll));
     if (!mapped) GA_HIP(hipMemcpyAsync(plan->h_compact, plan->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
+  }
+  if (fused) {
+    if (collect_tagged_records(plan, nf, seq)) return GLIM_AMD_OK;
+    // (cannot happen short of a device fault: fall back to the stream, then the granules must be there)
+    GA_HIP(hipStreamSynchronize(set->stream));
+    return collect_tagged_records(plan, nf, seq) ? GLIM_AMD_OK : GLIM_AMD_ERR_STATE;
   }
   if (!(poll && spin_until(plan->h_flag, seq))) GA_HIP(hipStreamSynchronize(set->stream));
   return GLIM_AMD_OK;

@@ -475,3 +475,71 @@ def test_stale_density_hint_does_not_leave_an_overfull_table(api, orc):
     # and the next sparse map builds directly with the corrected hint
     again = api.GaussianVoxelMapGPU(res, ctx=ctx).insert(sg).voxelmap_info()
     assert again["num_voxels"] == 64000 and again["num_voxels"] <= 0.35 * 2 * again["num_buckets"]
+
+
+def test_resident_session_lifecycle(api, ctx, orc, small_pair):
+    """The resident session (vgicp.hip resident_kernel): bits equal to the launch-per-call forms from the first request it serves; it idles out and
+    is restarted transparently; a second plan takes it over once the first has gone quiet; destroying the served set's inputs / the context while it
+    is alive is safe; error() and asynchronous calls keep working next to it."""
+    import time
+
+    tgt, src, tg, sg, delta = _full_size_pair(api, ctx, 64, 512)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    vm2 = api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(tg)
+    poses = [{0: np.eye(4), 1: delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + k))} for k in range(3)]
+    ctx.set_diag("resident=0,fuse=0")
+    ref = api.NonlinearFactorSetGPU(ctx)
+    ref.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+    want = [ref.linearize(v)[0] for v in poses]
+    ref2 = api.NonlinearFactorSetGPU(ctx)
+    ref2.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+    want2 = [ref2.linearize(v)[0] for v in poses]
+    want_err = ref.error(poses[1])
+    ctx.set_diag("resident_idle_us=500")
+
+    def same(L, B, what):
+        assert L["num_inliers"] == B["num_inliers"], what
+        for key in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+            np.testing.assert_array_equal(L[key], B[key], err_msg=f"{what} {key}")
+        assert L["error"] == B["error"], what
+
+    fset = api.NonlinearFactorSetGPU(ctx)
+    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+    for rep in range(40):  # calls 4.. are served by the session
+        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"rep {rep}")
+    assert fset.error(poses[1]) == want_err  # a launch-per-call evaluation next to the live session
+    same(fset.linearize(poses[2])[0], want[2], "after error()")
+    time.sleep(0.05)  # far beyond the idle time-out: the kernel has left; the next call restarts it
+    for rep in range(10):
+        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"after idle rep {rep}")
+    # a second plan: served launch-per-call while the first is hot, through the session once that has gone quiet
+    other = api.NonlinearFactorSetGPU(ctx)
+    other.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+    for rep in range(12):
+        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"interleaved a{rep}")
+        same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"interleaved b{rep}")
+    time.sleep(0.01)
+    for rep in range(12):
+        same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"takeover {rep}")
+    # fresh sets with the same factor list adopt the plan -- and its session (GLIM's per-iteration sets)
+    for rep in range(8):
+        fresh = api.NonlinearFactorSetGPU(ctx)
+        fresh.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+        same(fresh.linearize(poses[rep % 3])[0], want2[rep % 3], f"fresh {rep}")
+        fresh.close()
+    # tearing things down under a live session
+    other.close()
+    fset.close()
+    c2 = api.Context(0, 1)
+    t2 = api.PointCloudGPU.clone(small_pair["target"]["points"].astype(np.float64), small_pair["target"]["covs"], ctx=c2)
+    s2 = api.PointCloudGPU.clone(small_pair["source"]["points"].astype(np.float64), small_pair["source"]["covs"], ctx=c2)
+    m2 = api.GaussianVoxelMapGPU(0.5, ctx=c2).insert(t2)
+    f2 = api.NonlinearFactorSetGPU(c2)
+    f2.add(api.IntegratedVGICPFactorGPU(0, 1, m2, s2))
+    time.sleep(0.01)
+    outs = [f2.linearize({0: np.eye(4), 1: small_pair["delta"]})[0] for _ in range(10)]
+    for o in outs[1:]:
+        same(o, outs[0], "second context")
+    f2.close(); m2.close(); s2.close(); t2.close()
+    c2.close()
+    ctx.set_diag("")
