@@ -35,6 +35,13 @@
 
 using namespace glim_amd;
 
+// FP contraction as WRITTEN: a * b + c inside one expression becomes a fused multiply-add, nothing is fused across statements.  hipcc's default
+// (`fast`) lets the backend fuse across statements wherever it sees fit, and what it sees depends on the code AROUND an inlined function: the same
+// compute_row() inlined into the launch-per-call kernel and into the resident kernel then rounded a handful of products differently (8e-6
+// relative on H of a general-form factor) -- and every form of the synchronous call has to return the same bits
+// (tests/test_gpu_edge_cases.py).  The few cross-statement fusions the default found in the hot loop are written out as fmaf() below.
+#pragma clang fp contract(on)
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -124,6 +131,7 @@ struct FinalizeArgs {
 // round 3 serialised ~500 arrivals of a chip-wide factor on one counter (~10 ns per same-address atomic = 5 us).
 constexpr int TAG_PIECES = 10;
 constexpr int TAG_ROW_BYTES = TAG_PIECES * 16;
+constexpr unsigned int AUX_SYSTEM = 17u;                 // sc0 sc1: system scope (host-mapped memory: through to the host at once)
 constexpr unsigned int AUX_SC1 = 16u;                    // cache policy of the raw buffer intrinsics: agent-coherent (write-through / L2-bypass)
 constexpr unsigned int AUX_SC1_VOLATILE = 16u | (1u << 31);  // ... and not to be hoisted out of / merged across the polling loop
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -247,7 +255,10 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
     if (t < COMPACT) {
       const long long bits = __double_as_longlong(value);
       const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)fa.seq, 0};
-      *reinterpret_cast<__attribute__((address_space(1))) v4i_t*>(reinterpret_cast<uintptr_t>(fa.rec16 + ((size_t)f * COMPACT + t) * 16)) = g;
+      // system-scope (sc0 sc1) store: written through to host memory NOW.  A plain store may sit in the L2 until the kernel ends -- which a
+      // resident kernel does not do (measured: every request then took exactly one idle time-out).
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rec16 + (size_t)f * COMPACT * 16, 0, COMPACT * 16, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, t * 16, 0, AUX_SYSTEM);
     }
     return;
   }
@@ -429,8 +440,8 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
     // C_A = I - (1 - 1e-3) n n^T  =>  C_t = I - (1 - 1e-3) m m^T with m = R n (probe stage): 9 + 9 operations instead of the 45-operation sandwich
     const float mx = s.c0, my = s.c1, mz = s.c2;
     const float w = 0.999f, wx = w * mx, wy = w * my;
-    t00 = 1.f - wx * mx; t01 = -wx * my; t02 = -wx * mz;
-    t11 = 1.f - wy * my; t12 = -wy * mz; t22 = 1.f - w * mz * mz;
+    t00 = 1.f - wx * mx; t01 = wx * my; t02 = wx * mz;       // (off-diagonal entries carry the opposite sign: subtracted with one fma below)
+    t11 = 1.f - wy * my; t12 = wy * mz; t22 = 1.f - w * mz * mz;
   } else {
     t00 = s.c0; t01 = s.c1; t02 = s.c2; t11 = s.c3; t12 = s.c4; t22 = s.c5;
   }
@@ -439,8 +450,15 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
   // S = C_B + R C_A R^T (symmetric).  A lane without a match has read SOME record of the table -- another voxel's, or the zeros of an empty
   // way (voxelmap.hip initialises every record) -- so everything up to the determinant is finite for it too; idet = 0 (a select, not a
   // product) then zeroes its contributions exactly.  No per-coefficient selects.
-  const float S00 = r0.w + t00, S01 = r1.x + t01, S02 = r1.y + t02;
-  const float S11 = r1.z + t11, S12 = r1.w + t12, S22 = r2c22 + t22;
+  const float S00 = r0.w + t00, S11 = r1.z + t11, S22 = r2c22 + t22;
+  float S01, S02, S12;
+  if (PLANE) {
+    const float mx = s.c0, my = s.c1, mz = s.c2, wx = 0.999f * mx, wy = 0.999f * my;
+    S01 = fmaf(-wx, my, r1.x); S02 = fmaf(-wx, mz, r1.y); S12 = fmaf(-wy, mz, r1.w);
+  } else {
+    S01 = r1.x + t01; S02 = r1.y + t02; S12 = r1.w + t12;
+  }
+  (void)t01; (void)t02; (void)t12;
   // M = S^-1 by cofactors (symmetric, called A below)
   const float k00 = S11 * S22 - S12 * S12;
   const float k01 = S02 * S12 - S01 * S22;
@@ -575,9 +593,10 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // round robin to the factor's blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane
 // runs the algebra (a lane without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  On return
 // (after a block barrier) s_red[w][j] holds wavefront w's sum of accumulator j, s_red[w][28] its inlier count.
+// first: the stream data of this lane's first point when the caller has loaded it already (a resident worker does, while it waits for its pose).
 template <int MODE, bool FROZEN, bool PLANE>
 __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* __restrict__ Tl, const double* __restrict__ Te, int chunk, int prio_phase,
-                                            float (*s_red)[PARTIAL_STRIDE]) {
+                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr) {
   // rotation of the linearisation pose in FP32 (R[r][c])
   // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
@@ -604,7 +623,7 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
     // Software pipeline over the points of this lane (pipe_trip above): the key gather of a point is issued one trip before its algebra.
     // (Issuing it two trips ahead buys little: loads return in order, so the record gather of the trip in between would wait for it.)
     PipeCtx<PLANE> pc = {d, Tl, Te, R, base, stride, ppt, last, validate};
-    PointIn nxt = load_point<PLANE>(d, (unsigned int)min(base, last));
+    PointIn nxt = first ? *first : load_point<PLANE>(d, (unsigned int)min(base, last));
     Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base, ppt > 0, Tl, Te, R, validate, last);
     nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
     for (int it = 0; it < ppt; it++) {
@@ -715,8 +734,12 @@ struct ResidentArgs {
   char* rows16;                    // tagged partial rows (the plan's)
   char* rec16;                     // host-mapped record granules (the plan's)
   char* pose16;                    // device: num_factors x 12 pose granules {double, tag, 0}
-  const double* h_poses;           // host-mapped: num_factors x 12 doubles, complete before the host writes the request tag
-  unsigned int* mail;              // host-mapped: [0] request tag (host writes), [16] alive (1 while the kernel serves, 0 once it has left)
+  // host-mapped request lines of 64 bytes each: {7 doubles of the pose array, tag}.  The host writes every line's doubles, then every line's
+  // tag; a 64-byte line is read as a unit, so a line whose tag is the new one carries the new doubles -- tag and pose travel in ONE PCIe
+  // round trip (a separate request word costs a second one, ~1.2 us, before the first worker can start).
+  const unsigned long long* h_lines;
+  int num_lines;
+  unsigned int* mail;              // host-mapped: [16] alive (1 while the kernel serves, 0 once it has left)
   unsigned int first_tag;          // the last tag served before this launch
   unsigned int idle_polls;         // leader: empty polls before it leaves
 };
@@ -766,29 +789,59 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
       if (ra.blockmap[r].x >= 0) first_row = r;
   for (;;) {
     if (leader) {
-      // ---- wait for a request in host memory; re-publish the poses (device granules) or the end of the session
-      if (threadIdx.x == 0) {
-        unsigned int req = last;
-        for (unsigned int idle = 0;; idle++) {
-          req = __hip_atomic_load(ra.mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (req != last) break;
-          if (idle >= ra.idle_polls) {
-            req = RES_EXIT;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
+      // ---- wait for a request in host memory; re-publish the poses (device granules) or the end of the session.  Word w of the request
+      // lines (8 per line: 7 doubles + tag) is polled by thread w -- the first LEAD_WORDS words in one sweep; a longer request is read in
+      // further sweeps once its first lines carry the new tag.
+      constexpr int LEAD_WORDS = BLOCK;
+      const int words = ra.num_lines * 8;
+      unsigned int req = last;
+      unsigned long long w0 = 0;
+      for (unsigned int idle = 0;; idle++) {
+        bool ok = true;
+        if ((int)threadIdx.x < words) {
+          w0 = __hip_atomic_load(ra.h_lines + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // the tag word of this thread's line sits in lane (l | 7) of the same wavefront
+          const unsigned int t = (unsigned int)__shfl((unsigned int)w0, (int)((threadIdx.x & 63) | 7), 64);
+          if (threadIdx.x == 7) s_tag = t;  // line 0's tag decides
+          ok = t != last;
         }
-        s_tag = req;
+        const int all_new = __syncthreads_and(ok ? 1 : 0);
+        const unsigned int t0 = s_tag;
+        // (every polled line must carry the SAME new tag: a sweep can straddle the host's update)
+        bool same = true;
+        if ((int)threadIdx.x < words) same = (unsigned int)__shfl((unsigned int)w0, (int)((threadIdx.x & 63) | 7), 64) == t0;
+        const int consistent = __syncthreads_and(same ? 1 : 0);
+        if (all_new && consistent) {
+          req = t0;
+          break;
+        }
+        if (idle >= ra.idle_polls) {
+          req = RES_EXIT;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
       }
-      __syncthreads();
-      const unsigned int req = s_tag;
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.num_factors * 12 * 16, 0x00020000);
-      for (int i = threadIdx.x; i < ra.num_factors * 12; i += BLOCK) {
-        long long bits = 0;
-        if (req != RES_EXIT) bits = __double_as_longlong(__hip_atomic_load(ra.h_poses + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-        const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)req, 0};
-        __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, i * 16, 0, AUX_SC1);
+      const int nd = ra.num_factors * 12;
+      for (int base_w = 0; base_w < words; base_w += LEAD_WORDS) {
+        const int w = base_w + (int)threadIdx.x;
+        unsigned long long v = w0;
+        if (base_w > 0 && w < words && req != RES_EXIT) {
+          // later lines: read until their own tag is the request's (bounded: the host wrote every tag before it wrote line 0's)
+          for (int tries = 0; tries < 1000; tries++) {
+            v = __hip_atomic_load(ra.h_lines + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned int t = (unsigned int)__shfl((unsigned int)v, (int)((threadIdx.x & 63) | 7), 64);
+            if (__all(t == req)) break;
+          }
+        }
+        const int line = w >> 3, slot = w & 7, i = line * 7 + slot;  // index into the pose array
+        if (w < words && slot < 7 && i < nd) {
+          const long long bits = req != RES_EXIT ? (long long)v : 0ll;
+          const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)req, 0};
+          __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, i * 16, 0, AUX_SC1);
+        }
       }
+      if (threadIdx.x == 0) s_tag = req;
       if (req == RES_EXIT) {
         if (threadIdx.x == 0) __hip_atomic_store(ra.mail + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
@@ -830,6 +883,14 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
     for (int r = first_row; r < ra.total_rows; r += ra.workers) {
       const int2 bm = ra.blockmap[r];
       if (bm.x < 0) continue;
+      // everything that does not depend on the pose is fetched BEFORE the wait: the descriptor and this lane's first point
+      const FactorDesc d = ra.descs[bm.x];
+      PointIn p0;
+      {
+        const unsigned int i0 = (unsigned int)min(bm.y * BLOCK + (int)threadIdx.x, max(d.n - 1, 0));
+        if (d.plane) p0 = load_point<true>(d, i0);
+        else p0 = load_point<false>(d, i0);
+      }
       if (bm.x != have) {
         wait_pose(ra, bm.x, last, tag, s_pose, &s_tag);
         if (s_tag == RES_EXIT) return;
@@ -844,9 +905,8 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
           Tl[i] = __longlong_as_double(((long long)hi << 32) | (long long)lo);
         }
       }
-      const FactorDesc d = ra.descs[bm.x];
-      if (d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red);
-      else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red);
+      if (d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
+      else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
       publish_row_tagged<MODE_LINEARIZE>(s_red, ra.rows16, (size_t)(d.first_block + bm.y), tag);
       __syncthreads();  // s_red and s_pose are reused by the next row
     }
@@ -1516,14 +1576,16 @@ bool spin_until(const volatile unsigned int* word, unsigned int value) {
 // launch-per-call linearisations (a set that is linearised once or twice never starts one); it takes the session over from another plan
 // only when that one has not been asked for RESIDENT_TAKEOVER_US.
 constexpr int RESIDENT_MAX_FACTORS = 64, RESIDENT_WARMUP = 3;
+constexpr int RESIDENT_MAX_LINES = (RESIDENT_MAX_FACTORS * 12 + 6) / 7;
+
 constexpr long long RESIDENT_TAKEOVER_US = 1000;
 struct ResidentSession {
   std::mutex mu;
   FactorPlan* plan = nullptr;
   glim_amd_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
-  unsigned int *h_mail = nullptr, *h_mail_dev = nullptr;  // [0] request tag, [16] alive
-  double *h_poses = nullptr, *h_poses_dev = nullptr;      // RESIDENT_MAX_FACTORS x 12
+  unsigned int *h_mail = nullptr, *h_mail_dev = nullptr;  // [16] alive
+  unsigned long long *h_lines = nullptr, *h_lines_dev = nullptr;  // request lines {7 doubles, tag} (ResidentArgs::h_lines)
   char* d_pose16 = nullptr;
   unsigned int counter = 0, last_tag = 0;
   bool launched = false;
@@ -1538,11 +1600,23 @@ unsigned int next_session_tag(ResidentSession& S) {
   return 0x80000000u | S.counter;
 }
 
+// the request of a session: poses (n doubles) into the host-mapped lines -- every line's doubles first, then every line's tag, line 0's last
+void resident_post(ResidentSession& S, const double* poses, size_t n, unsigned int tag) {
+  volatile unsigned long long* L = S.h_lines;
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(poses);
+  const size_t lines = (n + 6) / 7;
+  for (size_t i = 0; i < n; i++) L[(i / 7) * 8 + (i % 7)] = src[i];
+  std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
+  for (size_t l = lines; l-- > 0;) L[l * 8 + 7] = tag;
+  std::atomic_thread_fence(std::memory_order_release);
+}
+
 // S.mu held.  Ends the resident kernel (if any) and waits for it.
 void resident_stop(ResidentSession& S) {
   if (!S.launched) return;
-  if (S.h_mail) {
-    reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = RES_EXIT;
+  if (S.h_lines) {
+    const size_t lines = RESIDENT_MAX_LINES;
+    for (size_t l = lines; l-- > 0;) reinterpret_cast<volatile unsigned long long*>(S.h_lines)[l * 8 + 7] = RES_EXIT;
     std::atomic_thread_fence(std::memory_order_seq_cst);
   }
   (void)hipStreamSynchronize(S.stream);
@@ -1559,8 +1633,9 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
     GA_HIP(pinned_malloc(&S.h_mail, 256));
     memset(S.h_mail, 0, 256);
     if (!host_device_view(S.h_mail, &S.h_mail_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
-    GA_HIP(pinned_malloc(&S.h_poses, (size_t)RESIDENT_MAX_FACTORS * 12 * sizeof(double)));
-    if (!host_device_view(S.h_poses, &S.h_poses_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
+    GA_HIP(pinned_malloc(&S.h_lines, (size_t)RESIDENT_MAX_LINES * 64));
+    memset(S.h_lines, 0, (size_t)RESIDENT_MAX_LINES * 64);
+    if (!host_device_view(S.h_lines, &S.h_lines_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
     GA_HIP(pool_malloc(&S.d_pose16, (size_t)RESIDENT_MAX_FACTORS * 12 * 16));
   }
   // descriptors, block map and finaliser map have to be on the device (a single-factor plan may never have uploaded them), and complete
@@ -1571,8 +1646,12 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
   }
   const int nf = (int)set->entries.size();
   volatile unsigned int* mail = S.h_mail;
-  mail[0] = S.last_tag;  // (a pending request overwrites this right after the launch)
   mail[16] = 1u;
+  // (an explicit stop leaves exit tags in the request lines; a pending request stays)
+  for (size_t l = 0; l < (size_t)RESIDENT_MAX_LINES; l++) {
+    volatile unsigned long long* tagw = reinterpret_cast<volatile unsigned long long*>(S.h_lines) + l * 8 + 7;
+    if ((unsigned int)*tagw == RES_EXIT) *tagw = S.last_tag;
+  }
   std::atomic_thread_fence(std::memory_order_seq_cst);
   GA_HIP(hipMemsetAsync(S.d_pose16, 0, (size_t)RESIDENT_MAX_FACTORS * 12 * 16, S.stream));  // stale granules (an earlier session's exit tags) must not be read as news
   ResidentArgs ra;
@@ -1586,7 +1665,8 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
   ra.rows16 = plan->d_rows16;
   ra.rec16 = plan->h_rec16_dev;
   ra.pose16 = S.d_pose16;
-  ra.h_poses = S.h_poses_dev;
+  ra.h_lines = S.h_lines_dev;
+  ra.num_lines = (nf * 12 + 6) / 7;
   ra.mail = S.h_mail_dev;
   ra.first_tag = S.last_tag;
   // one empty poll of the request word is one PCIe read (~1.2 us) plus a short sleep
@@ -1632,10 +1712,8 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
       const int rc = resident_launch(S, set, plan);
       if (rc != GLIM_AMD_OK) return rc == GLIM_AMD_ERR_UNSUPPORTED ? rc : rc;
     }
-    memcpy(S.h_poses, T_lin, nf * 12 * sizeof(double));
-    std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
     tag = next_session_tag(S);
-    reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = tag;
+    resident_post(S, T_lin, nf * 12, tag);
     S.busy.store(true);
     S.last_use = now;
     S.requests++;
@@ -1651,10 +1729,7 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
     (void)hipStreamSynchronize(S.stream);
     S.launched = false;
     int rc = resident_launch(S, set, plan);
-    if (rc == GLIM_AMD_OK) {
-      reinterpret_cast<volatile unsigned int*>(S.h_mail)[0] = tag;
-      ok = collect_tagged_records(plan, nf, tag, nullptr);
-    }
+    if (rc == GLIM_AMD_OK) ok = collect_tagged_records(plan, nf, tag, nullptr);  // (the request lines still hold this request)
     if (!ok) {
       resident_stop(S);
       S.busy.store(false);
@@ -1670,6 +1745,16 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
 }
 
 }  // namespace
+
+extern "C" int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive) {
+  if (device < 0 || device >= 16) return GLIM_AMD_ERR_INVALID;
+  ResidentSession& S = g_resident[device];
+  std::lock_guard<std::mutex> slock(S.mu);
+  if (launches) *launches = S.launches;
+  if (requests) *requests = S.requests;
+  if (alive) *alive = (S.launched && S.h_mail && reinterpret_cast<volatile unsigned int*>(S.h_mail)[16] != 0u) ? 1 : 0;
+  return GLIM_AMD_OK;
+}
 
 namespace glim_amd {
 void resident_release(glim_amd_ctx* ctx, FactorPlan* plan) {

@@ -280,6 +280,11 @@ int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_a
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
 int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
 
+/* parity / debug only: the device's resident session (repeated synchronous linearisations of a small factor list are served by a kernel that stays
+ * on the device and takes its requests through host-mapped memory; it leaves by itself after `resident_idle_us` without a request): kernel
+ * launches and requests served so far, whether one is alive right now. */
+int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive);
+
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
  * One process, N devices: a context + a host worker thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per

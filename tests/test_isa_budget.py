@@ -9,12 +9,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VALU_BUDGET = 230  # 225 today: 132 FP32, 36 FP64, 42 integer, 15 compare / select
+VALU_BUDGET = 230  # 225 today: 133 FP32, 36 FP64, 40 integer, 16 compare / select
 
 
 def test_vgicp_hot_loop_stays_within_budget():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_stats.py"), os.path.join(ROOT, "glim_amd", "csrc", "vgicp.hip"),
-                          "vgicp_kernelILi0ELb0ELb1ELb0E", "v_rcp_f32"], capture_output=True, text=True, timeout=600)
+                          "vgicp_kernelILi0ELb0ELb1ELb0ELb0E", "v_rcp_f32"]  # linearise, plane-form, not inline, not the single-dispatch form
+                         , capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"vgpr (\d+) sgpr \d+ \| longest loop: (\d+) instructions (\{.*\})", out.stdout)
     assert m, out.stdout
