@@ -357,14 +357,35 @@ def run_odometry128k(args, D, api, ctx):
             alt.profile_sync(T1, iters=50)
             by_variant[name] = alt.profile_sync(T1, iters=1000) * 1e3
             alt.close()
+        # what a live (idle) resident session costs everything else on the device: the batched 128-factor kernel timed alone and beside a
+        # session that is kept from idling out for the duration (its 513 blocks hold wave slots and poll)
+        small = api.NonlinearFactorSetGPU(ctx)  # a latency-bound launch: 8 factors of 131 072 points
+        for k in range(8):
+            small.add(api.IntegratedVGICPFactorGPU(k, k + 1, vmaps[k], clouds[k + 1]))
+        Ts = np.ascontiguousarray(deltas[:8])
+        api.resident_stop(ctx)
+        k_alone, _ = fset.profile(pose_sets[0], iters=40)
+        s_alone, _ = small.profile(Ts, iters=200)
+        ctx.set_diag("resident_idle_us=400000")
+        for _ in range(8):
+            single.linearize_poses(T1)  # restarts the session with the long idle time
+        k_beside, _ = fset.profile(pose_sets[0], iters=40)
+        s_beside, _ = small.profile(Ts, iters=200)
+        stats = api.resident_stats(ctx)
+        api.resident_stop(ctx)
         ctx.set_diag("")
+        small.close()
+        resident_cost = {"batched_128_factor_kernel_ms": {"alone": k_alone, "beside_an_idle_session": k_beside, "slowdown": k_beside / k_alone},
+                         "8_factor_kernel_ms": {"alone": s_alone, "beside_an_idle_session": s_beside, "slowdown": s_beside / s_alone},
+                         "session_alive_during_measurement": bool(stats["alive"]),
+                         "session_footprint": "512 worker blocks + 1 finalising / leading block of 256 threads, 168 VGPRs: 2 of a CU's wave slots per SIMD"}
         single_loop = {"calls_per_s": 1e3 / sync_ms_c, "us_per_call": sync_ms_c * 1e3, "calls": 1000,
                        "what": "one 131072-pt factor per call, the shipped path: after three launch-per-call linearisations the factor list is served by a "
                                "RESIDENT kernel (pose through a host-mapped mailbox, no launch on the request path; the session idles out after 2 ms); row "
                                "blocks hand their partial rows as tagged write-through granules to a finalising block (no counter, no fence); the 232-B record "
                                "comes back as self-validating host-mapped granules the host polls.  `single_dispatch`: the same hand-off inside ONE launch "
                                "per call; `two_dispatches`: factor kernel + finalise kernel per call (round 3's form)",
-                       "us_per_call_by_variant": by_variant}
+                       "us_per_call_by_variant": by_variant, "resident_session_cost": resident_cost}
         result = {
             "metric": "vgicp_linearize_calls_per_s", "value": value, "unit": "calls/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -95,6 +95,7 @@ SYMBOLS = {
     "glim_amd_preprocess_default_params": (_i, [C.POINTER(PreprocessParams)]),
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
+    "glim_amd_debug_resident_stop": (_i, [_i]),
     "glim_amd_debug_resident_stats": (_i, [_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
     "glim_amd_debug_deskew_table": (_i, [_i64, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _ip, _dp, _i32, _ip]),
     "glim_amd_cloud_deskew": (_i, [_vp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _i32, _pp]),

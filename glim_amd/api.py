@@ -623,6 +623,20 @@ class MultiDeviceCost:
             pass
 
 
+def resident_stats(ctx=None):
+    """Debug: the device's resident session (glim_amd_debug_resident_stats): kernel launches, requests served, alive right now."""
+    ctx = ctx or default_context()
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
+    check(lib().glim_amd_debug_resident_stats(int(getattr(ctx, "device", 0)), C.byref(a), C.byref(b), C.byref(c)), "glim_amd_debug_resident_stats")
+    return {"launches": a.value, "requests": b.value, "alive": bool(c.value)}
+
+
+def resident_stop(ctx=None):
+    """Debug: end the device's resident session now (it would idle out by itself after `resident_idle_us`)."""
+    ctx = ctx or default_context()
+    check(lib().glim_amd_debug_resident_stop(int(getattr(ctx, "device", 0))), "glim_amd_debug_resident_stop")
+
+
 def shard_bounds(costs, world):
     """glim_amd_shard_bounds: the C implementation of the sharding rule (host only; works without a device)."""
     c = np.ascontiguousarray(costs, dtype=np.float64)

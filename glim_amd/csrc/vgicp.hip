@@ -286,6 +286,7 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
 // rows as they arrive.  (group, piece) pair k = 10 g + p is handled by thread k, pairs 256..319 by threads 0..63 in a second round.  A
 // thread re-reads the <= 16 granules of a round until every tag is this call's; then it adds them.  The spin is bounded (~1 s): a row that
 // never arrives (cannot happen: the writing blocks wait for nothing) ends in a NaN record instead of a hung device.
+template <int INFLIGHT = 16>
 __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum,
                                                const double* __restrict__ T) {
   const int first = d.first_block, nb = d.num_blocks;
@@ -297,7 +298,6 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rows16 + (size_t)first * TAG_ROW_BYTES, 0, nb * TAG_ROW_BYTES, 0x00020000);
   const int seq = (int)fa.seq;
   bool lost = false;
-  constexpr int INFLIGHT = 16;
   for (int k = threadIdx.x; k < FIN_GROUPS * TAG_PIECES; k += BLOCK) {
     const int g = k / TAG_PIECES, p = k - g * TAG_PIECES;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -733,7 +733,9 @@ struct ResidentArgs {
   int total_rows, num_factors, workers, blocks_per_round;
   char* rows16;                    // tagged partial rows (the plan's)
   char* rec16;                     // host-mapped record granules (the plan's)
-  char* pose16;                    // device: num_factors x 12 pose granules {double, tag, 0}
+  char* pose16;                    // device: replicas x num_factors x 12 pose granules {double, tag, 0}
+  int replicas;                    // copies of the pose granules (block b watches copy b % replicas: 512 blocks polling ONE 192-byte spot is a hot
+                                   // spot on one memory channel that slows everything else on the device)
   // host-mapped request lines of 64 bytes each: {7 doubles of the pose array, tag}.  The host writes every line's doubles, then every line's
   // tag; a 64-byte line is read as a unit, so a line whose tag is the new one carries the new doubles -- tag and pose travel in ONE PCIe
   // round trip (a separate request word costs a second one, ~1.2 us, before the first worker can start).
@@ -750,7 +752,8 @@ constexpr unsigned int RES_EXIT = 0xffffffffu;
 __device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigned int last, unsigned int exact, double* s_pose, unsigned int* s_tag) {
   if (threadIdx.x < 64) {
     const int lane = (int)threadIdx.x < 12 ? (int)threadIdx.x : 0;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16 + (size_t)f * 12 * 16, 0, 12 * 16, 0x00020000);
+    const int copy = (int)blockIdx.x % ra.replicas;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16 + ((size_t)copy * ra.num_factors + f) * 12 * 16, 0, 12 * 16, 0x00020000);
     v4i_t g;
     unsigned int tag = RES_EXIT;
     const unsigned int limit = ra.idle_polls * 64u + (1u << 16);
@@ -764,7 +767,11 @@ __device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigne
         tag = t0;
         break;
       }
-      __builtin_amdgcn_s_sleep(4);
+      // back off: a request that follows the previous one within microseconds is seen at once; a session that has been quiet for a while
+      // polls every few microseconds instead of hammering the fabric beside whatever else runs on the device
+      if (spins < 32) __builtin_amdgcn_s_sleep(4);
+      else if (spins < 256) __builtin_amdgcn_s_sleep(24);
+      else __builtin_amdgcn_s_sleep(100);
     }
     if (threadIdx.x < 12) s_pose[threadIdx.x] = __longlong_as_double(((long long)(unsigned int)g.y << 32) | (long long)(unsigned int)g.x);
     if (threadIdx.x == 0) *s_tag = tag;
@@ -772,8 +779,12 @@ __device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigne
   __syncthreads();
 }
 
-// (3 waves per SIMD = 3 blocks per CU = 768 resident blocks: a session holds at most 2 x CUs workers + 64 finalisers)
-__global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs ra) {
+// PLANE_ONLY: every factor of the plan streams a plane-form cloud (the odometry's case).  That variant stays within the plane-form kernel's 96
+// registers -- what a session HOLDS while it idles is what everything else on the device cannot use: at 168 registers (both stream forms in one
+// kernel) two resident blocks per CU left room for ONE wave per SIMD of any other kernel, and an 8-factor launch beside an idle session took
+// 29 instead of 12 us (tools/res_probe.py).
+template <bool PLANE_ONLY>
+__global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(const ResidentArgs ra) {
   __shared__ double s_lds[(FIN_GROUPS + 1) * PARTIAL_STRIDE];
   __shared__ double s_pose[12];
   __shared__ unsigned int s_tag;
@@ -821,8 +832,8 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.num_factors * 12 * 16, 0x00020000);
       const int nd = ra.num_factors * 12;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.replicas * nd * 16, 0x00020000);
       for (int base_w = 0; base_w < words; base_w += LEAD_WORDS) {
         const int w = base_w + (int)threadIdx.x;
         unsigned long long v = w0;
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
         if (w < words && slot < 7 && i < nd) {
           const long long bits = req != RES_EXIT ? (long long)v : 0ll;
           const v4i_t g = {(int)(bits & 0xffffffffll), (int)(bits >> 32), (int)req, 0};
-          __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, i * 16, 0, AUX_SC1);
+          for (int c = 0; c < ra.replicas; c++) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (c * nd + i) * 16, 0, AUX_SC1);
         }
       }
       if (threadIdx.x == 0) s_tag = req;
@@ -864,7 +875,7 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
       fa.rec16 = ra.rec16;
       fa.finmap = ra.finmap;
       const FactorDesc d = ra.descs[f];
-      fused_finalize(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose);
+      fused_finalize<8>(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose);
       __syncthreads();
       last = tag;
       continue;
@@ -888,7 +899,7 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
       PointIn p0;
       {
         const unsigned int i0 = (unsigned int)min(bm.y * BLOCK + (int)threadIdx.x, max(d.n - 1, 0));
-        if (d.plane) p0 = load_point<true>(d, i0);
+        if (PLANE_ONLY || d.plane) p0 = load_point<true>(d, i0);
         else p0 = load_point<false>(d, i0);
       }
       if (bm.x != have) {
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(BLOCK, 3) void resident_kernel(const ResidentArgs r
           Tl[i] = __longlong_as_double(((long long)hi << 32) | (long long)lo);
         }
       }
-      if (d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
+      if (PLANE_ONLY || d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
       else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
       publish_row_tagged<MODE_LINEARIZE>(s_red, ra.rows16, (size_t)(d.first_block + bm.y), tag);
       __syncthreads();  // s_red and s_pose are reused by the next row
@@ -1078,6 +1089,7 @@ void resident_release(glim_amd_ctx* ctx, FactorPlan* plan);  // ends the residen
 namespace {
 
 constexpr size_t PLAN_CACHE_MAX = 16;    // idle plans kept per context
+constexpr int RESIDENT_MAX_FACTORS = 64;  // sets a resident session may serve (vgicp.hip "resident sessions")
 constexpr int FUSED_MAX_FACTORS = 1024, FUSED_MAX_ROWS = 16384;  // sets that may take the single-dispatch form (2.6 MB of tagged rows at most)
 constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many factors: poses read by the kernels from host-mapped memory (96 B per factor over PCIe)
 
@@ -1227,9 +1239,34 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     const long long resident = seg_target[seg], fine = (seg_points[seg] + BLOCK * PPT_MAX - 1) / (BLOCK * PPT_MAX);
     if (fine > 2 * resident) seg_target[seg] = ((fine + resident - 1) / resident) * resident;  // (up to two rounds' worth of points: one round of longer blocks)
   }
+  // Small sets (the odometry's: one to a few dozen factors of a frame each) are latency-bound, and their synchronous linearisation may be
+  // served by a resident session whose 2 x CUs worker blocks take one row each: the smallest points-per-thread <= 8 that brings the plan
+  // down to that many rows (XCD padding included) is used for every factor -- 34 factors of 10 000 points: 4 points per thread, 400 rows,
+  // 18.2 us per resident call against 21.9 us with 1 360 one-point rows (and 21.3 against 22.0 us launch-per-call); a single 131 072-pt
+  // factor keeps its 512 one-point rows.  Larger sets keep the throughput rule below.
+  int small_set_ppt = 0;
+  if (!forced_ppt && nf >= 1 && nf <= RESIDENT_MAX_FACTORS) {
+    const long long cap = 2ll * std::max(1, ctx->num_cus);
+    for (int p = 1; p <= 8 && !small_set_ppt; p++) {
+      long long rows = 0;
+      for (int seg = 0; seg < 2; seg++) {
+        std::vector<long long> nb;
+        for (int f = 0; f < nf; f++)
+          if ((plan->h_descs[f].plane != 0) == (seg == 0)) nb.push_back(std::max(1, (plan->h_descs[f].n + BLOCK * p - 1) / (BLOCK * p)));
+        if (nb.size() < 16) {
+          for (long long b : nb) rows += b;
+        } else {  // the XCD-aware map pads every XCD's list to the longest one
+          long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (long long b : nb) *std::min_element(load, load + 8) += b;
+          rows += 8 * *std::max_element(load, load + 8);
+        }
+      }
+      if (rows <= cap) small_set_ppt = p;
+    }
+  }
   for (int f = 0; f < nf; f++) {
     FactorDesc& d = plan->h_descs[f];
-    int ppt = forced_ppt;
+    int ppt = forced_ppt ? forced_ppt : small_set_ppt;
     if (!ppt) {
       const long long target_blocks = seg_target[d.plane ? 0 : 1], total_points = seg_points[d.plane ? 0 : 1];
       const long long share = std::max(1ll, (target_blocks * (long long)d.n + total_points / 2) / std::max(1ll, total_points));
@@ -1575,8 +1612,9 @@ bool spin_until(const volatile unsigned int* word, unsigned int value) {
 // from becoming resident would only get going again when one idles out.  A plan is served through the session after RESIDENT_WARMUP
 // launch-per-call linearisations (a set that is linearised once or twice never starts one); it takes the session over from another plan
 // only when that one has not been asked for RESIDENT_TAKEOVER_US.
-constexpr int RESIDENT_MAX_FACTORS = 64, RESIDENT_WARMUP = 3;
+constexpr int RESIDENT_WARMUP = 3;
 constexpr int RESIDENT_MAX_LINES = (RESIDENT_MAX_FACTORS * 12 + 6) / 7;
+constexpr size_t RESIDENT_POSE16_BYTES = (size_t)RESIDENT_MAX_FACTORS * 12 * 16;  // (8 replicas of <= 4 factors fit as well)
 
 constexpr long long RESIDENT_TAKEOVER_US = 1000;
 struct ResidentSession {
@@ -1636,7 +1674,7 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
     GA_HIP(pinned_malloc(&S.h_lines, (size_t)RESIDENT_MAX_LINES * 64));
     memset(S.h_lines, 0, (size_t)RESIDENT_MAX_LINES * 64);
     if (!host_device_view(S.h_lines, &S.h_lines_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
-    GA_HIP(pool_malloc(&S.d_pose16, (size_t)RESIDENT_MAX_FACTORS * 12 * 16));
+    GA_HIP(pool_malloc(&S.d_pose16, RESIDENT_POSE16_BYTES));
   }
   // descriptors, block map and finaliser map have to be on the device (a single-factor plan may never have uploaded them), and complete
   // before the session's stream reads them
@@ -1653,7 +1691,7 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
     if ((unsigned int)*tagw == RES_EXIT) *tagw = S.last_tag;
   }
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  GA_HIP(hipMemsetAsync(S.d_pose16, 0, (size_t)RESIDENT_MAX_FACTORS * 12 * 16, S.stream));  // stale granules (an earlier session's exit tags) must not be read as news
+  GA_HIP(hipMemsetAsync(S.d_pose16, 0, RESIDENT_POSE16_BYTES, S.stream));  // stale granules (an earlier session's exit tags) must not be read as news
   ResidentArgs ra;
   ra.descs = plan->d_descs;
   ra.blockmap = plan->d_blockmap;
@@ -1665,13 +1703,15 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
   ra.rows16 = plan->d_rows16;
   ra.rec16 = plan->h_rec16_dev;
   ra.pose16 = S.d_pose16;
+  ra.replicas = nf <= 4 ? 8 : 1;  // (a larger set's blocks watch different factors' granules anyway)
   ra.h_lines = S.h_lines_dev;
   ra.num_lines = (nf * 12 + 6) / 7;
   ra.mail = S.h_mail_dev;
   ra.first_tag = S.last_tag;
   // one empty poll of the request word is one PCIe read (~1.2 us) plus a short sleep
   ra.idle_polls = (unsigned int)std::max(100, ctx->diag.resident_idle_us * 2 / 3);
-  resident_kernel<<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
+  if (plan->plane_rows == plan->total_rows) resident_kernel<true><<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
+  else resident_kernel<false><<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
   GA_HIP(hipGetLastError());
   S.launched = true;
   S.plan = plan;
@@ -1696,6 +1736,9 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
     plan = set->plan;
     const Diag& diag = ctx->diag;
     if (!diag.resident || !diag.fuse || !diag.poll || !plan->d_rows16 || !plan->h_rec16_dev || nf > (size_t)RESIDENT_MAX_FACTORS) return GLIM_AMD_ERR_UNSUPPORTED;
+    // one row per worker block: a plan with more rows than the session has workers would walk them one after the other, slower than a launch
+    // whose blocks all run at once (34 factors of 131 072 points: 68 against 53 us)
+    if (plan->total_rows > 2 * std::max(1, ctx->num_cus)) return GLIM_AMD_ERR_UNSUPPORTED;
     if (++plan->sync_linearize_calls <= RESIDENT_WARMUP) return GLIM_AMD_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> slock(S.mu);
     if (S.busy.load()) return GLIM_AMD_ERR_UNSUPPORTED;  // another thread's request is in flight
@@ -1753,6 +1796,16 @@ extern "C" int glim_amd_debug_resident_stats(int device, uint64_t* launches, uin
   if (launches) *launches = S.launches;
   if (requests) *requests = S.requests;
   if (alive) *alive = (S.launched && S.h_mail && reinterpret_cast<volatile unsigned int*>(S.h_mail)[16] != 0u) ? 1 : 0;
+  return GLIM_AMD_OK;
+}
+
+extern "C" int glim_amd_debug_resident_stop(int device) {
+  if (device < 0 || device >= 16) return GLIM_AMD_ERR_INVALID;
+  ResidentSession& S = g_resident[device];
+  std::lock_guard<std::mutex> slock(S.mu);
+  if (S.busy.load()) return GLIM_AMD_ERR_STATE;
+  (void)hipSetDevice(device);
+  resident_stop(S);
   return GLIM_AMD_OK;
 }
 

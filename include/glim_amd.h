@@ -82,7 +82,9 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
  * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
- * pool=0|1 (GLIM_AMD_DIAG only), multi_rccl=0|1, multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
+ * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1 + resident_idle_us=<n> (repeated synchronous linearisations of a small set
+ * served by a resident kernel that leaves after <n> us without a request), pool=0|1 (GLIM_AMD_DIAG only), multi_rccl=0|1,
+ * multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
  * nothing changes.  get_diag prints the current state in the same syntax. */
 int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
 int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
@@ -284,6 +286,8 @@ int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_tar
  * on the device and takes its requests through host-mapped memory; it leaves by itself after `resident_idle_us` without a request): kernel
  * launches and requests served so far, whether one is alive right now. */
 int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive);
+/* ends the device's resident session now instead of letting it idle out (GLIM_AMD_ERR_STATE while a request is in flight). */
+int glim_amd_debug_resident_stop(int device);
 
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------

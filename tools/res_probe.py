@@ -19,3 +19,17 @@ for i in range(16):
     t0 = time.perf_counter(); fs.linearize_poses(T); dt = (time.perf_counter() - t0) * 1e6
     print(i, f"{dt:.1f} us", stats())
 print("profile_sync us:", fs.profile_sync(T, iters=200) * 1e3, stats())
+# ---- hold a session alive and look at what it costs a concurrent kernel
+big = api.NonlinearFactorSetGPU(ctx)
+for k in range(8): big.add(api.IntegratedVGICPFactorGPU(0, 1 + k, vm, sg))
+Tb = np.repeat(T, 8, axis=0)
+api.resident_stop(ctx); print("stopped", stats())
+print("8-factor kernel alone (ms):", big.profile(Tb, iters=100), stats())
+ctx.set_diag("resident_idle_us=400000"); print(ctx.get_diag() if hasattr(ctx, "get_diag") else "")
+for i in range(6):
+    fs.linearize_poses(T); print("restart", i, stats())
+time.sleep(0.005); print("after 5 ms", stats())
+print("8-factor kernel beside the session (ms):", big.profile(Tb, iters=100), stats())
+print("sync call itself (us):", fs.profile_sync(T, iters=200) * 1e3, stats())
+time.sleep(0.05); print("after 50 ms", stats())
+api.resident_stop(ctx); print("stopped", stats())
