@@ -13,5 +13,9 @@ extern "C" glim::OdometryEstimationBase* create_odometry_estimation_module() {
   static const bool hook_registered = (glim_amd::register_linearization_hook(), true);
   (void)hook_registered;
   glim::OdometryEstimationGPUParams params;
+  // the module's CUDAStream / StreamTempBufferRoundRobin members (odometry_estimation_gpu.cpp:76-77) are created inside this constructor call:
+  // the odometry's stream pools get the device's greatest stream priority, so that its 25 us linearisations are dispatched ahead of the
+  // mapping threads' millisecond kernels (async_sub_mapping.cpp:8, async_global_mapping.cpp:24 run beside it on the same device)
+  glim_amd::ScopedStreamPriority odometry_first(1);
   return new glim::OdometryEstimationGPU(params);
 }

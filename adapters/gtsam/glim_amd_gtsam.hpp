@@ -82,14 +82,15 @@ public:
   using shared_ptr = std::shared_ptr<IntegratedVGICPFactorHIP>;
 
   // binary factor between two pose variables (odometry_estimation_gpu.cpp:144, sub_mapping.cpp:307, global_mapping.cpp:335,466,860).
-  // The reference's trailing (CUstream_st*, TempBufferManager) arguments have no counterpart: streams and scratch belong to the context.
-  IntegratedVGICPFactorHIP(gtsam::Key target_key, gtsam::Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source)
+  // ctx: the context (stream pool) a set of such factors runs on -- the reference's trailing (CUstream_st*, TempBufferManager) pair.
+  IntegratedVGICPFactorHIP(gtsam::Key target_key, gtsam::Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source, Context ctx = nullptr)
   : gtsam::NonlinearFactor(gtsam::KeyVector{target_key, source_key}),
-    impl_(std::make_shared<IntegratedVGICPFactorGPU>((Key)target_key, (Key)source_key, std::move(target), std::move(source))) {}
+    impl_(std::make_shared<IntegratedVGICPFactorGPU>((Key)target_key, (Key)source_key, std::move(target), std::move(source), std::move(ctx))) {}
   // unary factor against a fixed target pose (odometry_estimation_gpu.cpp:161)
-  IntegratedVGICPFactorHIP(const gtsam::Pose3& fixed_target_pose, gtsam::Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source)
+  IntegratedVGICPFactorHIP(const gtsam::Pose3& fixed_target_pose, gtsam::Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source,
+                           Context ctx = nullptr)
   : gtsam::NonlinearFactor(gtsam::KeyVector{source_key}),
-    impl_(std::make_shared<IntegratedVGICPFactorGPU>(to_iso(fixed_target_pose), (Key)source_key, std::move(target), std::move(source))) {}
+    impl_(std::make_shared<IntegratedVGICPFactorGPU>(to_iso(fixed_target_pose), (Key)source_key, std::move(target), std::move(source), std::move(ctx))) {}
 
   size_t dim() const override { return 6; }
   gtsam::NonlinearFactor::shared_ptr clone() const override {  // odometry_estimation_gpu.cpp:380: shares the device data, not the cache

@@ -32,8 +32,9 @@ public:
   // init_num_buckets / max_bucket_scan_count / target_points_drop_rate are accepted and ignored: the table is sized from the cloud and no
   // point is ever dropped (include/glim_amd.h)
   GaussianVoxelMapGPU(float resolution, int init_num_buckets = 8192 * 2, int max_bucket_scan_count = 10, double target_points_drop_rate = 1e-3,
-                      CUstream_st* /*stream*/ = nullptr)
-  : impl_(std::make_shared<glim_amd::GaussianVoxelMapGPU>(resolution, init_num_buckets, max_bucket_scan_count, target_points_drop_rate)) {
+                      CUstream_st* stream = nullptr)
+  : impl_(std::make_shared<glim_amd::GaussianVoxelMapGPU>(resolution, init_num_buckets, max_bucket_scan_count, target_points_drop_rate,
+                                                          glim_amd::context_of(stream))) {
     voxelmap_info.num_voxels = 0;
     voxelmap_info.num_buckets = 0;
     voxelmap_info.max_bucket_scan_count = max_bucket_scan_count;
@@ -66,6 +67,7 @@ inline glim_amd::GaussianVoxelMapGPU::ConstPtr device_map(const GaussianVoxelMap
   return gpu->device();
 }
 
+// (stream: accepted for the signature; the call runs on the context of the target map, which is the calling module's own)
 inline double overlap_gpu(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta, CUstream_st* /*stream*/ = nullptr) {
   return glim_amd::overlap_gpu(device_map(target), device_cloud(source), delta);
 }

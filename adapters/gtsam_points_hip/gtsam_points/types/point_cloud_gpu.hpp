@@ -9,6 +9,7 @@
 #include <gtsam_points/types/point_cloud_cpu.hpp>
 
 #include <glim_amd_gtsam.hpp>
+#include <gtsam_points/cuda/cuda_stream.hpp>
 
 struct CUstream_st;
 
@@ -20,11 +21,12 @@ public:
   using ConstPtr = std::shared_ptr<const PointCloudGPU>;
 
   // deep copy of the host attributes + upload (Vector4d points / Matrix4d covariances / Vector4d normals -> device)
-  static Ptr clone(const PointCloud& frame, CUstream_st* /*stream*/ = nullptr) {
+  // stream: the module's CUDAStream, i.e. the context whose stream and mutex the upload uses
+  static Ptr clone(const PointCloud& frame, CUstream_st* stream = nullptr) {
     Ptr out(new PointCloudGPU());
     const PointCloudCPU::Ptr host = PointCloudCPU::clone(frame);
     static_cast<PointCloudCPU&>(*out) = *host;  // upstream keeps the CPU attributes alongside the device ones
-    out->device_ = glim_amd::clone(frame);
+    out->device_ = glim_amd::clone(frame, glim_amd::context_of(stream));
     out->points_gpu = reinterpret_cast<decltype(out->points_gpu)>(out->device_->handle());
     return out;
   }

@@ -367,11 +367,14 @@ def run_odometry128k(args, D, api, ctx):
         k_alone, _ = fset.profile(pose_sets[0], iters=40)
         s_alone, _ = small.profile(Ts, iters=200)
         ctx.set_diag("resident_idle_us=400000")
+        stats0 = api.resident_stats(ctx)
         for _ in range(8):
             single.linearize_poses(T1)  # restarts the session with the long idle time
+        stats1 = api.resident_stats(ctx)
         k_beside, _ = fset.profile(pose_sets[0], iters=40)
         s_beside, _ = small.profile(Ts, iters=200)
         stats = api.resident_stats(ctx)
+        log(f"resident session around the interference measurement: {stats0} -> {stats1} -> {stats}")
         api.resident_stop(ctx)
         ctx.set_diag("")
         small.close()
@@ -590,6 +593,131 @@ def run_submap20(args, D, api, ctx):
                    "factors": nf, "bundle_linearize_ms": elapsed / args.steps * 1e3, "lm_iteration_ms": lm_ms, "sync_linearize_ms": ms_lin_sync, "sync_error_ms": ms_err_sync,
                    "mean_inlier_fraction": inl, "sum_error": float(np.sum(errs))},
         "roofline": roofline_of(fset, deltas, n_pts, n_vox, max(5, args.steps)),
+    }
+
+
+def run_odometry_under_load(args, D, api, ctx):
+    """GLIM's THREE-THREAD model on one device (async_odometry_estimation.cpp:15, async_sub_mapping.cpp:8, async_global_mapping.cpp:24; each module
+    owns its stream pool: odometry_estimation_gpu.cpp:76-77, sub_mapping.cpp:86-87, global_mapping.cpp:110): the latency of the odometry's
+    linearisation -- a fresh 34-factor set of 10 000-pt frames per optimiser iteration, 50 us of host work between iterations -- alone and while a
+    second thread keeps the device busy with a mapping module's work on ITS OWN context: back-to-back linearisations of the 380-factor sub-mapping
+    bundle (20 x 65 536 pts, 0.21 ms kernels that fill the chip) and a merge_frames of 15 frames per loop.  p50 / p99 of the odometry call for:
+      own_context_high_priority   the shipped drop-in wiring: one context per module, the odometry's streams at the device's greatest priority
+      own_context                 the same without the priority
+      shared_context              round 3's wiring: every module on ONE context (one mutex, one stream pool)
+    each with the resident session on (default) and off (`launch_per_call`)."""
+    import threading
+
+    from glim_amd import synth
+
+    scene = synth.Scene.default()
+    K, WIN, LEVELS = 15, 2, 2
+    rng = np.random.default_rng(3)
+    dirs = synth.lidar_directions(128, 1024)
+    poses = synth.arc_trajectory(K + WIN + 1, step=0.4, yaw_step_deg=1.5)
+    scans = []
+    for i, T in enumerate(poses):
+        pts = synth.scan(scene, T, dirs, 500 + i)
+        scans.append(pts[np.sort(rng.choice(len(pts), 10000, replace=False))])
+    bg_poses = synth.arc_trajectory(20, step=0.5, yaw_step_deg=1.5)
+    bg_dirs = synth.lidar_directions(64, 1024)
+    bg_scans = [synth.scan(scene, T, bg_dirs, 900 + i) for i, T in enumerate(bg_poses)]
+
+    def odometry_problem(c):
+        frames = []
+        for pts in scans:
+            g = api.PointCloudGPU.clone(pts, ctx=c)
+            g.find_neighbors(10, download=False)
+            g.estimate_covariances(10)
+            frames.append(g)
+        res0 = api.adaptive_voxel_resolution(api.median_distance(scans[-1]), 0.25, 0.5, 5.0, 20.0)
+        levels = [res0 * 2.0 ** lv for lv in range(LEVELS)]
+        vmaps = [[api.GaussianVoxelMapGPU(r, ctx=c).insert(g) for r in levels] for g in frames[:-1]]
+        cur, cur_pose = frames[-1], poses[-1]
+        factors, deltas = [], []
+        for t in list(range(len(frames) - 1 - WIN, len(frames) - 1)) + list(range(K)):
+            binary = t >= len(frames) - 1 - WIN
+            for lv in range(LEVELS):
+                f = api.IntegratedVGICPFactorGPU(t if binary else poses[t], 99, vmaps[t][lv], cur)
+                f.set_enable_surface_validation(True)
+                factors.append(f)
+                deltas.append(api.pose12(synth.relative_pose(poses[t], cur_pose)))
+        return frames, vmaps, factors, np.stack(deltas)
+
+    def background_problem(c):
+        clouds = []
+        for s in bg_scans:
+            g = api.PointCloudGPU.clone(s, ctx=c)
+            g.find_neighbors(10, download=False)
+            g.estimate_covariances(10)
+            clouds.append(g)
+        vm = [[api.GaussianVoxelMapGPU(r, ctx=c).insert(g) for r in (0.25, 0.5)] for g in clouds]
+        fs = api.NonlinearFactorSetGPU(c)
+        d = []
+        for i in range(20):
+            for j in range(i + 1, 20):
+                for lv in range(2):
+                    fs.add(api.IntegratedVGICPFactorGPU(i, j, vm[i][lv], clouds[j]))
+                    d.append(api.pose12(synth.relative_pose(bg_poses[i], bg_poses[j])))
+        d = np.stack(d)
+        out = D.torch.zeros(len(d), api._lib.COMPACT_DOUBLES, dtype=D.torch.float64, device="cuda")
+        merge_in = []
+        for s in bg_scans[:15]:
+            sub = s[:: max(1, len(s) // 12288)][:12288].astype(np.float64)
+            merge_in.append((sub, np.tile(np.eye(3) * 1e-2, (len(sub), 1, 1))))
+        packed = api._pack_frames([np.eye(4)] * 15, [m[0] for m in merge_in], [m[1] for m in merge_in])
+        return clouds, vm, fs, d, out, packed
+
+    def percentiles(x):
+        return {"p50_us": float(np.percentile(x, 50)), "p99_us": float(np.percentile(x, 99)), "max_us": float(x.max()), "mean_us": float(x.mean())}
+
+    wirings = {}
+    for name, prio, shared in (("own_context_high_priority", 1, False), ("own_context", 0, False), ("shared_context", 0, True)):
+        c_odo = api.Context(D.local_rank, 8, priority=prio)
+        c_bg = c_odo if shared else api.Context(D.local_rank, 8)
+        odo = odometry_problem(c_odo)
+        bg = background_problem(c_bg)
+        factors, deltas = odo[2], odo[3]
+        _, _, bfs, bd, bout, packed = bg
+        entry = {}
+        for mode, diag in (("resident_session", ""), ("launch_per_call", "resident=0")):
+            c_odo.set_diag(diag)
+            idle = api.profile_fresh_sets_samples(factors, deltas, iters=2000, gap_us=50.0, ctx=c_odo)
+            stop = threading.Event()
+            loops = [0]
+
+            def background():
+                while not stop.is_set():
+                    for _ in range(4):
+                        bfs.linearize_device_async(bd, bout.data_ptr(), 0)
+                    c_bg.synchronize()
+                    api.merge_frames(None, None, None, downsample_resolution=0.25, ctx=c_bg, packed=packed).close()
+                    loops[0] += 1
+
+            th = threading.Thread(target=background)
+            th.start()
+            time.sleep(0.05)
+            t0 = time.perf_counter()
+            loaded = api.profile_fresh_sets_samples(factors, deltas, iters=2000, gap_us=50.0, ctx=c_odo)
+            wall = time.perf_counter() - t0
+            stop.set()
+            th.join()
+            entry[mode] = {"idle": percentiles(idle), "under_load": percentiles(loaded), "p99_ratio": float(np.percentile(loaded, 99) / np.percentile(idle, 99)),
+                           "p50_ratio": float(np.percentile(loaded, 50) / np.percentile(idle, 50)),
+                           "background_loops_per_s": loops[0] / max(wall, 1e-9)}
+            api.resident_stop(c_odo)
+        c_odo.set_diag("")
+        wirings[name] = entry
+        del odo, bg, bfs, bout
+    head = wirings["own_context_high_priority"]["resident_session"]
+    return {
+        "metric": "odometry_linearize_p99_us_under_load", "value": head["under_load"]["p99_us"], "unit": "us", "n_gpus": 1, "steps": 2000, "warmup": 5,
+        "ms_per_step": head["under_load"]["mean_us"] * 1e-3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "odometry_under_load: thread A = fresh 34-factor sets on 10 000-pt frames (surface validation on), 50 us between calls; thread B = "
+                               "380-factor sub-mapping bundle (20 x 65 536 pts) linearised back to back + merge_frames(15 x 12 288 pts), on its own context",
+                   "wirings": wirings,
+                   "reference_model": "three module threads, one stream pool each: async_odometry_estimation.cpp:15 + odometry_estimation_gpu.cpp:76-77, "
+                                      "async_sub_mapping.cpp:8 + sub_mapping.cpp:86-87, async_global_mapping.cpp:24 + global_mapping.cpp:110"},
     }
 
 
@@ -1041,7 +1169,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--opt-iters", type=int, default=3, help="odometry_frame: optimiser iterations (fresh-set linearisations) per frame")
-    ap.add_argument("--workload", default=None, choices=["odometry128k", "odometry_frame", "submap20", "global256", "rgbd300k", "frontend128k"],
+    ap.add_argument("--workload", default=None, choices=["odometry128k", "odometry_frame", "submap20", "global256", "rgbd300k", "frontend128k", "odometry_under_load"],
                     help="default: odometry128k (M1) on one GPU, global256 (M2, strong scaling) on several")
     ap.add_argument("--inner", type=int, default=256, help="odometry128k: linearisation passes per step")
     ap.add_argument("--submap-frames", type=int, default=4, help="global256: keyframes merged into one submap")
@@ -1077,7 +1205,7 @@ def main():
     ctx = api.Context(D.local_rank, 1, external_stream=stream.cuda_stream)
     workload = args.workload or ("odometry128k" if D.world == 1 else "global256")
     runner = {"odometry128k": run_odometry128k, "odometry_frame": run_odometry_frame, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k,
-              "frontend128k": run_frontend128k}[workload]
+              "frontend128k": run_frontend128k, "odometry_under_load": run_odometry_under_load}[workload]
     result = runner(args, D, api, ctx)
     if args.workload is None and D.world > 1:
         m1 = run_odometry128k(args, D, api, ctx)  # the weak-scaling form of M1, next to the M2 headline

@@ -84,6 +84,7 @@ SYMBOLS = {
     "glim_amd_last_hip_error": (C.c_char_p, []),
     "glim_amd_device_count": (_i, []),
     "glim_amd_ctx_create": (_i, [_i, _i, _vp, _pp]),
+    "glim_amd_ctx_create_ex": (_i, [_i, _i, _vp, _i, _pp]),
     "glim_amd_ctx_destroy": (_i, [_vp]),
     "glim_amd_ctx_synchronize": (_i, [_vp]),
     "glim_amd_ctx_set_diag": (_i, [_vp, C.c_char_p]),
@@ -95,6 +96,7 @@ SYMBOLS = {
     "glim_amd_preprocess_default_params": (_i, [C.POINTER(PreprocessParams)]),
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
+    "glim_amd_factor_set_profile_fresh_samples": (_i, [_vp, _i32, _pp, _pp, C.POINTER(C.c_uint32), _dp, _i, _d, _fp]),
     "glim_amd_debug_resident_stop": (_i, [_i]),
     "glim_amd_debug_resident_stats": (_i, [_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
     "glim_amd_debug_deskew_table": (_i, [_i64, _dp, _dp, _i32, _dp, _dp, _d, _dp, _dp, _ip, _dp, _i32, _ip]),

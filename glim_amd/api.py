@@ -51,14 +51,15 @@ def device_count():
 class Context:
     """Device + stream pool (gtsam_points::CUDAStream / StreamTempBufferRoundRobin)."""
 
-    def __init__(self, device=0, num_streams=1, external_stream=None):
+    def __init__(self, device=0, num_streams=1, external_stream=None, priority=0):
+        """priority: 0 default, 1 = the device's greatest stream priority (the odometry's context), -1 = its least."""
         h = C.c_void_p()
         ext = None
         if external_stream is not None:
             # 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns for torch's default stream): the C ABI
             # takes the HIP handle for it, hipStreamLegacy, because NULL means "create private streams"
             ext = C.c_void_p(int(external_stream) if int(external_stream) != 0 else STREAM_LEGACY)
-        check(lib().glim_amd_ctx_create(int(device), int(num_streams), ext, C.byref(h)), "glim_amd_ctx_create")
+        check(lib().glim_amd_ctx_create_ex(int(device), int(num_streams), ext, int(priority), C.byref(h)), "glim_amd_ctx_create_ex")
         self._h = h
         self.device = device
 
@@ -844,6 +845,21 @@ def profile_fresh_sets(factors, T_target_source, iters=200, ctx=None):
     us = C.c_float()
     check(lib().glim_amd_factor_set_profile_fresh(ctx._h, n, maps, srcs, flags, _dp(T), int(iters), C.byref(us)), "glim_amd_factor_set_profile_fresh")
     return us.value
+
+
+def profile_fresh_sets_samples(factors, T_target_source, iters=200, gap_us=0.0, ctx=None):
+    """profile_fresh_sets with every iteration timed on its own: microseconds per iteration (array of `iters`); `gap_us` of host work between
+    two iterations."""
+    ctx = ctx or factors[0].source.ctx
+    n = len(factors)
+    maps = (C.c_void_p * n)(*[f.target_voxelmap._h.value for f in factors])
+    srcs = (C.c_void_p * n)(*[f.source._h.value for f in factors])
+    flags = (C.c_uint32 * n)(*[f.flags() for f in factors])
+    T = np.ascontiguousarray(T_target_source, dtype=np.float64)
+    out = np.zeros(int(iters), dtype=np.float32)
+    check(lib().glim_amd_factor_set_profile_fresh_samples(ctx._h, n, maps, srcs, flags, _dp(T), int(iters), float(gap_us), out.ctypes.data_as(C.POINTER(C.c_float))),
+          "glim_amd_factor_set_profile_fresh_samples")
+    return out
 
 
 def overlap_gpu_batch(queries, ctx=None):

@@ -259,6 +259,9 @@ int detect_plane_form(glim_amd_cloud* c, hipStream_t st) {
 
 int ensure_factor_streams(glim_amd_cloud* c, hipStream_t st) {
   if (!c->has_covs || c->n <= 0) return GLIM_AMD_OK;
+  // a cloud may be reached from factor sets of several contexts / streams at once (GLIM's modules share frames): one builder, and the streams
+  // are COMPLETE before anybody sees their pointers
+  std::lock_guard<std::mutex> build_lock(c->build_mu);
   const bool want_plane = c->plane_form && c->normals;
   if (want_plane ? (c->pn4 && c->n2) : (c->gs0 != nullptr)) return GLIM_AMD_OK;
   const int n = (int)c->n;
@@ -275,7 +278,9 @@ int ensure_factor_streams(glim_amd_cloud* c, hipStream_t st) {
     general_stream_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, c->pts, c->covA, c->covB, c->normals, c->curve_rank, c->gs0, c->gs1, c->gs2, c->gsn);
   }
   GA_HIP(hipGetLastError());
-  return GLIM_AMD_OK;  // stream-ordered: the factor kernels that read the streams are enqueued behind this on streams of the same context
+  // once per cloud (~10 us): the next reader may sit on another stream, of this context or of another one
+  GA_HIP(hipStreamSynchronize(st));
+  return GLIM_AMD_OK;
 }
 
 }  // namespace glim_amd
@@ -379,8 +384,8 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (!c) return GLIM_AMD_OK;
   if (c->ctx) {
     (void)hipSetDevice(c->ctx->device);
-    c->ctx->quiesce();  // asynchronous factor launches may still be reading this cloud: its memory goes back to the pool below
-    c->ctx->mutation_epoch++;  // factor sets re-validate their plans
+    quiesce_device(c->ctx->device);  // asynchronous factor launches (of any context) may still be reading this cloud: its memory goes back to the pool below
+    global_mutation_epoch()++;  // factor sets re-validate their plans
   }
   if (c->gs0) (void)pool_free(c->gs0);
   if (c->gs1) (void)pool_free(c->gs1);

@@ -1,4 +1,5 @@
 // context.hip -- library, error and context entry points of the C ABI (include/glim_amd.h).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <string>
@@ -9,6 +10,19 @@ namespace glim_amd {
 
 static thread_local char g_hip_error[512] = "";
 static std::atomic<int> g_live_contexts{0};
+// every live context (quiesce_device walks it; guarded by g_ctx_registry_mu)
+static std::mutex g_ctx_registry_mu;
+static std::vector<glim_amd_ctx*> g_ctx_registry;
+
+std::atomic<uint64_t>& global_mutation_epoch() {
+  static std::atomic<uint64_t> e{1};
+  return e;
+}
+void quiesce_device(int device) {
+  std::lock_guard<std::mutex> lock(g_ctx_registry_mu);
+  for (glim_amd_ctx* c : g_ctx_registry)
+    if (c->device == device) c->quiesce();
+}
 
 void set_hip_error(hipError_t e, const char* what) {
   snprintf(g_hip_error, sizeof(g_hip_error), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
@@ -195,7 +209,11 @@ int glim_amd_device_count(void) {
 }
 
 int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim_amd_ctx** out) {
-  if (!out || num_streams < 0) return GLIM_AMD_ERR_INVALID;
+  return glim_amd_ctx_create_ex(device, num_streams, external_stream, 0, out);
+}
+
+int glim_amd_ctx_create_ex(int device, int num_streams, void* external_stream, int priority, glim_amd_ctx** out) {
+  if (!out || num_streams < 0 || priority < -1 || priority > 1) return GLIM_AMD_ERR_INVALID;
   *out = nullptr;
   const int ndev = glim_amd_device_count();
   if (ndev <= 0) return GLIM_AMD_ERR_NO_DEVICE;
@@ -213,9 +231,13 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
   } else {
     ctx->owns_streams = true;
     if (num_streams == 0) num_streams = 1;
+    int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    ctx->priority = priority;
     for (int i = 0; i < num_streams; i++) {
       hipStream_t s;
-      hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+      hipError_t e = priority == 0 ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking)
+                                   : hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? greatest : least);
       if (e != hipSuccess) {
         set_hip_error(e, "hipStreamCreateWithFlags");
         for (auto t : ctx->streams) (void)hipStreamDestroy(t);
@@ -226,6 +248,10 @@ int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim
     }
   }
   g_live_contexts++;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_registry_mu);
+    g_ctx_registry.push_back(ctx);
+  }
   *out = ctx;
   return GLIM_AMD_OK;
 }
@@ -234,6 +260,10 @@ int glim_amd_ctx_destroy(glim_amd_ctx* ctx) {
   if (!ctx) return GLIM_AMD_OK;
   if (ctx->live_children.load() != 0) return GLIM_AMD_ERR_STATE;  // children must be destroyed first; the context stays valid
   (void)hipSetDevice(ctx->device);
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_registry_mu);
+    g_ctx_registry.erase(std::remove(g_ctx_registry.begin(), g_ctx_registry.end(), ctx), g_ctx_registry.end());
+  }
   for (auto s : ctx->streams) (void)hipStreamSynchronize(s);
   ctx_release_factor_resources(ctx);
   if (ctx->pinned_scratch) (void)pinned_free(ctx->pinned_scratch);

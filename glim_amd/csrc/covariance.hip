@@ -166,9 +166,9 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->normals) GA_HIP(pool_malloc(&c->normals, nn * sizeof(float4)));
   // General factor streams built from earlier covariances are stale now, and factor plans hold their addresses: wait for asynchronous
   // launches that may still read them, then give the cloud a new identity so that every plan built from the old streams is rebuilt.
-  ctx->quiesce();
+  quiesce_device(ctx->device);
   c->uid = next_uid();
-  ctx->mutation_epoch++;
+  global_mutation_epoch()++;
   if (c->gs0) { (void)pool_free(c->gs0); c->gs0 = nullptr; }
   if (c->gs1) { (void)pool_free(c->gs1); c->gs1 = nullptr; }
   if (c->gs2) { (void)pool_free(c->gs2); c->gs2 = nullptr; }

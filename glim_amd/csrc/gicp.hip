@@ -371,7 +371,7 @@ unsigned int next_pow2(unsigned long long v) {
 int run_gicp(const glim_amd_nn_index* ix, const glim_amd_cloud* source, const double* T12, double max_dist, bool linearize, double* compact_host,
              int32_t* corr_host) {
   if (!ix || !source || !T12 || !(max_dist >= 0.0)) return GLIM_AMD_ERR_INVALID;
-  if (source->ctx != ix->ctx) return GLIM_AMD_ERR_INVALID;
+  if (source->ctx->device != ix->ctx->device) return GLIM_AMD_ERR_INVALID;
   if (!source->has_covs || !ix->covA) return GLIM_AMD_ERR_STATE;
   glim_amd_ctx* ctx = ix->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -75,7 +75,7 @@ struct Diag {
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
   int resident = 1;       // resident=0|1                       repeated synchronous linearisations of a small set go through a resident kernel (no launch per call)
-  int resident_idle_us = 300;   // resident_idle_us=<n>         the resident kernel leaves after this long without a request
+  int resident_idle_us = 1000;  // resident_idle_us=<n>         the resident kernel leaves after this long without a request
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
@@ -183,6 +183,12 @@ inline uint64_t next_uid() {
   return n.fetch_add(1);
 }
 
+// Clouds and voxel maps may be used across contexts of one device (GLIM's three modules own a stream pool each and hand frames / maps to one
+// another: sub_mapping.cpp:168, global_mapping.cpp:253-266), so what invalidates plans built from them is counted process-wide, not per context.
+std::atomic<uint64_t>& global_mutation_epoch();
+// waits for the asynchronous launches of EVERY context of `device` that may still be reading an object which is about to change or die
+void quiesce_device(int device);
+
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
 constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
 
@@ -203,8 +209,7 @@ struct glim_amd_ctx {
   // set by the *_async entry points: device work may still be reading buffers when the call returns, so the next call that recycles
   // device memory of this context (destroy / re-plan) synchronises the streams first (quiesce)
   std::atomic<bool> async_pending{false};
-  // bumped whenever a cloud / voxel map of this context changes identity or dies: a factor set re-validates its plan only then
-  std::atomic<uint64_t> mutation_epoch{1};
+  int priority = 0;  // 1: its streams were created with the device's greatest priority (glim_amd_ctx_create_ex)
   std::vector<FactorPlan*> plan_cache;  // idle factor plans, most recently released first (vgicp.hip; guarded by mu)
   // overlap scratch (vgicp.hip), allocated on first use: per-query arrival counters on the device, results + completion word in host-mapped memory
   static constexpr int OV_MAX_QUERIES = 1024;
@@ -250,6 +255,7 @@ struct CtxRef {
 
 struct glim_amd_cloud {
   CtxRef ctx;
+  std::mutex build_mu;  // lazily built members (factor streams, Hilbert rank) are built by one caller at a time, whatever its context
   uint64_t uid = glim_amd::next_uid();
   int64_t n = 0;
   float4* pts = nullptr;

@@ -1396,7 +1396,7 @@ void make_key(const glim_amd_factor_set* set, std::vector<PlanKey>& key) {
 // clear -> add -> linearize per optimiser iteration then costs no allocation, no upload and no synchronise.
 int factor_set_prepare(glim_amd_factor_set* set) {
   glim_amd_ctx* ctx = set->ctx;
-  const uint64_t epoch = ctx->mutation_epoch.load();
+  const uint64_t epoch = global_mutation_epoch().load();
   const Diag& diag = ctx->diag;
   if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt) return GLIM_AMD_OK;
   std::vector<PlanKey> key;
@@ -1916,7 +1916,8 @@ int glim_amd_factor_set_destroy(glim_amd_factor_set* set) {
 int glim_amd_factor_set_add(glim_amd_factor_set* set, const glim_amd_voxelmap* target, const glim_amd_cloud* source, uint32_t flags,
                             int32_t* factor_index) {
   if (!set || !target || !source) return GLIM_AMD_ERR_INVALID;
-  if (target->ctx != set->ctx || source->ctx != set->ctx) return GLIM_AMD_ERR_INVALID;
+  // maps and clouds of ANY context of the set's device (GLIM's modules hand frames and maps to one another); the set runs on its own context's streams
+  if (target->ctx->device != set->ctx->device || source->ctx->device != set->ctx->device) return GLIM_AMD_ERR_INVALID;
   if (!target->buckets || !source->has_covs) return GLIM_AMD_ERR_STATE;
   if (source->n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;  // 32-bit byte offsets into the point streams
   set->entries.push_back({target, source, flags});
@@ -2139,10 +2140,10 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
   if (num_queries > glim_amd_ctx::OV_MAX_QUERIES) return GLIM_AMD_ERR_UNSUPPORTED;
   int64_t total_targets = 0;
   for (int q = 0; q < num_queries; q++) {
-    if (num_targets[q] <= 0 || !sources[q] || sources[q]->ctx != ctx) return GLIM_AMD_ERR_INVALID;
+    if (num_targets[q] <= 0 || !sources[q] || sources[q]->ctx->device != ctx->device) return GLIM_AMD_ERR_INVALID;
     for (int t = 0; t < num_targets[q]; t++) {
       const glim_amd_voxelmap* m = targets[total_targets + t];
-      if (!m || m->ctx != ctx) return GLIM_AMD_ERR_INVALID;
+      if (!m || m->ctx->device != ctx->device) return GLIM_AMD_ERR_INVALID;
       if (!m->buckets) return GLIM_AMD_ERR_STATE;
     }
     total_targets += num_targets[q];
@@ -2250,6 +2251,30 @@ int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_a
   for (int i = 0; i < iters; i++) GA_TRY(once());
   const auto t1 = std::chrono::steady_clock::now();
   *us_per_iteration = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
+                                              const uint32_t* flags, const double* T, int iters, double gap_us, float* samples_us) {
+  if (!ctx || n <= 0 || !targets || !sources || !T || iters <= 0 || !samples_us || gap_us < 0.0) return GLIM_AMD_ERR_INVALID;
+  std::vector<glim_amd_linearized6> out((size_t)n);
+  auto once = [&]() -> int {
+    glim_amd_factor_set* set = nullptr;
+    GA_TRY(glim_amd_factor_set_create(ctx, &set));
+    int rc = GLIM_AMD_OK;
+    for (int f = 0; f < n && rc == GLIM_AMD_OK; f++) rc = glim_amd_factor_set_add(set, targets[f], sources[f], flags ? flags[f] : 0u, nullptr);
+    if (rc == GLIM_AMD_OK) rc = glim_amd_factor_set_linearize(set, T, out.data());
+    (void)glim_amd_factor_set_destroy(set);
+    return rc;
+  };
+  for (int i = 0; i < 5; i++) GA_TRY(once());
+  for (int i = 0; i < iters; i++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    GA_TRY(once());
+    const auto t1 = std::chrono::steady_clock::now();
+    samples_us[i] = (float)std::chrono::duration<double, std::micro>(t1 - t0).count();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count() < gap_us) cpu_relax();  // the optimiser's host work
+  }
   return GLIM_AMD_OK;
 }
 

@@ -362,16 +362,16 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (!m) return GLIM_AMD_OK;
   if (m->ctx) {
     (void)hipSetDevice(m->ctx->device);
-    m->ctx->quiesce();  // asynchronous factor launches may still be reading this table
+    quiesce_device(m->ctx->device);  // asynchronous factor launches (of any context) may still be reading this table
   }
-  if (m->ctx) m->ctx->mutation_epoch++;  // factor sets re-validate their plans
+  global_mutation_epoch()++;  // factor sets re-validate their plans
   if (m->buckets) (void)pool_free(m->buckets);
   delete m;
   return GLIM_AMD_OK;
 }
 
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) {
-  if (!m || !cloud || cloud->ctx != m->ctx) return GLIM_AMD_ERR_INVALID;
+  if (!m || !cloud || cloud->ctx->device != m->ctx->device) return GLIM_AMD_ERR_INVALID;  // (any context of the map's device)
   if (!cloud->has_covs) return GLIM_AMD_ERR_STATE;
   if (cloud->n > (int64_t)(1u << 28)) return GLIM_AMD_ERR_INVALID;
   glim_amd_ctx* ctx = m->ctx;
@@ -384,7 +384,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   constexpr int DIRECT_MAX_POINTS = 32768;
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
-  if (old) ctx->quiesce();  // asynchronous factor launches may still be reading the table that is about to be replaced
+  if (old) quiesce_device(ctx->device);  // asynchronous factor launches may still be reading the table that is about to be replaced
   // Direct build (keys straight into the final table, ONE synchronise: build_direct_kernel) needs the table size before the voxels are
   // counted.  Small clouds: 2 buckets per point (4 ways per point: load factor below 1/2 whatever the cloud).  Larger clouds: 6 buckets per
   // EXPECTED voxel, from the voxels-per-point ratio of the last map this context built at (about) this resolution -- consecutive frames of a
@@ -449,7 +449,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     m->num_buckets = nb;
     m->num_voxels = h_stats[0];
     m->uid = next_uid();
-    ctx->mutation_epoch++;
+    global_mutation_epoch()++;
     return GLIM_AMD_OK;
   } while (0);
   const unsigned int tsize0 = next_pow2((unsigned long long)std::max<long long>(32, (long long)n + (old ? (long long)m->num_voxels : 0ll)) * 2);
@@ -509,7 +509,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   m->num_buckets = nb;
   m->num_voxels = num_voxels;
   m->uid = next_uid();  // plans built from the previous table are rebuilt (factor_set_prepare)
-  ctx->mutation_epoch++;
+  global_mutation_epoch()++;
   return GLIM_AMD_OK;
 }
 

@@ -75,6 +75,14 @@ int glim_amd_device_count(void);
  * external_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to create `num_streams` streams.  The null stream is
  * named explicitly: pass hipStreamLegacy ((hipStream_t)1) or hipStreamPerThread ((hipStream_t)2), never 0. */
 int glim_amd_ctx_create(int device, int num_streams, void* external_stream, glim_amd_ctx** out);
+/* The same with a scheduling priority for the context's own streams: 0 = default, 1 = the device's greatest stream priority, -1 = its least.
+ * GLIM runs three modules in three threads on one device, each with its own stream pool (async_odometry_estimation.cpp:15 /
+ * odometry_estimation_gpu.cpp:76-77, async_sub_mapping.cpp:8 / sub_mapping.cpp:86-87, async_global_mapping.cpp:24 / global_mapping.cpp:110):
+ * one context per module, the odometry's with priority 1, keeps a 25 us odometry linearisation from queueing behind a sub-mapping merge on
+ * the host (a context's calls serialise on ITS mutex only) and behind a 10 ms global-mapping kernel on the device.
+ * Clouds, voxel maps and search indices may be used by calls and factor sets of ANY context of the same device (the modules hand frames and
+ * maps to one another); an object is destroyed through, and counted by, the context that created it. */
+int glim_amd_ctx_create_ex(int device, int num_streams, void* external_stream, int priority, glim_amd_ctx** out);
 /* GLIM_AMD_ERR_STATE (and the context stays valid) while clouds, voxel maps, factor sets or search indices created from it are alive. */
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
 int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
@@ -277,6 +285,12 @@ int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_t
  * times; microseconds per iteration, measured inside the library. */
 int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
                                       const uint32_t* flags, const double* T_target_source, int iters, float* us_per_iteration);
+
+/* The same pattern with every iteration timed on its own (samples_us: `iters` entries) and `gap_us` of host busy-waiting between iterations -- the
+ * optimiser's own work between two linearisations --, for latency percentiles while other threads load the device (bench.py
+ * --workload odometry_under_load). */
+int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
+                                              const uint32_t* flags, const double* T_target_source, int iters, double gap_us, float* samples_us);
 
 /* One Levenberg-Marquardt iteration as the optimisers drive it (sub_mapping.cpp:435-443, odometry_estimation_cpu.cpp:116-149): a synchronous
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */

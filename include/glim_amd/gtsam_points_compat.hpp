@@ -63,16 +63,34 @@ inline void check(int rc, const char* what) {
   }
 }
 
-// gtsam_points::CUDAStream + StreamTempBufferRoundRobin (odometry_estimation_gpu.cpp:76-77)
-class StreamTempBufferRoundRobin {
+// Stream priority of the contexts THIS THREAD creates from now on (0 default, 1 = the device's greatest priority, -1 its least).  GLIM builds
+// each module -- and with it the module's CUDAStream / StreamTempBufferRoundRobin members -- in one constructor call
+// (odometry_estimation_gpu.cpp:76-77, sub_mapping.cpp:86-87, global_mapping.cpp:109-110), so the module's plugin entry point brackets that
+// call: adapters/glim/odometry_estimation_hip_create.cpp raises the priority for the odometry, whose 25 us linearisations must not queue
+// behind the mapping threads' millisecond kernels.
+inline int& default_stream_priority() {
+  static thread_local int p = 0;
+  return p;
+}
+struct ScopedStreamPriority {
+  explicit ScopedStreamPriority(int p) : saved(default_stream_priority()) { default_stream_priority() = p; }
+  ~ScopedStreamPriority() { default_stream_priority() = saved; }
+  int saved;
+};
+
+// gtsam_points::CUDAStream + StreamTempBufferRoundRobin (odometry_estimation_gpu.cpp:76-77): a context = a pool of HIP streams with its own
+// mutex.  Every module owns its pools, as in the reference; clouds / voxel maps may be used across the contexts of a device.
+class StreamTempBufferRoundRobin : public std::enable_shared_from_this<StreamTempBufferRoundRobin> {
 public:
-  explicit StreamTempBufferRoundRobin(int num_streams = 8, int device = 0) { check(glim_amd_ctx_create(device, num_streams, nullptr, &ctx_), "ctx_create"); }
+  explicit StreamTempBufferRoundRobin(int num_streams = 8, int device = 0, int priority = default_stream_priority()) {
+    check(glim_amd_ctx_create_ex(device, num_streams, nullptr, priority, &ctx_), "ctx_create");
+  }
   ~StreamTempBufferRoundRobin() { glim_amd_ctx_destroy(ctx_); }
   StreamTempBufferRoundRobin(const StreamTempBufferRoundRobin&) = delete;
   StreamTempBufferRoundRobin& operator=(const StreamTempBufferRoundRobin&) = delete;
   glim_amd_ctx* context() const { return ctx_; }
   static std::shared_ptr<StreamTempBufferRoundRobin> default_instance() {
-    static std::shared_ptr<StreamTempBufferRoundRobin> inst = std::make_shared<StreamTempBufferRoundRobin>(8, 0);
+    static std::shared_ptr<StreamTempBufferRoundRobin> inst = std::make_shared<StreamTempBufferRoundRobin>(8, 0, 0);
     return inst;
   }
 
@@ -186,12 +204,17 @@ class IntegratedVGICPFactorGPU {
 public:
   using shared_ptr = std::shared_ptr<IntegratedVGICPFactorGPU>;
   // binary: (target_key, source_key, target voxel map, source frame)          odometry_estimation_gpu.cpp:144
-  IntegratedVGICPFactorGPU(Key target_key, Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source)
-      : is_binary_(true), target_key_(target_key), source_key_(source_key), target_(std::move(target)), source_(std::move(source)) {}
+  // ctx: the (stream, buffer) pair the reference's constructors take from the module's StreamTempBufferRoundRobin, i.e. the pool a set of
+  // such factors runs on; null = the context of the target map
+  IntegratedVGICPFactorGPU(Key target_key, Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source, Context ctx = nullptr)
+      : is_binary_(true), target_key_(target_key), source_key_(source_key), target_(std::move(target)), source_(std::move(source)),
+        ctx_(ctx ? std::move(ctx) : target_->context()) {}
   // unary: (fixed_target_pose, source_key, target voxel map, source frame)    odometry_estimation_gpu.cpp:161
-  IntegratedVGICPFactorGPU(const Isometry3d& fixed_target_pose, Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source)
+  IntegratedVGICPFactorGPU(const Isometry3d& fixed_target_pose, Key source_key, GaussianVoxelMapGPU::ConstPtr target, PointCloudGPU::ConstPtr source,
+                           Context ctx = nullptr)
       : is_binary_(false), target_key_(0), source_key_(source_key), fixed_target_pose_(fixed_target_pose), target_(std::move(target)),
-        source_(std::move(source)) {}
+        source_(std::move(source)), ctx_(ctx ? std::move(ctx) : target_->context()) {}
+  const Context& context() const { return ctx_; }
 
   void set_enable_surface_validation(bool enable) { surface_validation_ = enable; }
   std::vector<Key> keys() const { return is_binary_ ? std::vector<Key>{target_key_, source_key_} : std::vector<Key>{source_key_}; }
@@ -231,28 +254,35 @@ private:
   Isometry3d fixed_target_pose_;
   GaussianVoxelMapGPU::ConstPtr target_;
   PointCloudGPU::ConstPtr source_;
+  Context ctx_;
   bool surface_validation_ = false;
   bool linearized_valid_ = false;
   LinearizedSystem6 linearized_{};
 };
 
 // gtsam_points::NonlinearFactorSetGPU: one fused launch for every added factor.
+// A set made without a context (the optimisers' linearisation hook makes it that way: offline_viewer.cpp:29) runs on the context of the first
+// factor it is given -- i.e. on the stream pool of the module that built the factor.
 class NonlinearFactorSetGPU {
 public:
-  explicit NonlinearFactorSetGPU(Context ctx = nullptr) : ctx_(ctx ? ctx : StreamTempBufferRoundRobin::default_instance()) {
-    check(glim_amd_factor_set_create(ctx_->context(), &h_), "NonlinearFactorSetGPU");
+  explicit NonlinearFactorSetGPU(Context ctx = nullptr) : ctx_(std::move(ctx)) {
+    if (ctx_) check(glim_amd_factor_set_create(ctx_->context(), &h_), "NonlinearFactorSetGPU");
   }
   ~NonlinearFactorSetGPU() { glim_amd_factor_set_destroy(h_); }
   NonlinearFactorSetGPU(const NonlinearFactorSetGPU&) = delete;
   NonlinearFactorSetGPU& operator=(const NonlinearFactorSetGPU&) = delete;
   bool add(const IntegratedVGICPFactorGPU::shared_ptr& factor) {
     if (!factor) return false;
+    if (!h_) {
+      ctx_ = factor->context() ? factor->context() : StreamTempBufferRoundRobin::default_instance();
+      check(glim_amd_factor_set_create(ctx_->context(), &h_), "NonlinearFactorSetGPU");
+    }
     check(glim_amd_factor_set_add(h_, factor->target()->handle(), factor->source()->handle(), factor->flags(), nullptr), "NonlinearFactorSetGPU::add");
     factors_.push_back(factor);
     return true;
   }
   void clear() {
-    glim_amd_factor_set_clear(h_);
+    if (h_) glim_amd_factor_set_clear(h_);
     factors_.clear();
   }
   std::size_t size() const { return factors_.size(); }
@@ -285,7 +315,7 @@ private:
 
 inline const LinearizedSystem6& IntegratedVGICPFactorGPU::linearize(const Values& values) {
   glim_amd_factor_set* set = nullptr;
-  check(glim_amd_factor_set_create(source_->context()->context(), &set), "factor_set_create");
+  check(glim_amd_factor_set_create(ctx_->context(), &set), "factor_set_create");
   int rc = glim_amd_factor_set_add(set, target_->handle(), source_->handle(), flags(), nullptr);
   const Isometry3d d = calc_delta(values);
   LinearizedSystem6 out{};
@@ -298,7 +328,7 @@ inline const LinearizedSystem6& IntegratedVGICPFactorGPU::linearize(const Values
 
 inline double IntegratedVGICPFactorGPU::error(const Values& values, const Values* linearization_values) {
   glim_amd_factor_set* set = nullptr;
-  check(glim_amd_factor_set_create(source_->context()->context(), &set), "factor_set_create");
+  check(glim_amd_factor_set_create(ctx_->context(), &set), "factor_set_create");
   int rc = glim_amd_factor_set_add(set, target_->handle(), source_->handle(), flags(), nullptr);
   const Isometry3d d = calc_delta(values);
   Isometry3d dl;
