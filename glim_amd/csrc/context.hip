@@ -53,6 +53,7 @@ const DiagKey kDiagKeys[] = {
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
   {"fuse", &Diag::fuse, nullptr, 0, 1},
+  {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},
   {"resident", &Diag::resident, nullptr, 0, 1},
   {"resident_idle_us", &Diag::resident_idle_us, nullptr, 100, 1000000},
   {"pool", &Diag::pool, nullptr, 0, 1},

@@ -76,6 +76,7 @@ struct Diag {
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
   int resident = 1;       // resident=0|1                       repeated synchronous linearisations of a small set go through a resident kernel (no launch per call)
   int resident_idle_us = 1000;  // resident_idle_us=<n>         the resident kernel leaves after this long without a request
+  int pp_fast = 1;        // pp_fast=0|1                        random-grid preprocessing: one sort + counting ranks, one synchronise (preprocess.hip)
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)

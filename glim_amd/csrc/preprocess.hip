@@ -213,6 +213,17 @@ struct FilterParams {
   int crop, crop_imu;
   double bmin[3], bmax[3], T[12];
 };
+inline void fill_filter_params(FilterParams& fp, const glim_amd_preprocess_params* prm) {
+  fp.near2 = prm->distance_near_thresh * prm->distance_near_thresh;
+  fp.far2 = prm->distance_far_thresh * prm->distance_far_thresh;
+  fp.crop = prm->enable_cropbox_filter;
+  fp.crop_imu = prm->crop_bbox_frame_imu;
+  for (int a = 0; a < 3; a++) {
+    fp.bmin[a] = prm->crop_bbox_min[a];
+    fp.bmax[a] = prm->crop_bbox_max[a];
+  }
+  memcpy(fp.T, prm->T_imu_lidar, sizeof(fp.T));
+}
 
 __global__ __launch_bounds__(256) void pp_filter_flag_kernel(int m, const double4* __restrict__ P, const int* __restrict__ sel, FilterParams fp,
                                                              int* __restrict__ flags) {
@@ -270,6 +281,327 @@ __global__ __launch_bounds__(256) void pp_gather_out_kernel(int f, const u32* __
   pts[j] = make_float4((float)p.x, (float)p.y, (float)p.z, 1.0f);
   times[j] = zero_times ? 0.0 : T[i];
   if (inten) inten[j] = I[i];
+}
+
+
+// ============================================================================================================================================
+// Fast path of the random-grid branch (the shipped configuration: 131 072 raw points -> ~10 000).  Round 3's form sorted the raw scan three
+// times (by sample hash: 4 passes, by voxel: 3, for the 1.2x cap: 5 -- every frame of the shipped configuration hits the cap), sorted the
+// survivors by time with 8 more passes and went back to the host four times for counters: 0.80-0.90 ms per scan, 23 radix passes of it 0.28 ms.
+// Here ONE sort remains (by voxel); everything behind it is a counting rank on the device, sized by bounds the host knows in advance, with the
+// actual counts read from device memory:
+//   select   a point survives iff fewer than ppv points of its voxel have a smaller (hash >> 32, index): a walk over the voxel's run of the
+//            sorted order that stops as soon as ppv smaller ones have been seen (most points stop after a step or two);
+//   cap      when more than max_num survive: rank of every survivor among the survivors by (hash & 0xffffffff, index), counted against LDS tiles
+//            of the compacted candidate list; rank >= max_num drops out;
+//   time     the same counting rank on (time, index) replaces the stable radix sort by time.
+// After the cap at most max_num points are alive, so the output cloud is allocated for that many up front.  The counting ranks are quadratic in
+// the number of survivors: beyond RANK_FAST_MAX a flag is raised instead, and the caller repeats the call on the general (sorting) path.
+// Same results as the sorting path bit for bit (tests/test_preprocess.py runs both).
+// ============================================================================================================================================
+constexpr int RANK_FAST_MAX = 32768;  // survivors the counting ranks accept
+constexpr int RANK_TILE = 2048;       // keys per LDS tile of the counting rank
+constexpr int RANK_SPLIT = 8;         // blocks that share the tiles of one group of 256 candidates
+enum { C_VOXELS = 0, C_VALID = 1, C_KEPT = 2, C_FALLBACK = 3, C_CAND = 4, C_FINAL = 5, C_UNSORTED = 6, C_NUM = 8 };
+
+__global__ __launch_bounds__(256) void pp_hash32_kernel(int n, u64 seed, u32* __restrict__ hhi, u32* __restrict__ hlo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 h = sample_hash(seed, (u64)i);
+  hhi[i] = (u32)(h >> 32);
+  hlo[i] = (u32)(h & 0xFFFFFFFFull);
+}
+
+// ---- selection without a sort: voxels in a hash table, the ppv smallest (hash >> 32, index) of every voxel through an atomicMin cascade ----
+constexpr int PPV_MAX = 4;  // points per voxel the cascade keeps (shipped configuration: 1-3); a larger quota takes the sorting path
+constexpr u64 TABLE_EMPTY = ~0ull;
+
+// every valid point finds (or claims) the table slot of its voxel: slot_of[i] (-1: invalid point); counters[C_VOXELS] = occupied slots
+// Neighbouring raw indices are neighbouring points (scan order) and mostly share a voxel.  Device-scope atomics are served at the memory side
+// of the fabric, one after the other per address (~10 ns): 131 072 points probing, claiming and cascading one by one cost 50 + 108 us.  The
+// table kernels therefore work per GROUP of equal keys inside a wavefront: the lanes that hold the same voxel elect a leader, which alone
+// touches the table -- one probe per group, and of a group's values only the ppv smallest go into the cascade.
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
+  const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)(v & 0xffffffffull), lane, 64);
+  const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(v >> 32), lane, 64);
+  return ((u64)hi << 32) | (u64)lo;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)(v & 0xffffffffull), off, 64);
+    const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(v >> 32), off, 64);
+    const u64 o = ((u64)hi << 32) | (u64)lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u64 pp_voxel_key_of(const double4 p, double inv_res) {
+  const double t[3] = {p.x * inv_res, p.y * inv_res, p.z * inv_res};
+  bool valid = isfinite(p.w);
+#pragma unroll
+  for (int a = 0; a < 3; a++) valid = valid && (t[a] >= -1048576.0 && t[a] < 1048576.0);  // false for NaN / inf (pp_key_kernel's rule)
+  if (!valid) return TABLE_EMPTY;
+  return (u64)(fast_floor_d(t[0]) + KEY_OFFSET) | ((u64)(fast_floor_d(t[1]) + KEY_OFFSET) << 21) | ((u64)(fast_floor_d(t[2]) + KEY_OFFSET) << 42);
+}
+
+// every valid point learns the table slot of its voxel: slot_of[i] (-1: invalid point); counters[C_VOXELS] = occupied slots
+__global__ __launch_bounds__(256) void pp_table_insert_kernel(int n, const double4* __restrict__ p4, double inv_res, u64* __restrict__ table, unsigned int mask,
+                                                              int* __restrict__ slot_of, int* __restrict__ counters) {
+  __shared__ int s_new;
+  if (threadIdx.x == 0) s_new = 0;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const u64 key = i < n ? pp_voxel_key_of(p4[i], inv_res) : TABLE_EMPTY;
+  int slot = -1;
+  unsigned long long todo = __ballot(key != TABLE_EMPTY);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const u64 k = readlane_u64(key, leader);
+    const unsigned long long grp = __ballot(key == k) & todo;
+    int found = -1;
+    if (lane == leader) {
+      unsigned int h = (unsigned int)((k * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+      for (;;) {
+        u64 cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == TABLE_EMPTY) {
+          cur = atomicCAS(&table[h], TABLE_EMPTY, k);
+          if (cur == TABLE_EMPTY) {
+            atomicAdd(&s_new, 1);  // (LDS)
+            cur = k;
+          }
+        }
+        if (cur == k) break;
+        h = (h + 1) & mask;
+      }
+      found = (int)h;
+    }
+    found = __shfl(found, leader, 64);
+    if ((grp >> lane) & 1ull) slot = found;
+    todo &= ~grp;
+  }
+  if (i < n) slot_of[i] = slot;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_new) atomicAdd(&counters[C_VOXELS], s_new);  // one global atomic per block
+}
+
+// levels[slot][0 .. ppv) end up holding the ppv smallest packed (hash >> 32, index) of the voxel, ascending: a value offers itself to level 0
+// with atomicMin and the larger of (what was there, itself) is carried on to the next level -- whatever the interleaving, level t receives
+// every value except the final contents of the levels above it exactly once, so it ends as their minimum.  Per wavefront and voxel only the
+// ppv smallest values of the group can matter; its leader offers them, smallest first, and stops at the first one that is larger than the
+// current last level (levels only fall: it, and everything behind it, can never enter).
+__global__ __launch_bounds__(256) void pp_cascade_kernel(int n, double rate, const int* __restrict__ slot_of, const u32* __restrict__ hhi, u64* __restrict__ levels,
+                                                         int* __restrict__ counters) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int num_voxels = counters[C_VOXELS];
+  if (num_voxels <= 0) return;
+  const long long ppv = (long long)ceil((rate * (double)n) / (double)num_voxels);
+  if (ppv > PPV_MAX) {
+    if (i == 0) counters[C_FALLBACK] = 1;
+    return;
+  }
+  int slot = i < n ? slot_of[i] : -1;
+  u64 x = slot >= 0 ? (((u64)hhi[i] << 32) | (u64)(u32)i) : TABLE_EMPTY;
+  // ONE parallel look at every lane's last level first: a value above it can never enter (levels only fall).  Once a voxel's first few
+  // arrivals have settled its levels -- i.e. for almost every lane of a dense scan -- this load is all the kernel does.
+  if (slot >= 0 && x > __hip_atomic_load(&levels[(size_t)slot * PPV_MAX + (ppv - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) slot = -1;
+  // rank of this lane's value among the wavefront's values of the SAME voxel: only the ppv smallest of a voxel's values in this wavefront can
+  // be among the voxel's ppv smallest overall.  Those lanes run their cascades side by side (the cascade is correct under any interleaving);
+  // a leader walking a group's values one after the other made the kernel a chain of ppv^2 dependent returning atomics per group (76-108 us).
+  int smaller = 0;
+#pragma unroll
+  for (int j = 0; j < 64; j++) {
+    const int sj = __shfl(slot, j, 64);
+    const u64 xj = readlane_u64(x, j);
+    smaller += (int)(sj == slot) & (int)(xj < x);
+  }
+  if (slot >= 0 && smaller < (int)ppv) {
+    u64* L = levels + (size_t)slot * PPV_MAX;
+    u64 v = x;
+    for (int q = 0; q < (int)ppv; q++) {
+      const u64 old = atomicMin(&L[q], v);
+      v = old > v ? old : v;
+      if (v == TABLE_EMPTY) break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pp_select_table_kernel(int n, double rate, const int* __restrict__ slot_of, const u32* __restrict__ hhi,
+                                                              const u64* __restrict__ levels, int* __restrict__ counters, int* __restrict__ sel) {
+  __shared__ int s_tmp[16];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int num_voxels = counters[C_VOXELS];
+  int kept = 0;
+  if (i < n && num_voxels > 0) {
+    const long long ppv = (long long)ceil((rate * (double)n) / (double)num_voxels);
+    const int slot = slot_of[i];
+    if (slot >= 0 && ppv <= PPV_MAX) {
+      const u64 me = ((u64)hhi[i] << 32) | (u64)(u32)i;
+      const u64* L = levels + (size_t)slot * PPV_MAX;
+      for (int t = 0; t < (int)ppv; t++) kept |= (L[t] == me);
+      if (kept) sel[i] = 1;
+    }
+  }
+  kept = block_reduce_i<2>(kept, s_tmp);
+  if (threadIdx.x == 0 && kept) atomicAdd(&counters[C_KEPT], kept);
+}
+
+// candidates of the cap, compacted in index order: key = hash & 0xffffffff, value = index
+__global__ __launch_bounds__(256) void pp_cap_compact_kernel(int n, const int* __restrict__ sel, const int* __restrict__ pos, const u32* __restrict__ hlo,
+                                                             u64* __restrict__ ckeys, u32* __restrict__ cvals, int* __restrict__ counters, int max_num) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    const int m = pos[n];
+    counters[C_CAND] = m;
+    if (m > max_num && m > RANK_FAST_MAX) counters[C_FALLBACK] = 1;
+  }
+  if (i >= n || !sel[i]) return;
+  const int p = pos[i];
+  if (p < RANK_FAST_MAX) {
+    ckeys[p] = ((u64)hlo[i] << 32) | (u64)(u32)i;  // (hash & 0xffffffff, index) as ONE comparable word
+    cvals[p] = (u32)i;
+  }
+}
+
+// Counting rank: rank[j] += number of pairs of tiles s, s + RANK_SPLIT, ... that are smaller than pair j.  Block (x, s) serves the 256
+// candidates of group x against its share of the tiles; *count_ptr candidates exist (<= RANK_FAST_MAX, else nothing is done); only_above: the
+// rank is needed only when the count exceeds it (the cap), otherwise always (the time order).  PACKED: the key word alone orders the pairs
+// (index in its low bits); otherwise ties of the key are broken by the value.  Branch-free inner loop: every lane reads the same LDS word.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void pp_count_rank_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const int* __restrict__ count_ptr,
+                                                            int only_above, const int* __restrict__ needed, int* __restrict__ rank) {
+  __shared__ u64 s_k[RANK_TILE];
+  __shared__ u32 s_v[PACKED ? 1 : RANK_TILE];
+  const int m = *count_ptr;
+  if (m > RANK_FAST_MAX || m <= only_above || (needed && !*needed)) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.x * 256 >= m) return;
+  const bool live = j < m;
+  const u64 kj = live ? keys[j] : 0ull;
+  const u32 vj = (live && !PACKED) ? vals[j] : 0u;
+  int smaller = 0;
+  for (int t = blockIdx.y; t * RANK_TILE < m; t += RANK_SPLIT) {
+    const int base = t * RANK_TILE, len = min(RANK_TILE, m - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RANK_TILE; i += 256) {
+      const bool in = i < len;
+      s_k[i] = in ? keys[base + i] : ~0ull;  // padding compares as "not smaller" (a real pair can carry ~0ull only with a larger value... see below)
+      if (!PACKED) s_v[i] = in ? vals[base + i] : 0xffffffffu;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int i = 0; i < RANK_TILE; i++) {
+      const u64 ko = s_k[i];
+      if (PACKED) smaller += (int)(ko < kj);
+      else smaller += (int)(ko < kj) | ((int)(ko == kj) & (int)(s_v[i] < vj));
+    }
+  }
+  if (live && smaller) atomicAdd(&rank[j], smaller);
+}
+
+// The cap needs no ranks, only the max_num-th smallest packed (hash & 0xffffffff, index) among the candidates: ONE block finds it by radix
+// selection -- eight 8-bit digits from the top, a 256-bin LDS histogram of the candidates that share the prefix chosen so far -- and stores it;
+// candidates above it leave the selection.  (A counting rank of the 14 400 candidates of the shipped configuration cost 42 us.)
+__global__ __launch_bounds__(1024) void pp_cap_select_kernel(const u64* __restrict__ ckeys, const int* __restrict__ counters, int max_num, u64* __restrict__ threshold) {
+  __shared__ int s_hist[256];
+  __shared__ u64 s_prefix;
+  __shared__ int s_k;
+  const int m = counters[C_CAND];
+  if (m <= max_num || m > RANK_FAST_MAX) return;
+  if (threadIdx.x == 0) {
+    s_prefix = 0ull;
+    s_k = max_num;  // the k-th smallest (1-based) of what still matches the prefix
+  }
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 prefix = s_prefix;
+    for (int j = threadIdx.x; j < m; j += 1024) {
+      const u64 v = ckeys[j];
+      const bool match = shift == 56 || (v >> (shift + 8)) == (prefix >> (shift + 8));
+      if (match) atomicAdd(&s_hist[(int)((v >> shift) & 0xffull)], 1);
+    }
+    __syncthreads();
+    // the digit whose cumulative count first reaches k: inclusive scan of the 256 bins by the first four wavefronts (a serial walk of the
+    // bins by one thread is 256 dependent LDS reads per digit: 60 us for the eight digits)
+    __shared__ int s_wave_tot[4];
+    int incl = 0, mine = 0;
+    if (threadIdx.x < 256) {
+      mine = s_hist[threadIdx.x];
+      incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+      }
+      if ((threadIdx.x & 63) == 63) s_wave_tot[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int w = threadIdx.x >> 6;
+      for (int q = 0; q < w; q++) incl += s_wave_tot[q];
+      const int k = s_k;
+      if (incl >= k && incl - mine < k) {  // exactly one bin qualifies
+        s_k = k - (incl - mine);
+        s_prefix = prefix | ((u64)threadIdx.x << shift);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *threshold = s_prefix;
+}
+
+__global__ __launch_bounds__(256) void pp_cap_drop_kernel(const u64* __restrict__ ckeys, const u32* __restrict__ cvals, const u64* __restrict__ threshold,
+                                                          const int* __restrict__ counters, int max_num, int* __restrict__ sel) {
+  const int m = counters[C_CAND];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (m <= max_num || m > RANK_FAST_MAX || j >= m) return;
+  if (ckeys[j] > *threshold) sel[cvals[j]] = 0;
+}
+
+// filtered survivors -> (orderable time, raw index) pairs in index order; their number goes to counters[C_FINAL]
+__global__ __launch_bounds__(256) void pp_compact_time_fast_kernel(int m, const int* __restrict__ flags, const int* __restrict__ pos, const double* __restrict__ T,
+                                                                   u64* __restrict__ tkeys, u32* __restrict__ tvals, int* __restrict__ counters) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    const int f = pos[m];
+    counters[C_FINAL] = f;
+    if (f > RANK_FAST_MAX) counters[C_FALLBACK] = 1;
+  }
+  if (i >= m || !flags[i]) return;
+  const int p = pos[i];
+  if (p < RANK_FAST_MAX) {
+    tkeys[p] = orderable(T[i]);
+    tvals[p] = (u32)i;
+  }
+}
+
+// The survivors arrive in index order, which for most sensors already IS time order: one pass over neighbouring pairs sets counters[C_UNSORTED]
+// when it is not; the counting rank below then runs, otherwise the rank of survivor j is j.
+__global__ __launch_bounds__(256) void pp_check_sorted_kernel(const u64* __restrict__ tkeys, int* __restrict__ counters) {
+  const int f = counters[C_FINAL];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (f > RANK_FAST_MAX || j + 1 >= f) return;
+  if (tkeys[j] > tkeys[j + 1]) counters[C_UNSORTED] = 1;  // (equal stamps keep their index order)
+}
+
+// output position = rank in the (time, index) order
+__global__ __launch_bounds__(256) void pp_gather_out_ranked_kernel(const int* __restrict__ counters, const int* __restrict__ rank, const u32* __restrict__ tvals,
+                                                                   const double4* __restrict__ P, const double* __restrict__ T, const double* __restrict__ I,
+                                                                   int zero_times, float4* __restrict__ pts, double4* __restrict__ pts64,
+                                                                   double* __restrict__ times, double* __restrict__ inten) {
+  const int f = counters[C_FINAL];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (f > RANK_FAST_MAX || j >= f) return;
+  const u32 i = tvals[j];
+  const int o = counters[C_UNSORTED] ? rank[j] : j;
+  const double4 p = P[i];
+  pts64[o] = p;
+  pts[o] = make_float4((float)p.x, (float)p.y, (float)p.z, 1.0f);
+  times[o] = zero_times ? 0.0 : T[i];
+  if (inten) inten[o] = I[i];
 }
 
 // ---- statistical outlier removal (gtsam_points::remove_outliers): mean distance to the k nearest neighbours ----
@@ -542,6 +874,98 @@ int downsample_voxelgrid(glim_amd_ctx* ctx, hipStream_t st, int n, const double4
   return GLIM_AMD_OK;
 }
 
+
+// The random-grid branch on its fast path (see "Fast path of the random-grid branch" above): everything from the uploaded raw scan to the
+// output cloud with ONE synchronise and no sort.  *fallback = true: the quota per voxel or the number of survivors is beyond what the fast path
+// accepts -- nothing was produced, the caller takes the sorting path.  Caller holds ctx->mu.
+int preprocess_random_fast(glim_amd_ctx* ctx, hipStream_t st, int n, const double4* P, const double* T, const double* I, double rate,
+                           const glim_amd_preprocess_params* prm, const FilterParams& fp, SortBuffers& sb, bool has_int, glim_amd_cloud** out, bool* fallback) {
+  *fallback = false;
+  *out = nullptr;
+  const long long max_num = (long long)((double)n * rate * 1.2);
+  if (max_num < 1 || max_num > RANK_FAST_MAX) {
+    *fallback = true;
+    return GLIM_AMD_OK;
+  }
+  unsigned int slots = 1024;
+  while (slots < 2u * (unsigned int)n) slots <<= 1;
+  // every piece of scratch exists before the first launch (an error return must not hand memory back to the pool under running kernels)
+  // two blocks of scratch so that ONE fill each initialises them: [table | levels] = 0xff, [counters | rank x 2 | sel] = 0
+  DeviceTemp hh, pos, tiles, flags, cvals, ones, zeros, slot_of;
+  const size_t ones_bytes = (size_t)slots * (1 + PPV_MAX) * sizeof(u64);
+  const size_t zeros_ints = (size_t)C_NUM + 2 * (size_t)RANK_FAST_MAX + (size_t)(n + 1);
+  GA_HIP(pool_malloc(&hh.p, (size_t)n * 2 * sizeof(u32)));
+  GA_HIP(pool_malloc(&pos.p, (size_t)(n + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)n + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&flags.p, (size_t)(n + 1) * sizeof(int)));
+  GA_HIP(pool_malloc(&cvals.p, (size_t)RANK_FAST_MAX * sizeof(u32)));
+  GA_HIP(pool_malloc(&ones.p, ones_bytes));
+  GA_HIP(pool_malloc(&zeros.p, zeros_ints * sizeof(int)));
+  GA_HIP(pool_malloc(&slot_of.p, (size_t)n * sizeof(int)));
+  u64* table_p = ones.as<u64>();
+  u64* levels_p = ones.as<u64>() + slots;
+  int* sel_p = zeros.as<int>() + C_NUM + 2 * RANK_FAST_MAX;
+  CloudGuard result;
+  GA_TRY(alloc_frame_cloud(ctx, (int)max_num, has_int, &result.c));  // at most max_num points survive the cap
+  glim_amd_cloud* c = result.c;
+  double* h_times_stage = nullptr;
+  if (pinned_malloc(&h_times_stage, (size_t)max_num * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    h_times_stage = nullptr;
+  }
+  u32 *hhi = hh.as<u32>(), *hlo = hh.as<u32>() + n;
+  int* cnt = zeros.as<int>();
+  int *rank_cap = zeros.as<int>() + C_NUM, *rank_time = zeros.as<int>() + C_NUM + RANK_FAST_MAX;
+  u64* ckeys = sb.ka.as<u64>();  // (the sort scratch of the general path: >= n words)
+  hipError_t e = hipSuccess;
+  int rc = GLIM_AMD_OK;
+  do {
+    if ((e = hipMemsetAsync(zeros.p, 0, zeros_ints * sizeof(int), st)) != hipSuccess) break;
+    if ((e = hipMemsetAsync(ones.p, 0xff, ones_bytes, st)) != hipSuccess) break;
+    // ---- selection (randomgrid_sampling): voxel table, the ppv smallest (hash >> 32, index) per voxel ----
+    pp_hash32_kernel<<<grid_for(n), 256, 0, st>>>(n, prm->seed, hhi, hlo);
+    pp_table_insert_kernel<<<grid_for(n), 256, 0, st>>>(n, P, 1.0 / prm->downsample_resolution, table_p, slots - 1, slot_of.as<int>(), cnt);
+    pp_cascade_kernel<<<grid_for(n), 256, 0, st>>>(n, rate, slot_of.as<int>(), hhi, levels_p, cnt);
+    pp_select_table_kernel<<<grid_for(n), 256, 0, st>>>(n, rate, slot_of.as<int>(), hhi, levels_p, cnt, sel_p);
+    // ---- the 1.2x cap: survivors compacted, ranked by (hash & 0xffffffff, index), the tail dropped ----
+    if ((e = exclusive_scan_int(st, sel_p, (unsigned int)n + 1, tiles.as<int>(), pos.as<int>())) != hipSuccess) break;
+    pp_cap_compact_kernel<<<grid_for(n), 256, 0, st>>>(n, sel_p, pos.as<int>(), hlo, ckeys, cvals.as<u32>(), cnt, (int)max_num);
+    const dim3 rank_grid((unsigned int)(RANK_FAST_MAX / 256), RANK_SPLIT);
+    u64* threshold = reinterpret_cast<u64*>(rank_cap);  // (8-byte aligned: C_NUM ints precede it)
+    pp_cap_select_kernel<<<1, 1024, 0, st>>>(ckeys, cnt, (int)max_num, threshold);
+    pp_cap_drop_kernel<<<RANK_FAST_MAX / 256, 256, 0, st>>>(ckeys, cvals.as<u32>(), threshold, cnt, (int)max_num, sel_p);
+    // ---- range + cropbox filter, compaction, order by time (counting rank), output ----
+    pp_filter_flag_kernel<<<grid_for(n + 1), 256, 0, st>>>(n, P, sel_p, fp, flags.as<int>());
+    if ((e = exclusive_scan_int(st, flags.as<int>(), (unsigned int)n + 1, tiles.as<int>(), pos.as<int>())) != hipSuccess) break;
+    u64* tkeys = ckeys;  // (the cap is done with its candidates)
+    u32* tvals = cvals.as<u32>();
+    pp_compact_time_fast_kernel<<<grid_for(n), 256, 0, st>>>(n, flags.as<int>(), pos.as<int>(), T, tkeys, tvals, cnt);
+    pp_check_sorted_kernel<<<RANK_FAST_MAX / 256, 256, 0, st>>>(tkeys, cnt);
+    pp_count_rank_kernel<false><<<rank_grid, 256, 0, st>>>(tkeys, tvals, cnt + C_FINAL, -1, cnt + C_UNSORTED, rank_time);
+    pp_gather_out_ranked_kernel<<<(unsigned int)grid_for((int)max_num), 256, 0, st>>>(cnt, rank_time, tvals, P, T, I, prm->global_shutter, c->pts, c->pts64, c->times,
+                                                                                    c->intensities);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if (h_times_stage && (e = hipMemcpyAsync(h_times_stage, c->times, (size_t)max_num * sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    int h_cnt[C_NUM];
+    if ((e = read_back_sync(ctx, st, h_cnt, cnt, sizeof(h_cnt))) != hipSuccess) break;
+    if (h_cnt[C_FALLBACK]) {
+      *fallback = true;
+      break;
+    }
+    const int f = h_cnt[C_FINAL];
+    c->n = f;
+    if (h_times_stage) c->h_times.assign(h_times_stage, h_times_stage + f);
+  } while (0);
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(st);  // nothing enqueued may outlive the scratch released below
+    set_hip_error(e, "preprocess (random-grid fast path)");
+    rc = GLIM_AMD_ERR_HIP;
+  }
+  if (h_times_stage) (void)pinned_free(h_times_stage);
+  if (rc == GLIM_AMD_OK && !*fallback) *out = result.release();
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -610,9 +1034,22 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       const double* T = d_t.as<double>();
       const double* I = has_int ? d_i.as<double>() : nullptr;
       const int* sel = nullptr;
+      bool done = false;  // the random-grid fast path has produced the output cloud
       DeviceTemp avgP, avgT, avgI;
       int m = n;
-      if (!sample_all) {
+      if (!sample_all && random && ctx->diag.pp_fast) {
+        // the shipped configuration: no sort, no bounding box, one synchronise (see "Fast path of the random-grid branch")
+        FilterParams fp0;
+        fill_filter_params(fp0, prm);
+        bool fallback = false;
+        glim_amd_cloud* fast = nullptr;
+        GA_TRY(preprocess_random_fast(ctx, st, n, P, T, I, rate, prm, fp0, sb, has_int, &fast, &fallback));
+        if (!fallback) {
+          result.c = fast;
+          done = true;
+        }
+      }
+      if (!sample_all && !done) {
         int h_bb[6];
         init_bbox_kernel<<<1, 64, 0, st>>>(d_bb.as<int>());
         pp_key_kernel<<<reduce_grid_for(n), 256, 0, st>>>(n, d_p4.as<double4>(), 1.0 / prm->downsample_resolution, d_vkey.as<u64>(), d_bb.as<int>());
@@ -646,17 +1083,9 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       int f = 0;
       u32* order = nullptr;
       DeviceTemp flags, pos, tiles;
-      if (m > 0) {
+      if (!done && m > 0) {
         FilterParams fp;
-        fp.near2 = prm->distance_near_thresh * prm->distance_near_thresh;
-        fp.far2 = prm->distance_far_thresh * prm->distance_far_thresh;
-        fp.crop = prm->enable_cropbox_filter;
-        fp.crop_imu = prm->crop_bbox_frame_imu;
-        for (int a = 0; a < 3; a++) {
-          fp.bmin[a] = prm->crop_bbox_min[a];
-          fp.bmax[a] = prm->crop_bbox_max[a];
-        }
-        memcpy(fp.T, prm->T_imu_lidar, sizeof(fp.T));
+        fill_filter_params(fp, prm);
         GA_HIP(pool_malloc(&flags.p, (size_t)(m + 1) * sizeof(int)));
         GA_HIP(pool_malloc(&pos.p, (size_t)(m + 1) * sizeof(int)));
         GA_HIP(pool_malloc(&tiles.p, scan_scratch_ints((unsigned int)m + 1) * sizeof(int)));
@@ -669,9 +1098,9 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         u64* ks = nullptr;
         GA_HIP(radix_sort_pairs(st, f, 64, sb.ka.as<u64>(), sb.va.as<u32>(), sb.kb.as<u64>(), sb.vb.as<u32>(), false, sb.hist.as<int>(), &ks, &order));
       }
-      GA_TRY(alloc_frame_cloud(ctx, f, has_int, &result.c));
+      if (!done) GA_TRY(alloc_frame_cloud(ctx, f, has_int, &result.c));
       glim_amd_cloud* c = result.c;
-      if (f > 0) {
+      if (!done && f > 0) {
         pp_gather_out_kernel<<<grid_for(f), 256, 0, st>>>(f, order, P, T, I, prm->global_shutter, c->pts, c->pts64, c->times, c->intensities);
         GA_HIP(hipGetLastError());
         // no outlier removal behind this: the host copy of the time stamps rides on this scope's synchronise (pinned staging: a
@@ -681,7 +1110,7 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         else
           (void)hipGetLastError();
       }
-      const hipError_t se = hipStreamSynchronize(st);  // scratch of this scope is released below
+      const hipError_t se = done ? hipSuccess : hipStreamSynchronize(st);  // scratch of this scope is released below
       if (h_times_stage) {
         if (se == hipSuccess) c->h_times.assign(h_times_stage, h_times_stage + f);
         (void)pinned_free(h_times_stage);

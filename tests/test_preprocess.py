@@ -233,19 +233,25 @@ HIP_CASES = [
     dict(enable_cropbox_filter=1, crop_bbox_min=(-6.0, -4.0, -3.0), crop_bbox_max=(9.0, 4.0, 3.0), global_shutter=1),
     dict(enable_cropbox_filter=1, crop_bbox_frame_imu=1, crop_bbox_min=(-6.0, -4.0, -3.0), crop_bbox_max=(9.0, 4.0, 3.0)),
     dict(enable_outlier_removal=1, outlier_removal_k=8, outlier_std_mul_factor=1.0, downsample_target=20000),
+    # 5 cm voxels: (nearly) every point is alone in its voxel and survives the selection -> far more candidates for the cap than the counting rank
+    # of the fast path accepts: it raises its flag and the call is repeated on the sorting path
+    dict(downsample_target=0, downsample_rate=0.2, downsample_resolution=0.05),
 ]
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fast", "sorting"])
 @pytest.mark.parametrize("case", range(len(HIP_CASES)))
-def test_hip_preprocess_matches_oracle(orc, case):
-    """Bit-exact: surviving points (FP64), times, intensities, their order, and the neighbour lists."""
+def test_hip_preprocess_matches_oracle(orc, case, path):
+    """Bit-exact: surviving points (FP64), times, intensities, their order, and the neighbour lists -- on the random-grid fast path (one sort +
+    counting ranks, preprocess.hip) and on the general sorting path (pp_fast=0; also what the fast path falls back to)."""
     from glim_amd import api
 
     kw = dict(HIP_CASES[case])
     if kw.get("crop_bbox_frame_imu"):
         kw["T_imu_lidar"] = orc.se3_exp([0.02, -0.01, 0.5, 0.3, -0.2, 0.1])
     ctx = api.Context(0, 1)
+    ctx.set_diag("" if path == "fast" else "pp_fast=0")
     pts, times, inten = raw_scan(seed=2, n=131072)
     ref = orc.preprocess(pts, times, inten, orc.preprocess_params(seed=5, **kw))
     g = api.PointCloudGPU.preprocess(pts, times, inten, api.preprocess_params(seed=5, **kw), ctx=ctx)
