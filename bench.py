@@ -987,7 +987,14 @@ def run_global256(args, D, api, ctx, extra_only=False):
     predicted = None
     if D.world == 1 and not args.no_predict:
         predicted = predict_scaling(api, ctx, multi, pairs, deltas, clouds, vmaps, costs, host, sec * 1e3, torch)
+    native = None
+    if D.world == 1:
+        try:  # the same cost through the native C-ABI multi-device path, as world 1 (what an N-device node runs with `--gpus N --native`)
+            native = native_global256(args, api, submaps, pairs, deltas, 1, 5, 3)
+        except Exception as e:  # noqa: BLE001 -- reported, not fatal for the headline
+            native = {"error": repr(e)}
     return {
+        "native_c_abi_world1": native,
         "parity": parity, "predicted_scaling": predicted, "rank_breakdown": per_rank if per_rank else [breakdown], "exchange": exchange,
         "metric": "multi_scan_cost_eval_s", "value": sec, "unit": "s", "n_gpus": D.world, "steps": steps, "warmup": max(args.warmup, 3),
         "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -999,6 +1006,74 @@ def run_global256(args, D, api, ctx, extra_only=False):
                    "collective": (f"rccl_all_gather[{D.world} x {max_rows} x 29] f64 ({D.world * max_rows * 29 * 8 / 1e6:.1f} MB gathered per rank)"
                                   if D.world > 1 else "none")},
         "roofline": roof,
+    }
+
+
+def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
+    """The SAME all-pairs cost through the native multi-device path north_star names -- the C ABI glim_amd_multi_* (glim_amd/csrc/multi.hip): ONE
+    process, one context + host worker thread + RCCL communicator per device (ncclCommInitAll), clouds / maps replicated, the pair list cut into
+    contiguous cost-balanced shards, ONE ncclAllGather of the 29-double records -- next to the torch.distributed form above.  On one GPU it runs
+    as world 1 (the collective is still RCCL's).  submaps: [(pose, merged PointCloudGPU)] of the calling context (downloaded and re-uploaded
+    through the multi handle: every device gets its own replica)."""
+    devices = list(range(max(1, min(n_gpus, api.device_count()))))
+    M = api.MultiDeviceCost(devices)
+    t0 = time.time()
+    cloud_ids, map_ids = [], []
+    for _, g in submaps:
+        pts, covs = g.download_merged()
+        cid = M.add_cloud(pts, covs)
+        cloud_ids.append(cid)
+        map_ids.append(M.add_voxelmap(cid, 1.0))
+    M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
+    setup_s = time.time() - t0
+    T = np.ascontiguousarray(deltas, dtype=np.float64)
+    import ctypes as C
+
+    from glim_amd.api import check, lib
+
+    def evaluate():
+        check(lib().glim_amd_multi_linearize(M._h, T.ctypes.data_as(C.POINTER(C.c_double)), None, None), "glim_amd_multi_linearize")
+
+    for _ in range(max(warmup, 3)):
+        evaluate()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        evaluate()
+    sec = (time.perf_counter() - t1) / steps
+    kernel_ms, gather_ms = M.last_timing()
+    recs, total = M.linearize(T[: len(pairs)]) if len(pairs) <= 4096 else (None, None)
+    info = M.info()
+    out = {"form": "C ABI glim_amd_multi_*: one process, one worker thread + context + RCCL communicator per device, ncclAllGather of the owned rows",
+           "n_devices": info["num_devices"], "rccl_ranks": info["num_devices"] if info["uses_rccl"] else 0, "uses_rccl": info["uses_rccl"],
+           "seconds_per_evaluation": sec, "ms_per_evaluation": sec * 1e3, "steps": steps,
+           "per_device": [{"device": d, "pairs": int(b1 - b0), "kernels_ms": k, "all_gather_and_copy_out_ms": g}
+                          for d, (b0, b1, k, g) in enumerate(zip(M.shard()[:-1], M.shard()[1:], kernel_ms, gather_ms))],
+           "replication_and_setup_s": setup_s}
+    if total is not None:
+        out["total_error"] = total
+    M.close()
+    return out
+
+
+def run_global256_native(args, D, api, ctx):
+    """`bench.py --gpus N --native`: configs[3] / M2 through glim_amd_multi_* only (no torch.distributed): one process drives the N devices."""
+    from glim_amd import synth
+
+    S = args.submaps
+    submaps = make_merged_submaps(api, ctx, S, args.submap_frames, args.submap_rings, args.submap_azimuths)
+    poses = [T for T, _ in submaps]
+    sizes = [g.size() for _, g in submaps]
+    pairs = [(i, j) for j in range(S) for i in range(j)]
+    deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
+    steps, warmup = args.steps, max(args.warmup, 3)
+    nat = native_global256(args, api, submaps, pairs, deltas, args.gpus, steps, warmup)
+    return {
+        "metric": "multi_scan_cost_eval_s", "value": nat["seconds_per_evaluation"], "unit": "s", "n_gpus": nat["n_devices"], "steps": steps, "warmup": warmup,
+        "ms_per_step": nat["ms_per_evaluation"], "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3] global256 (native C-ABI multi-device path): {S} merged submaps x {int(np.mean(sizes))} pts, all {len(pairs)} pairs, "
+                               "1.0 m voxels, binary factors", "pairs": len(pairs), "parallelism": f"pair list sharded over {nat['n_devices']} device(s), data replicated",
+                   "collective": f"ncclAllGather over {nat['rccl_ranks']} RCCL rank(s)" if nat["uses_rccl"] else "host gather (no RCCL)"},
+        "native": nat,
     }
 
 
@@ -1186,6 +1261,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="global256 on several GPUs: do not try the two-halves form of the exchange")
     ap.add_argument("--no-predict", action="store_true", help="global256 on one GPU: skip the per-shard timing behind `predicted_scaling`")
+    ap.add_argument("--native", action="store_true", help="configs[3] through the native multi-device C-ABI path (glim_amd_multi_*: ONE process drives --gpus "
+                                                         "devices, ncclAllGather) instead of one torch.distributed rank per GPU; run it as a plain `python bench.py`")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: libraries that print banners to fd 1 (RCCL prints its version there at init) are
@@ -1194,7 +1271,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    D = Dist(args.gpus)
+    D = Dist(1 if args.native else args.gpus)  # --native: ONE process drives all the devices through glim_amd_multi_*
     from glim_amd import api
 
     # One dedicated (non-default) torch stream is made current for the whole run and handed to the library: our kernels, torch's tensor
@@ -1206,6 +1283,8 @@ def main():
     workload = args.workload or ("odometry128k" if D.world == 1 else "global256")
     runner = {"odometry128k": run_odometry128k, "odometry_frame": run_odometry_frame, "submap20": run_submap20, "global256": run_global256, "rgbd300k": run_rgbd300k,
               "frontend128k": run_frontend128k, "odometry_under_load": run_odometry_under_load}[workload]
+    if args.native:
+        runner = run_global256_native
     result = runner(args, D, api, ctx)
     if args.workload is None and D.world > 1:
         m1 = run_odometry128k(args, D, api, ctx)  # the weak-scaling form of M1, next to the M2 headline
@@ -1215,7 +1294,7 @@ def main():
         m2 = run_global256(args, D, api, ctx, extra_only=True)
         if result is not None and m2 is not None:
             result["m2_global256"] = {k: m2[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline", "parity", "predicted_scaling",
-                                                         "rank_breakdown", "exchange") if k in m2}
+                                                         "rank_breakdown", "exchange", "native_c_abi_world1") if k in m2}
     D.finish()
     sys.stdout.flush()
     if D.rank == 0 and result is not None:

@@ -612,6 +612,13 @@ class MultiDeviceCost:
         check(lib().glim_amd_multi_profile(self._h, _dp(T), int(iters), C.byref(ms)), "glim_amd_multi_profile")
         return ms.value
 
+    def last_timing(self):
+        """Per device: HIP-event ms of the last evaluation's kernels and of its collective + copy-out."""
+        nd = self.info()["num_devices"]
+        k, g = np.zeros(nd, dtype=np.float32), np.zeros(nd, dtype=np.float32)
+        check(lib().glim_amd_multi_last_timing(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), g.ctypes.data_as(C.POINTER(C.c_float))), "glim_amd_multi_last_timing")
+        return k.tolist(), g.tolist()
+
     def close(self):
         if self._h:
             lib().glim_amd_multi_destroy(self._h)

@@ -89,6 +89,9 @@ struct glim_amd_multi {
   bool use_rccl = false;
   bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
   std::vector<Worker*> workers;
+  // HIP events per device around the two phases of the LAST evaluation (kernels, then collective + copy-out): glim_amd_multi_last_timing
+  std::vector<hipEvent_t> ev;  // 3 per device: start, kernels enqueued-and-done boundary, end
+  std::vector<float> kernel_ms, gather_ms;
 
   // run fn(device index) on every device's worker thread concurrently; first non-zero return code wins
   int run_all(const std::function<int(int)>& fn) {
@@ -226,12 +229,45 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
     w->th = std::thread(worker_loop, w, devices[d]);
     m->workers.push_back(w);
   }
+  m->kernel_ms.assign(num_devices, 0.f);
+  m->gather_ms.assign(num_devices, 0.f);
+  for (int d = 0; d < num_devices; d++) {
+    (void)hipSetDevice(devices[d]);
+    for (int e = 0; e < 3; e++) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreate(&ev) != hipSuccess) {
+        (void)hipGetLastError();
+        ev = nullptr;
+      }
+      m->ev.push_back(ev);
+    }
+  }
+  for (hipEvent_t e : m->ev)
+    if (!e) {  // no timing then
+      for (hipEvent_t x : m->ev)
+        if (x) (void)hipEventDestroy(x);
+      m->ev.clear();
+      break;
+    }
   *out = m;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_last_timing(const glim_amd_multi* m, float* kernel_ms, float* gather_ms) {
+  if (!m) return GLIM_AMD_ERR_INVALID;
+  if (m->ev.empty()) return GLIM_AMD_ERR_UNSUPPORTED;
+  for (int d = 0; d < m->ndev; d++) {
+    if (kernel_ms) kernel_ms[d] = m->kernel_ms[d];
+    if (gather_ms) gather_ms[d] = m->gather_ms[d];
+  }
   return GLIM_AMD_OK;
 }
 
 int glim_amd_multi_destroy(glim_amd_multi* m) {
   if (!m) return GLIM_AMD_OK;
+  for (hipEvent_t e : m->ev)
+    if (e) (void)hipEventDestroy(e);
+  m->ev.clear();
   for (Worker* w : m->workers) {
     {
       std::lock_guard<std::mutex> lock(w->mu);
@@ -382,7 +418,10 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   GA_TRY(m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
     const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
+    hipStream_t st = m->ctxs[d]->stream();
+    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d], st));
     if (hi > lo) GA_TRY(glim_amd_factor_set_linearize_device_async(m->sets[d], T + 12 * lo, m->d_gather[d], (int64_t)d * m->max_rows));
+    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d + 1], st));
     return (int)GLIM_AMD_OK;
   }));
   const int rc = m->run_all([&](int d) -> int {
@@ -400,7 +439,12 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       // no collective library: every device hands its own slot to the host (PCIe); single-device and explicitly allowed setups only
       GA_HIP(hipMemcpyAsync(m->h_gather + (size_t)d * slot, m->d_gather[d] + (size_t)d * slot, slot * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d + 2], st));
     GA_HIP(hipStreamSynchronize(st));
+    if (m->ev.size() == (size_t)3 * m->ndev) {
+      (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[3 * d], m->ev[3 * d + 1]);
+      (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[3 * d + 1], m->ev[3 * d + 2]);
+    }
     return (int)GLIM_AMD_OK;
   });
   if (rc != GLIM_AMD_OK) {

@@ -332,6 +332,9 @@ int glim_amd_multi_shard(const glim_amd_multi* multi, int64_t* bounds);
 int glim_amd_multi_linearize(glim_amd_multi* multi, const double* T_target_source, glim_amd_linearized6* out, double* total_error);
 /* wall-clock milliseconds per whole-cost evaluation (all devices + collective + host expansion skipped), over `iters` evaluations */
 int glim_amd_multi_profile(glim_amd_multi* multi, const double* T_target_source, int iters, float* ms_per_evaluation);
+/* per device, HIP-event milliseconds of the LAST evaluation: its factor kernels + finalise (kernel_ms[d]) and the collective + copy-out behind
+ * them (gather_ms[d]); num_devices entries each, either may be NULL */
+int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, float* gather_ms);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
 
