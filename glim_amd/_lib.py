@@ -97,6 +97,7 @@ SYMBOLS = {
     "glim_amd_preprocess": (_i, [_vp, _i64, _dp, _dp, _dp, C.POINTER(PreprocessParams), _pp]),
     "glim_amd_cloud_download_frame": (_i, [_vp, _dp, _dp, _dp, _ip]),
     "glim_amd_factor_set_profile_fresh_samples": (_i, [_vp, _i32, _pp, _pp, C.POINTER(C.c_uint32), _dp, _i, _d, _fp]),
+    "glim_amd_factor_set_trip_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "glim_amd_multi_last_timing": (_i, [_vp, _fp, _fp]),
     "glim_amd_debug_resident_stop": (_i, [_i]),
     "glim_amd_debug_resident_stats": (_i, [_i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),

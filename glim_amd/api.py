@@ -526,6 +526,12 @@ class NonlinearFactorSetGPU:
         check(lib().glim_amd_factor_set_profile(self._h, _dp(T), int(iters), C.byref(a), C.byref(b)), "glim_amd_factor_set_profile")
         return a.value, b.value
 
+    def trip_stats(self, reset=False):
+        """(skipped wavefront trips since the last reset, trips per evaluation) of the general factor kernel: glim_amd_factor_set_trip_stats."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().glim_amd_factor_set_trip_stats(self._h, C.byref(a), C.byref(b), int(bool(reset))), "glim_amd_factor_set_trip_stats")
+        return a.value, b.value
+
     def profile_sync(self, T_target_source, iters=200):
         """milliseconds per synchronous linearize() call measured inside the library (no binding overhead)."""
         T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))

@@ -333,6 +333,7 @@ struct FactorPlan {
   glim_amd::FactorDesc* d_descs = nullptr;
   int2* d_blockmap = nullptr;     // total_rows x int2
   float* d_partials = nullptr;
+  unsigned long long* d_trip_stats = nullptr;  // 64 counters of skipped wavefront trips (general kernel; glim_amd_factor_set_trip_stats)
   char* d_rows16 = nullptr;       // tagged partial rows of the single-dispatch synchronous form (vgicp.hip TAG_ROW_BYTES per row), or null
   int* d_finmap = nullptr;        // factor ids the trailing blocks of each segment's single-dispatch launch finalise (plane-form segment first)
   int fin_count[2] = {0, 0};

@@ -118,6 +118,7 @@ struct FinalizeArgs {
   int num_factors;
   // single-dispatch form (vgicp_kernel<..., FUSED>): tagged partial rows and, per launch segment, the factors its trailing blocks finalise
   char* rows16;              // TAG_ROW_BYTES per plan row
+  unsigned long long* trip_stats;  // 64 counters: skipped wavefront trips of the factors f with f % 64 == slot (null: not collected)
   char* rec16;               // host-mapped record granules (COMPACT x 16 B per factor) of the single-dispatch form, or null
   const int* finmap;         // factor ids, plane-form segment first (null for a single-factor set: factor 0)
 };
@@ -238,6 +239,7 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
   }
   __syncthreads();
   const int t = threadIdx.x;
+  if (t == 29 && fa.trip_stats && s_sum[29] > 0.0) atomicAdd(&fa.trip_stats[f & 63], (unsigned long long)s_sum[29]);
   __shared__ double s_rot[32];
   if (mode == MODE_LINEARIZE) {
     if (t < 4) rotate_part(t, s_sum, Tl, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
@@ -524,7 +526,7 @@ struct PipeCtx {  // wave-uniform context of the pipelined loop
 // dependent memory round trips (one of them HBM) exposed per trip per wave, which 5 waves per SIMD could not cover (waves parked on
 // memory 71 % of their cycles; 50 % with this form -- tools/pmc_kexp.sh, profiles/r02/probe/).
 template <int MODE, bool FROZEN, bool PLANE>
-__device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers) {
+__device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers, int& wave_skips) {
   constexpr int AHEAD = 1;
   const FactorDesc& d = pc.d;
   // (1) resolve point `it`
@@ -550,6 +552,7 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   const unsigned long long hit_lanes = __ballot(hit);
   wave_inliers += __popcll(hit_lanes);  // wave-uniform count: scalar registers, no per-lane counter
   const bool any_hit = PLANE || hit_lanes != 0ull;  // wave-uniform: a scalar branch
+  if (!PLANE) wave_skips += any_hit ? 0 : 1;         // (scalar) trips that skip the record gather and the algebra: reported per run, glim_amd_factor_set_trip_stats
   // every lane reads a record (way 0 of the last bucket when there is no hit) so the wavefront does not diverge
   const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
@@ -610,6 +613,7 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
 #pragma unroll
   for (int j = 0; j < NACC; j++) acc[j] = 0.f;
   int wave_inliers = 0;  // wave-uniform count (scalar registers)
+  int wave_skips = 0;    // wave-uniform: trips of this wavefront without any correspondence (general kernel)
 
   const int ppt = d.ppt;
   // Points of a factor are dealt to its blocks in 256-point hands, round robin: trip t of block (chunk) c covers points
@@ -628,7 +632,7 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
     nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
     for (int it = 0; it < ppt; it++) {
       rotate_priority(it + prio_phase);
-      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers);
+      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers, wave_skips);
     }
   }
 
@@ -646,6 +650,7 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
   }
   {
     if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
+    if (lane == 63) s_red[wave][29] = (float)wave_skips;    // <= ppt
   }
   __syncthreads();
 }
@@ -653,7 +658,7 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
 // value j of the block's partial row from the four wavefront sums (the same expression wherever a row is published: same bits)
 template <int MODE>
 __device__ __forceinline__ float row_value(const float (*s_red)[PARTIAL_STRIDE], int j) {
-  const bool live = (MODE == MODE_LINEARIZE) ? (j <= 28) : (j == 27 || j == 28);
+  const bool live = (MODE == MODE_LINEARIZE) ? (j <= 29) : (j >= 27 && j <= 29);  // 0..26 sums, 27 error, 28 inliers, 29 skipped trips
   return live ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.f;
 }
 
@@ -872,6 +877,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
       fa.seq = tag;
       fa.num_factors = ra.num_factors;
       fa.rows16 = ra.rows16;
+      fa.trip_stats = nullptr;
       fa.rec16 = ra.rec16;
       fa.finmap = ra.finmap;
       const FactorDesc d = ra.descs[f];
@@ -971,6 +977,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_short_kernel(const FactorDesc*
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
+  if (t == 29 && fa.trip_stats && s_sum[wave][29] > 0.0) atomicAdd(&fa.trip_stats[f & 63], (unsigned long long)s_sum[wave][29]);
   if (t == 0) o[0] = s_sum[wave][28];
   if (t == 1) o[1] = s_sum[wave][27];
   if (mode == MODE_LINEARIZE) {
@@ -1101,6 +1108,7 @@ void plan_free(FactorPlan* p) {
   if (p->d_descs) (void)pool_free(p->d_descs);
   if (p->d_blockmap) (void)pool_free(p->d_blockmap);
   if (p->d_partials) (void)pool_free(p->d_partials);
+  if (p->d_trip_stats) (void)pool_free(p->d_trip_stats);
   if (p->d_rows16) (void)pool_free(p->d_rows16);
   if (p->d_finmap) (void)pool_free(p->d_finmap);
   if (p->d_poses) (void)pool_free(p->d_poses);
@@ -1340,6 +1348,8 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
   GA_HIP(pool_malloc(&plan->d_done, sizeof(int)));
   GA_HIP(hipMemsetAsync(plan->d_done, 0, sizeof(int), set->stream));
+  GA_HIP(pool_malloc(&plan->d_trip_stats, 64 * sizeof(unsigned long long)));
+  GA_HIP(hipMemsetAsync(plan->d_trip_stats, 0, 64 * sizeof(unsigned long long), set->stream));
   // single-dispatch form (small synchronous sets only): tagged rows, every tag 0 = "no call yet" (sequence numbers start at 1)
   if (nf >= 1 && nf <= FUSED_MAX_FACTORS && total_blocks <= FUSED_MAX_ROWS) {
     GA_HIP(pool_malloc(&plan->d_rows16, (size_t)total_blocks * TAG_ROW_BYTES));
@@ -1448,6 +1458,7 @@ FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long lon
   fa.seq = plan->poll_seq;
   fa.num_factors = (int)set->entries.size();
   fa.rows16 = plan->d_rows16;
+  fa.trip_stats = plan->d_trip_stats;
   fa.rec16 = nullptr;
   fa.finmap = plan->d_finmap;
   return fa;
@@ -2251,6 +2262,27 @@ int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_a
   for (int i = 0; i < iters; i++) GA_TRY(once());
   const auto t1 = std::chrono::steady_clock::now();
   *us_per_iteration = (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_trips, uint64_t* total_trips, int reset) {
+  if (!set) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  FactorPlan* plan = set->plan;
+  GA_HIP(hipStreamSynchronize(set->stream));
+  unsigned long long h[64];
+  GA_HIP(hipMemcpy(h, plan->d_trip_stats, sizeof(h), hipMemcpyDeviceToHost));
+  unsigned long long sk = 0;
+  for (unsigned long long v : h) sk += v;
+  if (skipped_trips) *skipped_trips = sk;
+  if (total_trips) {
+    unsigned long long tot = 0;
+    for (const FactorDesc& d : plan->h_descs) tot += (unsigned long long)d.num_blocks * (BLOCK / 64) * (unsigned long long)d.ppt;
+    *total_trips = tot;
+  }
+  if (reset) GA_HIP(hipMemset(plan->d_trip_stats, 0, sizeof(h)));
   return GLIM_AMD_OK;
 }
 

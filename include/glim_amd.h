@@ -286,6 +286,11 @@ int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_t
 int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
                                       const uint32_t* flags, const double* T_target_source, int iters, float* us_per_iteration);
 
+/* Measurement aid: wavefront trips of the general (36 B/pt) factor kernel that found no correspondence in any lane and skipped the record gather
+ * and the algebra, summed over every evaluation of the set's current plan since the last reset, and the trips ONE evaluation of the plan makes
+ * (blocks x 4 wavefronts x points per thread).  bench.py prices the kernel's instruction floor with the measured share instead of a constant. */
+int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_trips, uint64_t* total_trips_per_evaluation, int reset);
+
 /* The same pattern with every iteration timed on its own (samples_us: `iters` entries) and `gap_us` of host busy-waiting between iterations -- the
  * optimiser's own work between two linearisations --, for latency percentiles while other threads load the device (bench.py
  * --workload odometry_under_load). */
