@@ -32,9 +32,19 @@ if [ -z "$SKIP_GLOBAL256_PMC" ]; then
   rm -rf gpurun_out/prof_${TAG}_g
 fi
 timeout 250 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null
-for w in odometry_frame submap20 global256 rgbd300k frontend128k; do
+for w in odometry_frame submap20 global256 rgbd300k frontend128k odometry_under_load; do
   timeout 300 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err < /dev/null
 done
+# configs[3] through the native multi-device C-ABI path (world 1 here)
+timeout 300 python bench.py --gpus 1 --native > $OUT/bench_global256_native.json 2> $OUT/bench_global256_native.err < /dev/null
+# kernel breakdown of the scan preprocessing (rocprofv3 kernel trace of 45 calls on a raw 131 072-pt scan) and its wall time
+python tools/preprocess_profile.py > $OUT/preprocess_time.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && PYTHONPATH=$REPO timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG}_pre -- python $REPO/tools/preprocess_profile.py > /dev/null 2>&1)
+cp $(find gpurun_out/prof_${TAG}_pre -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_preprocess.csv 2>/dev/null
+rm -rf gpurun_out/prof_${TAG}_pre
+# the floor of a synchronous call on this box (launch / mailbox round trips) and the resident session's lifecycle
+(hipcc -O3 --offload-arch=gfx950 tools/ubench/sync_floor.hip -o /tmp/sync_floor && timeout 120 /tmp/sync_floor) > $OUT/sync_floor.txt 2>&1
+timeout 120 python tools/res_probe.py > $OUT/resident_probe.txt 2>&1
 timeout 200 python tools/batch_sweep.py > $OUT/batch_sweep.json 2> $OUT/batch_sweep.err < /dev/null
 du -sh $REPO/gpurun_out
 cat $OUT/gputest.log | tail -3
