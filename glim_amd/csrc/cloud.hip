@@ -4,6 +4,7 @@
 #include <string>
 
 #include "internal.hpp"
+#include "scope_sync.hpp"
 
 using namespace glim_amd;
 
@@ -324,6 +325,7 @@ int glim_amd_cloud_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
       set_hip_error(e, "cloud_create upload/pack");
+      (void)hipStreamSynchronize(s);  // copies that did get enqueued must not outlive their staging blocks or the cloud's arrays
       glim_amd_cloud_destroy(c);
       return GLIM_AMD_ERR_HIP;
     }
@@ -365,6 +367,7 @@ int glim_amd_cloud_create_f32(glim_amd_ctx* ctx, int64_t n, const float* xyz, co
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
       set_hip_error(e, "cloud_create_f32 upload/pack");
+      (void)hipStreamSynchronize(s);  // copies that did get enqueued must not outlive their staging blocks or the cloud's arrays
       glim_amd_cloud_destroy(c);
       return GLIM_AMD_ERR_HIP;
     }
@@ -431,6 +434,7 @@ int glim_amd_cloud_download(const glim_amd_cloud* c, float* xyz, float* cov33, f
   hipStream_t s = ctx->stream();
   const int64_t n = c->n;
   DeviceTemp dx, dc, dn;
+  SyncOnExit in_flight(s);
   if (xyz) GA_HIP(pool_malloc(&dx.p, (size_t)n * 3 * sizeof(float)));
   if (cov33) GA_HIP(pool_malloc(&dc.p, (size_t)n * 9 * sizeof(float)));
   if (normals3) GA_HIP(pool_malloc(&dn.p, (size_t)n * 3 * sizeof(float)));
@@ -443,6 +447,7 @@ int glim_amd_cloud_download(const glim_amd_cloud* c, float* xyz, float* cov33, f
   if (normals3) GA_HIP(hipMemcpyAsync(normals3, dn.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
   if (neighbors) GA_HIP(hipMemcpyAsync(neighbors, c->neighbors, (size_t)n * c->k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   GA_HIP(hipStreamSynchronize(s));
+  in_flight.dismiss();
   return GLIM_AMD_OK;
 }
 

@@ -173,6 +173,13 @@ int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values) {
     ctx->diag = process_diag();
     return GLIM_AMD_OK;
   }
+  // pool / multi_rccl / multi_host_gather are read from the PROCESS defaults only (pool_disabled, glim_amd_multi_create): setting them on a
+  // context would be accepted and do nothing, so it is refused (they belong in GLIM_AMD_DIAG)
+  for (const char* key : {"pool=", "multi_rccl=", "multi_host_gather="}) {
+    const size_t len = strlen(key);
+    for (const char* q = key_values; (q = strstr(q, key)) != nullptr; q += len)
+      if (q == key_values || q[-1] == ',') return GLIM_AMD_ERR_INVALID;
+  }
   return diag_parse(ctx->diag, key_values);
 }
 

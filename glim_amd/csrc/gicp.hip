@@ -23,6 +23,7 @@
 
 #include "device_math.hpp"
 #include "internal.hpp"
+#include "scope_sync.hpp"
 #include "scan.hpp"
 
 using namespace glim_amd;
@@ -410,6 +411,7 @@ int run_gicp(const glim_amd_nn_index* ix, const glim_amd_cloud* source, const do
   a.ppt = std::max(1, std::min(64, (n + BLOCK * target_blocks - 1) / (BLOCK * target_blocks)));
   const int nb = (n + BLOCK * a.ppt - 1) / (BLOCK * a.ppt);
   DeviceTemp partials, compact, corr;
+  SyncOnExit in_flight(st);  // an error exit after the launches waits for the stream before the scratch goes back to the pool
   GA_HIP(pool_malloc(&partials.p, (size_t)nb * PARTIAL_STRIDE * sizeof(float)));
   GA_HIP(pool_malloc(&compact.p, COMPACT * sizeof(double)));
   if (corr_host) GA_HIP(pool_malloc(&corr.p, (size_t)n * sizeof(int32_t)));
@@ -420,6 +422,7 @@ int run_gicp(const glim_amd_nn_index* ix, const glim_amd_cloud* source, const do
   GA_HIP(hipMemcpyAsync(compact_host, compact.p, COMPACT * sizeof(double), hipMemcpyDeviceToHost, st));
   if (corr_host) GA_HIP(hipMemcpyAsync(corr_host, corr.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GA_HIP(hipStreamSynchronize(st));
+  in_flight.dismiss();
   return GLIM_AMD_OK;
 }
 
@@ -457,6 +460,8 @@ int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspond
     return GLIM_AMD_OK;
   }
   DeviceTemp vkey, bb, ka, kb, va, vb, hist;
+  // (declared after the index object too: an error exit waits for the stream before scratch AND the half-built index are released)
+  SyncOnExit in_flight(st);
   GA_HIP(pool_malloc(&vkey.p, nn * sizeof(u64)));
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   GA_HIP(pool_malloc(&ka.p, nn * sizeof(u64)));
@@ -506,6 +511,7 @@ int glim_amd_nn_index_create(const glim_amd_cloud* target, double max_correspond
                                                 target->has_covs ? target->covB : nullptr, ix->sorted, ix->covA, ix->covB, ix->keys, ix->runs, ix->mask);
   GA_HIP(hipGetLastError());
   GA_HIP(hipStreamSynchronize(st));
+  in_flight.dismiss();
   *out = ix.release();
   return GLIM_AMD_OK;
 }

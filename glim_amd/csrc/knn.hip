@@ -285,6 +285,7 @@ int knn_grid(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k,
   // ---- cell edge from the data: a surface-like cloud of n points in its bounding box, ~3 points per occupied cell ----
   DeviceTemp bb, unresolved_a, unresolved_b;
   GridBuffers g;
+  SyncOnExit in_flight(st);  // (cross-check path: the extra wait on the exits that have synchronised already is not worth dismissing)
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   init_bbox_kernel<<<1, 64, 0, st>>>(bb.as<int>());
   bbox_kernel<<<std::max(1, std::min((n + 2047) / 2048, 128)), 256, 0, st>>>(n, pts, (int*)bb.p);
@@ -479,7 +480,8 @@ __global__ void knn_scratch_init_kernel(int* __restrict__ bb, int* __restrict__ 
 }
 
 int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k, int32_t* out, unsigned int* rank) {
-  DeviceTemp bb, ka, kb, va, vb, hist, sorted, box, stats, box32;  // (all returned to the pool after the synchronise at the end)
+  DeviceTemp bb, ka, kb, va, vb, hist, sorted, box, stats, box32, dbg;  // (all returned to the pool after the synchronise at the end)
+  SyncOnExit in_flight(st);  // an early return after the first launch waits for the stream before the scratch above goes back to the pool
   const int C = (n + CHUNK - 1) / CHUNK;
   GA_HIP(pool_malloc(&bb.p, 6 * sizeof(int)));
   GA_HIP(pool_malloc(&ka.p, (size_t)n * sizeof(unsigned long long)));
@@ -499,7 +501,6 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   unsigned int* order = nullptr;
   GA_HIP(radix_sort_pairs(st, n, 3 * bits, ka.as<unsigned long long>(), va.as<unsigned int>(), kb.as<unsigned long long>(), vb.as<unsigned int>(), true,
                           hist.as<int>(), &ks, &order));
-  DeviceTemp dbg;
   const Diag& diag = ctx->diag;
   if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
   const bool pair_lanes = !dbg.p && k > 0 && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
@@ -535,6 +536,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   }
   int h_stats[4];
   GA_HIP(read_back_sync(ctx, st, h_stats, stats.p, sizeof(h_stats)));
+  in_flight.dismiss();  // synchronised
   if (h_stats[1] != 0 || h_stats[2] == 1) return GLIM_AMD_ERR_RANGE;
   if (h_stats[2] == 2 && k > 0) {  // astronomic extent: the chunk kernels stood down
     DISPATCH_K(launch_brute, st, n, pts, k, out, (const int*)nullptr, n);

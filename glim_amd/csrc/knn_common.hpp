@@ -6,6 +6,7 @@
 
 #include "device_math.hpp"
 #include "internal.hpp"
+#include "scope_sync.hpp"
 
 namespace glim_amd {
 // 64-query chunk kernel over the Hilbert-ordered points (`sorted`, C chunks of 64 with boxes `box`, which also has room for the boxes of the

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "internal.hpp"
+#include "scope_sync.hpp"
 #include "device_math.hpp"
 #include "scan.hpp"
 
@@ -1010,7 +1011,10 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       GA_TRY(alloc_frame_cloud(ctx, 0, has_int, &result.c));
     } else {
       // ---- upload the raw scan ----
-      DeviceTemp d_p4, d_t, d_i, d_vkey, d_ckey, d_bb, d_counters, d_sel;
+      DeviceTemp d_p4, d_t, d_i, d_vkey, d_ckey, d_bb, d_counters, d_sel, avgP, avgT, avgI, flags, pos, tiles;
+      SortBuffers sb;
+      PinnedTemp times_stage;
+      SyncOnExit in_flight(st);  // declared after every temporary of this scope: an early return waits for the stream before they are released
       GA_HIP(pool_malloc(&d_p4.p, (size_t)n * sizeof(double4)));
       GA_HIP(pool_malloc(&d_t.p, (size_t)n * sizeof(double)));
       if (has_int) GA_HIP(pool_malloc(&d_i.p, (size_t)n * sizeof(double)));
@@ -1021,10 +1025,8 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       GA_HIP(hipMemcpyAsync(d_p4.p, points4, (size_t)n * sizeof(double4), hipMemcpyHostToDevice, st));
       GA_HIP(hipMemcpyAsync(d_t.p, times, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
       if (has_int) GA_HIP(hipMemcpyAsync(d_i.p, intensities, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-      SortBuffers sb;
       GA_TRY(sb.alloc(n));
       int h_counters[4] = {0, 0, 0, 0};
-      double* h_times_stage = nullptr;
 
       // ---- downsampling (cloud_preprocessor.cpp:103-109) ----
       const double rate = prm->downsample_target > 0 ? (double)prm->downsample_target / (double)n : prm->downsample_rate;
@@ -1035,7 +1037,6 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       const double* I = has_int ? d_i.as<double>() : nullptr;
       const int* sel = nullptr;
       bool done = false;  // the random-grid fast path has produced the output cloud
-      DeviceTemp avgP, avgT, avgI;
       int m = n;
       if (!sample_all && random && ctx->diag.pp_fast) {
         // the shipped configuration: no sort, no bounding box, one synchronise (see "Fast path of the random-grid branch")
@@ -1082,7 +1083,6 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
       // ---- range + cropbox filter (:117-128, :143-160), compaction, sort by time (:134-136), global shutter (:138-140) ----
       int f = 0;
       u32* order = nullptr;
-      DeviceTemp flags, pos, tiles;
       if (!done && m > 0) {
         FilterParams fp;
         fill_filter_params(fp, prm);
@@ -1105,17 +1105,14 @@ int glim_amd_preprocess(glim_amd_ctx* ctx, int64_t n64, const double* points4, c
         GA_HIP(hipGetLastError());
         // no outlier removal behind this: the host copy of the time stamps rides on this scope's synchronise (pinned staging: a
         // device-to-host copy into pageable memory is staged by the runtime and costs a second round trip)
-        if (!prm->enable_outlier_removal && pinned_malloc(&h_times_stage, (size_t)f * sizeof(double)) == hipSuccess)
-          GA_HIP(hipMemcpyAsync(h_times_stage, c->times, (size_t)f * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (!prm->enable_outlier_removal && pinned_malloc_impl(&times_stage.p, (size_t)f * sizeof(double)) == hipSuccess)
+          GA_HIP(hipMemcpyAsync(times_stage.p, c->times, (size_t)f * sizeof(double), hipMemcpyDeviceToHost, st));
         else
           (void)hipGetLastError();
       }
-      const hipError_t se = done ? hipSuccess : hipStreamSynchronize(st);  // scratch of this scope is released below
-      if (h_times_stage) {
-        if (se == hipSuccess) c->h_times.assign(h_times_stage, h_times_stage + f);
-        (void)pinned_free(h_times_stage);
-      }
-      GA_HIP(se);
+      if (!done) GA_HIP(hipStreamSynchronize(st));  // scratch of this scope is released below
+      in_flight.dismiss();                          // (the fast path synchronised with its counter read-back)
+      if (times_stage.p) c->h_times.assign(times_stage.as<double>(), times_stage.as<double>() + f);
     }
   }
 

@@ -1878,10 +1878,20 @@ int overlap_scratch(glim_amd_ctx* ctx, hipStream_t st) {
   const size_t cbytes = (size_t)glim_amd_ctx::OV_MAX_QUERIES * sizeof(unsigned long long) + 64;
   GA_HIP(pool_malloc(&ctx->ov_counters, cbytes));
   GA_HIP(hipMemsetAsync(ctx->ov_counters, 0, cbytes, st));
+  if (ctx->ov_host) return GLIM_AMD_OK;  // (the counters alone are re-made after a failed call: overlap_discard_counters)
   GA_HIP(pinned_malloc(&ctx->ov_host, (size_t)(1 + glim_amd_ctx::OV_MAX_QUERIES) * sizeof(unsigned int)));
   memset(ctx->ov_host, 0, (size_t)(1 + glim_amd_ctx::OV_MAX_QUERIES) * sizeof(unsigned int));
   if (!host_device_view(ctx->ov_host, &ctx->ov_host_dev)) return GLIM_AMD_ERR_HIP;
   return GLIM_AMD_OK;
+}
+
+// After a failed overlap launch / wait the arrival counters may be left non-zero, which would poison the next call's counts: wait for whatever
+// did get enqueued and drop the block -- overlap_scratch hands the next call a freshly zeroed one.
+void overlap_discard_counters(glim_amd_ctx* ctx, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  (void)hipGetLastError();
+  if (ctx->ov_counters) (void)pool_free(ctx->ov_counters);
+  ctx->ov_counters = nullptr;
 }
 
 void fill_overlap_target(OverlapTarget& o, const glim_amd_voxelmap* m, const double* T12) {
@@ -2191,8 +2201,13 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
     in.q.num_blocks = overlap_blocks(ctx, sources[q]->n);
     for (int t = 0; t < num_targets[q]; t++) fill_overlap_target(in.t[t], targets[first_target[(size_t)q] + t], T + 12 * (first_target[(size_t)q] + t));
     overlap_kernel<true><<<in.q.num_blocks, BLOCK, 0, st>>>(in, nullptr, nullptr, nullptr, 1, ctx->ov_counters, nullptr, ctx->ov_host_dev + 1, ctx->ov_host_dev, seq);
-    GA_HIP(hipGetLastError());
-    if (!spin_until(ctx->ov_host, seq)) GA_HIP(hipStreamSynchronize(st));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !spin_until(ctx->ov_host, seq)) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      set_hip_error(e, "overlap");
+      overlap_discard_counters(ctx, st);
+      return GLIM_AMD_ERR_HIP;
+    }
     overlaps[q] = (double)ctx->ov_host[1] / (double)sources[q]->n;
     return GLIM_AMD_OK;
   }
@@ -2235,11 +2250,13 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
                                                         ctx->ov_host_dev + 1, ctx->ov_host_dev, seq);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && !spin_until(ctx->ov_host, seq)) e = hipStreamSynchronize(st);
-  (void)pinned_free(stage);
   if (e != hipSuccess) {
     set_hip_error(e, "overlap_batch");
+    overlap_discard_counters(ctx, st);  // (waits for the stream: the kernel reads `stage` directly)
+    (void)pinned_free(stage);
     return GLIM_AMD_ERR_HIP;
   }
+  (void)pinned_free(stage);
   for (size_t i = 0; i < live.size(); i++) overlaps[live[i]] = (double)ctx->ov_host[1 + i] / (double)sources[live[i]]->n;
   return GLIM_AMD_OK;
 }

@@ -19,6 +19,7 @@
 
 #include "device_math.hpp"
 #include "internal.hpp"
+#include "scope_sync.hpp"
 
 using namespace glim_amd;
 
@@ -381,6 +382,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   const int n = (int)cloud->n;
 
   DeviceTemp tkeys, pkeys, stats, acc;
+  SyncOnExit in_flight(st);  // every exit that has not synchronised itself waits for the stream before the scratch above goes back to the pool
   constexpr int DIRECT_MAX_POINTS = 32768;
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
@@ -426,9 +428,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     }
     if (e != hipSuccess) {
       set_hip_error(e, "voxelmap_insert");
+      (void)hipStreamSynchronize(st);  // (whatever did get enqueued must not outlive the table)
       (void)pool_free(buckets);
       return GLIM_AMD_ERR_HIP;
     }
+    in_flight.dismiss();  // synchronised
     if (h_stats[1] != 0) {
       (void)pool_free(buckets);
       return GLIM_AMD_ERR_RANGE;
@@ -443,6 +447,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       stats.p = nullptr;
       (void)pool_free(acc.p);
       acc.p = nullptr;
+      in_flight.armed = true;  // the counting path enqueues again
       break;
     }
     m->buckets = buckets;
@@ -500,9 +505,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
     set_hip_error(e, "voxelmap_insert");
+    (void)hipStreamSynchronize(st);
     (void)pool_free(buckets);
     return GLIM_AMD_ERR_HIP;
   }
+  in_flight.dismiss();
   if (old) (void)pool_free(old);
   else if (n > 0) remember_voxel_ratio(ctx, res_class, (double)num_voxels / (double)n);
   m->buckets = buckets;

@@ -91,9 +91,10 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
  * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1 + resident_idle_us=<n> (repeated synchronous linearisations of a small set
- * served by a resident kernel that leaves after <n> us without a request), pool=0|1 (GLIM_AMD_DIAG only), multi_rccl=0|1,
- * multi_host_gather=0|1, knn_debug=<file>.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and
- * nothing changes.  get_diag prints the current state in the same syntax. */
+ * served by a resident kernel that leaves after <n> us without a request), pp_fast=0|1 (random-grid preprocessing without sorts),
+ * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,
+ * multi_host_gather=0|1.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and nothing changes.  get_diag prints the current state in the
+ * same syntax. */
 int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
 int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
 /* gtsam_points::cuda_device_names / cuda_mem_get_info (src/glim/util/debug.cpp:84, viewer/memory_monitor.cpp:39). */
@@ -234,7 +235,13 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int init_num_
                              double target_points_drop_rate, glim_amd_voxelmap** out);
 /* build from a cloud that has covariances.  Voxel = mean of member means, mean of member covariances.  A second insert into the same map
  * adds its points to the voxels already there (GaussianVoxelMapCPU semantics: odometry_estimation_cpu.cpp:66-67,189); the map is rebuilt, so
- * GLIM's GPU callers, which insert once per map, pay nothing for it. */
+ * GLIM's GPU callers, which insert once per map, pay nothing for it.
+ * DEVIATION (unverified, gtsam_points is not under the reference tree): upstream's GaussianVoxelMapGPU::insert is believed to REBUILD the table
+ * from the new frame only.  Every GPU call site of the reference inserts exactly once per map (odometry_estimation_gpu.cpp:103-104,
+ * sub_mapping.cpp:398-399, global_mapping.cpp:265-266,747-748), so both semantics give the same map there; a port that re-inserts into a GPU map
+ * and wants upstream's behaviour creates a new map per frame instead.  The re-opened voxels pass through their FP32 records (mean * n,
+ * cov * n), i.e. each further insert adds a rounding of 1 FP32 ulp to the old voxels' statistics
+ * (tests/test_gpu_parity.py::test_voxelmap_incremental_insert_matches_oracle bounds it against the FP64 oracle's merged map). */
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* vmap, const glim_amd_cloud* cloud);
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* vmap);
 /* VoxelMapInfo (standard_viewer_mem.cpp:76-77): num_voxels, num_buckets, resolution, device bytes. */

@@ -175,6 +175,8 @@ public:
     glim_amd_voxelmap_info(h_, nullptr, nullptr, &r, nullptr);
     return r;
   }
+  // A second insert MERGES into the voxels already there (GaussianVoxelMapCPU semantics); upstream's GPU map is believed to rebuild from the new
+  // frame only (unverified).  GLIM's GPU call sites insert once per map, where both agree; see glim_amd_voxelmap_insert in glim_amd.h.
   void insert(const PointCloudGPU& frame) { check(glim_amd_voxelmap_insert(h_, frame.handle()), "GaussianVoxelMapGPU::insert"); }
   struct VoxelMapInfo {
     int num_voxels, num_buckets;

@@ -639,7 +639,8 @@ def test_diag_switches_parse_and_reject(api, ctx):
     assert base["knn_path"] == "auto" and base["plane"] == "1" and base["knn_select"] == "1"
     ctx.set_diag("knn_path=grid,ppt=3")
     assert ctx.get_diag()["knn_path"] == "grid" and ctx.get_diag()["ppt"] == "3"
-    for bad in ("no_such_key=1", "knn_path=fast", "ppt=-1", "plane"):
+    # pool / multi_rccl / multi_host_gather are process-wide (GLIM_AMD_DIAG only): a context refuses them instead of accepting a no-op
+    for bad in ("no_such_key=1", "knn_path=fast", "ppt=-1", "plane", "pool=0", "plane=0,multi_rccl=0", "multi_host_gather=1"):
         with pytest.raises(api.GlimAmdError):
             ctx.set_diag(bad)
         assert ctx.get_diag()["knn_path"] == "grid"
