@@ -38,10 +38,10 @@ struct DiagKey {
   int lo, hi;
 };
 const char* const kPathWords[] = {"auto", "grid", "chunks", "brute", nullptr};
-const char* const kKernelWords[] = {"auto", "wave64", "pair", nullptr};
+const char* const kKernelWords[] = {"auto", "wave64", "pair", "qgroup", nullptr};
 const DiagKey kDiagKeys[] = {
   {"knn_path", &Diag::knn_path, kPathWords, 0, 3},
-  {"knn_kernel", &Diag::knn_kernel, kKernelWords, 0, 2},
+  {"knn_kernel", &Diag::knn_kernel, kKernelWords, 0, 3},
   {"knn_select", &Diag::knn_select, nullptr, 0, 1},
   {"plane", &Diag::plane, nullptr, 0, 1},
   {"curve_order", &Diag::curve_order, nullptr, 0, 1},

@@ -503,23 +503,30 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
                           hist.as<int>(), &ks, &order));
   const Diag& diag = ctx->diag;
   if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
-  const bool pair_lanes = !dbg.p && k > 0 && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
+  // Which kernel answers (all three return identical lists; diag knn_kernel=wave64 / pair / qgroup forces one):
+  //  * qgroup (knn_qgroup.hip; the default since round 4): lanes are CANDIDATES, a wavefront answers 2 (clouds below 32 768 points) or 4
+  //    consecutive queries -- n / 4 short independent work items instead of n / 64 long lock-step chains, so there is no tail and small clouds
+  //    fill the chip.  Per call, same box, against the kernels below: 10 000 points 0.279 -> 0.124 ms, 32 768 0.399 -> 0.289, 65 536
+  //    0.268 -> 0.190, 131 072 0.311 -> 0.259, 307 104 0.562 -> 0.468 ms (profiles/r04/probe/knn_qgroup.txt).
+  //  * wave64 (knn_chunks.hip) / pair (knn_pairs.hip): a query per lane (64 or 32 queries per wavefront).  Both are tail-bound -- the launch
+  //    lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt scan: mean wavefront 157 us, kernel 266 us; 41 % VALU
+  //    utilisation).  Kept as independent cross-checks: wave64 from 98 304 points up, pair below (k <= 16), as round 3 shipped them.
+  const bool qgroup = k > 0 && (diag.knn_kernel == KNN_KERNEL_QGROUP || diag.knn_kernel == KNN_KERNEL_AUTO);
+  if (qgroup && dbg.p) GA_HIP(hipMemsetAsync(dbg.p, 0, (size_t)C * 4 * sizeof(int), st));
+  const bool pair_lanes = !qgroup && !dbg.p && k > 0 && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
   if (pair_lanes) GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
   curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), box32.as<float>(), rank);
-  // Which of the two chunk kernels: both are tail-bound -- the launch lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt
-  // scan: mean wavefront 157 us, kernel 266 us; 41 % VALU utilisation) -- and the pair-lane kernel shortens the average wavefront by only ~18 %
-  // for ~20-34 % more instructions (the lock-step insertion loop costs max-over-lanes rounds either way).  It wins where the 64-query kernel
-  // leaves SIMDs empty (65 536 points: 204 -> 165 us kernel, 0.44 -> 0.33 ms per call), ties at 131 072 and loses at 307 200 (517 -> 785 us).
-  // diag knn_kernel=wave64 / pair forces one or the other.
-  // Also measured and removed: 2 / 4 wavefronts per query chunk, each owning every 2nd / 4th candidate chunk with its own top-k list, the query's
+  // Measured and removed: 2 / 4 wavefronts per query chunk, each owning every 2nd / 4th candidate chunk with its own top-k list, the query's
   // bound shared through LDS (ds_min_u64) and the lists merged by rank at the end -- bit-identical lists, but 0.73 / 0.62 ms against 0.50 ms
   // at 131 072 points and 1.06 / 1.19 against 0.77 ms at 307 104: every list has to be filled and pruned on its own, so the total work grows
   // faster than the longest wavefront shrinks.
-  // The FP32 mask passes of both chunk kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than 1e18 m is
-  // answered by the exhaustive FP64 kernel instead.
+  // The FP32 mask passes of the lane-per-query kernels need finite FP32 squared distances (3 ext^2 < FLT_MAX): a cloud that spans more than
+  // 1e18 m is answered by the exhaustive FP64 kernel instead.
   const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
   const int* guard = stats.as<int>() + 2;
-  if (pair_lanes) {
+  if (qgroup) {
+    knn_launch_qgroup(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, guard, n < 32768 ? 2 : 4, dbg.as<int>());
+  } else if (pair_lanes) {
     knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select, guard);
     GA_HIP(hipGetLastError());
   } else if (k > 0) {
@@ -528,6 +535,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(hipGetLastError());
   if (dbg.p) {
     std::vector<int> hd((size_t)C * 4);
+    GA_HIP(hipStreamSynchronize(st));  // (the context's streams do not synchronise with the null stream the copy below runs on)
     GA_HIP(hipMemcpy(hd.data(), dbg.p, hd.size() * sizeof(int), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(diag.knn_debug, "wb")) {
       fwrite(hd.data(), sizeof(int), hd.size(), f);

@@ -284,8 +284,10 @@ void launch_chunks(hipStream_t st, int n, int C, const float4* sorted, const flo
 
 namespace glim_amd {
 
+void knn_launch_group_boxes(hipStream_t st, int C, float* box) { group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box); }
+
 void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select, const int* guard) {
-  group_box_kernel<<<((C + CHUNK - 1) / CHUNK + 3) / 4, 256, 0, st>>>(C, box);
+  knn_launch_group_boxes(st, C, box);
   DISPATCH_K(launch_chunks, st, n, C, sorted, box, k, out, dbg, select, guard);
 }
 

@@ -13,6 +13,12 @@ namespace glim_amd {
 // groups of 64 chunks: this call fills them first).  dbg: optional per-wavefront counters.  select: see knn_chunks.hip.
 // guard: one device int, non-zero = do nothing (the caller found the cloud's extent unusable for the FP32 mask pass)
 void knn_launch_chunks(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, int* dbg, bool select, const int* guard);
+// boxes of the groups of 64 chunks, behind the chunk boxes (knn_launch_chunks does it itself)
+void knn_launch_group_boxes(hipStream_t st, int C, float* box);
+// query-group kernel (knn_qgroup.hip): lanes are candidates, a wavefront answers `queries_per_wave` (2 or 4) consecutive queries; fills the group boxes first
+// dbg: optional 5 zeroed ints (wavefronts, chunk scans, exact query-chunk evaluations, insertions, chunk-test rounds)
+void knn_launch_qgroup(hipStream_t st, int n, int C, const float4* sorted, float* box, int k, int32_t* out, const int* guard, int queries_per_wave, int* dbg);
+constexpr int KNN_KERNEL_QGROUP = 3;  // diag knn_kernel=qgroup (internal.hpp has auto / wave64 / pair)
 // pair-lane kernel over 32-point half chunks (C32 of them, boxes `box32`); k <= 16
 void knn_launch_pairs(hipStream_t st, int n, int C32, const float4* sorted, const float* box32, int k, int32_t* out, bool select, const int* guard);
 }  // namespace glim_amd

@@ -88,7 +88,7 @@ int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
 int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
- * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair,
+ * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair|qgroup,
  * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1 + resident_idle_us=<n> (repeated synchronous linearisations of a small set
  * served by a resident kernel that leaves after <n> us without a request), pp_fast=0|1 (random-grid preprocessing without sorts),

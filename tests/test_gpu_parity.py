@@ -535,9 +535,10 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc):
     pts = np.vstack([dense, sparse, line, dense[:500]]).astype(np.float32)  # the last 500 duplicate earlier points exactly
     ref = orc.knn(pts.astype(np.float64), 10)
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
-    got_chunk = g.find_neighbors(10)  # 32 437 points: the pair-lane chunk kernel
-    ctx.set_diag("knn_kernel=wave64")
-    np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    got_chunk = g.find_neighbors(10)  # the default: the query-group kernel (knn_qgroup.hip), 2 queries per wavefront at this size
+    for variant in ("wave64", "pair"):  # the lane-per-query kernels
+        ctx.set_diag(f"knn_kernel={variant}")
+        np.testing.assert_array_equal(g.find_neighbors(10), ref)
     ctx.set_diag("knn_kernel=auto")
     ctx.set_diag("knn_path=grid")
     got_grid = g.find_neighbors(10)
@@ -573,7 +574,7 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, name):
     ref = orc.knn(pts.astype(np.float64), 10, method="brute")
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
     ctx.set_diag("knn_path=chunks")
-    for variant in ("wave64", "pair"):  # 64 queries per wavefront / 32 queries with two lanes each
+    for variant in ("wave64", "pair", "qgroup"):  # 64 queries per wavefront / 32 queries with two lanes each / lanes = candidates
         ctx.set_diag(f"knn_kernel={variant}")
         np.testing.assert_array_equal(g.find_neighbors(10), ref)
         for k in (3, 16, 32):
@@ -597,7 +598,7 @@ def test_knn_refuses_non_finite_points_and_the_context_survives(api, ctx, orc, b
     ref = orc.knn(pts.astype(np.float64), 10, method="brute")
     broken = pts.copy()
     broken[1234, 1] = bad
-    for variant in ("wave64", "pair"):
+    for variant in ("wave64", "pair", "qgroup"):
         ctx.set_diag(f"knn_path=chunks,knn_kernel={variant}")
         with pytest.raises(GlimAmdError) as err:
             api.PointCloudGPU.clone(broken, ctx=ctx).find_neighbors(10)
@@ -627,7 +628,7 @@ def test_knn_threshold_selection_is_exact(api, ctx, orc):
         for k in (10, 5):
             ref = orc.knn(pts.astype(np.float64), k, method="brute")
             for select in (1, 0):
-                for variant in ("wave64", "pair"):
+                for variant in ("wave64", "pair", "qgroup"):
                     ctx.set_diag(f"knn_path=chunks,knn_kernel={variant},knn_select={select}")
                     np.testing.assert_array_equal(g.find_neighbors(k), ref, err_msg=f"{name} k={k} {variant} select={select}")
     ctx.set_diag("")
