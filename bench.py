@@ -513,9 +513,11 @@ def run_odometry_frame(args, D, api, ctx):
         n4[:, :3] = n32
         reps = 30
         t_clone = t_maps = t_first = t_second = 0.0
+        first_use = []
         for rep in range(-2, reps):  # two untimed passes: the first launch of a kernel variant loads its code object (tens of ms, once per process)
             if rep == 0:
                 t_clone = t_maps = t_first = t_second = 0.0
+                first_use = []
             t0 = time.perf_counter()
             g = api.PointCloudGPU.clone_packed(p4, c16, n4, ctx=ctx)
             t1 = time.perf_counter()
@@ -533,12 +535,14 @@ def run_odometry_frame(args, D, api, ctx):
             t_maps += t2 - t1
             t_first += t3 - t2
             t_second += t4 - t3
+            first_use.append((t3 - t2) - (t4 - t3))
             one.close()
             for m in ms:
                 m.close()
             g.close()
         r["create_frame_us"] = {"clone_upload_pack": t_clone / reps * 1e6, "two_voxelmap_inserts": t_maps / reps * 1e6,
-                                "factor_streams_on_first_use": max(0.0, (t_first - t_second) / reps * 1e6),
+                                "factor_streams_on_first_use": max(0.0, float(np.median(first_use)) * 1e6),
+                                "factor_streams_on_first_use_mean_max": [max(0.0, (t_first - t_second) / reps * 1e6), float(np.max(first_use)) * 1e6],
                                 "upload_bytes": int(p4.nbytes + c16.nbytes + n4.nbytes), "note": "pageable host arrays, as GLIM hands them over"}
         frame_us = (r["create_frame_us"]["clone_upload_pack"] + r["create_frame_us"]["two_voxelmap_inserts"] + r["create_frame_us"]["factor_streams_on_first_use"]
                     + ITERS * r["fresh_set_linearize_us"] + r["overlap_15_targets_us"])

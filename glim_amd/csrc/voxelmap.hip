@@ -177,62 +177,77 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
 }
 
 // Direct build (fresh maps whose table size is known before the voxels are counted, glim_amd_voxelmap_insert): the keys go straight into the
-// FINAL table, and in the same pass the leader of every key group of a wavefront adds its group's sums to the accumulators of the slot it has
-// just claimed or found -- a slot is usable from the moment its key is in place, no matter which wavefront put it there.  One grouping pass
-// instead of two, no per-point key array, one host synchronise per map instead of two, three launches instead of six.
+// FINAL table and the sums to the accumulators of the slot a key has claimed or found -- a slot is usable from the moment its key is in place,
+// no matter which block put it there.  No per-point key array, one host synchronise per map, three launches.
+// Round 4: the 256 points of a block are first summed per voxel in an LDS hash table (512 slots; integer LDS atomics, order-free like the
+// global ones), and only the block's DISTINCT voxels -- about 40 of a scan's 256 consecutive points -- go to the global table: one claim
+// and ten atomics each.  Round 3 grouped equal keys per wavefront with ballots and gathered a group's values with shuffles: 9 values x 2 words
+// x (largest group) permutes per wavefront, a 1 200-instruction chain on 2 048 wavefronts that were alone on their SIMDs (32-44 us at
+// 131 072 points).
 // stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
+constexpr int LDS_SLOTS = 512;
 __global__ __launch_bounds__(256) void build_direct_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
                                                            const float2* __restrict__ covB, double inv_res, VoxelBucket* __restrict__ buckets,
                                                            unsigned int num_buckets, long long* __restrict__ acc, int* __restrict__ stats) {
+  __shared__ unsigned long long s_key[LDS_SLOTS];
+  __shared__ unsigned long long s_acc[ACC_STRIDE][LDS_SLOTS];  // value-major: the lanes of a wavefront that add value j to different slots hit different banks
+  __shared__ int s_claimed;  // voxels this block was the first to put into the global table: ONE atomic per block on the shared counter
+  if (threadIdx.x == 0) s_claimed = 0;
+  for (int s = threadIdx.x; s < LDS_SLOTS; s += 256) {
+    s_key[s] = EMPTY_KEY;
+#pragma unroll
+    for (int j = 0; j < ACC_STRIDE; j++) s_acc[j][s] = 0ull;
+  }
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long key = EMPTY_KEY;
-  long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
     const float4 p = pts[i];
     const float4 a = covA[i];
     const float2 b = covB[i];
-    key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
-    if (key == EMPTY_KEY) atomicAdd(&stats[1], 1);
-    v[0] = __double2ll_rn((double)p.x * MEAN_SCALE);
-    v[1] = __double2ll_rn((double)p.y * MEAN_SCALE);
-    v[2] = __double2ll_rn((double)p.z * MEAN_SCALE);
-    v[3] = __double2ll_rn((double)a.x * COV_SCALE);
-    v[4] = __double2ll_rn((double)a.y * COV_SCALE);
-    v[5] = __double2ll_rn((double)a.z * COV_SCALE);
-    v[6] = __double2ll_rn((double)a.w * COV_SCALE);
-    v[7] = __double2ll_rn((double)b.x * COV_SCALE);
-    v[8] = __double2ll_rn((double)b.y * COV_SCALE);
-  }
-  unsigned long long group;
-  const bool leader = wave_group_by_key(key, key != EMPTY_KEY, group);
-  long long sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long rest = leader ? group : 0ull;
-  while (__ballot(rest != 0ull)) {
-    const int src = rest ? (__ffsll((long long)rest) - 1) : 0;
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-      const long long t = shfl_ll(v[j], src);
-      if (rest) sum[j] += t;
+    const unsigned long long key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
+    if (key == EMPTY_KEY) {
+      atomicAdd(&stats[1], 1);
+    } else {
+      unsigned int s = hash_key(key) & (LDS_SLOTS - 1);
+      for (;;) {  // at most 256 of the 512 slots are ever taken
+        const unsigned long long prev = atomicCAS(&s_key[s], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) break;
+        s = (s + 1) & (LDS_SLOTS - 1);
+      }
+      atomicAdd(&s_acc[0][s], (unsigned long long)__double2ll_rn((double)p.x * MEAN_SCALE));
+      atomicAdd(&s_acc[1][s], (unsigned long long)__double2ll_rn((double)p.y * MEAN_SCALE));
+      atomicAdd(&s_acc[2][s], (unsigned long long)__double2ll_rn((double)p.z * MEAN_SCALE));
+      atomicAdd(&s_acc[3][s], (unsigned long long)__double2ll_rn((double)a.x * COV_SCALE));
+      atomicAdd(&s_acc[4][s], (unsigned long long)__double2ll_rn((double)a.y * COV_SCALE));
+      atomicAdd(&s_acc[5][s], (unsigned long long)__double2ll_rn((double)a.z * COV_SCALE));
+      atomicAdd(&s_acc[6][s], (unsigned long long)__double2ll_rn((double)a.w * COV_SCALE));
+      atomicAdd(&s_acc[7][s], (unsigned long long)__double2ll_rn((double)b.x * COV_SCALE));
+      atomicAdd(&s_acc[8][s], (unsigned long long)__double2ll_rn((double)b.y * COV_SCALE));
+      atomicAdd(&s_acc[9][s], 1ull);
     }
-    rest &= rest - 1ull;
   }
-  if (!leader) return;
-  unsigned int b = bucket_of(key, num_buckets);
-  int slot = -1;
-  while (slot < 0) {
+  __syncthreads();
+  for (int s = threadIdx.x; s < LDS_SLOTS; s += 256) {
+    const unsigned long long key = s_key[s];
+    if (key == EMPTY_KEY) continue;
+    unsigned int b = bucket_of(key, num_buckets);
+    int slot = -1;
+    while (slot < 0) {
 #pragma unroll
-    for (int w = 0; w < 2; w++) {
-      if (slot >= 0) continue;
-      const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
-      if (prev == EMPTY_KEY) atomicAdd(&stats[0], 1);
-      if (prev == EMPTY_KEY || prev == key) slot = (int)(2u * b + (unsigned int)w);
+      for (int w = 0; w < 2; w++) {
+        if (slot >= 0) continue;
+        const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY) atomicAdd(&s_claimed, 1);
+        if (prev == EMPTY_KEY || prev == key) slot = (int)(2u * b + (unsigned int)w);
+      }
+      b = (b + 1 == num_buckets) ? 0u : b + 1;
     }
-    b = (b + 1 == num_buckets) ? 0u : b + 1;
-  }
-  long long* dst = acc + (size_t)slot * ACC_STRIDE;
+    long long* dst = acc + (size_t)slot * ACC_STRIDE;
 #pragma unroll
-  for (int j = 0; j < 9; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), (unsigned long long)sum[j]);
-  atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)__popcll(group));
+    for (int j = 0; j < ACC_STRIDE; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), s_acc[j][s]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_claimed) atomicAdd(&stats[0], s_claimed);
 }
 
 // ---- incremental insert (a second insert() into a map: GaussianVoxelMapCPU semantics, gtsam_points GaussianVoxel::add re-opens a finalised voxel

@@ -45,6 +45,10 @@ rm -rf gpurun_out/prof_${TAG}_pre
 # the floor of a synchronous call on this box (launch / mailbox round trips) and the resident session's lifecycle
 (hipcc -O3 --offload-arch=gfx950 tools/ubench/sync_floor.hip -o /tmp/sync_floor && timeout 120 /tmp/sync_floor) > $OUT/sync_floor.txt 2>&1
 timeout 120 python tools/res_probe.py > $OUT/resident_probe.txt 2>&1
+# kNN kernels against each other and the oracle (lists, wall time, per-wavefront counters of the query-group kernel); voxel-map insert wall time
+mkdir -p $OUT/probe
+timeout 300 python tools/knn_qgroup_probe.py 2>&1 | grep -v '^[WE]20' > $OUT/probe/knn_qgroup.txt
+timeout 100 python tools/voxelmap_time.py 2>&1 | grep -v '^[WE]20' > $OUT/voxelmap_time.txt
 timeout 200 python tools/batch_sweep.py > $OUT/batch_sweep.json 2> $OUT/batch_sweep.err < /dev/null
 du -sh $REPO/gpurun_out
 cat $OUT/gputest.log | tail -3
