@@ -33,7 +33,7 @@ for name, pts in clouds.items():
     small = len(pts) <= 40000
     for k in ((10, 5, 16, 32, 1) if small else (10,)):
         ref = orc.knn(pts.astype(np.float64), k, method="brute") if small else None
-        ctx.set_diag("knn_path=chunks")
+        ctx.set_diag("knn_path=chunks,knn_kernel=wave64")
         base = g.find_neighbors(k)
         ctx.set_diag("knn_path=chunks,knn_kernel=qgroup")
         got = g.find_neighbors(k)
@@ -51,25 +51,24 @@ for name, pts in (("scan10000", clouds["scan10000"]), ("scan32768", clouds["scan
     pts = np.asarray(pts).astype(np.float32)
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
     row = {}
-    for variant in ("auto", "qgroup", "qgroup_alt"):
+    variants = ("qgroup", "wave64") + (("pair",) if len(pts) <= 131072 else ())
+    for variant in variants:
         ctx.set_diag("")
-        ctx.set_diag("knn_kernel=qgroup,knn_select=0" if variant == "qgroup_alt" else f"knn_kernel={variant}")
+        ctx.set_diag(f"knn_kernel={variant}")
         g.find_neighbors(10, download=False)
         ts = []
         for _ in range(7):
             t = time.perf_counter(); g.find_neighbors(10, download=False); ts.append(time.perf_counter() - t)
         row[variant] = min(ts) * 1e3
-        res = g.find_neighbors(10)
-        row[variant + "_lists"] = res
-    same = bool((row["auto_lists"] == row["qgroup_lists"]).all()) and bool((row["auto_lists"] == row["qgroup_alt_lists"]).all())
+        row[variant + "_lists"] = g.find_neighbors(10)
+    same = all(bool((row["qgroup_lists"] == row[v + "_lists"]).all()) for v in variants)
     ok_all &= same
-    print(f"time {name:12s} n={len(pts):6d}  shipped {row['auto']:.3f} ms   qgroup {row['qgroup']:.3f} ms   other group size {row['qgroup_alt']:.3f} ms   identical={same}", flush=True)
-    for alt in (0, 1):
-        ctx.set_diag("")
-        ctx.set_diag(f"knn_kernel=qgroup,knn_select={1 - alt},knn_debug=/tmp/knn_dbg.bin")
-        g.find_neighbors(10, download=False)
-        c = np.fromfile("/tmp/knn_dbg.bin", dtype=np.int32)[:5].astype(np.float64)
-        print(f"     counters ({'other' if alt else 'default'} group size): waves {int(c[0])}, queries per wave {len(pts) / c[0]:.2f}; per wave: chunk scans {c[1] / c[0]:.1f}, "
-              f"exact query-chunk evaluations {c[2] / c[0]:.1f}, insertions {c[3] / c[0]:.1f}, test rounds {c[4] / c[0]:.1f}", flush=True)
+    print(f"time {name:12s} n={len(pts):6d}  " + "   ".join(f"{v} {row[v]:.3f} ms" for v in variants) + f"   identical={same}", flush=True)
+    ctx.set_diag("")
+    ctx.set_diag("knn_kernel=qgroup,knn_debug=/tmp/knn_dbg.bin")
+    g.find_neighbors(10, download=False)
+    c = np.fromfile("/tmp/knn_dbg.bin", dtype=np.int32)[:5].astype(np.float64)
+    print(f"     query-group kernel: {int(c[0])} wavefronts of {len(pts) / c[0]:.2f} queries; per wavefront: chunk scans {c[1] / c[0]:.1f}, "
+          f"exact query-chunk evaluations {c[2] / c[0]:.1f}, insertions {c[3] / c[0]:.1f}, chunk-test rounds {c[4] / c[0]:.1f}", flush=True)
 ctx.set_diag("")
 print("ALL_OK", ok_all)
