@@ -1,6 +1,6 @@
-// knn_common.hpp -- shared by the three translation units of kernel group K2 (knn.hip: host side, grid and exhaustive kernels, curve order;
-// knn_chunks.hip: the 64-query chunk kernel; knn_pairs.hip: the pair-lane chunk kernel).  The chunk kernels are the slow ones to compile
-// (every list size is its own instantiation), so they build in parallel with the rest.
+// knn_common.hpp -- shared by the four translation units of kernel group K2 (knn.hip: host side, grid and exhaustive kernels, curve order;
+// knn_qgroup.hip: the query-group kernel, the default; knn_chunks.hip: the 64-query chunk kernel; knn_pairs.hip: the pair-lane chunk kernel).
+// The chunk kernels are the slow ones to compile (every list size is its own instantiation), so they build in parallel with the rest.
 #pragma once
 #include <cstdint>
 
