@@ -504,10 +504,11 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   const Diag& diag = ctx->diag;
   if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
   // Which kernel answers (all three return identical lists; diag knn_kernel=wave64 / pair / qgroup forces one):
-  //  * qgroup (knn_qgroup.hip; the default since round 4): lanes are CANDIDATES, a wavefront answers 2 (clouds below 32 768 points) or 4
-  //    consecutive queries -- n / 4 short independent work items instead of n / 64 long lock-step chains, so there is no tail and small clouds
-  //    fill the chip.  Per call, same box, against the kernels below: 10 000 points 0.279 -> 0.124 ms, 32 768 0.399 -> 0.289, 65 536
-  //    0.268 -> 0.190, 131 072 0.311 -> 0.259, 307 104 0.562 -> 0.468 ms (profiles/r04/probe/knn_qgroup.txt).
+  //  * qgroup (knn_qgroup.hip; the default since round 4): lanes are CANDIDATES, a wavefront answers 1 (clouds below 49 152 points) or 2
+  //    consecutive queries -- n or n / 2 short independent work items instead of n / 64 long lock-step chains, so there is no tail and small
+  //    clouds fill the chip.  Per call, same box, against the faster of the kernels below: 10 000 points 0.294 -> 0.112 ms, 32 768 0.381 -> 0.167,
+  //    65 536 0.267 -> 0.169, 131 072 0.305 -> 0.233, 307 104 0.551 -> 0.437 ms (profiles/r04/probe/knn_qgroup.txt).  Four queries per
+  //    wavefront share more of the walk but need 82 registers (5 wavefronts per SIMD instead of 8): 0.252 / 0.466 ms at the two large sizes.
   //  * wave64 (knn_chunks.hip) / pair (knn_pairs.hip): a query per lane (64 or 32 queries per wavefront).  Both are tail-bound -- the launch
   //    lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt scan: mean wavefront 157 us, kernel 266 us; 41 % VALU
   //    utilisation).  Kept as independent cross-checks: wave64 from 98 304 points up, pair below (k <= 16), as round 3 shipped them.
@@ -525,7 +526,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
   const int* guard = stats.as<int>() + 2;
   if (qgroup) {
-    knn_launch_qgroup(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, guard, n < 32768 ? 2 : 4, dbg.as<int>());
+    knn_launch_qgroup(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, guard, n < 49152 ? 1 : 2, dbg.as<int>());
   } else if (pair_lanes) {
     knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select, guard);
     GA_HIP(hipGetLastError());

@@ -3,7 +3,7 @@
 // The 64-query kernel (knn_chunks.hip) and the pair-lane kernel (knn_pairs.hip) give every LANE a query: a wavefront is a lock-step chain of
 // (candidate chunks scanned) x 64 candidate steps + (insertion rounds of its slowest lane), all wavefronts are resident at once and the launch
 // lasts as long as the slowest of them -- twice the mean at 131 072 points -- while a 10 000-point cloud fills 313 of the chip's 1 024 SIMDs with one
-// such chain each.  Here the lanes are the CANDIDATES: a wavefront answers Q consecutive queries of the curve order, a scanned chunk is ONE
+// such chain each.  Here the lanes are the CANDIDATES: a wavefront answers Q (1 or 2) consecutive queries of the curve order, a scanned chunk is ONE
 // coalesced load (lane j holds candidate j), the Q distances per lane are the oracle's FP64 expression directly (no FP32 pre-pass to undo),
 // v_cmp against the query's k-th best IS the ballot of candidates that enter, and each query's list lives in lanes 0..K-1 (lane j = j-th best),
 // so an insertion is a vote, a population count and a one-lane shift.  A cloud of n points is n / Q short independent work items: no tail, and
@@ -70,7 +70,7 @@ __device__ __forceinline__ void sort64(double& d, int& idx, int lane) {
   sort_merge<64, 32>(d, idx, lane);
 }
 
-template <int K, int Q>
+template <int K, int Q, bool DBG>
 __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const float4* __restrict__ sorted, const float* __restrict__ box, int k,
                                                          int32_t* __restrict__ out, const int* __restrict__ guard, int* __restrict__ dbg) {
   static_assert(CHUNK % Q == 0 && K <= 32, "query groups tile a chunk; a list fits the lower half of a wavefront");
@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
     const int raw = __float_as_int(p.w);
     const bool valid = raw >= 0;  // (< 0: padding of the last chunk)
     const int cidx = valid ? raw : 0x7fffffff;
-    const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
-    dbg_scans++;
+    if constexpr (DBG) dbg_scans++;
 #pragma unroll
     for (int i = 0; i < Q; i++) {
       if (!first) {
@@ -141,8 +140,8 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
         const float dx = qxf[i] - p.x, dy = qyf[i] - p.y, dz = qzf[i] - p.z;
         if (__ballot(valid & (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= bd32[i])) == 0ull) continue;
       }
-      dbg_exact++;
-      double d = sqdist(qx[i], qy[i], qz[i], px, py, pz);
+      if constexpr (DBG) dbg_exact++;
+      double d = sqdist(qx[i], qy[i], qz[i], (double)p.x, (double)p.y, (double)p.z);
       d = valid ? d : inf;
       if (first) {
         int idx = cidx;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
         ld[i] = lane > pos ? sd : (lane == pos ? dc : ld[i]);
         li[i] = lane > pos ? si : (lane == pos ? ic : li[i]);
         refresh_bound(i);
-        dbg_inserts++;
+        if constexpr (DBG) dbg_inserts++;
         m &= m - 1ull;
         m &= __ballot(before(d, cidx, bd[i], bi[i]));  // the bound has tightened: candidates it now excludes are dropped without a visit
       }
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
     }
     unsigned long long todo = __ballot(mine);
     while (todo) {
-      dbg_tests++;
+      if constexpr (DBG) dbg_tests++;
       todo &= __ballot(mine & gaps_may_help(g2));
       if (!todo) break;
       const int j = (int)__builtin_ctzll(todo);
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
 #pragma unroll
   for (int i = 0; i < Q; i++)
     if (self[i] >= 0 && lane < k && lane < K) out[(size_t)self[i] * k + lane] = li[i];
-  if (dbg && lane == 0) {  // diag knn_debug: totals over the launch
+  if (DBG && dbg && lane == 0) {  // diag knn_debug: totals over the launch
     atomicAdd(dbg + 0, 1);
     atomicAdd(dbg + 1, dbg_scans);
     atomicAdd(dbg + 2, dbg_exact);
@@ -291,8 +290,12 @@ __global__ __launch_bounds__(256) void knn_qgroup_kernel(int n, int C, const flo
 template <int K>
 void launch_qgroup(hipStream_t st, int n, int C, const float4* sorted, const float* box, int k, int32_t* out, const int* guard, int q, int* dbg) {
   auto grid = [&](int per_chunk) { return (unsigned int)((((C * per_chunk + 3) / 4 + 7) / 8) * 8); };  // 4 query groups per workgroup, whole rounds of the 8 XCDs
-  if (q == 2) knn_qgroup_kernel<K, 2><<<grid(CHUNK / 2), 256, 0, st>>>(n, C, sorted, box, k, out, guard, dbg);
-  else knn_qgroup_kernel<K, 4><<<grid(CHUNK / 4), 256, 0, st>>>(n, C, sorted, box, k, out, guard, dbg);
+  if (dbg) {  // the counting instantiation (diag knn_debug): two queries per wavefront
+    knn_qgroup_kernel<K, 2, true><<<grid(CHUNK / 2), 256, 0, st>>>(n, C, sorted, box, k, out, guard, dbg);
+    return;
+  }
+  if (q == 1) knn_qgroup_kernel<K, 1, false><<<grid(CHUNK), 256, 0, st>>>(n, C, sorted, box, k, out, guard, dbg);
+  else knn_qgroup_kernel<K, 2, false><<<grid(CHUNK / 2), 256, 0, st>>>(n, C, sorted, box, k, out, guard, dbg);
 }
 
 }  // namespace
