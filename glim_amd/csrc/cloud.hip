@@ -105,11 +105,13 @@ constexpr int64_t HOST_PACK_MAX_POINTS = 32768;
 __global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __restrict__ s_pts, const float4* __restrict__ s_covA,
                                                       const float2* __restrict__ s_covB, const float4* __restrict__ s_nrm, float4* __restrict__ pts,
                                                       float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm,
-                                                      unsigned int* __restrict__ host_violations) {
+                                                      unsigned int* __restrict__ host_violations, float4* __restrict__ pn4, float2* __restrict__ n2,
+                                                      float4* __restrict__ gs0, float4* __restrict__ gs1, float* __restrict__ gs2, float4* __restrict__ gsn) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool bad = false;
   if (i < n) {
-    pts[i] = s_pts[i];
+    const float4 p = s_pts[i];
+    pts[i] = p;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), v = a;
     float2 b = make_float2(0.f, 0.f);
     if (s_covA) {
@@ -118,6 +120,19 @@ __global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __res
     }
     if (s_nrm) nrm[i] = v = s_nrm[i];
     bad = s_covA && s_nrm && off_plane_form(a.x, a.y, a.z, a.w, b.x, b.y, v.x, v.y, v.z);
+    // The factor streams of the cloud (plane_stream_kernel / general_stream_kernel; arrival order: clouds of this size carry no Hilbert rank), in
+    // BOTH forms while the values are in registers -- which form the factor kernel reads is only known when every block has tested its points;
+    // the host drops the other.  The first factor that streams the cloud then finds them in place (no kernel, no synchronise at first use).
+    if (pn4) {
+      pn4[i] = make_float4(p.x, p.y, p.z, v.x);
+      n2[i] = make_float2(v.y, v.z);
+    }
+    if (gs0) {
+      gs0[i] = make_float4(p.x, p.y, p.z, a.x);
+      gs1[i] = make_float4(a.y, a.z, a.w, b.x);
+      gs2[i] = b.y;
+      if (gsn) gsn[i] = v;
+    }
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_violations, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -151,6 +166,22 @@ void host_pack_f64(int64_t n, const double* points4, const double* covs16, const
     }
 }
 
+void drop_general_streams(glim_amd_cloud* c) {
+  if (c->gs0) (void)pool_free(c->gs0);
+  if (c->gs1) (void)pool_free(c->gs1);
+  if (c->gs2) (void)pool_free(c->gs2);
+  if (c->gsn) (void)pool_free(c->gsn);
+  c->gs0 = c->gs1 = nullptr;
+  c->gs2 = nullptr;
+  c->gsn = nullptr;
+}
+void drop_plane_streams(glim_amd_cloud* c) {
+  if (c->pn4) (void)pool_free(c->pn4);
+  if (c->n2) (void)pool_free(c->n2);
+  c->pn4 = nullptr;
+  c->n2 = nullptr;
+}
+
 // upload of a small cloud through the pinned staging block; GLIM_AMD_ERR_UNSUPPORTED: no device view of pinned memory here (caller takes the general path)
 int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4) {
   const int64_t n = c->n;
@@ -171,11 +202,25 @@ int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4
   volatile unsigned int* violations = reinterpret_cast<unsigned int*>(stage + 14 * n);
   *violations = 0u;
   hipStream_t s = ctx->stream();
+  // factor streams written by the same kernel (see unstage_kernel); an allocation that fails only means they are built on first use instead
+  if (covs16) {
+    const size_t nn = (size_t)n;
+    bool ok = pool_malloc(&c->gs0, nn * sizeof(float4)) == hipSuccess && pool_malloc(&c->gs1, nn * sizeof(float4)) == hipSuccess &&
+              pool_malloc(&c->gs2, nn * sizeof(float)) == hipSuccess && (!normals4 || pool_malloc(&c->gsn, nn * sizeof(float4)) == hipSuccess);
+    if (ok && normals4) ok = pool_malloc(&c->pn4, nn * sizeof(float4)) == hipSuccess && pool_malloc(&c->n2, nn * sizeof(float2)) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      drop_general_streams(c);
+      drop_plane_streams(c);
+    }
+  }
   unstage_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((int)n, reinterpret_cast<const float4*>(dev), covs16 ? reinterpret_cast<const float4*>(dev + 4 * n) : nullptr,
                                                         reinterpret_cast<const float2*>(dev + 12 * n), normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr,
-                                                        c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n));
+                                                        c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n), c->pn4, c->n2, c->gs0,
+                                                        c->gs1, c->gs2, c->gsn);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(s);
+  else (void)hipStreamSynchronize(s);
   const bool plane = covs16 && normals4 && *violations == 0u;
   (void)pinned_free(stage);
   if (e != hipSuccess) {
@@ -183,6 +228,8 @@ int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4
     return GLIM_AMD_ERR_HIP;
   }
   c->plane_form = plane;
+  if (plane && c->pn4) drop_general_streams(c);  // the factor kernel reads the form the cloud has; the other copy goes back to the pool
+  else drop_plane_streams(c);
   return GLIM_AMD_OK;
 }
 

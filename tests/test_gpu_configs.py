@@ -250,8 +250,10 @@ def test_uploaded_plane_covariances_take_the_plane_kernel(api, ctx, orc, monkeyp
         fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, cloud))
         res[name] = fset.linearize({0: np.eye(4), 1: delta})[0]
         check_factor(res[name], ref)
-    # the plane-form stream (24 B per point) was built for it, not the general one (36 B per point)
-    assert sg.memory_usage_gpu() - base == len(src) * 24
+    # the plane-form stream (24 B per point) serves it, not the general one (36 B per point): written by the upload kernel itself for clouds of
+    # up to 32 768 points (nothing is added on first use), by the first factor otherwise
+    assert sg.memory_usage_gpu() - base in (0, len(src) * 24)
+    assert sg.memory_usage_gpu() == len(src) * (56 + 24)  # points + covariances + normals: 56 B per point
     ctx.set_diag("plane=0")
     fset = api.NonlinearFactorSetGPU(ctx)
     fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
@@ -267,7 +269,8 @@ def test_uploaded_plane_covariances_take_the_plane_kernel(api, ctx, orc, monkeyp
     fset = api.NonlinearFactorSetGPU(ctx)
     fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, g))
     r = fset.linearize({0: np.eye(4), 1: delta})[0]
-    assert g.memory_usage_gpu() - b0 == len(src) * (36 + 16)  # general stream + stream-ordered normals
+    assert g.memory_usage_gpu() - b0 in (0, len(src) * (36 + 16))
+    assert g.memory_usage_gpu() == len(src) * (56 + 36 + 16)  # general stream + stream-ordered normals
     check_factor(r, orc.vgicp_linearize(orc.VoxelMap(0.5).insert(tgt, c32(ct)), src, c32(bad), delta))
 
 

@@ -79,7 +79,9 @@ def test_cloud_roundtrip_f64_and_f32_layouts(api, ctx, small_pair):
         np.testing.assert_array_equal(xyz, s["points"])
         np.testing.assert_array_equal(covs, s["covs"].astype(np.float32))
         np.testing.assert_array_equal(nrm, s["normals"].astype(np.float32))
-    assert g64.memory_usage_gpu() == len(s["points"]) * (16 + 24 + 16)
+    # points + covariances + normals, and -- a cloud of this size gets them from the upload kernel -- its factor stream (24 B per point in the
+    # plane form, 36 + 16 otherwise)
+    assert g64.memory_usage_gpu() in (len(s["points"]) * (16 + 24 + 16 + 24), len(s["points"]) * (16 + 24 + 16 + 36 + 16))
 
 
 def test_small_cloud_host_pack_equals_the_device_pack(api, ctx, orc, small_pair):

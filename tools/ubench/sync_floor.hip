@@ -143,7 +143,15 @@ static double median_us(F&& f, int warm, int iters) {
   return t[t.size() / 2];
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // optional argument: spin | yield | blocking -> hipSetDeviceFlags(hipDeviceSchedule...) before anything else touches the device:
+  // what hipStreamSynchronize costs under each wait policy (the row null_1_stream_synchronize)
+  if (argc > 1) {
+    const char c = argv[1][0];
+    const unsigned int flag = c == 's' ? hipDeviceScheduleSpin : c == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync;
+    const hipError_t e = hipSetDeviceFlags(flag);
+    printf("hipSetDeviceFlags(%s): %s\n", argv[1], hipGetErrorString(e));
+  }
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   unsigned int *h = nullptr, *d = nullptr;
@@ -165,6 +173,20 @@ int main() {
   const double two = median_us([&] { null_kernel<<<512, 256, 0, st>>>(d + 3, ++seq, 0); null_kernel<<<1, 256, 0, st>>>(d + 1, seq, 0); ok &= spin(h + 1, seq); }, 200, 2000);
   const double syncd = median_us([&] { null_kernel<<<1, 256, 0, st>>>(d + 1, ++seq, 0); (void)hipStreamSynchronize(st); }, 200, 2000);
   printf("null_1 %.2f us  null_513 %.2f us  granule_513 %.2f us  two_kernels %.2f us  null_1_stream_synchronize %.2f us  (ok=%d)\n", null1, null513, gran, two, syncd, (int)ok);
+  // completion WITHOUT a word written by the kernel itself (i.e. ordered after the kernel's end, as hipStreamSynchronize is):
+  //   write_value   null kernel (touches nothing) + hipStreamWriteValue32 of the sequence number into the host-mapped word, host spins on it
+  //   event_query   null kernel + hipEventRecord, host spins on hipEventQuery
+  {
+    unsigned int* sink = nullptr;
+    CK(hipMalloc(&sink, 64));
+    hipEvent_t ev;
+    CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t we = hipSuccess;
+    const double wv = median_us([&] { null_kernel<<<1, 256, 0, st>>>(sink, ++seq, 0); we = hipStreamWriteValue32(st, d + 4, seq, 0); ok &= (we == hipSuccess) && spin(h + 4, seq); }, 200, 2000);
+    const double eq = median_us([&] { null_kernel<<<1, 256, 0, st>>>(sink, ++seq, 0); (void)hipEventRecord(ev, st); while (hipEventQuery(ev) == hipErrorNotReady) __builtin_ia32_pause(); }, 200, 2000);
+    printf("null_1_write_value32 %.2f us (%s)  null_1_event_query %.2f us  (ok=%d)\n", wv, hipGetErrorString(we), eq, (int)ok);
+    (void)hipGetLastError();
+  }
   CK(hipStreamSynchronize(st));
   for (int workers : {0, 255, 512}) {
     h[0] = 0; h[1] = 0; h[2] = 1;
