@@ -360,6 +360,12 @@ struct FactorPlan {
   std::vector<glim_amd::FactorDesc> h_descs;
   std::vector<int2> h_blockmap;
   bool uploaded = false;              // d_descs / d_blockmap hold h_descs / h_blockmap (single-factor plans upload on first non-inline launch)
+  // d_descs | d_blockmap | d_finmap are ONE device block filled by ONE copy from the pinned block h_upload (three pageable copies cost a new
+  // plan ~15 us, and GLIM's odometry builds a new plan with every frame); d_done | d_trip_stats | d_rows16 are ONE block cleared by one memset
+  char* d_upload = nullptr;
+  char* h_upload = nullptr;
+  size_t upload_bytes = 0;
+  char* d_zeroed = nullptr;
   hipStream_t last_stream = nullptr;  // stream of the last enqueue
   bool maybe_busy = false;            // an asynchronous enqueue may still be running on last_stream
 };

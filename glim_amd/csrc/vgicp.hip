@@ -1105,15 +1105,12 @@ void plan_free(FactorPlan* p) {
   resident_release(nullptr, p);  // a resident session that serves this plan ends first
   // nothing enqueued earlier (asynchronous entry points included) may still be using the buffers that go back to the pool
   if (p->maybe_busy && p->last_stream) (void)hipStreamSynchronize(p->last_stream);
-  if (p->d_descs) (void)pool_free(p->d_descs);
-  if (p->d_blockmap) (void)pool_free(p->d_blockmap);
+  if (p->d_upload) (void)pool_free(p->d_upload);  // d_descs | d_blockmap | d_finmap
+  if (p->h_upload) (void)pinned_free(p->h_upload);
+  if (p->d_zeroed) (void)pool_free(p->d_zeroed);  // d_done | d_trip_stats | d_rows16
   if (p->d_partials) (void)pool_free(p->d_partials);
-  if (p->d_trip_stats) (void)pool_free(p->d_trip_stats);
-  if (p->d_rows16) (void)pool_free(p->d_rows16);
-  if (p->d_finmap) (void)pool_free(p->d_finmap);
   if (p->d_poses) (void)pool_free(p->d_poses);
   if (p->d_compact) (void)pool_free(p->d_compact);
-  if (p->d_done) (void)pool_free(p->d_done);
   if (p->h_poses) (void)pinned_free(p->h_poses);
   if (p->h_compact) (void)pinned_free(p->h_compact);
   if (p->h_flag) (void)pinned_free(p->h_flag);
@@ -1177,9 +1174,14 @@ int plan_upload(glim_amd_factor_set* set, FactorPlan* plan) {
   if (plan->uploaded) return GLIM_AMD_OK;
   const size_t nf = plan->h_descs.size();
   if (nf > 0) {
-    GA_HIP(hipMemcpyAsync(plan->d_descs, plan->h_descs.data(), nf * sizeof(FactorDesc), hipMemcpyHostToDevice, set->stream));
-    GA_HIP(hipMemcpyAsync(plan->d_blockmap, plan->h_blockmap.data(), plan->h_blockmap.size() * sizeof(int2), hipMemcpyHostToDevice, set->stream));
-    if (plan->d_finmap) GA_HIP(hipMemcpyAsync(plan->d_finmap, plan->h_finmap.data(), plan->h_finmap.size() * sizeof(int), hipMemcpyHostToDevice, set->stream));
+    // the three tables travel as one copy out of the plan's pinned block (the block lives as long as the plan: no synchronise needed)
+    char* h = plan->h_upload;
+    memcpy(h + ((char*)plan->d_descs - plan->d_upload), plan->h_descs.data(), nf * sizeof(FactorDesc));
+    memcpy(h + ((char*)plan->d_blockmap - plan->d_upload), plan->h_blockmap.data(), plan->h_blockmap.size() * sizeof(int2));
+    if (plan->d_finmap) memcpy(h + ((char*)plan->d_finmap - plan->d_upload), plan->h_finmap.data(), plan->h_finmap.size() * sizeof(int));
+    GA_HIP(hipMemcpyAsync(plan->d_upload, h, plan->upload_bytes, hipMemcpyHostToDevice, set->stream));
+    plan->last_stream = set->stream;
+    plan->maybe_busy = true;  // (plan_free waits for the copy before the pinned image goes back to its pool)
   }
   plan->uploaded = true;
   return GLIM_AMD_OK;
@@ -1341,20 +1343,32 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   plan->plane_rows = seg_rows[0];
   plan->total_rows = (int)blockmap.size();
   const size_t nfa = (size_t)std::max(1, nf), nba = std::max<size_t>(1, blockmap.size());
-  GA_HIP(pool_malloc(&plan->d_descs, nfa * sizeof(FactorDesc)));
-  GA_HIP(pool_malloc(&plan->d_blockmap, nba * sizeof(int2)));
+  // single-dispatch form (small synchronous sets only): tagged rows, every tag 0 = "no call yet" (sequence numbers start at 1)
+  const bool fused_form = nf >= 1 && nf <= FUSED_MAX_FACTORS && total_blocks <= FUSED_MAX_ROWS;
+  auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  {  // descriptors | block map | finaliser map: one device block, one pinned image, one copy (plan_upload)
+    const size_t o_map = up16(nfa * sizeof(FactorDesc)), o_fin = o_map + up16(nba * sizeof(int2));
+    plan->upload_bytes = o_fin + (fused_form ? up16((size_t)nf * sizeof(int)) : 0);
+    GA_HIP(pool_malloc(&plan->d_upload, plan->upload_bytes));
+    GA_HIP(pinned_malloc(&plan->h_upload, plan->upload_bytes));
+    memset(plan->h_upload, 0, plan->upload_bytes);
+    plan->d_descs = reinterpret_cast<FactorDesc*>(plan->d_upload);
+    plan->d_blockmap = reinterpret_cast<int2*>(plan->d_upload + o_map);
+    plan->d_finmap = fused_form ? reinterpret_cast<int*>(plan->d_upload + o_fin) : nullptr;
+  }
+  {  // completion counter | skipped-trip counters | tagged rows: one block, one memset
+    const size_t o_trip = 64, o_rows = o_trip + 64 * sizeof(unsigned long long);
+    const size_t zero_bytes = o_rows + (fused_form ? (size_t)total_blocks * TAG_ROW_BYTES : 0);
+    GA_HIP(pool_malloc(&plan->d_zeroed, zero_bytes));
+    GA_HIP(hipMemsetAsync(plan->d_zeroed, 0, zero_bytes, set->stream));
+    plan->d_done = reinterpret_cast<int*>(plan->d_zeroed);
+    plan->d_trip_stats = reinterpret_cast<unsigned long long*>(plan->d_zeroed + o_trip);
+    plan->d_rows16 = fused_form ? plan->d_zeroed + o_rows : nullptr;
+  }
   GA_HIP(pool_malloc(&plan->d_partials, (size_t)std::max(1ll, total_blocks) * PARTIAL_STRIDE * sizeof(float)));
   GA_HIP(pool_malloc(&plan->d_poses, nfa * 24 * sizeof(double)));
   GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
-  GA_HIP(pool_malloc(&plan->d_done, sizeof(int)));
-  GA_HIP(hipMemsetAsync(plan->d_done, 0, sizeof(int), set->stream));
-  GA_HIP(pool_malloc(&plan->d_trip_stats, 64 * sizeof(unsigned long long)));
-  GA_HIP(hipMemsetAsync(plan->d_trip_stats, 0, 64 * sizeof(unsigned long long), set->stream));
-  // single-dispatch form (small synchronous sets only): tagged rows, every tag 0 = "no call yet" (sequence numbers start at 1)
-  if (nf >= 1 && nf <= FUSED_MAX_FACTORS && total_blocks <= FUSED_MAX_ROWS) {
-    GA_HIP(pool_malloc(&plan->d_rows16, (size_t)total_blocks * TAG_ROW_BYTES));
-    GA_HIP(hipMemsetAsync(plan->d_rows16, 0, (size_t)total_blocks * TAG_ROW_BYTES, set->stream));
-    GA_HIP(pool_malloc(&plan->d_finmap, (size_t)nf * sizeof(int)));
+  if (fused_form) {
     const size_t rec_bytes = (size_t)nf * COMPACT * 16;
     if (pinned_malloc(&plan->h_rec16, rec_bytes) == hipSuccess) {
       memset(plan->h_rec16, 0, rec_bytes);
@@ -1388,9 +1402,9 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   // Descriptors and block map go to the device when a launch first needs them THERE (plan_upload): a single-factor set linearised
   // synchronously takes both through the kernel arguments, so the per-frame "new cloud, new map, one factor" pattern of the odometry front
   // end builds its plan without a single transfer.  The host copies live in the plan, so no synchronise is needed either way.
-  if (nf > 1) GA_TRY(plan_upload(set, plan));
   plan->last_stream = set->stream;
   plan->maybe_busy = false;
+  if (nf > 1) GA_TRY(plan_upload(set, plan));
   return GLIM_AMD_OK;
 }
 
