@@ -358,32 +358,34 @@ def run_odometry128k(args, D, api, ctx):
             by_variant[name] = alt.profile_sync(T1, iters=1000) * 1e3
             alt.close()
         ctx.set_diag("")  # (set_diag adds to the current switches: back to the defaults)
-        # what a live (idle) resident session costs everything else on the device: the batched 128-factor kernel timed alone and beside a
-        # session that is kept from idling out for the duration (its 513 blocks hold wave slots and poll)
-        small = api.NonlinearFactorSetGPU(ctx)  # a latency-bound launch: 8 factors of 131 072 points
-        for k in range(8):
-            small.add(api.IntegratedVGICPFactorGPU(k, k + 1, vmaps[k], clouds[k + 1]))
-        Ts = np.ascontiguousarray(deltas[:8])
-        api.resident_stop(ctx)
-        k_alone, _ = fset.profile(pose_sets[0], iters=40)
-        s_alone, _ = small.profile(Ts, iters=200)
-        ctx.set_diag("resident_idle_us=400000")
-        stats0 = api.resident_stats(ctx)
-        for _ in range(8):
-            single.linearize_poses(T1)  # restarts the session with the long idle time
-        stats1 = api.resident_stats(ctx)
-        k_beside, _ = fset.profile(pose_sets[0], iters=40)
-        s_beside, _ = small.profile(Ts, iters=200)
-        stats = api.resident_stats(ctx)
-        log(f"resident session around the interference measurement: {stats0} -> {stats1} -> {stats}")
-        api.resident_stop(ctx)
-        ctx.set_diag("")
-        small.close()
-        resident_cost = {"batched_128_factor_kernel_ms": {"alone": k_alone, "beside_an_idle_session": k_beside, "slowdown": k_beside / k_alone},
-                         "8_factor_kernel_ms": {"alone": s_alone, "beside_an_idle_session": s_beside, "slowdown": s_beside / s_alone},
-                         "session_alive_during_measurement": bool(stats["alive"]),
-                         "session_footprint": "512 worker blocks + 1 finalising / leading block of 256 threads at 125 VGPRs (plane-form plans): 2 of a SIMD's "
-                                              "wave slots and half its registers while the session is alive (it leaves after resident_idle_us = 1 ms without a request)"}
+        resident_cost = None
+        if not args.no_resident_cost:  # (profiling runs skip it: its launches beside the session would be averaged into the dominant kernel's row)
+            # what a live (idle) resident session costs everything else on the device: the batched 128-factor kernel timed alone and beside a
+            # session that is kept from idling out for the duration (its 513 blocks hold wave slots and poll)
+            small = api.NonlinearFactorSetGPU(ctx)  # a latency-bound launch: 8 factors of 131 072 points
+            for k in range(8):
+                small.add(api.IntegratedVGICPFactorGPU(k, k + 1, vmaps[k], clouds[k + 1]))
+            Ts = np.ascontiguousarray(deltas[:8])
+            api.resident_stop(ctx)
+            k_alone, _ = fset.profile(pose_sets[0], iters=40)
+            s_alone, _ = small.profile(Ts, iters=200)
+            ctx.set_diag("resident_idle_us=400000")
+            stats0 = api.resident_stats(ctx)
+            for _ in range(8):
+                single.linearize_poses(T1)  # restarts the session with the long idle time
+            stats1 = api.resident_stats(ctx)
+            k_beside, _ = fset.profile(pose_sets[0], iters=40)
+            s_beside, _ = small.profile(Ts, iters=200)
+            stats = api.resident_stats(ctx)
+            log(f"resident session around the interference measurement: {stats0} -> {stats1} -> {stats}")
+            api.resident_stop(ctx)
+            ctx.set_diag("")
+            small.close()
+            resident_cost = {"batched_128_factor_kernel_ms": {"alone": k_alone, "beside_an_idle_session": k_beside, "slowdown": k_beside / k_alone},
+                             "8_factor_kernel_ms": {"alone": s_alone, "beside_an_idle_session": s_beside, "slowdown": s_beside / s_alone},
+                             "session_alive_during_measurement": bool(stats["alive"]),
+                             "session_footprint": "512 worker blocks + 1 finalising / leading block of 256 threads at 125 VGPRs (plane-form plans): 2 of a SIMD's "
+                                                  "wave slots and half its registers while the session is alive (it leaves after resident_idle_us = 1 ms without a request)"}
         single_loop = {"calls_per_s": 1e3 / sync_ms_c, "us_per_call": sync_ms_c * 1e3, "calls": 1000,
                        "what": "one 131072-pt factor per call, the shipped path: after three launch-per-call linearisations the factor list is served by a "
                                "RESIDENT kernel (pose through a host-mapped mailbox, no launch on the request path; the session idles out after 1 ms); row "
@@ -1277,6 +1279,7 @@ def main():
     ap.add_argument("--submap-frames", type=int, default=4, help="global256: keyframes merged into one submap")
     ap.add_argument("--submap-rings", type=int, default=40)
     ap.add_argument("--submap-azimuths", type=int, default=512)
+    ap.add_argument("--no-resident-cost", action="store_true", help="skip the interference measurement (factor kernels timed beside an idle resident session)")
     ap.add_argument("--no-m2", action="store_true", help="N = 1 default run: skip the 256-submap cost evaluation that is attached as `m2_global256` (~17 s)")
     ap.add_argument("--factors", type=int, default=128, help="odometry128k: factors per GPU per step")
     ap.add_argument("--rings", type=int, default=128)
