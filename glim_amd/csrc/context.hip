@@ -447,7 +447,10 @@ hipError_t pinned_free(void* p) {
   return hipHostFree(p);
 }
 
+void voxelmap_drop_cleared_tables(int device);  // voxelmap.hip: its cache of pre-cleared tables holds pool blocks
+
 void pool_trim(int device) {
+  voxelmap_drop_cleared_tables(device);
   {
     PinnedPool& H = pinned_pool();
     std::vector<void*> blocks;

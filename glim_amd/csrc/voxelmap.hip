@@ -359,7 +359,104 @@ unsigned int next_pow2(unsigned long long v) {
   return (unsigned int)p;
 }
 
+// ---- pre-cleared tables --------------------------------------------------------------------------------------------------------------------
+// A direct build starts with a launch that only writes EMPTY keys and zeros (init_tables_kernel: 3.5 us at 10 000 points, 6.5 us at 131 072,
+// plus a launch boundary) -- a seventh of a map's wall time.  Maps come and go at frame rate (the odometry builds two per frame and drops two
+// when a frame leaves its window) in tables of a few recurring sizes (round_buckets), so a table that a destroyed map hands back is cleared on a
+// side stream at once, together with a matching block of accumulators and counters, and kept for the next map of that size: its build then
+// starts with the keys.  The host takes a table only after it has SEEN the clearing kernel's event complete.
+struct ClearedTable {
+  VoxelBucket* buckets = nullptr;
+  long long* acc = nullptr;
+  int* stats = nullptr;
+  unsigned int nb = 0;
+  hipEvent_t done = nullptr;
+};
+struct ClearedCache {
+  std::mutex mu;
+  std::vector<ClearedTable> tables;
+  hipStream_t stream = nullptr;
+  size_t bytes = 0;
+};
+constexpr size_t CLEARED_MAX_TABLES = 8, CLEARED_MAX_BYTES = 256ull << 20, CLEARED_MAX_TABLE_BYTES = 48ull << 20;
+ClearedCache& cleared_cache(int device) {
+  static ClearedCache* caches = new ClearedCache[64];  // leaked on purpose, like the memory pools
+  return caches[(device >= 0 && device < 64) ? device : 0];
+}
+size_t cleared_bytes(unsigned int nb) { return (size_t)nb * (sizeof(VoxelBucket) + 2 * ACC_STRIDE * sizeof(long long)); }
+
+// the table of a map that is going away (nobody reads it any more: the caller has quiesced the device): cleared for re-use, or back to the pool
+void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
+  ClearedCache& C = cleared_cache(device);
+  const size_t bytes = cleared_bytes(nb);
+  ClearedTable t;
+  bool keep = nb >= 16 && bytes <= CLEARED_MAX_TABLE_BYTES;
+  if (keep) {
+    std::lock_guard<std::mutex> lock(C.mu);
+    keep = C.tables.size() < CLEARED_MAX_TABLES && C.bytes + bytes <= CLEARED_MAX_BYTES;
+    if (keep && !C.stream && hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking) != hipSuccess) keep = false;
+  }
+  if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 2 * sizeof(int)) == hipSuccess &&
+                   hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+  if (keep) {
+    const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
+    init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, C.stream>>>(buckets, nb, (uint4*)t.acc, acc_words, t.stats);
+    keep = hipGetLastError() == hipSuccess && hipEventRecord(t.done, C.stream) == hipSuccess;
+    if (!keep) (void)hipStreamSynchronize(C.stream);
+  }
+  if (!keep) {
+    (void)hipGetLastError();
+    if (t.acc) (void)pool_free(t.acc);
+    if (t.stats) (void)pool_free(t.stats);
+    if (t.done) (void)hipEventDestroy(t.done);
+    (void)pool_free(buckets);
+    return;
+  }
+  t.buckets = buckets;
+  t.nb = nb;
+  std::lock_guard<std::mutex> lock(C.mu);
+  C.tables.push_back(t);
+  C.bytes += bytes;
+}
+
+// a cleared table of exactly nb buckets whose clearing the host has seen finished; false: none (the caller clears one itself)
+bool take_cleared_table(int device, unsigned int nb, ClearedTable* out) {
+  ClearedCache& C = cleared_cache(device);
+  std::lock_guard<std::mutex> lock(C.mu);
+  for (size_t i = 0; i < C.tables.size(); i++) {
+    if (C.tables[i].nb != nb || hipEventQuery(C.tables[i].done) != hipSuccess) continue;
+    *out = C.tables[i];
+    C.tables.erase(C.tables.begin() + (long)i);
+    C.bytes -= cleared_bytes(nb);
+    (void)hipEventDestroy(out->done);
+    out->done = nullptr;
+    return true;
+  }
+  (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error)
+  return false;
+}
+
 }  // namespace
+
+namespace glim_amd {
+// every cached table back to the pool (pool_trim: the device is short of memory)
+void voxelmap_drop_cleared_tables(int device) {
+  ClearedCache& C = cleared_cache(device);
+  std::vector<ClearedTable> all;
+  {
+    std::lock_guard<std::mutex> lock(C.mu);
+    all.swap(C.tables);
+    C.bytes = 0;
+  }
+  if (!all.empty() && C.stream) (void)hipStreamSynchronize(C.stream);
+  for (ClearedTable& t : all) {
+    (void)pool_free(t.buckets);
+    (void)pool_free(t.acc);
+    (void)pool_free(t.stats);
+    (void)hipEventDestroy(t.done);
+  }
+}
+}  // namespace glim_amd
 
 extern "C" {
 
@@ -381,7 +478,10 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
     quiesce_device(m->ctx->device);  // asynchronous factor launches (of any context) may still be reading this table
   }
   global_mutation_epoch()++;  // factor sets re-validate their plans
-  if (m->buckets) (void)pool_free(m->buckets);
+  if (m->buckets) {
+    if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
+    else (void)pool_free(m->buckets);
+  }
   delete m;
   return GLIM_AMD_OK;
 }
@@ -421,16 +521,25 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (want > (1ull << 25)) break;  // the counting path sizes the table from the voxels actually present (few voxels of a huge cloud still fit)
     const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, want));
     VoxelBucket* buckets = nullptr;
-    GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
-    GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
-    GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
+    ClearedTable cleared;
+    const bool have_cleared = take_cleared_table(ctx->device, nb, &cleared);  // (a map of this size went away a moment ago: "pre-cleared tables")
+    if (have_cleared) {
+      buckets = cleared.buckets;
+      acc.p = cleared.acc;
+      stats.p = cleared.stats;
+    } else {
+      GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
+      GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
+      GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
+    }
     // three launches and one synchronise: tables, keys + sums, records (the last one also hands the counters to the host)
     static_assert((2 * ACC_STRIDE * sizeof(long long)) % sizeof(uint4) == 0, "accumulators are cleared in 16-byte words");
     const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
     int *h_view = nullptr, *d_view = nullptr;
     const bool mapped = pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view));
     int h_stats[2] = {0, 0};
-    init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
+    if (!have_cleared)
+      init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
     build_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, m->inv_resolution, buckets, nb, (long long*)acc.p, (int*)stats.p);
     finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr);
     hipError_t e = hipGetLastError();
