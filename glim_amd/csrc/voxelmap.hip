@@ -392,9 +392,24 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
   ClearedTable t;
   bool keep = nb >= 16 && bytes <= CLEARED_MAX_TABLE_BYTES;
   if (keep) {
-    std::lock_guard<std::mutex> lock(C.mu);
-    keep = C.tables.size() < CLEARED_MAX_TABLES && C.bytes + bytes <= CLEARED_MAX_BYTES;
-    if (keep && !C.stream && hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking) != hipSuccess) keep = false;
+    // room is made by the OLDEST tables (sizes nobody has asked for since): a cache full of yesterday's sizes must not keep today's out
+    std::vector<ClearedTable> evicted;
+    {
+      std::lock_guard<std::mutex> lock(C.mu);
+      while (!C.tables.empty() && (C.tables.size() >= CLEARED_MAX_TABLES || C.bytes + bytes > CLEARED_MAX_BYTES)) {
+        evicted.push_back(C.tables.front());
+        C.bytes -= cleared_bytes(C.tables.front().nb);
+        C.tables.erase(C.tables.begin());
+      }
+      if (!C.stream && hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking) != hipSuccess) keep = false;
+    }
+    for (ClearedTable& old : evicted) {
+      (void)hipEventSynchronize(old.done);  // (its clearing kernel was enqueued at least a cache's worth of maps ago)
+      (void)hipEventDestroy(old.done);
+      (void)pool_free(old.buckets);
+      (void)pool_free(old.acc);
+      (void)pool_free(old.stats);
+    }
   }
   if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 2 * sizeof(int)) == hipSuccess &&
                    hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
