@@ -1,6 +1,7 @@
 """CPU-only checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol declared in
 include/glim_amd.h; host-only entry points behave; no compute calls are made (there is no GPU here)."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -131,3 +132,22 @@ def test_committed_traffic_files_were_measured_on_the_current_factor_kernel():
         got = bench.measured_traffic(tag)
         assert got is not None, tag
         assert got[2], f"{got[1]} was measured on another version of the factor kernel ({tag})"
+
+
+def test_committed_rocprof_average_agrees_with_the_bench_line_of_the_same_run():
+    """Evidence hygiene (bench contract: the rocprofv3 --kernel-trace average of the dominant kernel must agree with the live HIP-event figure):
+    the newest profiles/*/summary.json row of the batched factor kernel and the `roofline.kernel_ms` of the bench line taken INSIDE that profiler
+    run (bench_under_rocprof.json) are within 5 % of each other, and the traffic file beside them is the one summarised from the same run."""
+    import glob
+
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r*")) if os.path.exists(os.path.join(d, "summary.json")))
+    assert dirs
+    d = dirs[-1]
+    summary = json.load(open(os.path.join(d, "summary.json")))
+    line = json.load(open(os.path.join(d, "bench_under_rocprof.json")))
+    traffic = json.load(open(os.path.join(d, "traffic.json")))
+    row = summary["kernel_trace_by_grid"][0]  # rows are ordered by total time: the dominant kernel first
+    assert "vgicp_kernel" in row["kernel"] and row["calls"] >= 100
+    live_us = line["roofline"]["kernel_ms"] * 1e3
+    assert abs(row["avg_us"] - live_us) <= 0.05 * live_us, (row["avg_us"], live_us)
+    assert abs(traffic["kernel_avg_us_rocprof"] - row["avg_us"]) < 1e-6
