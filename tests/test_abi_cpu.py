@@ -151,3 +151,19 @@ def test_committed_rocprof_average_agrees_with_the_bench_line_of_the_same_run():
     live_us = line["roofline"]["kernel_ms"] * 1e3
     assert abs(row["avg_us"] - live_us) <= 0.05 * live_us, (row["avg_us"], live_us)
     assert abs(traffic["kernel_avg_us_rocprof"] - row["avg_us"]) < 1e-6
+
+
+def test_every_diagnostic_key_is_documented():
+    """Doc-drift guard: every key glim_amd_ctx_set_diag accepts (context.hip kDiagKeys + knn_debug) is named in the header comment of
+    glim_amd_ctx_set_diag and in DESIGN.md 4.9, and the value words of the enumerated keys are listed there too."""
+    src = open(os.path.join(ROOT, "glim_amd", "csrc", "context.hip")).read()
+    keys = re.findall(r'\{"([a-z_0-9]+)", &Diag::', src) + ["knn_debug"]
+    assert len(keys) >= 20
+    header = open(os.path.join(ROOT, "include", "glim_amd.h")).read()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for k in keys:
+        assert k + "=" in header, f"diag key {k} is not documented in include/glim_amd.h"
+        assert k + "=" in design or f"`{k}`" in design, f"diag key {k} is not documented in DESIGN.md"
+    for words in re.findall(r'k(?:Path|Kernel)Words\[\] = \{([^}]*)\}', src):
+        for w in re.findall(r'"([a-z0-9]+)"', words):
+            assert w in header and w in design, w
