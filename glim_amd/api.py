@@ -70,6 +70,25 @@ class Context:
         """Diagnostic switches of this context ("key=value,key=value"; "" restores the process defaults): include/glim_amd.h."""
         check(lib().glim_amd_ctx_set_diag(self._h, key_values.encode()), "glim_amd_ctx_set_diag")
 
+    def diag(self, key_values=""):
+        """Context manager: the process defaults + `key_values` inside the block, the process defaults again on the way out -- whatever
+        happens inside.  (set_diag ADDS to the switches in force; tests and measurements that flip kernel paths use this instead, so that a
+        failure between two set_diag calls cannot leave a shared context in the wrong mode.)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self.set_diag("")
+            try:
+                if key_values:
+                    self.set_diag(key_values)
+                yield self
+            finally:
+                if self._h:
+                    self.set_diag("")
+
+        return scope()
+
     def get_diag(self):
         buf = C.create_string_buffer(1024)
         check(lib().glim_amd_ctx_get_diag(self._h, buf, 1024), "glim_amd_ctx_get_diag")
@@ -539,6 +558,15 @@ class NonlinearFactorSetGPU:
         check(lib().glim_amd_factor_set_profile_sync(self._h, _dp(T), int(iters), C.byref(a)), "glim_amd_factor_set_profile_sync")
         return a.value
 
+    def linearize_repeat(self, pose_sets, iters):
+        """EXACTLY `iters` synchronous linearize() calls issued from C (no binding overhead, no warm-up, no clock: the caller times it), call i at
+        pose_sets[i % len(pose_sets)]; returns the last call's records (glim_amd_factor_set_linearize_repeat)."""
+        nf = len(self.factors)
+        T = np.ascontiguousarray(np.asarray(pose_sets, dtype=np.float64).reshape(-1, nf, 12))
+        out = (Linearized6 * nf)()
+        check(lib().glim_amd_factor_set_linearize_repeat(self._h, _dp(T), T.shape[0], int(iters), out), "glim_amd_factor_set_linearize_repeat")
+        return [_lin_to_dict(L) for L in out]
+
     def profile_lm(self, T_target_source, iters=20):
         """(ms per synchronous linearize(), ms per synchronous error()) of the whole set, timed inside the library."""
         T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(len(self.factors), 12))
@@ -624,6 +652,18 @@ class MultiDeviceCost:
         k, g = np.zeros(nd, dtype=np.float32), np.zeros(nd, dtype=np.float32)
         check(lib().glim_amd_multi_last_timing(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), g.ctypes.data_as(C.POINTER(C.c_float))), "glim_amd_multi_last_timing")
         return k.tolist(), g.tolist()
+
+    BREAKDOWN_FIELDS = ("post", "wake", "pose_stage", "enqueue", "barrier", "collective", "wait", "join", "scan", "total")
+
+    def last_breakdown(self, device=0):
+        """Host-side account of the last evaluation on one device's thread, microseconds (glim_amd_multi_last_breakdown)."""
+        us = np.zeros(len(self.BREAKDOWN_FIELDS), dtype=np.float64)
+        check(lib().glim_amd_multi_last_breakdown(self._h, int(device), _dp(us), len(us)), "glim_amd_multi_last_breakdown")
+        return dict(zip(self.BREAKDOWN_FIELDS, us.tolist()))
+
+    def set_split(self, mode):
+        """-1: two halves per shard when there is more than one device (default); 0 / 1: forced.  Applies to the next set_factors."""
+        check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
 
     def close(self):
         if self._h:

@@ -305,7 +305,7 @@ int detect_plane_form(glim_amd_cloud* c, hipStream_t st) {
   return GLIM_AMD_OK;
 }
 
-int ensure_factor_streams(glim_amd_cloud* c, hipStream_t st) {
+int ensure_factor_streams(glim_amd_cloud* c, glim_amd_ctx* held, hipStream_t st) {
   if (!c->has_covs || c->n <= 0) return GLIM_AMD_OK;
   // a cloud may be reached from factor sets of several contexts / streams at once (GLIM's modules share frames): one builder, and the streams
   // are COMPLETE before anybody sees their pointers
@@ -313,7 +313,7 @@ int ensure_factor_streams(glim_amd_cloud* c, hipStream_t st) {
   const bool want_plane = c->plane_form && c->normals;
   if (want_plane ? (c->pn4 && c->n2) : (c->gs0 != nullptr)) return GLIM_AMD_OK;
   const int n = (int)c->n;
-  GA_TRY(cloud_curve_rank(c, st));
+  GA_TRY(cloud_curve_rank(c, held, st));
   if (want_plane) {
     if (!c->pn4) GA_HIP(pool_malloc(&c->pn4, (size_t)n * sizeof(float4)));
     if (!c->n2) GA_HIP(pool_malloc(&c->n2, (size_t)n * sizeof(float2)));

@@ -19,6 +19,7 @@ std::atomic<uint64_t>& global_mutation_epoch() {
   return e;
 }
 void quiesce_device(int device) {
+  resident_stop_device(device);  // its workers hold descriptors into memory that is about to be recycled
   std::lock_guard<std::mutex> lock(g_ctx_registry_mu);
   for (glim_amd_ctx* c : g_ctx_registry)
     if (c->device == device) c->quiesce();
@@ -39,6 +40,7 @@ struct DiagKey {
 };
 const char* const kPathWords[] = {"auto", "grid", "chunks", "brute", nullptr};
 const char* const kKernelWords[] = {"auto", "wave64", "pair", "qgroup", nullptr};
+const char* const kResidentWords[] = {"0", "1", "auto", nullptr};
 const DiagKey kDiagKeys[] = {
   {"knn_path", &Diag::knn_path, kPathWords, 0, 3},
   {"knn_kernel", &Diag::knn_kernel, kKernelWords, 0, 3},
@@ -54,7 +56,7 @@ const DiagKey kDiagKeys[] = {
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
   {"fuse", &Diag::fuse, nullptr, 0, 1},
   {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},
-  {"resident", &Diag::resident, nullptr, 0, 1},
+  {"resident", &Diag::resident, kResidentWords, 0, 2},
   {"resident_idle_us", &Diag::resident_idle_us, nullptr, 100, 1000000},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
@@ -233,6 +235,7 @@ int glim_amd_ctx_create_ex(int device, int num_streams, void* external_stream, i
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
   ctx->diag = process_diag();
+  ctx->priority = priority;
   if (external_stream) {
     ctx->owns_streams = false;
     ctx->streams.push_back((hipStream_t)external_stream);
@@ -241,7 +244,6 @@ int glim_amd_ctx_create_ex(int device, int num_streams, void* external_stream, i
     if (num_streams == 0) num_streams = 1;
     int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    ctx->priority = priority;
     for (int i = 0; i < num_streams; i++) {
       hipStream_t s;
       hipError_t e = priority == 0 ? hipStreamCreateWithFlags(&s, hipStreamNonBlocking)

@@ -177,7 +177,7 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->n2) GA_HIP(pool_malloc(&c->n2, nn * sizeof(float2)));
   if (c->n > 0) {
     const int n = (int)c->n;
-    GA_TRY(cloud_curve_rank(c, ctx->stream()));
+    GA_TRY(cloud_curve_rank(c, ctx, ctx->stream()));
     if (c->pts64)
       covariance_kernel<true><<<(n + 255) / 256, 256, 0, ctx->stream()>>>(n, c->pts, c->pts64, c->neighbors, c->k, k_neighbors, c->covA, c->covB, c->normals,
                                                                           c->pn4, c->n2, c->curve_rank);

@@ -53,9 +53,11 @@ struct DeviceTemp {
 };
 
 // Hilbert rank of a cloud's points (knn.hip); no-op when present, tiny, or disabled
-int cloud_curve_rank(::glim_amd_cloud* c, hipStream_t st);
-// factor streams of a cloud that has covariances (cloud.hip); no-op when present.  Caller holds the context mutex.
-int ensure_factor_streams(::glim_amd_cloud* c, hipStream_t st);
+int cloud_curve_rank(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
+// factor streams of a cloud that has covariances (cloud.hip); no-op when present.  `held`: the context whose mutex the caller holds -- its
+// switches and its read-back scratch are the ones used (a cloud may be reached from a factor set of ANOTHER context than its owner's, whose
+// mutex the caller does not hold: ADVICE r4).  Same for cloud_curve_rank.
+int ensure_factor_streams(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
 // plane-form test of a freshly uploaded cloud with covariances and normals (cloud.hip): sets c->plane_form
 int detect_plane_form(::glim_amd_cloud* c, hipStream_t st);
 // Diagnostic / tuning switches.  None is needed in production; they exist for A/B measurements and for the cross-checks of the parity
@@ -74,7 +76,8 @@ struct Diag {
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
-  int resident = 1;       // resident=0|1                       repeated synchronous linearisations of a small set go through a resident kernel (no launch per call)
+  int resident = 2;       // resident=0|1|auto                  repeated synchronous linearisations of a small set go through a resident kernel (no launch per
+                          //                                    call); auto (default): only in a context created with priority 1 (the odometry module's)
   int resident_idle_us = 1000;  // resident_idle_us=<n>         the resident kernel leaves after this long without a request
   int pp_fast = 1;        // pp_fast=0|1                        random-grid preprocessing: one sort + counting ranks, one synchronise (preprocess.hip)
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
@@ -84,6 +87,7 @@ struct Diag {
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
   char knn_debug[256] = "";   // knn_debug=<file>                dump per-wavefront work counters of the 64-query chunk kernel
 };
+enum { RESIDENT_OFF = 0, RESIDENT_ON = 1, RESIDENT_AUTO = 2 };
 enum { KNN_PATH_AUTO = 0, KNN_PATH_GRID = 1, KNN_PATH_CHUNKS = 2, KNN_PATH_BRUTE = 3 };
 enum { KNN_KERNEL_AUTO = 0, KNN_KERNEL_WAVE64 = 1, KNN_KERNEL_PAIR = 2 };
 const Diag& process_diag();                        // GLIM_AMD_DIAG, parsed once
@@ -189,6 +193,7 @@ inline uint64_t next_uid() {
 std::atomic<uint64_t>& global_mutation_epoch();
 // waits for the asynchronous launches of EVERY context of `device` that may still be reading an object which is about to change or die
 void quiesce_device(int device);
+void resident_stop_device(int device);  // vgicp.hip: ends the device's resident session (waits for a request in flight)
 
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
 constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
@@ -233,6 +238,12 @@ struct glim_amd_ctx {
     return s;
   }
 };
+// The resident session (vgicp.hip) holds wave slots and registers on every SIMD while it is alive and costs whatever else runs on the device
+// 1.3-1.4x: it is OPT-IN -- on for a context created with priority 1 (GLIM's odometry thread, adapters/glim/odometry_estimation_hip_create.cpp)
+// or with the switch resident=1, off for every other context (the mapping threads' contexts never start one).
+inline bool resident_enabled(const glim_amd_ctx* c) {
+  return c->diag.resident == glim_amd::RESIDENT_ON || (c->diag.resident == glim_amd::RESIDENT_AUTO && c->priority > 0);
+}
 
 // Back-pointer of a child object to its context that also keeps the context's live-children count: destroying a context that still
 // has children is refused (GLIM_AMD_ERR_STATE) instead of leaving them dangling (SURVEY.md 8b "Ownership").
@@ -384,6 +395,7 @@ struct glim_amd_factor_set {
   FactorPlan* plan = nullptr;    // owned while set; parked in ctx->plan_cache on clear / destroy
   glim_amd::InlineArgs inline_args{};  // single-factor sets: pose + descriptor ride in the kernel arguments
   const double* poses_dev = nullptr;   // where this call's kernels read their poses (the plan's device array, or a host-mapped pinned slot)
+  double last_pose_stage_us = 0.0;     // host time the last call spent copying poses into the pinned ring (glim_amd_multi_last_breakdown)
 };
 
 namespace glim_amd {

@@ -502,7 +502,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   GA_HIP(radix_sort_pairs(st, n, 3 * bits, ka.as<unsigned long long>(), va.as<unsigned int>(), kb.as<unsigned long long>(), vb.as<unsigned int>(), true,
                           hist.as<int>(), &ks, &order));
   const Diag& diag = ctx->diag;
-  if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)C * 4 * sizeof(int)));
+  if (diag.knn_debug[0]) GA_HIP(pool_malloc(&dbg.p, (size_t)std::max(C * 4, 8) * sizeof(int)));  // (the query-group kernel writes 5 counters whatever C)
   // Which kernel answers (all three return identical lists; diag knn_kernel=wave64 / pair / qgroup forces one):
   //  * qgroup (knn_qgroup.hip; the default since round 4): lanes are CANDIDATES, a wavefront answers 1 (clouds below 49 152 points) or 2
   //    consecutive queries -- n or n / 2 short independent work items instead of n / 64 long lock-step chains, so there is no tail and small
@@ -513,7 +513,7 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   //    lasts as long as its slowest wavefront (rocprofv3 + SQ counters, 131 072-pt scan: mean wavefront 157 us, kernel 266 us; 41 % VALU
   //    utilisation).  Kept as independent cross-checks: wave64 from 98 304 points up, pair below (k <= 16), as round 3 shipped them.
   const bool qgroup = k > 0 && (diag.knn_kernel == KNN_KERNEL_QGROUP || diag.knn_kernel == KNN_KERNEL_AUTO);
-  if (qgroup && dbg.p) GA_HIP(hipMemsetAsync(dbg.p, 0, (size_t)C * 4 * sizeof(int), st));
+  if (qgroup && dbg.p) GA_HIP(hipMemsetAsync(dbg.p, 0, (size_t)std::max(C * 4, 8) * sizeof(int), st));
   const bool pair_lanes = !qgroup && !dbg.p && k > 0 && k <= 16 && diag.knn_kernel != KNN_KERNEL_WAVE64 && (n <= 98304 || diag.knn_kernel == KNN_KERNEL_PAIR);
   if (pair_lanes) GA_HIP(pool_malloc(&box32.p, (size_t)C * 2 * 6 * sizeof(float)));
   curve_gather_kernel<<<(C * CHUNK + 255) / 256, 256, 0, st>>>(n, C, pts, order, sorted.as<float4>(), box.as<float>(), box32.as<float>(), rank);
@@ -560,14 +560,14 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
 namespace glim_amd {
 
 // Hilbert rank of every point of a cloud that has none yet (clouds whose neighbours came from the host or from the grid path).
-// Caller holds ctx->mu.  Clouds with non-finite points simply stay in arrival order, and so do clouds below 32 768 points: sorting a cloud
+// Caller holds held->mu (the cloud's owner may be another context: its mutex is NOT held, so nothing of c->ctx is touched here).  Clouds with non-finite points simply stay in arrival order, and so do clouds below 32 768 points: sorting a cloud
 // ONLY for its rank costs 70 us at 10 000 points, which GLIM's odometry would pay for every frame (the frame arrives with CPU covariances,
 // so no kNN runs here whose by-product the rank would be) to gain 0.5 us per 34-factor linearisation
 // (`bench.py --workload odometry_frame`, create_frame_us.factor_streams_on_first_use: 115 -> 44 us).
-int cloud_curve_rank(glim_amd_cloud* c, hipStream_t st) {
-  if (c->curve_rank || c->n < 32768 || c->n > (int64_t)(1 << 28) || !c->ctx->diag.curve_order) return GLIM_AMD_OK;
+int cloud_curve_rank(glim_amd_cloud* c, glim_amd_ctx* held, hipStream_t st) {
+  if (c->curve_rank || c->n < 32768 || c->n > (int64_t)(1 << 28) || !held->diag.curve_order) return GLIM_AMD_OK;
   GA_HIP(pool_malloc(&c->curve_rank, (size_t)c->n * sizeof(unsigned int)));
-  const int rc = knn_curve(c->ctx, st, (int)c->n, c->pts, 0, nullptr, c->curve_rank);
+  const int rc = knn_curve(held, st, (int)c->n, c->pts, 0, nullptr, c->curve_rank);
   if (rc != GLIM_AMD_OK) {
     (void)pool_free(c->curve_rank);
     c->curve_rank = nullptr;

@@ -22,6 +22,7 @@ typedef enum { ncclDouble = 8 } ncclDataType_t;
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -62,16 +63,45 @@ RcclApi& rccl() {
   return api;
 }
 
+// A device's host thread.  Tasks are posted under the mutex; the thread SPINS on `posted` for a while after each task before it goes to
+// sleep on the condition variable: back-to-back evaluations (an optimiser's relinearisations, 1-10 ms apart) then never pay a futex
+// wake-up (30-60 us on these hosts, twice per evaluation in round 4's form), while an idle handle costs no CPU.
 struct Worker {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
   std::function<int()> task;
-  bool has_task = false, done = false, quit = false;
+  std::atomic<uint32_t> posted{0}, finished{0};
+  bool quit = false;
   int rc = 0;
 };
+constexpr int WORKER_SPIN_US = 3000;
+
+inline double us_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+inline void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
 
 }  // namespace
+
+// host-side account of one evaluation on one device's thread (microseconds); glim_amd_multi_last_breakdown
+enum {
+  BD_POST = 0,        // caller: handing the evaluation to the other devices' threads
+  BD_WAKE,            // this thread: from the caller's entry to the start of its task (0 for the caller's own device)
+  BD_POSE_STAGE,      // poses of this shard copied into the plan's pinned ring (both halves)
+  BD_ENQUEUE,         // plan check + H2D pose copy + kernel launches (both halves), pose staging excluded
+  BD_BARRIER,         // waiting until EVERY device has enqueued its kernels (a collective must not start otherwise)
+  BD_COLLECTIVE,      // ncclAllGather calls + copy-out enqueue
+  BD_WAIT,            // hipStreamSynchronize: the device working
+  BD_JOIN,            // caller: waiting for the other devices' threads after its own device is done
+  BD_SCAN,            // caller: total error + expansion of the records in factor order
+  BD_TOTAL,           // caller: the whole call
+  BD_FIELDS
+};
 
 struct glim_amd_multi {
   int ndev = 0;
@@ -79,37 +109,63 @@ struct glim_amd_multi {
   std::vector<glim_amd_ctx*> ctxs;
   std::vector<std::vector<glim_amd_cloud*>> clouds;   // [device][cloud id]
   std::vector<std::vector<glim_amd_voxelmap*>> maps;  // [device][map id]
-  std::vector<glim_amd_factor_set*> sets;             // [device]
+  std::vector<glim_amd_factor_set*> sets;             // [device * 2 + half]: a device's shard as one or two factor sets
   std::vector<int64_t> bounds;                        // ndev + 1: device d owns factors [bounds[d], bounds[d + 1])
   std::vector<uint32_t> flags;
   int64_t nf = 0, max_rows = 0;
+  // The gathered array holds two regions: rows [0, ndev * half_rows) = first halves of every shard (device d at d * half_rows), then
+  // ndev * (max_rows - half_rows) rows of second halves.  Unsplit: half_rows == max_rows and the second region is empty.
+  int64_t half_rows = 0;
+  int split_mode = -1;            // -1: split when more than one device; 0 / 1: forced (glim_amd_multi_set_split)
   std::vector<double*> d_gather;  // [device]: ndev x max_rows x COMPACT
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
   bool use_rccl = false;
   bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
-  std::vector<Worker*> workers;
-  // HIP events per device around the two phases of the LAST evaluation (kernels, then collective + copy-out): glim_amd_multi_last_timing
-  std::vector<hipEvent_t> ev;  // 3 per device: start, kernels enqueued-and-done boundary, end
+  std::mutex abort_mu;
+  std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
+  std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next half run beside it)
+  std::vector<hipEvent_t> half_ev;   // [device * 2 + half]: "this half's records are written", recorded on the factor sets' stream
+  // HIP events per device around the two phases of the LAST evaluation (kernels, then what is left of collective + copy-out): glim_amd_multi_last_timing
+  std::vector<hipEvent_t> ev;  // 3 per device: start (sets' stream), kernels done (sets' stream), end (collective stream)
   std::vector<float> kernel_ms, gather_ms;
+  std::vector<double> breakdown;  // [device][BD_FIELDS]
+  // host barrier of one evaluation: every device's thread arrives after it has enqueued its kernels
+  std::atomic<uint64_t> arrived{0};
+  std::atomic<int> failed{0};
+  uint64_t generation = 0;
 
-  // run fn(device index) on every device's worker thread concurrently; first non-zero return code wins
-  int run_all(const std::function<int(int)>& fn) {
-    for (int d = 0; d < ndev; d++) {
+  int64_t row_of(int d, int64_t k) const {  // row of the k-th factor of device d's shard in the gathered array
+    return k < half_rows ? (int64_t)d * half_rows + k : (int64_t)ndev * half_rows + (int64_t)d * (max_rows - half_rows) + (k - half_rows);
+  }
+
+  // run fn(device index) on every device concurrently -- device 0 on the calling thread -- ; first non-zero return code wins
+  int run_all(const std::function<int(int)>& fn, double* post_us = nullptr, double* join_us = nullptr) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint32_t> ticket((size_t)ndev, 0u);
+    for (int d = 1; d < ndev; d++) {
       Worker* w = workers[d];
       std::lock_guard<std::mutex> lock(w->mu);
       w->task = [fn, d] { return fn(d); };
-      w->has_task = true;
-      w->done = false;
-      w->cv.notify_all();
+      ticket[(size_t)d] = w->posted.load(std::memory_order_relaxed) + 1;
+      w->posted.store(ticket[(size_t)d], std::memory_order_release);
+      w->cv.notify_one();
     }
-    int rc = GLIM_AMD_OK;
-    for (int d = 0; d < ndev; d++) {
+    if (post_us) *post_us = us_since(t0);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    int rc = fn(0);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int d = 1; d < ndev; d++) {
       Worker* w = workers[d];
-      std::unique_lock<std::mutex> lock(w->mu);
-      w->cv.wait(lock, [w] { return w->done; });
+      for (unsigned long spins = 0; w->finished.load(std::memory_order_acquire) != ticket[(size_t)d]; spins++) {
+        if (spins < 200000) relax();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
       if (rc == GLIM_AMD_OK && w->rc != GLIM_AMD_OK) rc = w->rc;
     }
+    if (join_us) *join_us = us_since(t1);
     return rc;
   }
 };
@@ -118,22 +174,24 @@ namespace {
 
 void worker_loop(Worker* w, int device) {
   (void)hipSetDevice(device);
+  uint32_t seen = 0;
   for (;;) {
+    // spin first (see Worker), then sleep
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0; w->posted.load(std::memory_order_acquire) == seen; spins++) {
+      relax();
+      if ((spins & 0xff) == 0xff && us_since(t0) > WORKER_SPIN_US) break;
+    }
     std::function<int()> task;
     {
       std::unique_lock<std::mutex> lock(w->mu);
-      w->cv.wait(lock, [w] { return w->has_task || w->quit; });
+      w->cv.wait(lock, [&] { return w->posted.load(std::memory_order_relaxed) != seen || w->quit; });
       if (w->quit) return;
+      seen = w->posted.load(std::memory_order_relaxed);
       task = std::move(w->task);
-      w->has_task = false;
     }
-    const int rc = task();
-    {
-      std::lock_guard<std::mutex> lock(w->mu);
-      w->rc = rc;
-      w->done = true;
-      w->cv.notify_all();
-    }
+    w->rc = task();
+    w->finished.store(seen, std::memory_order_release);
   }
 }
 
@@ -141,14 +199,29 @@ void release_factors(glim_amd_multi* m) {
   for (int d = 0; d < m->ndev; d++) {
     (void)hipSetDevice(m->devices[d]);
     if (d < (int)m->ctxs.size() && m->ctxs[d]) (void)glim_amd_ctx_synchronize(m->ctxs[d]);  // asynchronous linearisations write into d_gather
-    if (d < (int)m->sets.size() && m->sets[d]) (void)glim_amd_factor_set_destroy(m->sets[d]);
+    if (d < (int)m->cstream.size() && m->cstream[d]) (void)hipStreamSynchronize(m->cstream[d]);
+    for (int h = 0; h < 2; h++)
+      if ((size_t)(2 * d + h) < m->sets.size() && m->sets[2 * d + h]) (void)glim_amd_factor_set_destroy(m->sets[2 * d + h]);
     if (d < (int)m->d_gather.size() && m->d_gather[d]) (void)pool_free(m->d_gather[d]);
   }
-  m->sets.assign(m->ndev, nullptr);
+  m->sets.assign((size_t)2 * m->ndev, nullptr);
   m->d_gather.assign(m->ndev, nullptr);
   if (m->h_gather) (void)pinned_free(m->h_gather);
   m->h_gather = nullptr;
-  m->nf = m->max_rows = 0;
+  m->nf = m->max_rows = m->half_rows = 0;
+}
+
+// A device failed before or inside its ncclAllGather: the others would wait in theirs for ever.  Abort every communicator (their kernels
+// leave, their streams drain) and retire the handle -- a communicator cannot be used after an abort.  Any device's thread may call it.
+void abort_collectives(glim_amd_multi* m) {
+  std::lock_guard<std::mutex> lock(m->abort_mu);
+  if (m->broken || !m->use_rccl || !rccl().CommAbort) return;
+  for (auto& c : m->comms)
+    if (c) {
+      (void)rccl().CommAbort(c);
+      c = nullptr;
+    }
+  m->broken = true;
 }
 
 }  // namespace
@@ -192,8 +265,9 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->devices.assign(devices, devices + num_devices);
   m->clouds.resize(num_devices);
   m->maps.resize(num_devices);
-  m->sets.assign(num_devices, nullptr);
+  m->sets.assign((size_t)2 * num_devices, nullptr);
   m->d_gather.assign(num_devices, nullptr);
+  m->breakdown.assign((size_t)num_devices * BD_FIELDS, 0.0);
   for (int d = 0; d < num_devices; d++) {
     glim_amd_ctx* ctx = nullptr;
     const int rc = glim_amd_ctx_create(devices[d], 1, nullptr, &ctx);
@@ -224,13 +298,31 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
       }
     }
   }
-  for (int d = 0; d < num_devices; d++) {
+  m->workers.assign(num_devices, nullptr);
+  for (int d = 1; d < num_devices; d++) {  // (device 0 is driven by the calling thread)
     Worker* w = new Worker();
     w->th = std::thread(worker_loop, w, devices[d]);
-    m->workers.push_back(w);
+    m->workers[d] = w;
   }
   m->kernel_ms.assign(num_devices, 0.f);
   m->gather_ms.assign(num_devices, 0.f);
+  m->cstream.assign(num_devices, nullptr);
+  m->half_ev.assign((size_t)2 * num_devices, nullptr);
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
+  bool streams_ok = true;
+  for (int d = 0; d < num_devices; d++) {
+    (void)hipSetDevice(devices[d]);
+    if (hipStreamCreateWithFlags(&m->cstream[d], hipStreamNonBlocking) != hipSuccess) streams_ok = false;
+    for (int h = 0; h < 2; h++)
+      if (hipEventCreateWithFlags(&m->half_ev[2 * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+  }
+  if (!streams_ok) {
+    set_hip_error(hipGetLastError(), "glim_amd_multi_create: collective streams / events");
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    (void)glim_amd_multi_destroy(m);
+    return GLIM_AMD_ERR_HIP;
+  }
   for (int d = 0; d < num_devices; d++) {
     (void)hipSetDevice(devices[d]);
     for (int e = 0; e < 3; e++) {
@@ -249,6 +341,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
       m->ev.clear();
       break;
     }
+  if (prev_device >= 0) (void)hipSetDevice(prev_device);
   *out = m;
   return GLIM_AMD_OK;
 }
@@ -269,15 +362,24 @@ int glim_amd_multi_destroy(glim_amd_multi* m) {
     if (e) (void)hipEventDestroy(e);
   m->ev.clear();
   for (Worker* w : m->workers) {
+    if (!w) continue;
     {
       std::lock_guard<std::mutex> lock(w->mu);
       w->quit = true;
+      w->posted.fetch_add(1, std::memory_order_release);  // (ends the spin phase)
       w->cv.notify_all();
     }
     w->th.join();
     delete w;
   }
+  m->workers.clear();
   release_factors(m);
+  for (int d = 0; d < m->ndev; d++) {
+    (void)hipSetDevice(m->devices[d]);
+    if (d < (int)m->cstream.size() && m->cstream[d]) (void)hipStreamDestroy(m->cstream[d]);
+    for (int h = 0; h < 2; h++)
+      if ((size_t)(2 * d + h) < m->half_ev.size() && m->half_ev[2 * d + h]) (void)hipEventDestroy(m->half_ev[2 * d + h]);
+  }
   for (int d = 0; d < m->ndev; d++) {
     (void)hipSetDevice(m->devices[d]);
     for (auto v : m->maps[d]) (void)glim_amd_voxelmap_destroy(v);
@@ -366,6 +468,11 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   GA_TRY(glim_amd_shard_bounds(costs.data(), num_factors, m->ndev, bounds.data()));
   int64_t max_rows = 1;
   for (int d = 0; d < m->ndev; d++) max_rows = std::max<int64_t>(max_rows, bounds[(size_t)d + 1] - bounds[(size_t)d]);
+  // Two halves per shard when the records travel between devices: the all-gather of the first halves (the collective's stream) runs beside
+  // the kernels of the second halves (glim_amd/multi.py `gather_device_halves` is the same exchange for one process per GPU).  On one
+  // device there is nothing to hide and two shorter launches only add a second launch tail.
+  const bool split = (m->split_mode < 0 ? m->ndev > 1 : m->split_mode != 0) && max_rows >= 2;
+  const int64_t half_rows = split ? (max_rows + 1) / 2 : max_rows;
   const size_t gather_doubles = (size_t)m->ndev * (size_t)max_rows * COMPACT;
   if (pinned_malloc(&m->h_gather, gather_doubles * sizeof(double)) != hipSuccess) {
     (void)hipGetLastError();
@@ -377,11 +484,17 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   for (int64_t f = 0; f < num_factors; f++) m->flags[(size_t)f] = flags ? flags[f] : 0u;
   m->nf = num_factors;
   m->max_rows = max_rows;
+  m->half_rows = half_rows;
   const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
-    GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[d]));
-    for (int64_t f = m->bounds[d]; f < m->bounds[d + 1]; f++)
-      GA_TRY(glim_amd_factor_set_add(m->sets[d], m->maps[d][target_map_ids[f]], m->clouds[d][source_cloud_ids[f]], m->flags[(size_t)f], nullptr));
+    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1], mid = std::min(lo + half_rows, hi);
+    for (int h = 0; h < 2; h++) {
+      const int64_t f0 = h ? mid : lo, f1 = h ? hi : mid;
+      if (f1 <= f0) continue;
+      GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[2 * d + h]));
+      for (int64_t f = f0; f < f1; f++)
+        GA_TRY(glim_amd_factor_set_add(m->sets[2 * d + h], m->maps[d][target_map_ids[f]], m->clouds[d][source_cloud_ids[f]], m->flags[(size_t)f], nullptr));
+    }
     GA_HIP(pool_malloc(&m->d_gather[d], gather_doubles * sizeof(double)));
     GA_HIP(hipMemsetAsync(m->d_gather[d], 0, gather_doubles * sizeof(double), m->ctxs[d]->stream()));
     GA_HIP(hipStreamSynchronize(m->ctxs[d]->stream()));
@@ -396,6 +509,12 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   return rc;
 }
 
+int glim_amd_multi_set_split(glim_amd_multi* m, int32_t mode) {
+  if (!m || mode < -1 || mode > 1) return GLIM_AMD_ERR_INVALID;
+  m->split_mode = mode;  // takes effect with the next glim_amd_multi_set_factors
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
   if (!m || !bounds || m->bounds.empty()) return GLIM_AMD_ERR_INVALID;
   for (int d = 0; d <= m->ndev; d++) bounds[d] = m->bounds[d];
@@ -403,6 +522,16 @@ int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
 }
 
 // One evaluation of the whole cost: H / b / error of every factor at T_target_source (n x 12), records in the original factor order.
+//
+// ONE hand-over per evaluation (round 4 handed the devices' threads two tasks -- enqueue, then collective -- and woke them through a
+// condition variable each time; the driver's box showed 2.2 ms of host time per evaluation nobody could name).  Every device's thread -- the
+// caller's own for device 0 -- now runs the whole sequence:
+//   poses of half A -> pinned ring -> H2D, kernels of half A, event A        (the factor sets' stream)
+//   the same for half B, event B                                            (pose staging of B overlaps the kernels of A)
+//   host barrier: has EVERY device enqueued its kernels?                     (a device that failed must keep the others out of the collective)
+//   ncclAllGather of the first halves behind event A, of the second halves behind event B, copy-out on device 0     (the collective's stream)
+//   one synchronise.
+// The host barrier costs no device time: the kernels are running while the threads meet.  glim_amd_multi_last_breakdown names every phase.
 int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linearized6* out, double* total_error) {
   if (!m) return GLIM_AMD_ERR_INVALID;
   if (m->nf == 0) {
@@ -411,63 +540,131 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   }
   if (!T) return GLIM_AMD_ERR_INVALID;
   if (m->broken) return GLIM_AMD_ERR_STATE;
-  const size_t slot = (size_t)m->max_rows * COMPACT;
-  // Two rounds over the workers: the kernels are enqueued first and the collective only if EVERY device managed to -- a device that failed
-  // before its ncclAllGather would leave the others waiting in theirs for ever.  (The first round only enqueues; the extra hand-over between
-  // the host threads costs ~20 us per evaluation.)
-  GA_TRY(m->run_all([&](int d) -> int {
-    GA_HIP(hipSetDevice(m->devices[d]));
-    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
-    hipStream_t st = m->ctxs[d]->stream();
-    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d], st));
-    if (hi > lo) GA_TRY(glim_amd_factor_set_linearize_device_async(m->sets[d], T + 12 * lo, m->d_gather[d], (int64_t)d * m->max_rows));
-    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d + 1], st));
-    return (int)GLIM_AMD_OK;
-  }));
-  const int rc = m->run_all([&](int d) -> int {
-    GA_HIP(hipSetDevice(m->devices[d]));
-    hipStream_t st = m->ctxs[d]->stream();
-    if (m->use_rccl) {
-      // in place: this device's slot is both the send buffer and its own segment of the receive buffer
-      const ncclResult_t r = rccl().AllGather(m->d_gather[d] + (size_t)d * slot, m->d_gather[d], slot, ncclDouble, m->comms[d], st);
-      if (r != ncclSuccess) {
-        set_hip_error(hipErrorUnknown, "ncclAllGather");
+  const auto t_call = std::chrono::steady_clock::now();
+  const int ndev = m->ndev;
+  const int64_t hA = m->half_rows, hB = m->max_rows - m->half_rows;
+  const size_t regionB = (size_t)ndev * (size_t)hA * COMPACT;  // first double of the second region
+  const bool timed = m->ev.size() == (size_t)3 * ndev;
+  m->generation += 1;
+  const uint64_t all_arrived = m->generation * (uint64_t)ndev;
+  m->failed.store(0);
+  std::fill(m->breakdown.begin(), m->breakdown.end(), 0.0);
+  double post_us = 0.0, join_us = 0.0;
+  const int rc = m->run_all(
+    [&](int d) -> int {
+      double* bd = &m->breakdown[(size_t)d * BD_FIELDS];
+      bd[BD_WAKE] = d ? us_since(t_call) : 0.0;
+      int rc_d = GLIM_AMD_OK;
+      hipStream_t sst = nullptr;  // the factor sets' stream
+      auto enqueue_kernels = [&]() -> int {
+        GA_HIP(hipSetDevice(m->devices[d]));
+        const int64_t lo = m->bounds[d], hi = m->bounds[d + 1], mid = std::min(lo + hA, hi);
+        glim_amd_factor_set* first = m->sets[2 * d] ? m->sets[2 * d] : m->sets[2 * d + 1];
+        sst = first ? first->stream : m->ctxs[d]->stream();
+        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d], sst));
+        for (int h = 0; h < 2; h++) {
+          glim_amd_factor_set* set = m->sets[2 * d + h];
+          const int64_t f0 = h ? mid : lo;
+          if (set) {
+            const auto t0 = std::chrono::steady_clock::now();
+            GA_TRY(glim_amd_factor_set_linearize_device_async(set, T + 12 * f0, m->d_gather[d], m->row_of(d, f0 - lo)));
+            bd[BD_POSE_STAGE] += set->last_pose_stage_us;
+            bd[BD_ENQUEUE] += us_since(t0) - set->last_pose_stage_us;
+          }
+          GA_HIP(hipEventRecord(m->half_ev[2 * d + h], set ? set->stream : sst));
+        }
+        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 1], m->sets[2 * d + 1] ? m->sets[2 * d + 1]->stream : sst));
+        return (int)GLIM_AMD_OK;
+      };
+      rc_d = enqueue_kernels();
+      if (rc_d != GLIM_AMD_OK) {
+        int none = 0;
+        (void)m->failed.compare_exchange_strong(none, rc_d);  // the first failure's own code is what every device reports
+      }
+      // ---- every device has enqueued (or one has failed: then nobody starts a collective) ----
+      const auto t_bar = std::chrono::steady_clock::now();
+      m->arrived.fetch_add(1, std::memory_order_acq_rel);
+      for (unsigned long spins = 0; m->arrived.load(std::memory_order_acquire) < all_arrived; spins++) {
+        if (spins < 100000) relax();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      bd[BD_BARRIER] = us_since(t_bar);
+      if (m->failed.load()) {
+        if (sst) (void)hipStreamSynchronize(sst);  // what this device did enqueue must not outlive the call
+        return rc_d != GLIM_AMD_OK ? rc_d : m->failed.load();
+      }
+      // ---- collective + copy-out on the collective's stream ----
+      const auto t_col = std::chrono::steady_clock::now();
+      hipStream_t cst = m->cstream[d];
+      auto collective = [&]() -> int {
+        for (int h = 0; h < 2; h++) {
+          const int64_t rows = h ? hB : hA;
+          if (rows == 0) continue;
+          double* region = m->d_gather[d] + (h ? regionB : 0);
+          const size_t slot = (size_t)rows * COMPACT;
+          GA_HIP(hipStreamWaitEvent(cst, m->half_ev[2 * d + h], 0));
+          if (m->use_rccl) {
+            // in place: this device's slot is both the send buffer and its own segment of the receive buffer
+            const ncclResult_t r = rccl().AllGather(region + (size_t)d * slot, region, slot, ncclDouble, m->comms[d], cst);
+            if (r != ncclSuccess) {
+              set_hip_error(hipErrorUnknown, "ncclAllGather");
+              return (int)GLIM_AMD_ERR_HIP;
+            }
+            if (d == 0)
+              GA_HIP(hipMemcpyAsync(m->h_gather + (h ? regionB : 0), region, (size_t)ndev * slot * sizeof(double), hipMemcpyDeviceToHost, cst));
+          } else {
+            // no collective library: every device hands its own slot to the host (PCIe); single-device and explicitly allowed setups only
+            GA_HIP(hipMemcpyAsync(m->h_gather + (h ? regionB : 0) + (size_t)d * slot, region + (size_t)d * slot, slot * sizeof(double),
+                                  hipMemcpyDeviceToHost, cst));
+          }
+        }
+        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 2], cst));
+        return (int)GLIM_AMD_OK;
+      };
+      rc_d = collective();
+      bd[BD_COLLECTIVE] = us_since(t_col);
+      if (rc_d != GLIM_AMD_OK) {
+        abort_collectives(m);  // the others are inside (or about to enter) their ncclAllGather
+        return rc_d;
+      }
+      const auto t_wait = std::chrono::steady_clock::now();
+      const hipError_t e = hipStreamSynchronize(cst);
+      bd[BD_WAIT] = us_since(t_wait);
+      if (e != hipSuccess) {
+        set_hip_error(e, "glim_amd_multi_linearize: synchronise");
+        abort_collectives(m);
         return (int)GLIM_AMD_ERR_HIP;
       }
-      if (d == 0) GA_HIP(hipMemcpyAsync(m->h_gather, m->d_gather[0], (size_t)m->ndev * slot * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else {
-      // no collective library: every device hands its own slot to the host (PCIe); single-device and explicitly allowed setups only
-      GA_HIP(hipMemcpyAsync(m->h_gather + (size_t)d * slot, m->d_gather[d] + (size_t)d * slot, slot * sizeof(double), hipMemcpyDeviceToHost, st));
-    }
-    if (m->ev.size() == (size_t)3 * m->ndev) GA_HIP(hipEventRecord(m->ev[3 * d + 2], st));
-    GA_HIP(hipStreamSynchronize(st));
-    if (m->ev.size() == (size_t)3 * m->ndev) {
-      (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[3 * d], m->ev[3 * d + 1]);
-      (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[3 * d + 1], m->ev[3 * d + 2]);
-    }
-    return (int)GLIM_AMD_OK;
-  });
-  if (rc != GLIM_AMD_OK) {
-    // A device that failed before or inside its ncclAllGather leaves the others blocked in theirs: abort every communicator so that their
-    // streams drain, and retire the handle (a communicator cannot be used after an abort).
-    if (m->use_rccl && rccl().CommAbort) {
-      for (auto& c : m->comms)
-        if (c) {
-          (void)rccl().CommAbort(c);
-          c = nullptr;
-        }
-      m->broken = true;
-    }
-    return rc;
-  }
+      if (timed) {
+        (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[3 * d], m->ev[3 * d + 1]);
+        (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[3 * d + 1], m->ev[3 * d + 2]);
+      }
+      return (int)GLIM_AMD_OK;
+    },
+    &post_us, &join_us);
+  double* bd0 = &m->breakdown[0];
+  bd0[BD_POST] = post_us;
+  bd0[BD_JOIN] = join_us;
+  if (rc != GLIM_AMD_OK) return rc;
+  const auto t_scan = std::chrono::steady_clock::now();
   double total = 0.0;
-  for (int d = 0; d < m->ndev; d++)
-    for (int64_t f = m->bounds[d]; f < m->bounds[d + 1]; f++) {
-      const double* rec = m->h_gather + (size_t)d * slot + (size_t)(f - m->bounds[d]) * COMPACT;
+  for (int d = 0; d < ndev; d++) {
+    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
+    for (int64_t f = lo; f < hi; f++) {
+      const double* rec = m->h_gather + (size_t)m->row_of(d, f - lo) * COMPACT;
       total += rec[1];
       if (out) glim_amd_expand_compact(rec, T + 12 * f, m->flags[(size_t)f], &out[f]);
     }
+  }
   if (total_error) *total_error = total;
+  bd0[BD_SCAN] = us_since(t_scan);
+  bd0[BD_TOTAL] = us_since(t_call);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_last_breakdown(const glim_amd_multi* m, int32_t device, double* us, int32_t num_fields) {
+  if (!m || !us || device < 0 || device >= m->ndev || num_fields <= 0) return GLIM_AMD_ERR_INVALID;
+  for (int i = 0; i < num_fields; i++) us[i] = i < BD_FIELDS ? m->breakdown[(size_t)device * BD_FIELDS + i] : 0.0;
   return GLIM_AMD_OK;
 }
 

@@ -28,6 +28,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 #include <unordered_map>
 
 #include "device_math.hpp"
@@ -1216,11 +1217,11 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     if (!allow_plane && src->plane_form && !src->gs0) {
       // diagnostic switch: run a plane-form cloud through the general kernel (its covariance arrays hold the same matrix)
       src->plane_form = false;
-      const int rc = ensure_factor_streams(src, set->stream);
+      const int rc = ensure_factor_streams(src, ctx, set->stream);
       src->plane_form = true;
       GA_TRY(rc);
     } else {
-      GA_TRY(ensure_factor_streams(src, set->stream));
+      GA_TRY(ensure_factor_streams(src, ctx, set->stream));
     }
     FactorDesc& d = plan->h_descs[f];
     d.pts = src->pts;
@@ -1558,16 +1559,23 @@ bool collect_tagged_records(FactorPlan* plan, size_t nf, unsigned int seq, const
   return true;
 }
 
+// the record of a factor whose finalising block gave up on a row (fused_finalize: NaN sums): its count slot is NaN, which no real result is
+bool records_lost(const FactorPlan* plan, size_t nf) {
+  for (size_t f = 0; f < nf; f++)
+    if (std::isnan(plan->h_compact[f * COMPACT])) return true;
+  return false;
+}
+
 // enqueue (no sync): poses already on the device / in the inline arguments; writes compact records to `out` rows [row_offset, row_offset + n).
 // Two or three launches: the fused kernel per plan segment + the FP64 finalise.
-int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll) {
+int enqueue(glim_amd_factor_set* set, int mode, bool frozen, double* out, long long row_offset, bool poll, bool allow_fused = true) {
   const int nf = (int)set->entries.size();
   if (nf == 0) return GLIM_AMD_OK;
   FactorPlan* plan = set->plan;
   if (!set->inline_args.valid) GA_TRY(plan_upload(set, plan));  // (the inline kernels read pose and descriptor from their arguments)
   FinalizeArgs fa = finalize_args(set, out, row_offset, poll);
   // small synchronous sets whose completion the host polls: ONE dispatch per segment, the factors are finalised inside it
-  const bool fused = use_single_dispatch(set, poll);
+  const bool fused = allow_fused && use_single_dispatch(set, poll);
   if (fused) fa.rec16 = plan->h_rec16_dev;
   launch_vgicp(set, mode, frozen, fa, plan->d_partials, fused);
   if (fused) {
@@ -1602,8 +1610,10 @@ int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_
     plan->pose_pending[slot] = false;
   }
   double* h = plan->h_poses + (size_t)slot * plan->cap_factors * 24;
+  const auto t_stage = std::chrono::steady_clock::now();
   memcpy(h, T_lin, nf * 12 * sizeof(double));
   if (T_eval) memcpy(h + nf * 12, T_eval, nf * 12 * sizeof(double));
+  set->last_pose_stage_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stage).count();
   if (!async_call && plan->h_poses_dev && nf <= HOST_POSES_MAX && set->ctx->diag.host_poses) {
     // small synchronous set: the kernels read the poses straight from this pinned slot (the call returns only after they have run)
     set->poses_dev = plan->h_poses_dev + (size_t)slot * plan->cap_factors * 24;
@@ -1692,14 +1702,31 @@ void resident_stop(ResidentSession& S) {
 int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* plan) {
   glim_amd_ctx* ctx = set->ctx;
   if (!S.stream) GA_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  // every resource on its own test: a failure half way leaves the rest to the next attempt instead of a kernel launched with null pointers
+  // (ADVICE r4).  Any failure here is "this call takes the launch-per-call path" to the caller.
+  auto unsupported = [](hipError_t e) {
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e != hipSuccess;
+  };
   if (!S.h_mail) {
-    GA_HIP(pinned_malloc(&S.h_mail, 256));
+    if (unsupported(pinned_malloc(&S.h_mail, 256))) {
+      S.h_mail = nullptr;
+      return GLIM_AMD_ERR_UNSUPPORTED;
+    }
     memset(S.h_mail, 0, 256);
-    if (!host_device_view(S.h_mail, &S.h_mail_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
-    GA_HIP(pinned_malloc(&S.h_lines, (size_t)RESIDENT_MAX_LINES * 64));
+  }
+  if (!S.h_mail_dev && !host_device_view(S.h_mail, &S.h_mail_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
+  if (!S.h_lines) {
+    if (unsupported(pinned_malloc(&S.h_lines, (size_t)RESIDENT_MAX_LINES * 64))) {
+      S.h_lines = nullptr;
+      return GLIM_AMD_ERR_UNSUPPORTED;
+    }
     memset(S.h_lines, 0, (size_t)RESIDENT_MAX_LINES * 64);
-    if (!host_device_view(S.h_lines, &S.h_lines_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
-    GA_HIP(pool_malloc(&S.d_pose16, RESIDENT_POSE16_BYTES));
+  }
+  if (!S.h_lines_dev && !host_device_view(S.h_lines, &S.h_lines_dev)) return GLIM_AMD_ERR_UNSUPPORTED;
+  if (!S.d_pose16 && unsupported(pool_malloc(&S.d_pose16, RESIDENT_POSE16_BYTES))) {
+    S.d_pose16 = nullptr;
+    return GLIM_AMD_ERR_UNSUPPORTED;
   }
   // descriptors, block map and finaliser map have to be on the device (a single-factor plan may never have uploaded them), and complete
   // before the session's stream reads them
@@ -1760,7 +1787,7 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
     GA_TRY(factor_set_prepare(set));
     plan = set->plan;
     const Diag& diag = ctx->diag;
-    if (!diag.resident || !diag.fuse || !diag.poll || !plan->d_rows16 || !plan->h_rec16_dev || nf > (size_t)RESIDENT_MAX_FACTORS) return GLIM_AMD_ERR_UNSUPPORTED;
+    if (!resident_enabled(ctx) || !diag.fuse || !diag.poll || !plan->d_rows16 || !plan->h_rec16_dev || nf > (size_t)RESIDENT_MAX_FACTORS) return GLIM_AMD_ERR_UNSUPPORTED;
     // one row per worker block: a plan with more rows than the session has workers would walk them one after the other, slower than a launch
     // whose blocks all run at once (34 factors of 131 072 points: 68 against 53 us)
     if (plan->total_rows > 2 * std::max(1, ctx->num_cus)) return GLIM_AMD_ERR_UNSUPPORTED;
@@ -1777,8 +1804,8 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
       S.launched = false;
     }
     if (!S.launched) {
-      const int rc = resident_launch(S, set, plan);
-      if (rc != GLIM_AMD_OK) return rc == GLIM_AMD_ERR_UNSUPPORTED ? rc : rc;
+      // a session that cannot be started is never an error of the call: the launch-per-call path computes the same bits
+      if (resident_launch(S, set, plan) != GLIM_AMD_OK) return GLIM_AMD_ERR_UNSUPPORTED;
     }
     tag = next_session_tag(S);
     resident_post(S, T_lin, nf * 12, tag);
@@ -1809,6 +1836,8 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
     S.last_tag = tag;
     S.busy.store(false);
   }
+  // a finalising block that gave up on a row (bounded spin) publishes NaN under this call's tag: not a result -- the launch-per-call path answers
+  if (records_lost(plan, nf)) return GLIM_AMD_ERR_UNSUPPORTED;
   return GLIM_AMD_OK;
 }
 
@@ -1835,6 +1864,28 @@ extern "C" int glim_amd_debug_resident_stop(int device) {
 }
 
 namespace glim_amd {
+// Memory of this device is about to be recycled (a cloud / voxel map destroyed or rebuilt: quiesce_device): the session's workers hold
+// descriptors into such memory and prefetch from it while they wait, so the session ends here rather than by its idle time-out.
+// A request in flight (another thread's) is allowed to finish first.
+void resident_stop_device(int device) {
+  if (device < 0 || device >= 16) return;
+  ResidentSession& S = g_resident[device];
+  for (int tries = 0; tries < 20000; tries++) {
+    {
+      std::lock_guard<std::mutex> slock(S.mu);
+      if (!S.launched) return;
+      if (!S.busy.load()) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        resident_stop(S);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return;
+      }
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(10));
+  }
+}
 void resident_release(glim_amd_ctx* ctx, FactorPlan* plan) {
   for (ResidentSession& S : g_resident) {
     std::lock_guard<std::mutex> slock(S.mu);
@@ -1854,9 +1905,9 @@ namespace {
 //  * large sets: device records + one copy + stream synchronise.
 // The context mutex is held only while the work is enqueued, so factor sets of one context (different streams of its pool) overlap on
 // the device when driven from different host threads, like the reference's StreamTempBufferRoundRobin factors.
-int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval) {
+int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval, bool allow_fast = true) {
   const size_t nf = set->entries.size();
-  if (mode == MODE_LINEARIZE && !T_eval && nf <= (size_t)RESIDENT_MAX_FACTORS && set->ctx->diag.resident) {
+  if (allow_fast && mode == MODE_LINEARIZE && !T_eval && nf <= (size_t)RESIDENT_MAX_FACTORS && resident_enabled(set->ctx)) {
     const int rc = run_resident(set, T_lin);
     if (rc != GLIM_AMD_ERR_UNSUPPORTED) return rc;
   }
@@ -1873,15 +1924,21 @@ int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const doub
     const bool mapped = plan->h_compact_dev && nf <= 1024;
     poll = mapped && plan->h_flag && diag.poll;
     if (poll) seq = ++plan->poll_seq;
-    fused = use_single_dispatch(set, poll);
-    GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll));
+    fused = allow_fast && use_single_dispatch(set, poll);
+    GA_TRY(enqueue(set, mode, T_eval != nullptr, mapped ? plan->h_compact_dev : plan->d_compact, 0, poll, allow_fast));
     if (!mapped) GA_HIP(hipMemcpyAsync(plan->h_compact, plan->d_compact, nf * COMPACT * sizeof(double), hipMemcpyDeviceToHost, set->stream));
   }
   if (fused) {
-    if (collect_tagged_records(plan, nf, seq)) return GLIM_AMD_OK;
-    // (cannot happen short of a device fault: fall back to the stream, then the granules must be there)
-    GA_HIP(hipStreamSynchronize(set->stream));
-    return collect_tagged_records(plan, nf, seq) ? GLIM_AMD_OK : GLIM_AMD_ERR_STATE;
+    bool got = collect_tagged_records(plan, nf, seq);
+    if (!got) {
+      // (cannot happen short of a device fault: fall back to the stream, then the granules must be there)
+      GA_HIP(hipStreamSynchronize(set->stream));
+      got = collect_tagged_records(plan, nf, seq);
+    }
+    if (!got) return GLIM_AMD_ERR_STATE;
+    // a lost row (the finaliser's bounded spin ran out) arrives as a NaN record under a valid tag: answer with the two-dispatch form
+    if (records_lost(plan, nf)) return run_sync(set, mode, T_lin, T_eval, false);
+    return GLIM_AMD_OK;
   }
   if (!(poll && spin_until(plan->h_flag, seq))) GA_HIP(hipStreamSynchronize(set->stream));
   return GLIM_AMD_OK;
@@ -2052,6 +2109,16 @@ int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T, 
   for (int i = 0; i < iters; i++) GA_TRY(glim_amd_factor_set_linearize(set, T, out.data()));
   const auto t1 = std::chrono::steady_clock::now();
   *ms_per_call = (float)(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_linearize_repeat(glim_amd_factor_set* set, const double* T, int num_pose_sets, int iters, glim_amd_linearized6* out_last) {
+  if (!set || !T || num_pose_sets <= 0 || iters <= 0) return GLIM_AMD_ERR_INVALID;
+  const size_t nf = set->entries.size();
+  if (nf == 0) return GLIM_AMD_ERR_STATE;
+  std::vector<glim_amd_linearized6> out(nf);
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_factor_set_linearize(set, T + (size_t)(i % num_pose_sets) * nf * 12, out.data()));
+  if (out_last) memcpy(out_last, out.data(), nf * sizeof(glim_amd_linearized6));
   return GLIM_AMD_OK;
 }
 

@@ -286,6 +286,11 @@ int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T_target
 /* wall-clock milliseconds per synchronous glim_amd_factor_set_linearize call (pose upload, launches, result in host memory),
  * measured inside the library so that no binding overhead is included. */
 int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_per_call);
+/* timing aid: EXACTLY `iters` synchronous glim_amd_factor_set_linearize calls from C, no warm-up, no clock -- the caller times it.  Call i
+ * linearises at pose set i % num_pose_sets of T_target_source (num_pose_sets x n x 12: an optimiser moves the poses between its
+ * relinearisations); out_last (n records, may be NULL) receives the last call's result. */
+int glim_amd_factor_set_linearize_repeat(glim_amd_factor_set* set, const double* T_target_source, int num_pose_sets, int iters,
+                                         glim_amd_linearized6* out_last);
 
 /* GLIM's live call pattern (odometry_estimation_gpu.cpp:383-385; the optimisers' linearisation hook does clear -> add(graph) -> linearize per
  * iteration): a FRESH factor set per linearisation -- create, add the n factors, synchronous linearize (poses T: n x 12), destroy -- `iters`
@@ -317,10 +322,12 @@ int glim_amd_debug_resident_stop(int device);
 
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
- * One process, N devices: a context + a host worker thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per
- * device.  Clouds and voxel maps are replicated on every device, the factor list is sharded into contiguous cost-balanced chunks, every
- * device linearises its chunk and ONE ncclAllGather of the 29-double compact records over xGMI completes the result; records are
- * expanded on the host in the original factor order.  All calls are synchronous and must come from one host thread at a time. */
+ * One process, N devices: a context + a host thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per
+ * device (device 0 is driven by the CALLING thread).  Clouds and voxel maps are replicated on every device, the factor list is sharded into
+ * contiguous cost-balanced chunks, every device linearises its chunk -- as two halves when there is more than one device, so that the
+ * ncclAllGather of the first halves' 29-double compact records travels over xGMI while the second halves' kernels run -- and the records
+ * are expanded on the host in the original factor order.  One hand-over to the devices' threads per evaluation.  All calls are
+ * synchronous and must come from one host thread at a time. */
 typedef struct glim_amd_multi glim_amd_multi;
 /* devices: distinct HIP device ordinals.  A multi-device handle without a working RCCL is refused (GLIM_AMD_ERR_HIP) rather than
  * silently gathering over PCIe; a single device works either way (GLIM_AMD_DIAG="multi_rccl=0" skips the collective there). */
@@ -347,6 +354,23 @@ int glim_amd_multi_profile(glim_amd_multi* multi, const double* T_target_source,
 /* per device, HIP-event milliseconds of the LAST evaluation: its factor kernels + finalise (kernel_ms[d]) and the collective + copy-out behind
  * them (gather_ms[d]); num_devices entries each, either may be NULL */
 int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, float* gather_ms);
+/* host-side account of the LAST evaluation on one device's thread, microseconds, GLIM_AMD_MULTI_BREAKDOWN_FIELDS values:
+ *   [0] post        caller: handing the evaluation to the other devices' threads          (device 0 only)
+ *   [1] wake        from the caller's entry to the start of this device's task            (0 for device 0: the caller's own thread)
+ *   [2] pose_stage  this shard's poses copied into the pinned ring
+ *   [3] enqueue     plan check + H2D pose copy + kernel launches
+ *   [4] barrier     waiting until every device has enqueued (no collective starts before)
+ *   [5] collective  ncclAllGather calls + copy-out enqueue
+ *   [6] wait        hipStreamSynchronize: the device working
+ *   [7] join        caller: waiting for the other devices' threads                        (device 0 only)
+ *   [8] scan        caller: total error + expansion of the records in factor order        (device 0 only)
+ *   [9] total       the whole glim_amd_multi_linearize call                                (device 0 only) */
+#define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 10
+int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
+/* how a device's shard is evaluated: 1 = as two halves, the all-gather of the first overlapping the kernels of the second; 0 = as one
+ * set and one all-gather; -1 (default) = two halves when the handle has more than one device.  Takes effect with the next
+ * glim_amd_multi_set_factors. */
+int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
 

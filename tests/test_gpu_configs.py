@@ -254,11 +254,10 @@ def test_uploaded_plane_covariances_take_the_plane_kernel(api, ctx, orc, monkeyp
     # up to 32 768 points (nothing is added on first use), by the first factor otherwise
     assert sg.memory_usage_gpu() - base in (0, len(src) * 24)
     assert sg.memory_usage_gpu() == len(src) * (56 + 24)  # points + covariances + normals: 56 B per point
-    ctx.set_diag("plane=0")
-    fset = api.NonlinearFactorSetGPU(ctx)
-    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
-    gen = fset.linearize({0: np.eye(4), 1: delta})[0]
-    ctx.set_diag("plane=1")
+    with ctx.diag("plane=0"):
+        fset = api.NonlinearFactorSetGPU(ctx)
+        fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        gen = fset.linearize({0: np.eye(4), 1: delta})[0]
     assert gen["num_inliers"] == res["f64"]["num_inliers"]
     assert np.abs(gn_step(gen) - gn_step(res["f64"])).max() < 1e-5
     # a cloud whose covariances are NOT of that form stays general even though it has normals

@@ -242,17 +242,16 @@ def test_synchronous_call_variants_give_identical_bits(api, ctx, orc):
         for target in (0, np.eye(4)):
             factors = [api.IntegratedVGICPFactorGPU(target, 1 + k, vms[k % 2], sg) for k in range(copies)]
             res = {}
-            for mode in ("", "fuse=0", "poll=0", "host_poses=0", "inline_pose=0", "fuse=0,inline_pose=0", "inline_pose=0,host_poses=0,poll=0"):
-                ctx.set_diag(mode)
-                fset = api.NonlinearFactorSetGPU(ctx)
-                for f in factors:
-                    fset.add(f)
-                for rep in range(5):
-                    values = {0: np.eye(4)}
-                    for k in range(copies):
-                        values[1 + k] = delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + 0.05 * rep))
-                    res[(mode, rep)] = (fset.linearize(values), fset.error(values))
-            ctx.set_diag("")
+            for mode in ("", "resident=1", "fuse=0", "poll=0", "host_poses=0", "inline_pose=0", "fuse=0,inline_pose=0", "inline_pose=0,host_poses=0,poll=0"):
+                with ctx.diag(mode):  # (each mode on top of the DEFAULTS: set_diag alone would pile the switches up)
+                    fset = api.NonlinearFactorSetGPU(ctx)
+                    for f in factors:
+                        fset.add(f)
+                    for rep in range(5):
+                        values = {0: np.eye(4)}
+                        for k in range(copies):
+                            values[1 + k] = delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + 0.05 * rep))
+                        res[(mode, rep)] = (fset.linearize(values), fset.error(values))
             assert res[("", 0)][0][0]["num_inliers"] > 100
             for (mode, rep), (Ls, es) in res.items():
                 base = res[("inline_pose=0,host_poses=0,poll=0", rep)]
@@ -288,12 +287,11 @@ def test_single_dispatch_form_under_repetition_and_mixed_segments(api, ctx, orc,
                 d = small_pair["delta"] if (name == "mixed" and k % 3 == 0) else delta
                 values[1 + k] = d @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + 3.0 * which))
             poses.append(values)
-        ctx.set_diag("fuse=0")
-        ref_set = api.NonlinearFactorSetGPU(ctx)
-        for f in factors:
-            ref_set.add(f)
-        want = [(ref_set.linearize(v), ref_set.error(v)) for v in poses]
-        ctx.set_diag("")
+        with ctx.diag("fuse=0"):
+            ref_set = api.NonlinearFactorSetGPU(ctx)
+            for f in factors:
+                ref_set.add(f)
+            want = [(ref_set.linearize(v), ref_set.error(v)) for v in poses]
         fset = api.NonlinearFactorSetGPU(ctx)
         for f in factors:
             fset.add(f)
@@ -324,7 +322,6 @@ def test_wave_per_factor_finalise_gives_the_block_finalise_bits(api, ctx, orc, s
     values = {0: np.eye(4)}
     for k in range(nf):
         values[1 + k] = small_pair["delta"] @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.01 * k))
-    ctx.set_diag("ppt=2")
 
     def run(lo, hi):
         fs = api.NonlinearFactorSetGPU(ctx)
@@ -334,9 +331,9 @@ def test_wave_per_factor_finalise_gives_the_block_finalise_bits(api, ctx, orc, s
         fs.close()
         return out
 
-    big = run(0, nf)
-    parts = [run(lo, min(nf, lo + 700)) for lo in range(0, nf, 700)]
-    ctx.set_diag("")
+    with ctx.diag("ppt=2"):
+        big = run(0, nf)
+        parts = [run(lo, min(nf, lo + 700)) for lo in range(0, nf, 700)]
     want_L = [L for part in parts for L in part[0]]
     want_e = [e for part in parts for e in part[1]]
     assert len(want_L) == nf and sum(L["num_inliers"] for L in want_L) > 100 * nf
@@ -365,9 +362,8 @@ def test_plan_cache_serves_fresh_sets_and_follows_object_identity(api, ctx, orc,
         fs.close()
         return out
 
-    ctx.set_diag("plan_cache=0")
-    want = fresh()
-    ctx.set_diag("")
+    with ctx.diag("plan_cache=0"):
+        want = fresh()
     for _ in range(4):  # the second and later iterations adopt the plan the first one parked
         got = fresh()
         for a, b in zip(got, want):
@@ -487,15 +483,23 @@ def test_resident_session_lifecycle(api, ctx, orc, small_pair):
     vm = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
     vm2 = api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(tg)
     poses = [{0: np.eye(4), 1: delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + k))} for k in range(3)]
-    ctx.set_diag("resident=0,fuse=0")
-    ref = api.NonlinearFactorSetGPU(ctx)
-    ref.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
-    want = [ref.linearize(v)[0] for v in poses]
-    ref2 = api.NonlinearFactorSetGPU(ctx)
-    ref2.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
-    want2 = [ref2.linearize(v)[0] for v in poses]
-    want_err = ref.error(poses[1])
-    ctx.set_diag("resident_idle_us=500")
+    with ctx.diag("resident=0,fuse=0"):
+        ref = api.NonlinearFactorSetGPU(ctx)
+        ref.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        want = [ref.linearize(v)[0] for v in poses]
+        ref2 = api.NonlinearFactorSetGPU(ctx)
+        ref2.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+        want2 = [ref2.linearize(v)[0] for v in poses]
+        want_err = ref.error(poses[1])
+    # the session is opt-in (a context created with priority 1, or resident=1): without either, no session is ever started
+    api.resident_stop(ctx)
+    before = api.resident_stats(ctx)
+    plain = api.NonlinearFactorSetGPU(ctx)
+    plain.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+    for rep in range(8):
+        plain.linearize(poses[rep % 3])
+    assert api.resident_stats(ctx)["launches"] == before["launches"] and not api.resident_stats(ctx)["alive"]
+    plain.close()
 
     def same(L, B, what):
         assert L["num_inliers"] == B["num_inliers"], what
@@ -503,43 +507,45 @@ def test_resident_session_lifecycle(api, ctx, orc, small_pair):
             np.testing.assert_array_equal(L[key], B[key], err_msg=f"{what} {key}")
         assert L["error"] == B["error"], what
 
-    fset = api.NonlinearFactorSetGPU(ctx)
-    fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
-    for rep in range(40):  # calls 4.. are served by the session
-        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"rep {rep}")
-    assert fset.error(poses[1]) == want_err  # a launch-per-call evaluation next to the live session
-    same(fset.linearize(poses[2])[0], want[2], "after error()")
-    time.sleep(0.05)  # far beyond the idle time-out: the kernel has left; the next call restarts it
-    for rep in range(10):
-        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"after idle rep {rep}")
-    # a second plan: served launch-per-call while the first is hot, through the session once that has gone quiet
-    other = api.NonlinearFactorSetGPU(ctx)
-    other.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
-    for rep in range(12):
-        same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"interleaved a{rep}")
-        same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"interleaved b{rep}")
-    time.sleep(0.01)
-    for rep in range(12):
-        same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"takeover {rep}")
-    # fresh sets with the same factor list adopt the plan -- and its session (GLIM's per-iteration sets)
-    for rep in range(8):
-        fresh = api.NonlinearFactorSetGPU(ctx)
-        fresh.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
-        same(fresh.linearize(poses[rep % 3])[0], want2[rep % 3], f"fresh {rep}")
-        fresh.close()
-    # tearing things down under a live session
-    other.close()
-    fset.close()
-    c2 = api.Context(0, 1)
-    t2 = api.PointCloudGPU.clone(small_pair["target"]["points"].astype(np.float64), small_pair["target"]["covs"], ctx=c2)
-    s2 = api.PointCloudGPU.clone(small_pair["source"]["points"].astype(np.float64), small_pair["source"]["covs"], ctx=c2)
-    m2 = api.GaussianVoxelMapGPU(0.5, ctx=c2).insert(t2)
-    f2 = api.NonlinearFactorSetGPU(c2)
-    f2.add(api.IntegratedVGICPFactorGPU(0, 1, m2, s2))
-    time.sleep(0.01)
-    outs = [f2.linearize({0: np.eye(4), 1: small_pair["delta"]})[0] for _ in range(10)]
-    for o in outs[1:]:
-        same(o, outs[0], "second context")
-    f2.close(); m2.close(); s2.close(); t2.close()
-    c2.close()
-    ctx.set_diag("")
+    with ctx.diag("resident=1,resident_idle_us=500"):
+        fset = api.NonlinearFactorSetGPU(ctx)
+        fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        for rep in range(40):  # calls 4.. are served by the session
+            same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"rep {rep}")
+        assert fset.error(poses[1]) == want_err  # a launch-per-call evaluation next to the live session
+        same(fset.linearize(poses[2])[0], want[2], "after error()")
+        time.sleep(0.05)  # far beyond the idle time-out: the kernel has left; the next call restarts it
+        for rep in range(10):
+            same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"after idle rep {rep}")
+        # a second plan: served launch-per-call while the first is hot, through the session once that has gone quiet
+        other = api.NonlinearFactorSetGPU(ctx)
+        other.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+        for rep in range(12):
+            same(fset.linearize(poses[rep % 3])[0], want[rep % 3], f"interleaved a{rep}")
+            same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"interleaved b{rep}")
+        time.sleep(0.01)
+        for rep in range(12):
+            same(other.linearize(poses[rep % 3])[0], want2[rep % 3], f"takeover {rep}")
+        # fresh sets with the same factor list adopt the plan -- and its session (GLIM's per-iteration sets)
+        for rep in range(8):
+            fresh = api.NonlinearFactorSetGPU(ctx)
+            fresh.add(api.IntegratedVGICPFactorGPU(0, 1, vm2, sg))
+            same(fresh.linearize(poses[rep % 3])[0], want2[rep % 3], f"fresh {rep}")
+            fresh.close()
+        # tearing things down under a live session
+        other.close()
+        fset.close()
+        c2 = api.Context(0, 1, priority=1)  # (the odometry's kind of context: the session is on by itself)
+        t2 = api.PointCloudGPU.clone(small_pair["target"]["points"].astype(np.float64), small_pair["target"]["covs"], ctx=c2)
+        s2 = api.PointCloudGPU.clone(small_pair["source"]["points"].astype(np.float64), small_pair["source"]["covs"], ctx=c2)
+        m2 = api.GaussianVoxelMapGPU(0.5, ctx=c2).insert(t2)
+        f2 = api.NonlinearFactorSetGPU(c2)
+        f2.add(api.IntegratedVGICPFactorGPU(0, 1, m2, s2))
+        time.sleep(0.01)
+        outs = [f2.linearize({0: np.eye(4), 1: small_pair["delta"]})[0] for _ in range(10)]
+        for o in outs[1:]:
+            same(o, outs[0], "second context")
+        served = api.resident_stats(ctx)
+        assert served["launches"] > before["launches"] and served["requests"] >= before["requests"] + 60, (before, served)
+        f2.close(); m2.close(); s2.close(); t2.close()
+        c2.close()

@@ -95,9 +95,8 @@ def test_small_cloud_host_pack_equals_the_device_pack(api, ctx, orc, small_pair)
     for covs in (s["covs"], general):
         out = {}
         for mode in ("host_pack=1", "host_pack=0"):
-            ctx.set_diag(mode)
-            g = api.PointCloudGPU.clone(s["points"].astype(np.float64), covs, s["normals"], ctx=ctx)
-            ctx.set_diag("")
+            with ctx.diag(mode):
+                g = api.PointCloudGPU.clone(s["points"].astype(np.float64), covs, s["normals"], ctx=ctx)
             fset = api.NonlinearFactorSetGPU(ctx)
             fset.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, g))
             out[mode] = (g.download(), fset.linearize({1: small_pair["delta"]})[0])
@@ -108,9 +107,8 @@ def test_small_cloud_host_pack_equals_the_device_pack(api, ctx, orc, small_pair)
         np.testing.assert_array_equal(La["H_ss"], Lb["H_ss"])
         np.testing.assert_array_equal(La["b_s"], Lb["b_s"])
     # without covariances / normals
-    ctx.set_diag("host_pack=1")
-    bare = api.PointCloudGPU.clone(s["points"].astype(np.float64), ctx=ctx)
-    ctx.set_diag("")
+    with ctx.diag("host_pack=1"):
+        bare = api.PointCloudGPU.clone(s["points"].astype(np.float64), ctx=ctx)
     np.testing.assert_array_equal(bare.download(covs=False, normals=False)[0], s["points"])
 
 
@@ -316,10 +314,10 @@ def test_points_per_thread_variants_agree(api, ctx, small_pair):
     T = api.pose12(small_pair["delta"])[None]
     results = []
     for ppt in ("1", "3", "8"):
-        ctx.set_diag(f"ppt={ppt}")
-        fset = api.NonlinearFactorSetGPU(ctx)
-        fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
-        results.append(fset.linearize_poses(T)[0])
+        with ctx.diag(f"ppt={ppt}"):
+            fset = api.NonlinearFactorSetGPU(ctx)
+            fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+            results.append(fset.linearize_poses(T)[0])
     for r in results[1:]:
         assert r["num_inliers"] == results[0]["num_inliers"]
         np.testing.assert_allclose(r["H_ss"], results[0]["H_ss"], rtol=1e-5, atol=1e-3)
@@ -511,15 +509,13 @@ def test_plane_form_kernel_matches_general_kernel_and_oracle(api, ctx, orc):
     ref = orc.vgicp_linearize(orc.VoxelMap(0.5).insert(tgt, ct.astype(np.float64)), src, cs.astype(np.float64), delta, want_corr=True)
     results = {}
     for mode in ("plane", "general"):
-        if mode == "general":
-            ctx.set_diag("plane=0")
-        for sv in (False, True):
-            f = api.IntegratedVGICPFactorGPU(0, 1, vm, sg)
-            f.set_enable_surface_validation(sv)
-            fset = api.NonlinearFactorSetGPU(ctx)
-            fset.add(f)
-            results[(mode, sv)] = fset.linearize({0: np.eye(4), 1: delta})[0]
-    ctx.set_diag("plane=1")
+        with ctx.diag("plane=1" if mode == "plane" else "plane=0"):
+            for sv in (False, True):
+                f = api.IntegratedVGICPFactorGPU(0, 1, vm, sg)
+                f.set_enable_surface_validation(sv)
+                fset = api.NonlinearFactorSetGPU(ctx)
+                fset.add(f)
+                results[(mode, sv)] = fset.linearize({0: np.eye(4), 1: delta})[0]
     for mode in ("plane", "general"):
         assert_linearization_close(results[(mode, False)], ref, True)
     # surface validation reads the normals from the plane-form stream in one kernel and from the normal array in the other
@@ -539,12 +535,10 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc):
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
     got_chunk = g.find_neighbors(10)  # the default: the query-group kernel (knn_qgroup.hip), 2 queries per wavefront at this size
     for variant in ("wave64", "pair"):  # the lane-per-query kernels
-        ctx.set_diag(f"knn_kernel={variant}")
-        np.testing.assert_array_equal(g.find_neighbors(10), ref)
-    ctx.set_diag("knn_kernel=auto")
-    ctx.set_diag("knn_path=grid")
-    got_grid = g.find_neighbors(10)
-    ctx.set_diag("knn_path=auto")
+        with ctx.diag(f"knn_kernel={variant}"):
+            np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    with ctx.diag("knn_path=grid"):
+        got_grid = g.find_neighbors(10)
     np.testing.assert_array_equal(got_chunk, ref)
     np.testing.assert_array_equal(got_grid, ref)
     for k in (1, 5, 16, 32):
@@ -553,8 +547,8 @@ def test_knn_chunk_and_grid_paths_agree(api, ctx, orc):
     small = api.PointCloudGPU.clone(pts[::7], ctx=ctx)
     ref_small = orc.knn(pts[::7].astype(np.float64), 10)
     np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
-    ctx.set_diag("knn_path=chunks")
-    np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
+    with ctx.diag("knn_path=chunks"):
+        np.testing.assert_array_equal(small.find_neighbors(10), ref_small)
 
 
 @pytest.mark.parametrize("name", ["lattice", "identical", "offset", "two_scales", "astronomic"])
@@ -575,18 +569,15 @@ def test_knn_exact_on_degenerate_distributions(api, ctx, orc, name):
     pts = pts.astype(np.float32)
     ref = orc.knn(pts.astype(np.float64), 10, method="brute")
     g = api.PointCloudGPU.clone(pts, ctx=ctx)
-    ctx.set_diag("knn_path=chunks")
     for variant in ("wave64", "pair", "qgroup"):  # 64 queries per wavefront / 32 queries with two lanes each / lanes = candidates
-        ctx.set_diag(f"knn_kernel={variant}")
-        np.testing.assert_array_equal(g.find_neighbors(10), ref)
-        for k in (3, 16, 32):
-            np.testing.assert_array_equal(g.find_neighbors(k), orc.knn(pts.astype(np.float64), k, method="brute"))
-        ctx.set_diag("knn_kernel=auto")
-    ctx.set_diag("knn_path=auto")
+        with ctx.diag(f"knn_path=chunks,knn_kernel={variant}"):
+            np.testing.assert_array_equal(g.find_neighbors(10), ref)
+            for k in (3, 16, 32):
+                np.testing.assert_array_equal(g.find_neighbors(k), orc.knn(pts.astype(np.float64), k, method="brute"))
     if name == "astronomic":
         return
-    ctx.set_diag("knn_path=grid")
-    np.testing.assert_array_equal(g.find_neighbors(10), ref)
+    with ctx.diag("knn_path=grid"):
+        np.testing.assert_array_equal(g.find_neighbors(10), ref)
 
 
 @pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
@@ -601,12 +592,11 @@ def test_knn_refuses_non_finite_points_and_the_context_survives(api, ctx, orc, b
     broken = pts.copy()
     broken[1234, 1] = bad
     for variant in ("wave64", "pair", "qgroup"):
-        ctx.set_diag(f"knn_path=chunks,knn_kernel={variant}")
-        with pytest.raises(GlimAmdError) as err:
-            api.PointCloudGPU.clone(broken, ctx=ctx).find_neighbors(10)
-        assert err.value.code == -4
-        np.testing.assert_array_equal(api.PointCloudGPU.clone(pts, ctx=ctx).find_neighbors(10), ref)
-    ctx.set_diag("")
+        with ctx.diag(f"knn_path=chunks,knn_kernel={variant}"):
+            with pytest.raises(GlimAmdError) as err:
+                api.PointCloudGPU.clone(broken, ctx=ctx).find_neighbors(10)
+            assert err.value.code == -4
+            np.testing.assert_array_equal(api.PointCloudGPU.clone(pts, ctx=ctx).find_neighbors(10), ref)
 
 
 def test_knn_threshold_selection_is_exact(api, ctx, orc):
@@ -631,21 +621,26 @@ def test_knn_threshold_selection_is_exact(api, ctx, orc):
             ref = orc.knn(pts.astype(np.float64), k, method="brute")
             for select in (1, 0):
                 for variant in ("wave64", "pair", "qgroup"):
-                    ctx.set_diag(f"knn_path=chunks,knn_kernel={variant},knn_select={select}")
-                    np.testing.assert_array_equal(g.find_neighbors(k), ref, err_msg=f"{name} k={k} {variant} select={select}")
-    ctx.set_diag("")
+                    with ctx.diag(f"knn_path=chunks,knn_kernel={variant},knn_select={select}"):
+                        np.testing.assert_array_equal(g.find_neighbors(k), ref, err_msg=f"{name} k={k} {variant} select={select}")
 
 
 def test_diag_switches_parse_and_reject(api, ctx):
     """glim_amd_ctx_set_diag: known keys change the context's switches, unknown keys / bad values change nothing; "" restores the defaults."""
     base = ctx.get_diag()
-    assert base["knn_path"] == "auto" and base["plane"] == "1" and base["knn_select"] == "1"
-    ctx.set_diag("knn_path=grid,ppt=3")
-    assert ctx.get_diag()["knn_path"] == "grid" and ctx.get_diag()["ppt"] == "3"
-    # pool / multi_rccl / multi_host_gather are process-wide (GLIM_AMD_DIAG only): a context refuses them instead of accepting a no-op
-    for bad in ("no_such_key=1", "knn_path=fast", "ppt=-1", "plane", "pool=0", "plane=0,multi_rccl=0", "multi_host_gather=1"):
-        with pytest.raises(api.GlimAmdError):
-            ctx.set_diag(bad)
-        assert ctx.get_diag()["knn_path"] == "grid"
-    ctx.set_diag("")
+    assert base["knn_path"] == "auto" and base["plane"] == "1" and base["knn_select"] == "1" and base["resident"] == "auto"
+    with ctx.diag("knn_path=grid,ppt=3"):
+        assert ctx.get_diag()["knn_path"] == "grid" and ctx.get_diag()["ppt"] == "3"
+        ctx.set_diag("plane=0")  # set_diag ADDS to the switches in force
+        assert ctx.get_diag()["knn_path"] == "grid" and ctx.get_diag()["plane"] == "0"
+        # pool / multi_rccl / multi_host_gather are process-wide (GLIM_AMD_DIAG only): a context refuses them instead of accepting a no-op
+        for bad in ("no_such_key=1", "knn_path=fast", "ppt=-1", "plane", "pool=0", "plane=0,multi_rccl=0", "multi_host_gather=1", "resident=2"):
+            with pytest.raises(api.GlimAmdError):
+                ctx.set_diag(bad)
+            assert ctx.get_diag()["knn_path"] == "grid"
+    assert ctx.get_diag() == base  # the scope restores the process defaults
+    with pytest.raises(RuntimeError):
+        with ctx.diag("plane=0"):
+            raise RuntimeError("a failure inside the scope")
+    assert ctx.get_diag() == base
     assert ctx.get_diag() == base

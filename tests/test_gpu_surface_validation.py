@@ -98,27 +98,26 @@ def test_config1_full_size_scan_with_surface_validation(api, ctx, orc):
     cs64, ns64 = cs.astype(np.float64), ns.astype(np.float64)
     report = {}
     for mode in ("plane", "general"):
-        ctx.set_diag("plane=1" if mode == "plane" else "plane=0")
-        for binary in (False, True):
-            f = api.IntegratedVGICPFactorGPU(0 if binary else np.eye(4), 1, vm, sg)
-            f.set_enable_surface_validation(True)
-            fset = api.NonlinearFactorSetGPU(ctx)
-            fset.add(f)
-            values = {0: np.eye(4), 1: delta}
-            got = fset.linearize(values)[0]
-            ref, n_boundary, n_rejected = validated_reference(orc, fset, 0, ref_map, src, cs64, ns64, delta)
-            worst = compare(got, ref, binary, (mode, binary))
-            assert n_rejected > 0  # the predicate does something on this scan pair
-            # error() with the GPU factor's frozen-correspondence semantics (LM's trial step) sums over the same validated set
-            moved = delta @ orc.se3_exp([1e-3, -2e-3, 1e-3, 0.01, -0.02, 0.01])
-            e_got = fset.error({0: np.eye(4), 1: moved}, values_lin=values)[0]
-            e_ref, inl_ref = orc.vgicp_error_frozen_sv(ref_map, src, cs64, ns64, delta, moved, force=ref["force"])
-            assert int(fset.last_error_inliers[0]) == inl_ref == ref["num_inliers"]
-            np.testing.assert_allclose(e_got, e_ref, rtol=2e-4)
-            report[f"{mode}.{'binary' if binary else 'unary'}"] = {
-                "points": int(len(src)), "inliers": int(got["num_inliers"]), "rejected_by_validation": n_rejected,
-                "points_within_fp32_resolution_of_the_boundary": n_boundary, "gn_step_err": worst}
-    ctx.set_diag("")
+        with ctx.diag("plane=1" if mode == "plane" else "plane=0"):
+            for binary in (False, True):
+                f = api.IntegratedVGICPFactorGPU(0 if binary else np.eye(4), 1, vm, sg)
+                f.set_enable_surface_validation(True)
+                fset = api.NonlinearFactorSetGPU(ctx)
+                fset.add(f)
+                values = {0: np.eye(4), 1: delta}
+                got = fset.linearize(values)[0]
+                ref, n_boundary, n_rejected = validated_reference(orc, fset, 0, ref_map, src, cs64, ns64, delta)
+                worst = compare(got, ref, binary, (mode, binary))
+                assert n_rejected > 0  # the predicate does something on this scan pair
+                # error() with the GPU factor's frozen-correspondence semantics (LM's trial step) sums over the same validated set
+                moved = delta @ orc.se3_exp([1e-3, -2e-3, 1e-3, 0.01, -0.02, 0.01])
+                e_got = fset.error({0: np.eye(4), 1: moved}, values_lin=values)[0]
+                e_ref, inl_ref = orc.vgicp_error_frozen_sv(ref_map, src, cs64, ns64, delta, moved, force=ref["force"])
+                assert int(fset.last_error_inliers[0]) == inl_ref == ref["num_inliers"]
+                np.testing.assert_allclose(e_got, e_ref, rtol=2e-4)
+                report[f"{mode}.{'binary' if binary else 'unary'}"] = {
+                    "points": int(len(src)), "inliers": int(got["num_inliers"]), "rejected_by_validation": n_rejected,
+                    "points_within_fp32_resolution_of_the_boundary": n_boundary, "gn_step_err": worst}
     print("surface validation ON, configs[1]:", report)
     _write("surface_validation_config1.json", report)
 

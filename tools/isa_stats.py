@@ -2,8 +2,12 @@
 """Static look at a kernel's hot loop (no GPU needed): compiles a .hip file to gfx950 assembly and prints, for every kernel whose
 mangled name contains the given substring, the VGPR / SGPR counts and the instruction mix of its longest loop.
   python tools/isa_stats.py glim_amd/csrc/vgicp.hip vgicp_kernelILi0ELb0ELb1ELb0E v_rcp_f32 [extra hipcc flags]
+Also prints the loop's floating-point operation count per trip (= per point per lane): fma / fmac / mad count 2, every other f32 / f64 arithmetic
+instruction 1, conversions / moves / compares 0 -- bench.py prices the VALU-bound general kernel against the 157.3 TFLOP/s FP32 vector peak with it.
+ISA_STATS_JSON=<file>: append one JSON line per kernel (name, registers, instruction mix, flops) to <file>.
 """
 import collections
+import os
 import re
 import subprocess
 import sys
@@ -59,7 +63,21 @@ def main():
                 cat["lds"] += c
             else:
                 cat["other"] += c
+        def flops(kind):
+            total = 0
+            for op, c in ops.items():
+                if not op.startswith("v_") or kind not in op or op.startswith(("v_cvt", "v_cmp", "v_cndmask", "v_mov")):
+                    continue
+                total += c * (2 if re.match(r"v_(pk_)?(fma|fmac|mac|mad)", op) else 1) * (2 if op.startswith("v_pk_") else 1)
+            return total
+        fl32, fl64 = flops("f32"), flops("f64")
+        if os.environ.get("ISA_STATS_JSON"):
+            import json
+            with open(os.environ["ISA_STATS_JSON"], "a") as jf:
+                jf.write(json.dumps({"kernel": name, "vgpr": meta[".amdhsa_next_free_vgpr"], "sgpr": meta[".amdhsa_next_free_sgpr"], "loop_instructions": sum(ops.values()),
+                                     "mix": dict(cat), "fp32_flops_per_point": fl32, "fp64_flops_per_point": fl64, "ops": dict(ops)}) + "\n")
         print(name[:90])
+        print("  fp32 flops per trip:", fl32, "| fp64 flops per trip:", fl64)
         print("  vgpr", meta[".amdhsa_next_free_vgpr"], "sgpr", meta[".amdhsa_next_free_sgpr"], "| longest loop:", sum(ops.values()), "instructions", dict(cat))
         print("  scratch:", any("scratch_" in l for l in body), "| top:", ", ".join(f"{c} {o}" for o, c in ops.most_common(12)))
 
