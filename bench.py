@@ -168,6 +168,82 @@ def roofline_of(fset, poses, n_pts, n_vox, iters, traffic=None):
     return out
 
 
+def cpu_baseline_and_parity(api, target_cloud, source_cloud, delta12, resolution, gpu_result, budget_s=12.0):
+    """Time the FP64 OpenMP oracle (restatement of gtsam_points::IntegratedVGICPFactor::linearize) on one factor of the same
+    workload and check the GPU Gauss-Newton step against it."""
+    import ctypes as C
+
+    from oracle import oracle as orc
+
+    tgt_xyz, tgt_cov, _ = target_cloud.download(normals=False)
+    src_xyz, src_cov, _ = source_cloud.download(normals=False)
+    vm = orc.VoxelMap(resolution).insert(tgt_xyz, tgt_cov.astype(np.float64))
+    p4 = orc.points4(src_xyz)
+    c16 = orc.covs16(src_cov.astype(np.float64))
+    tp4 = orc.points4(tgt_xyz)
+    tc16 = orc.covs16(tgt_cov.astype(np.float64))
+    T = np.ascontiguousarray(delta12)
+    L = orc.Linearized6()
+    lib = orc.lib()
+    cores = min(orc.max_threads(), effective_cores())
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    # TIMING runs on a second build of the same restatement with SURVEY 8d's flags (-O3 -march=native, compiled on this box); the parity
+    # check below always uses the bit-exact checker build
+    fast = orc.fast_lib()
+    tlib, tmap = lib, vm._h
+    if fast is not None:
+        tlib, tmap = fast, C.c_void_p(fast.orc_voxelmap_create(float(resolution)))
+        fast.orc_voxelmap_insert(tmap, dp(tp4), dp(tc16), len(tp4))
+
+    def run(threads, budget):
+        Lt = orc.Linearized6()
+        tlib.orc_vgicp_linearize(tmap, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(Lt), None)  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tlib.orc_vgicp_linearize(tmap, dp(p4), dp(c16), len(p4), dp(T), threads, C.byref(Lt), None)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or n >= 4000:
+                return n / dt, n
+
+    # thread curve first (short samples; the team is warm after the first call of each size), then the headline sample on the fastest count
+    curve = {}
+    t = 1
+    while t < cores:
+        curve[t] = run(t, budget_s / 10)[0]
+        t *= 2
+    rate_all, n_all = run(cores, budget_s / 2)
+    curve[cores] = rate_all
+    best_t = max(curve, key=lambda k: curve[k])
+    if best_t != cores:  # a box where fewer threads are faster (SMT / quota effects): the headline sample is taken there
+        rate_all, n_all = run(best_t, budget_s / 3)
+        cores = best_t
+        curve[cores] = max(curve[cores], rate_all)
+    rate_ref = curve.get(min(2, cores), rate_all)  # the reference's shipped num_threads (config_odometry_cpu.json:36)
+    rate_1 = curve.get(1, rate_all)
+    if fast is not None:
+        fast.orc_voxelmap_destroy(tmap)
+    lib.orc_vgicp_linearize(vm._h, dp(p4), dp(c16), len(p4), dp(T), cores, C.byref(L), None)  # the checker build: the parity reference
+    ref = orc._lin_to_dict(L)
+    d_got = np.linalg.solve(gpu_result["H_ss"], -gpu_result["b_s"])
+    d_ref = np.linalg.solve(ref["H_ss"], -ref["b_s"])
+    parity = {
+        "inliers_equal": bool(gpu_result["num_inliers"] == ref["num_inliers"]),
+        "max_pose_delta_err": float(np.abs(d_got - d_ref).max()),
+        "tolerance": 1e-4,
+    }
+    base = {
+        "value": rate_all, "unit": "calls/s", "cores": cores, "kind": "port",
+        "sample": f"{n_all} linearize() calls of one {len(p4)}-pt factor (oracle/vgicp_oracle.c, OpenMP guided,8, usable host cores = min(affinity, cgroup quota))",
+        "build": "gcc -O3 -march=native -fopenmp (oracle.fast_lib)" if fast is not None else "gcc -O2 -march=x86-64-v3 -ffp-contract=off (the checker build: no compiler for the -O3 build)",
+        "value_2_threads": rate_ref, "value_1_thread": rate_1, "points_per_s_per_core": rate_1 * len(p4),
+        "thread_curve_calls_per_s": {str(k): v for k, v in sorted(curve.items())},
+        "thread_curve_note": "per-thread sums live on each thread's own stack since round 5 (the heap array of round 4 put neighbouring threads' hot fields into one "
+                             "cache line: 2 threads ran slower than 1); threads are left to the scheduler (OMP_PROC_BIND unset: binding changed nothing here)",
+    }
+    return base, parity
+
+
 class Dist:
     """torch.distributed plumbing (RCCL on GPU boxes)."""
 
@@ -1065,8 +1141,10 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
     Tp = T.ctypes.data_as(C.POINTER(C.c_double))
     steps = max(steps, 20)  # (a 5-step sample on the driver's box carried 2.2 ms per evaluation nobody could name: VERDICT r4)
 
-    def evaluate():
-        check(lib().glim_amd_multi_linearize(M._h, Tp, None, None), "glim_amd_multi_linearize")
+    tot = C.c_double()
+
+    def evaluate():  # the records stay in the handle's pinned array, the cost (sum of the errors) is summed by the devices
+        check(lib().glim_amd_multi_linearize(M._h, Tp, None, C.byref(tot)), "glim_amd_multi_linearize")
 
     def measure():
         for _ in range(max(warmup, 3)):
@@ -1103,16 +1181,19 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
                                          "barrier = until every device has enqueued; collective = ncclAllGather + copy-out enqueue; wait = hipStreamSynchronize "
                                          "(the device working); join = the other threads; scan = total error over the records"},
            "replication_and_setup_s": setup_s}
-    if len(devices) == 1:
-        # the two-halves form on one device (forced): what the split costs when there is nothing to hide behind it
-        M.set_split(1)
+    out["total_error"] = tot.value
+    out["pieces_per_shard"] = "default: 2 (glim_amd_multi_set_split)"
+    # the same evaluation with the shard in 1 / 2 / 4 pieces (the exchange and the pose upload of one piece overlap the kernels of the next)
+    sweep = {}
+    for pieces in (1, 4):
+        M.set_split(pieces)
         M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
         sec2, bd2, k2, g2 = measure()
-        out["two_halves_forced"] = {"ms_per_evaluation": sec2 * 1e3, "kernels_ms": k2[0], "collective_and_copy_out_after_the_kernels_ms": g2[0], "wait_us": bd2[0]["wait"]}
-        M.set_split(-1)
-    recs, total = M.linearize(T[: len(pairs)]) if len(pairs) <= 4096 else (None, None)
-    if total is not None:
-        out["total_error"] = total
+        sweep[str(pieces)] = {"ms_per_evaluation": sec2 * 1e3, "kernels_ms": k2, "collective_and_copy_out_after_the_kernels_ms": g2, "wait_us": bd2[0]["wait"]}
+    sweep["default"] = {"ms_per_evaluation": sec * 1e3}
+    out["pieces_sweep"] = sweep
+    M.set_split(-1)
+    M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
     M.close()
     return out
 

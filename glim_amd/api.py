@@ -662,8 +662,22 @@ class MultiDeviceCost:
         return dict(zip(self.BREAKDOWN_FIELDS, us.tolist()))
 
     def set_split(self, mode):
-        """-1: two halves per shard when there is more than one device (default); 0 / 1: forced.  Applies to the next set_factors."""
+        """-1: 2 pieces per shard (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
         check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
+
+    def evaluate(self, T_target_source):
+        """One evaluation that leaves the records in the handle (records()) and returns the total error, summed by the devices."""
+        T = np.ascontiguousarray(np.asarray(T_target_source, dtype=np.float64).reshape(self._n, 12))
+        tot = C.c_double()
+        check(lib().glim_amd_multi_linearize(self._h, _dp(T), None, C.byref(tot)), "glim_amd_multi_linearize")
+        return tot.value
+
+    def records(self, first=0, count=None):
+        """Compact 29-double records of the last evaluation, factor order (glim_amd_multi_records)."""
+        count = self._n - first if count is None else count
+        out = np.zeros((count, 29), dtype=np.float64)
+        check(lib().glim_amd_multi_records(self._h, int(first), int(count), _dp(out)), "glim_amd_multi_records")
+        return out
 
     def close(self):
         if self._h:
@@ -697,6 +711,17 @@ def shard_bounds(costs, world):
     b = np.zeros(int(world) + 1, dtype=np.int64)
     check(lib().glim_amd_shard_bounds(_dp(c) if len(c) else None, len(c), int(world), b.ctypes.data_as(C.POINTER(C.c_int64))), "glim_amd_shard_bounds")
     return [int(x) for x in b]
+
+
+def shard_layout(bounds, split_mode=-1):
+    """glim_amd_shard_layout: (row of every factor in the gathered array, max_rows, pieces, piece_rows) -- host only, no device needed."""
+    b = np.ascontiguousarray(bounds, dtype=np.int64)
+    world = len(b) - 1
+    rows = np.zeros(max(1, int(b[-1])), dtype=np.int64)
+    mr, pc, pr = C.c_int64(), C.c_int32(), C.c_int64()
+    lp = C.POINTER(C.c_int64)
+    check(lib().glim_amd_shard_layout(b.ctypes.data_as(lp), world, int(split_mode), rows.ctypes.data_as(lp), C.byref(mr), C.byref(pc), C.byref(pr)), "glim_amd_shard_layout")
+    return rows[: int(b[-1])], mr.value, pc.value, pr.value
 
 
 def preprocess_params(**kw):

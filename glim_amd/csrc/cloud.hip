@@ -434,7 +434,7 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (!c) return GLIM_AMD_OK;
   if (c->ctx) {
     (void)hipSetDevice(c->ctx->device);
-    quiesce_device(c->ctx->device);  // asynchronous factor launches (of any context) may still be reading this cloud: its memory goes back to the pool below
+    quiesce_device(c->ctx->device, c->uid);  // asynchronous factor launches (of any context) may still be reading this cloud: its memory goes back to the pool below
     global_mutation_epoch()++;  // factor sets re-validate their plans
   }
   if (c->gs0) (void)pool_free(c->gs0);

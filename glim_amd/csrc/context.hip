@@ -18,8 +18,8 @@ std::atomic<uint64_t>& global_mutation_epoch() {
   static std::atomic<uint64_t> e{1};
   return e;
 }
-void quiesce_device(int device) {
-  resident_stop_device(device);  // its workers hold descriptors into memory that is about to be recycled
+void quiesce_device(int device, uint64_t uid) {
+  resident_stop_device(device, uid);  // its workers hold descriptors into memory that is about to be recycled
   std::lock_guard<std::mutex> lock(g_ctx_registry_mu);
   for (glim_amd_ctx* c : g_ctx_registry)
     if (c->device == device) c->quiesce();
@@ -54,6 +54,7 @@ const DiagKey kDiagKeys[] = {
   {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
+  {"view_fused", &Diag::view_fused, nullptr, 0, 1},
   {"fuse", &Diag::fuse, nullptr, 0, 1},
   {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},
   {"resident", &Diag::resident, kResidentWords, 0, 2},

@@ -166,7 +166,7 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (!c->normals) GA_HIP(pool_malloc(&c->normals, nn * sizeof(float4)));
   // General factor streams built from earlier covariances are stale now, and factor plans hold their addresses: wait for asynchronous
   // launches that may still read them, then give the cloud a new identity so that every plan built from the old streams is rebuilt.
-  quiesce_device(ctx->device);
+  quiesce_device(ctx->device, c->uid);
   c->uid = next_uid();
   global_mutation_epoch()++;
   if (c->gs0) { (void)pool_free(c->gs0); c->gs0 = nullptr; }

@@ -81,6 +81,7 @@ struct Diag {
   int resident_idle_us = 1000;  // resident_idle_us=<n>         the resident kernel leaves after this long without a request
   int pp_fast = 1;        // pp_fast=0|1                        random-grid preprocessing: one sort + counting ranks, one synchronise (preprocess.hip)
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
+  int view_fused = 1;     // view_fused=0|1                      a map built from a plane-form cloud gets its plane view (A_B records) from the finalise kernel; 0: on first use
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
@@ -192,8 +193,10 @@ inline uint64_t next_uid() {
 // another: sub_mapping.cpp:168, global_mapping.cpp:253-266), so what invalidates plans built from them is counted process-wide, not per context.
 std::atomic<uint64_t>& global_mutation_epoch();
 // waits for the asynchronous launches of EVERY context of `device` that may still be reading an object which is about to change or die
-void quiesce_device(int device);
-void resident_stop_device(int device);  // vgicp.hip: ends the device's resident session (waits for a request in flight)
+// uid: the cloud / voxel map whose memory is about to be recycled (0: unknown -- any object).  The device's resident session ends only when ITS plan
+// uses that object: a mapping thread that drops an unrelated cloud must not take the odometry's session down with it.
+void quiesce_device(int device, uint64_t uid = 0);
+void resident_stop_device(int device, uint64_t uid);  // vgicp.hip (waits for a request in flight)
 
 constexpr int PARTIAL_STRIDE = 32;  // floats per block partial: 6 Hww + 9 Hwv + 6 Hvv + 3 (u x p) + 3 u + 1 err + 1 count(int) + pad
 constexpr int COMPACT = GLIM_AMD_COMPACT_DOUBLES;
@@ -321,7 +324,15 @@ struct glim_amd_voxelmap {
   int32_t num_voxels = 0;
   uint32_t num_buckets = 0;  // 0 until insert()
   glim_amd::VoxelBucket* buckets = nullptr;
+  // "Plane view" of the same table for factors whose source cloud is plane-form (vgicp.hip, GLIM_AMD_PLANE_SM): same keys, same means, but the
+  // six covariance slots of a record hold A_B = (C_B + I)^-1 (inverted in FP64 from the FP32 record), and one extra, all-zero bucket at index
+  // num_buckets that lanes without a correspondence read.  Built on first use (ensure_plane_view), dropped whenever the table is rebuilt.
+  glim_amd::VoxelBucket* buckets_sm = nullptr;
+  std::mutex view_mu;
 };
+namespace glim_amd {
+int ensure_plane_view(::glim_amd_voxelmap* m, hipStream_t st);  // voxelmap.hip; complete (synchronised) before it returns
+}
 
 // Device plan of a factor list: descriptors, the block -> (factor, chunk) map, partial rows, pose / result staging.  Building one costs
 // six pool allocations, three uploads and a stream synchronise, and GLIM builds a FRESH NonlinearFactorSetGPU for every linearisation
@@ -358,6 +369,8 @@ struct FactorPlan {
   double* h_poses = nullptr;      // POSE_RING x (2 x n x 12)
   double* h_poses_dev = nullptr;  // device view of h_poses
   hipEvent_t pose_events[POSE_RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t poses_free_event = nullptr;  // upload_stream form: "the kernels that read d_poses are done" (the next copy into d_poses waits for it)
+  bool poses_free_pending = false;
   bool pose_pending[POSE_RING] = {false, false, false, false};
   int pose_slot = 0;
   double* h_compact = nullptr;       // pinned, host-mapped
@@ -396,6 +409,9 @@ struct glim_amd_factor_set {
   glim_amd::InlineArgs inline_args{};  // single-factor sets: pose + descriptor ride in the kernel arguments
   const double* poses_dev = nullptr;   // where this call's kernels read their poses (the plan's device array, or a host-mapped pinned slot)
   double last_pose_stage_us = 0.0;     // host time the last call spent copying poses into the pinned ring (glim_amd_multi_last_breakdown)
+  // asynchronous calls only (glim_amd_multi: one per device): the pose copy goes to THIS stream and the set's stream waits for it, so that the
+  // upload of one piece of a shard runs beside the kernels of the piece before it instead of queueing behind them
+  hipStream_t upload_stream = nullptr;
 };
 
 namespace glim_amd {

@@ -76,6 +76,22 @@ struct Worker {
   int rc = 0;
 };
 constexpr int WORKER_SPIN_US = 3000;
+constexpr int MAX_PIECES = 8;  // a device's shard is evaluated as up to this many factor sets (glim_amd_multi_set_split)
+
+// Where a shard's records sit in the gathered array (see glim_amd_multi: one region per piece, equal slots per device inside a region).
+// Pure arithmetic, shared by the evaluation, the device-side error sum and glim_amd_shard_layout (which the CPU tests drive for 8 devices).
+inline int64_t layout_rows_of_piece(int64_t piece_rows, int64_t max_rows, int p) { return std::max<int64_t>(0, std::min(piece_rows, max_rows - (int64_t)p * piece_rows)); }
+inline int64_t layout_row(int ndev, int64_t piece_rows, int64_t max_rows, int d, int64_t k) {
+  const int p = (int)(k / piece_rows);
+  return (int64_t)ndev * (int64_t)p * piece_rows + (int64_t)d * layout_rows_of_piece(piece_rows, max_rows, p) + (k - (int64_t)p * piece_rows);
+}
+inline void layout_pieces(int64_t max_rows, int ndev, int split_mode, int* pieces, int64_t* piece_rows) {
+  (void)ndev;
+  int want = split_mode < 0 ? 2 : std::max(1, split_mode);
+  want = (int)std::min<int64_t>(std::min(want, MAX_PIECES), std::max<int64_t>(1, max_rows / 64));  // (a piece of a few rows is all launch tail)
+  *piece_rows = (max_rows + want - 1) / want;
+  *pieces = (int)((max_rows + *piece_rows - 1) / *piece_rows);
+}
 
 inline double us_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -109,14 +125,16 @@ struct glim_amd_multi {
   std::vector<glim_amd_ctx*> ctxs;
   std::vector<std::vector<glim_amd_cloud*>> clouds;   // [device][cloud id]
   std::vector<std::vector<glim_amd_voxelmap*>> maps;  // [device][map id]
-  std::vector<glim_amd_factor_set*> sets;             // [device * 2 + half]: a device's shard as one or two factor sets
+  std::vector<glim_amd_factor_set*> sets;             // [device * MAX_PIECES + piece]: a device's shard as `pieces` factor sets
   std::vector<int64_t> bounds;                        // ndev + 1: device d owns factors [bounds[d], bounds[d + 1])
   std::vector<uint32_t> flags;
   int64_t nf = 0, max_rows = 0;
-  // The gathered array holds two regions: rows [0, ndev * half_rows) = first halves of every shard (device d at d * half_rows), then
-  // ndev * (max_rows - half_rows) rows of second halves.  Unsplit: half_rows == max_rows and the second region is empty.
-  int64_t half_rows = 0;
-  int split_mode = -1;            // -1: split when more than one device; 0 / 1: forced (glim_amd_multi_set_split)
+  // A shard is evaluated in `pieces` consecutive pieces of piece_rows rows (the last one shorter).  The gathered array holds one REGION per
+  // piece: region p = the p-th pieces of every shard, device d's at d * rows_of_piece(p) inside it -- so that each piece is one in-place
+  // ncclAllGather of equal slots, issued as soon as that piece's kernels are done while the next piece's kernels run.
+  int pieces = 1;
+  int64_t piece_rows = 0;
+  int split_mode = -1;            // -1: default (2 pieces); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
   std::vector<double*> d_gather;  // [device]: ndev x max_rows x COMPACT
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
@@ -124,8 +142,10 @@ struct glim_amd_multi {
   bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
   std::mutex abort_mu;
   std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
-  std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next half run beside it)
-  std::vector<hipEvent_t> half_ev;   // [device * 2 + half]: "this half's records are written", recorded on the factor sets' stream
+  std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next piece run beside it)
+  std::vector<hipStream_t> ustream;  // [device]: pose uploads (the upload of the next piece runs beside the kernels of this one)
+  std::vector<hipEvent_t> piece_ev;  // [device * MAX_PIECES + piece]: "this piece's records are written", recorded on the factor sets' stream
+  std::vector<double*> h_total, h_total_dev;  // [device]: this shard's error sum, written by the device into host-mapped memory (sum_error_kernel)
   // HIP events per device around the two phases of the LAST evaluation (kernels, then what is left of collective + copy-out): glim_amd_multi_last_timing
   std::vector<hipEvent_t> ev;  // 3 per device: start (sets' stream), kernels done (sets' stream), end (collective stream)
   std::vector<float> kernel_ms, gather_ms;
@@ -135,9 +155,9 @@ struct glim_amd_multi {
   std::atomic<int> failed{0};
   uint64_t generation = 0;
 
-  int64_t row_of(int d, int64_t k) const {  // row of the k-th factor of device d's shard in the gathered array
-    return k < half_rows ? (int64_t)d * half_rows + k : (int64_t)ndev * half_rows + (int64_t)d * (max_rows - half_rows) + (k - half_rows);
-  }
+  int64_t rows_of_piece(int p) const { return layout_rows_of_piece(piece_rows, max_rows, p); }
+  int64_t region_start(int p) const { return (int64_t)ndev * (int64_t)p * piece_rows; }  // (every earlier region is full)
+  int64_t row_of(int d, int64_t k) const { return layout_row(ndev, piece_rows, max_rows, d, k); }  // row of the k-th factor of device d's shard
 
   // run fn(device index) on every device concurrently -- device 0 on the calling thread -- ; first non-zero return code wins
   int run_all(const std::function<int(int)>& fn, double* post_us = nullptr, double* join_us = nullptr) {
@@ -200,15 +220,17 @@ void release_factors(glim_amd_multi* m) {
     (void)hipSetDevice(m->devices[d]);
     if (d < (int)m->ctxs.size() && m->ctxs[d]) (void)glim_amd_ctx_synchronize(m->ctxs[d]);  // asynchronous linearisations write into d_gather
     if (d < (int)m->cstream.size() && m->cstream[d]) (void)hipStreamSynchronize(m->cstream[d]);
-    for (int h = 0; h < 2; h++)
-      if ((size_t)(2 * d + h) < m->sets.size() && m->sets[2 * d + h]) (void)glim_amd_factor_set_destroy(m->sets[2 * d + h]);
+    if (d < (int)m->ustream.size() && m->ustream[d]) (void)hipStreamSynchronize(m->ustream[d]);
+    for (int h = 0; h < MAX_PIECES; h++)
+      if ((size_t)(MAX_PIECES * d + h) < m->sets.size() && m->sets[MAX_PIECES * d + h]) (void)glim_amd_factor_set_destroy(m->sets[MAX_PIECES * d + h]);
     if (d < (int)m->d_gather.size() && m->d_gather[d]) (void)pool_free(m->d_gather[d]);
   }
-  m->sets.assign((size_t)2 * m->ndev, nullptr);
+  m->sets.assign((size_t)MAX_PIECES * m->ndev, nullptr);
   m->d_gather.assign(m->ndev, nullptr);
   if (m->h_gather) (void)pinned_free(m->h_gather);
   m->h_gather = nullptr;
-  m->nf = m->max_rows = m->half_rows = 0;
+  m->nf = m->max_rows = m->piece_rows = 0;
+  m->pieces = 1;
 }
 
 // A device failed before or inside its ncclAllGather: the others would wait in theirs for ever.  Abort every communicator (their kernels
@@ -222,6 +244,42 @@ void abort_collectives(glim_amd_multi* m) {
       c = nullptr;
     }
   m->broken = true;
+}
+
+
+// error sum of device d's own rows of the gathered array (column 1 of the 29-double records), fixed order: thread t of ONE 1024-thread block adds
+// rows t, t + 1024, ... in FP64 -- eight independent loads in flight at a time: the first version, a 256-thread dependent chain of 128 uncached
+// loads, took 0.2 ms for 32 640 rows -- and the 1024 partial sums are added in a fixed tree: bit-reproducible.
+__global__ __launch_bounds__(1024) void sum_error_kernel(const double* __restrict__ gathered, int d, long long own_rows, long long piece_rows, long long max_rows,
+                                                         int ndev, double* __restrict__ host_total) {
+  __shared__ double s_part[1024];
+  double acc = 0.0;
+  for (long long k0 = threadIdx.x; k0 < own_rows; k0 += 8 * 1024) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const long long k = k0 + (long long)u * 1024;
+      v[u] = 0.0;
+      if (k < own_rows) {
+        const long long p = k / piece_rows;
+        const long long rows_p = min(piece_rows, max_rows - p * piece_rows);
+        const long long row = (long long)ndev * p * piece_rows + (long long)d * rows_p + (k - p * piece_rows);
+        v[u] = gathered[(size_t)row * COMPACT + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u];
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) s_part[threadIdx.x] += s_part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(host_total, s_part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void sum_error_launch(hipStream_t st, const double* gathered, int d, int64_t own_rows, int64_t piece_rows, int64_t max_rows, int ndev, double* host_total) {
+  sum_error_kernel<<<1, 1024, 0, st>>>(gathered, d, (long long)own_rows, (long long)piece_rows, (long long)max_rows, ndev, host_total);
 }
 
 }  // namespace
@@ -250,6 +308,26 @@ int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t
   return GLIM_AMD_OK;
 }
 
+int glim_amd_shard_layout(const int64_t* bounds, int32_t world, int32_t split_mode, int64_t* rows, int64_t* max_rows_out, int32_t* pieces_out,
+                          int64_t* piece_rows_out) {
+  if (!bounds || world <= 0 || split_mode < -1 || split_mode > MAX_PIECES || bounds[0] != 0) return GLIM_AMD_ERR_INVALID;
+  int64_t max_rows = 1;
+  for (int d = 0; d < world; d++) {
+    if (bounds[d + 1] < bounds[d]) return GLIM_AMD_ERR_INVALID;
+    max_rows = std::max<int64_t>(max_rows, bounds[d + 1] - bounds[d]);
+  }
+  int pieces = 1;
+  int64_t piece_rows = max_rows;
+  layout_pieces(max_rows, world, split_mode, &pieces, &piece_rows);
+  if (rows)
+    for (int d = 0; d < world; d++)
+      for (int64_t f = bounds[d]; f < bounds[d + 1]; f++) rows[f] = layout_row(world, piece_rows, max_rows, d, f - bounds[d]);
+  if (max_rows_out) *max_rows_out = max_rows;
+  if (pieces_out) *pieces_out = pieces;
+  if (piece_rows_out) *piece_rows_out = piece_rows;
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out) {
   if (!out || num_devices <= 0 || !devices) return GLIM_AMD_ERR_INVALID;
   *out = nullptr;
@@ -265,7 +343,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->devices.assign(devices, devices + num_devices);
   m->clouds.resize(num_devices);
   m->maps.resize(num_devices);
-  m->sets.assign((size_t)2 * num_devices, nullptr);
+  m->sets.assign((size_t)MAX_PIECES * num_devices, nullptr);
   m->d_gather.assign(num_devices, nullptr);
   m->breakdown.assign((size_t)num_devices * BD_FIELDS, 0.0);
   for (int d = 0; d < num_devices; d++) {
@@ -307,15 +385,21 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->kernel_ms.assign(num_devices, 0.f);
   m->gather_ms.assign(num_devices, 0.f);
   m->cstream.assign(num_devices, nullptr);
-  m->half_ev.assign((size_t)2 * num_devices, nullptr);
+  m->ustream.assign(num_devices, nullptr);
+  m->piece_ev.assign((size_t)MAX_PIECES * num_devices, nullptr);
+  m->h_total.assign(num_devices, nullptr);
+  m->h_total_dev.assign(num_devices, nullptr);
   int prev_device = -1;
   (void)hipGetDevice(&prev_device);
   bool streams_ok = true;
   for (int d = 0; d < num_devices; d++) {
     (void)hipSetDevice(devices[d]);
     if (hipStreamCreateWithFlags(&m->cstream[d], hipStreamNonBlocking) != hipSuccess) streams_ok = false;
-    for (int h = 0; h < 2; h++)
-      if (hipEventCreateWithFlags(&m->half_ev[2 * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+    if (hipStreamCreateWithFlags(&m->ustream[d], hipStreamNonBlocking) != hipSuccess) streams_ok = false;
+    for (int h = 0; h < MAX_PIECES; h++)
+      if (hipEventCreateWithFlags(&m->piece_ev[MAX_PIECES * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+    if (pinned_malloc(&m->h_total[d], 64) != hipSuccess || hipHostGetDevicePointer(reinterpret_cast<void**>(&m->h_total_dev[d]), m->h_total[d], 0) != hipSuccess)
+      streams_ok = false;
   }
   if (!streams_ok) {
     set_hip_error(hipGetLastError(), "glim_amd_multi_create: collective streams / events");
@@ -377,8 +461,10 @@ int glim_amd_multi_destroy(glim_amd_multi* m) {
   for (int d = 0; d < m->ndev; d++) {
     (void)hipSetDevice(m->devices[d]);
     if (d < (int)m->cstream.size() && m->cstream[d]) (void)hipStreamDestroy(m->cstream[d]);
-    for (int h = 0; h < 2; h++)
-      if ((size_t)(2 * d + h) < m->half_ev.size() && m->half_ev[2 * d + h]) (void)hipEventDestroy(m->half_ev[2 * d + h]);
+    if (d < (int)m->ustream.size() && m->ustream[d]) (void)hipStreamDestroy(m->ustream[d]);
+    for (int h = 0; h < MAX_PIECES; h++)
+      if ((size_t)(MAX_PIECES * d + h) < m->piece_ev.size() && m->piece_ev[MAX_PIECES * d + h]) (void)hipEventDestroy(m->piece_ev[MAX_PIECES * d + h]);
+    if (d < (int)m->h_total.size() && m->h_total[d]) (void)pinned_free(m->h_total[d]);
   }
   for (int d = 0; d < m->ndev; d++) {
     (void)hipSetDevice(m->devices[d]);
@@ -468,11 +554,13 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   GA_TRY(glim_amd_shard_bounds(costs.data(), num_factors, m->ndev, bounds.data()));
   int64_t max_rows = 1;
   for (int d = 0; d < m->ndev; d++) max_rows = std::max<int64_t>(max_rows, bounds[(size_t)d + 1] - bounds[(size_t)d]);
-  // Two halves per shard when the records travel between devices: the all-gather of the first halves (the collective's stream) runs beside
-  // the kernels of the second halves (glim_amd/multi.py `gather_device_halves` is the same exchange for one process per GPU).  On one
-  // device there is nothing to hide and two shorter launches only add a second launch tail.
-  const bool split = (m->split_mode < 0 ? m->ndev > 1 : m->split_mode != 0) && max_rows >= 2;
-  const int64_t half_rows = split ? (max_rows + 1) / 2 : max_rows;
+  // Several pieces per shard: the all-gather and the copy-out of piece p (the collective's stream) run beside the kernels of piece p + 1, and
+  // the pose upload of piece p + 1 beside the kernels of piece p; only the LAST piece's exchange is exposed.  glim_amd/multi.py
+  // `gather_device_halves` is the two-piece form of the same exchange for one process per GPU.  More pieces = a shorter exposed tail but one
+  // more launch tail each (every further launch cost the one-GPU shard simulation 40-60 us): 2 by default.
+  int pieces = 1;
+  int64_t piece_rows = max_rows;
+  layout_pieces(max_rows, m->ndev, m->split_mode, &pieces, &piece_rows);
   const size_t gather_doubles = (size_t)m->ndev * (size_t)max_rows * COMPACT;
   if (pinned_malloc(&m->h_gather, gather_doubles * sizeof(double)) != hipSuccess) {
     (void)hipGetLastError();
@@ -484,16 +572,18 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   for (int64_t f = 0; f < num_factors; f++) m->flags[(size_t)f] = flags ? flags[f] : 0u;
   m->nf = num_factors;
   m->max_rows = max_rows;
-  m->half_rows = half_rows;
+  m->piece_rows = piece_rows;
+  m->pieces = pieces;
   const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
-    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1], mid = std::min(lo + half_rows, hi);
-    for (int h = 0; h < 2; h++) {
-      const int64_t f0 = h ? mid : lo, f1 = h ? hi : mid;
+    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
+    for (int h = 0; h < m->pieces; h++) {
+      const int64_t f0 = std::min(lo + (int64_t)h * piece_rows, hi), f1 = std::min(f0 + piece_rows, hi);
       if (f1 <= f0) continue;
-      GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[2 * d + h]));
+      GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[MAX_PIECES * d + h]));
+      m->sets[MAX_PIECES * d + h]->upload_stream = m->ustream[d];
       for (int64_t f = f0; f < f1; f++)
-        GA_TRY(glim_amd_factor_set_add(m->sets[2 * d + h], m->maps[d][target_map_ids[f]], m->clouds[d][source_cloud_ids[f]], m->flags[(size_t)f], nullptr));
+        GA_TRY(glim_amd_factor_set_add(m->sets[MAX_PIECES * d + h], m->maps[d][target_map_ids[f]], m->clouds[d][source_cloud_ids[f]], m->flags[(size_t)f], nullptr));
     }
     GA_HIP(pool_malloc(&m->d_gather[d], gather_doubles * sizeof(double)));
     GA_HIP(hipMemsetAsync(m->d_gather[d], 0, gather_doubles * sizeof(double), m->ctxs[d]->stream()));
@@ -510,7 +600,7 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
 }
 
 int glim_amd_multi_set_split(glim_amd_multi* m, int32_t mode) {
-  if (!m || mode < -1 || mode > 1) return GLIM_AMD_ERR_INVALID;
+  if (!m || mode < -1 || mode > MAX_PIECES) return GLIM_AMD_ERR_INVALID;
   m->split_mode = mode;  // takes effect with the next glim_amd_multi_set_factors
   return GLIM_AMD_OK;
 }
@@ -526,11 +616,12 @@ int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
 // ONE hand-over per evaluation (round 4 handed the devices' threads two tasks -- enqueue, then collective -- and woke them through a
 // condition variable each time; the driver's box showed 2.2 ms of host time per evaluation nobody could name).  Every device's thread -- the
 // caller's own for device 0 -- now runs the whole sequence:
-//   poses of half A -> pinned ring -> H2D, kernels of half A, event A        (the factor sets' stream)
-//   the same for half B, event B                                            (pose staging of B overlaps the kernels of A)
-//   host barrier: has EVERY device enqueued its kernels?                     (a device that failed must keep the others out of the collective)
-//   ncclAllGather of the first halves behind event A, of the second halves behind event B, copy-out on device 0     (the collective's stream)
-//   one synchronise.
+//   for every piece p of its shard: poses -> pinned ring -> H2D, kernels, event p          (the factor sets' stream; the pose staging of
+//                                                                                          piece p + 1 overlaps the kernels of piece p)
+//   host barrier: has EVERY device enqueued its kernels?                                   (a device that failed must keep the others out of the collective)
+//   for every piece p, behind event p: ncclAllGather of the p-th pieces over xGMI, then THIS device's own rows to the host   (the collective's
+//                                                                                          stream: every device copies out over its own PCIe link)
+//   the shard's error sum, by the device, into host-mapped memory; one synchronise.
 // The host barrier costs no device time: the kernels are running while the threads meet.  glim_amd_multi_last_breakdown names every phase.
 int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linearized6* out, double* total_error) {
   if (!m) return GLIM_AMD_ERR_INVALID;
@@ -541,9 +632,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   if (!T) return GLIM_AMD_ERR_INVALID;
   if (m->broken) return GLIM_AMD_ERR_STATE;
   const auto t_call = std::chrono::steady_clock::now();
-  const int ndev = m->ndev;
-  const int64_t hA = m->half_rows, hB = m->max_rows - m->half_rows;
-  const size_t regionB = (size_t)ndev * (size_t)hA * COMPACT;  // first double of the second region
+  const int ndev = m->ndev, P = m->pieces;
   const bool timed = m->ev.size() == (size_t)3 * ndev;
   m->generation += 1;
   const uint64_t all_arrived = m->generation * (uint64_t)ndev;
@@ -556,24 +645,30 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       bd[BD_WAKE] = d ? us_since(t_call) : 0.0;
       int rc_d = GLIM_AMD_OK;
       hipStream_t sst = nullptr;  // the factor sets' stream
+      const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
       auto enqueue_kernels = [&]() -> int {
         GA_HIP(hipSetDevice(m->devices[d]));
-        const int64_t lo = m->bounds[d], hi = m->bounds[d + 1], mid = std::min(lo + hA, hi);
-        glim_amd_factor_set* first = m->sets[2 * d] ? m->sets[2 * d] : m->sets[2 * d + 1];
-        sst = first ? first->stream : m->ctxs[d]->stream();
+        sst = m->ctxs[d]->stream();
+        for (int h = 0; h < P; h++)
+          if (m->sets[MAX_PIECES * d + h]) {
+            sst = m->sets[MAX_PIECES * d + h]->stream;
+            break;
+          }
         if (timed) GA_HIP(hipEventRecord(m->ev[3 * d], sst));
-        for (int h = 0; h < 2; h++) {
-          glim_amd_factor_set* set = m->sets[2 * d + h];
-          const int64_t f0 = h ? mid : lo;
+        hipStream_t last = sst;
+        for (int h = 0; h < P; h++) {
+          glim_amd_factor_set* set = m->sets[MAX_PIECES * d + h];
+          const int64_t f0 = std::min(lo + (int64_t)h * m->piece_rows, hi);
           if (set) {
             const auto t0 = std::chrono::steady_clock::now();
             GA_TRY(glim_amd_factor_set_linearize_device_async(set, T + 12 * f0, m->d_gather[d], m->row_of(d, f0 - lo)));
             bd[BD_POSE_STAGE] += set->last_pose_stage_us;
             bd[BD_ENQUEUE] += us_since(t0) - set->last_pose_stage_us;
+            last = set->stream;
           }
-          GA_HIP(hipEventRecord(m->half_ev[2 * d + h], set ? set->stream : sst));
+          GA_HIP(hipEventRecord(m->piece_ev[MAX_PIECES * d + h], last));
         }
-        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 1], m->sets[2 * d + 1] ? m->sets[2 * d + 1]->stream : sst));
+        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 1], last));
         return (int)GLIM_AMD_OK;
       };
       rc_d = enqueue_kernels();
@@ -597,26 +692,41 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       const auto t_col = std::chrono::steady_clock::now();
       hipStream_t cst = m->cstream[d];
       auto collective = [&]() -> int {
-        for (int h = 0; h < 2; h++) {
-          const int64_t rows = h ? hB : hA;
+        for (int h = 0; h < P; h++) {
+          const int64_t rows = m->rows_of_piece(h);
           if (rows == 0) continue;
-          double* region = m->d_gather[d] + (h ? regionB : 0);
-          const size_t slot = (size_t)rows * COMPACT;
-          GA_HIP(hipStreamWaitEvent(cst, m->half_ev[2 * d + h], 0));
-          if (m->use_rccl) {
+          const size_t start = (size_t)m->region_start(h) * COMPACT, slot = (size_t)rows * COMPACT;
+          double* region = m->d_gather[d] + start;
+          GA_HIP(hipStreamWaitEvent(cst, m->piece_ev[MAX_PIECES * d + h], 0));
+          if (m->use_rccl && ndev > 1) {
             // in place: this device's slot is both the send buffer and its own segment of the receive buffer
             const ncclResult_t r = rccl().AllGather(region + (size_t)d * slot, region, slot, ncclDouble, m->comms[d], cst);
             if (r != ncclSuccess) {
               set_hip_error(hipErrorUnknown, "ncclAllGather");
               return (int)GLIM_AMD_ERR_HIP;
             }
-            if (d == 0)
-              GA_HIP(hipMemcpyAsync(m->h_gather + (h ? regionB : 0), region, (size_t)ndev * slot * sizeof(double), hipMemcpyDeviceToHost, cst));
-          } else {
-            // no collective library: every device hands its own slot to the host (PCIe); single-device and explicitly allowed setups only
-            GA_HIP(hipMemcpyAsync(m->h_gather + (h ? regionB : 0) + (size_t)d * slot, region + (size_t)d * slot, slot * sizeof(double),
-                                  hipMemcpyDeviceToHost, cst));
+          } else if (m->use_rccl && h == P - 1) {
+            // one device: the collective is a copy onto itself; it is issued ONCE per evaluation (over the last piece) so that the library call
+            // the N-device node makes is made on a 1-GPU box as well
+            const ncclResult_t r = rccl().AllGather(region, region, slot, ncclDouble, m->comms[d], cst);
+            if (r != ncclSuccess) {
+              set_hip_error(hipErrorUnknown, "ncclAllGather");
+              return (int)GLIM_AMD_ERR_HIP;
+            }
           }
+          // copy-out: every device hands ITS OWN rows of the piece to the host over its own PCIe link (round 4: device 0 copied the whole
+          // gathered array, 7.6 MB behind the collective; the devices' links work in parallel and need not wait for xGMI)
+          const int64_t own = std::max<int64_t>(0, std::min(rows, (hi - lo) - (int64_t)h * m->piece_rows));
+          if (own > 0)
+            GA_HIP(hipMemcpyAsync(m->h_gather + start + (size_t)d * slot, region + (size_t)d * slot, (size_t)own * COMPACT * sizeof(double),
+                                  hipMemcpyDeviceToHost, cst));
+        }
+        // the shard's error sum, by the device (the host would stream the whole 232-B-per-factor array through its caches for it: 190 us for
+        // 32 640 factors on the round's boxes)
+        if (total_error && !out) {
+          *m->h_total[d] = 0.0;
+          if (hi > lo) sum_error_launch(cst, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->h_total_dev[d]);
+          GA_HIP(hipGetLastError());
         }
         if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 2], cst));
         return (int)GLIM_AMD_OK;
@@ -648,17 +758,31 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   if (rc != GLIM_AMD_OK) return rc;
   const auto t_scan = std::chrono::steady_clock::now();
   double total = 0.0;
-  for (int d = 0; d < ndev; d++) {
-    const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
-    for (int64_t f = lo; f < hi; f++) {
-      const double* rec = m->h_gather + (size_t)m->row_of(d, f - lo) * COMPACT;
-      total += rec[1];
-      if (out) glim_amd_expand_compact(rec, T + 12 * f, m->flags[(size_t)f], &out[f]);
+  if (out) {
+    for (int d = 0; d < ndev; d++) {
+      const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
+      for (int64_t f = lo; f < hi; f++) {
+        const double* rec = m->h_gather + (size_t)m->row_of(d, f - lo) * COMPACT;
+        total += rec[1];
+        glim_amd_expand_compact(rec, T + 12 * f, m->flags[(size_t)f], &out[f]);
+      }
     }
+  } else if (total_error) {
+    for (int d = 0; d < ndev; d++) total += *m->h_total[d];
   }
   if (total_error) *total_error = total;
   bd0[BD_SCAN] = us_since(t_scan);
   bd0[BD_TOTAL] = us_since(t_call);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_records(const glim_amd_multi* m, int64_t first, int64_t count, double* compact29) {
+  if (!m || !compact29 || first < 0 || count < 0 || first + count > m->nf) return GLIM_AMD_ERR_INVALID;
+  for (int64_t f = first; f < first + count; f++) {
+    int d = 0;
+    while (d + 1 < m->ndev && f >= m->bounds[d + 1]) d++;
+    memcpy(compact29 + (size_t)(f - first) * COMPACT, m->h_gather + (size_t)m->row_of(d, f - m->bounds[d]) * COMPACT, COMPACT * sizeof(double));
+  }
   return GLIM_AMD_OK;
 }
 
@@ -670,9 +794,10 @@ int glim_amd_multi_last_breakdown(const glim_amd_multi* m, int32_t device, doubl
 
 int glim_amd_multi_profile(glim_amd_multi* m, const double* T, int iters, float* ms_per_evaluation) {
   if (!m || !T || iters <= 0 || !ms_per_evaluation) return GLIM_AMD_ERR_INVALID;
-  for (int i = 0; i < 3; i++) GA_TRY(glim_amd_multi_linearize(m, T, nullptr, nullptr));
+  double total = 0.0;  // (the cost itself is part of an evaluation: the devices sum their shards' errors)
+  for (int i = 0; i < 3; i++) GA_TRY(glim_amd_multi_linearize(m, T, nullptr, &total));
   const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_multi_linearize(m, T, nullptr, nullptr));
+  for (int i = 0; i < iters; i++) GA_TRY(glim_amd_multi_linearize(m, T, nullptr, &total));
   const auto t1 = std::chrono::steady_clock::now();
   *ms_per_evaluation = (float)(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
   return GLIM_AMD_OK;

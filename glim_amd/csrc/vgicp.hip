@@ -346,6 +346,14 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
 #define GLIM_AMD_MINW_GENERAL 4
 #endif
 
+// Plane-form factors read the "plane view" of the target table (A_B = (C_B + I)^-1 in the covariance slots, voxelmap.hip plane_view_kernel)
+// and form M by Sherman-Morrison instead of building S = C_B + R C_A R^T and inverting it by cofactors: 26 FP32
+// operations instead of 39, same conditioning (the denominator 1 - 0.999 m^T A_B m >= 0.002 carries the cancellation the determinant of S
+// carried).  0: the cofactor form on the plain table (A/B builds: tools/ab_variant.sh sm0 -DGLIM_AMD_PLANE_SM=0).
+#ifndef GLIM_AMD_PLANE_SM
+#define GLIM_AMD_PLANE_SM 1
+#endif
+
 struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: lives in SGPRs)
   float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
@@ -450,6 +458,26 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
   }
   // residual mu - q, both relative to the voxel centre
   const float rx = r0.x - s.qr0, ry = r0.y - s.qr1, rz = r0.z - s.qr2;
+  float A00, A01, A02, A11, A12, A22;
+  if (PLANE && GLIM_AMD_PLANE_SM) {
+    // the record holds A_B = (C_B + I)^-1 (plane view of the table).  M = A_B + c w w^T, w = A_B m, c = 0.999 / (1 - 0.999 m.w).  A lane
+    // without a match has read the table's all-zero record: w = 0, M = 0, every contribution an exact zero -- no select.
+    // Explicit fmaf chains: this function is inlined into four kernels that must return the same bits.
+    const float a00 = r0.w, a01 = r1.x, a02 = r1.y, a11 = r1.z, a12 = r1.w, a22 = r2c22;
+    const float mx = s.c0, my = s.c1, mz = s.c2;
+    const float wx = fmaf(a02, mz, fmaf(a01, my, a00 * mx));
+    const float wy = fmaf(a12, mz, fmaf(a11, my, a01 * mx));
+    const float wz = fmaf(a22, mz, fmaf(a12, my, a02 * mx));
+    const float mw = fmaf(mz, wz, fmaf(my, wy, mx * wx));
+    const float den = fmaf(-0.999f, mw, 1.0f);
+    float iden = __builtin_amdgcn_rcpf(den);
+    iden = fmaf(fmaf(-den, iden, 1.0f), iden, iden);
+    const float c = 0.999f * iden;
+    const float cx = c * wx, cy = c * wy, cz = c * wz;
+    A00 = fmaf(cx, wx, a00); A01 = fmaf(cx, wy, a01); A02 = fmaf(cx, wz, a02);
+    A11 = fmaf(cy, wy, a11); A12 = fmaf(cy, wz, a12); A22 = fmaf(cz, wz, a22);
+    (void)hit; (void)t00; (void)t01; (void)t02; (void)t11; (void)t12; (void)t22;
+  } else {
   // S = C_B + R C_A R^T (symmetric).  A lane without a match has read SOME record of the table -- another voxel's, or the zeros of an empty
   // way (voxelmap.hip initialises every record) -- so everything up to the determinant is finite for it too; idet = 0 (a select, not a
   // product) then zeroes its contributions exactly.  No per-coefficient selects.
@@ -470,10 +498,11 @@ __device__ __forceinline__ void accumulate_point(float (&acc)[NACC], bool hit, c
   float idet = __builtin_amdgcn_rcpf(det);         // 1 ulp hardware reciprocal ...
   idet = fmaf(fmaf(-det, idet, 1.0f), idet, idet);  // ... + one Newton step (full FP32 accuracy, no division sequence)
   idet = hit ? idet : 0.f;
-  const float A00 = k00 * idet, A01 = k01 * idet, A02 = k02 * idet;
-  const float A11 = (S00 * S22 - S02 * S02) * idet;
-  const float A12 = (S01 * S02 - S00 * S12) * idet;
-  const float A22 = (S00 * S11 - S01 * S01) * idet;
+  A00 = k00 * idet; A01 = k01 * idet; A02 = k02 * idet;
+  A11 = (S00 * S22 - S02 * S02) * idet;
+  A12 = (S01 * S02 - S00 * S12) * idet;
+  A22 = (S00 * S11 - S01 * S01) * idet;
+  }
   // u = M r,  e = r . u   (r = mu - q is already a target-frame vector)
   const float ux = A00 * rx + A01 * ry + A02 * rz;
   const float uy = A01 * rx + A11 * ry + A12 * rz;
@@ -555,7 +584,9 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   const bool any_hit = PLANE || hit_lanes != 0ull;  // wave-uniform: a scalar branch
   if (!PLANE) wave_skips += any_hit ? 0 : 1;         // (scalar) trips that skip the record gather and the algebra: reported per run, glim_amd_factor_set_trip_stats
   // every lane reads a record (way 0 of the last bucket when there is no hit) so the wavefront does not diverge
-  const char* rp = reinterpret_cast<const char*>(d.buckets) + (b * 128u + (in1 ? 64u : 16u));
+  // (plane view: a lane without a correspondence reads the all-zero record of the extra bucket behind the table, so its M is exactly 0)
+  const unsigned int rec_off = (PLANE && GLIM_AMD_PLANE_SM) ? (hit ? b * 128u + (in1 ? 64u : 16u) : d.num_buckets * 128u + 16u) : b * 128u + (in1 ? 64u : 16u);
+  const char* rp = reinterpret_cast<const char*>(d.buckets) + rec_off;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2 = 0.f;
   if (any_hit) {
@@ -1118,6 +1149,7 @@ void plan_free(FactorPlan* p) {
   if (p->h_rec16) (void)pinned_free(p->h_rec16);
   for (int i = 0; i < FactorPlan::POSE_RING; i++)
     if (p->pose_events[i]) (void)hipEventDestroy(p->pose_events[i]);
+  if (p->poses_free_event) (void)hipEventDestroy(p->poses_free_event);
   delete p;
 }
 
@@ -1240,6 +1272,11 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     }
     d.buckets = e.target->buckets;
     d.num_buckets = e.target->num_buckets;
+    if (GLIM_AMD_PLANE_SM && d.plane) {
+      glim_amd_voxelmap* tm = const_cast<glim_amd_voxelmap*>(e.target);  // the lazily built view is a cache, not a change of the map
+      GA_TRY(ensure_plane_view(tm, set->stream));
+      d.buckets = tm->buckets_sm;
+    }
     d.n = (int)src->n;
     d.inv_res = e.target->inv_resolution;
     d.res = e.target->resolution;
@@ -1620,11 +1657,14 @@ int upload_poses(glim_amd_factor_set* set, const double* T_lin, const double* T_
     return GLIM_AMD_OK;
   }
   set->poses_dev = plan->d_poses;
-  GA_HIP(hipMemcpyAsync(plan->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, set->stream));
+  hipStream_t up = (async_call && set->upload_stream) ? set->upload_stream : set->stream;
+  if (up != set->stream && plan->poses_free_pending) GA_HIP(hipStreamWaitEvent(up, plan->poses_free_event, 0));  // the previous call's kernels still read d_poses
+  GA_HIP(hipMemcpyAsync(plan->d_poses, h, nf * (T_eval ? 24 : 12) * sizeof(double), hipMemcpyHostToDevice, up));
   if (async_call) {
     if (!plan->pose_events[slot]) GA_HIP(hipEventCreateWithFlags(&plan->pose_events[slot], hipEventDisableTiming));
-    GA_HIP(hipEventRecord(plan->pose_events[slot], set->stream));
+    GA_HIP(hipEventRecord(plan->pose_events[slot], up));
     plan->pose_pending[slot] = true;
+    if (up != set->stream) GA_HIP(hipStreamWaitEvent(set->stream, plan->pose_events[slot], 0));
   }
   return GLIM_AMD_OK;
 }
@@ -1864,16 +1904,22 @@ extern "C" int glim_amd_debug_resident_stop(int device) {
 }
 
 namespace glim_amd {
-// Memory of this device is about to be recycled (a cloud / voxel map destroyed or rebuilt: quiesce_device): the session's workers hold
-// descriptors into such memory and prefetch from it while they wait, so the session ends here rather than by its idle time-out.
+// Memory of a cloud / voxel map is about to be recycled (destroyed or rebuilt: quiesce_device): when the session's plan uses that object, its
+// workers hold descriptors into that memory and prefetch from it while they wait, so the session ends here rather than by its idle time-out
+// (ADVICE r4).  Objects the session does not use leave it alone.
 // A request in flight (another thread's) is allowed to finish first.
-void resident_stop_device(int device) {
+void resident_stop_device(int device, uint64_t uid) {
   if (device < 0 || device >= 16) return;
   ResidentSession& S = g_resident[device];
   for (int tries = 0; tries < 20000; tries++) {
     {
       std::lock_guard<std::mutex> slock(S.mu);
       if (!S.launched) return;
+      if (uid != 0 && S.plan) {  // does the session's plan use the object? (the plan is alive while the session serves it)
+        bool used = false;
+        for (const PlanKey& k : S.plan->key) used = used || k.target_uid == uid || k.source_uid == uid;
+        if (!used) return;
+      }
       if (!S.busy.load()) {
         int prev = -1;
         (void)hipGetDevice(&prev);
@@ -2152,7 +2198,14 @@ int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const d
   GA_TRY(upload_poses(set, T, nullptr, true));
   set->ctx->async_pending.store(true);  // clouds / maps destroyed later must wait for this work (glim_amd_ctx::quiesce)
   set->plan->maybe_busy = true;         // ... and so must whoever frees or adopts this plan from another stream
-  return enqueue(set, MODE_LINEARIZE, false, out_device, out_row_offset, false);
+  GA_TRY(enqueue(set, MODE_LINEARIZE, false, out_device, out_row_offset, false));
+  if (set->upload_stream) {
+    FactorPlan* plan = set->plan;
+    if (!plan->poses_free_event) GA_HIP(hipEventCreateWithFlags(&plan->poses_free_event, hipEventDisableTiming));
+    GA_HIP(hipEventRecord(plan->poses_free_event, set->stream));
+    plan->poses_free_pending = true;
+  }
+  return GLIM_AMD_OK;
 }
 
 int glim_amd_factor_set_error(glim_amd_factor_set* set, const double* T_lin, const double* T_eval, double* errors, int64_t* inliers) {

@@ -296,20 +296,73 @@ __global__ __launch_bounds__(256) void reopen_old_voxels_kernel(const VoxelBucke
   atomicAdd(reinterpret_cast<unsigned long long*>(dst + 9), (unsigned long long)cnt);
 }
 
+// The plane view of a finished table (internal.hpp glim_amd_voxelmap::buckets_sm): one thread per (bucket, way) of num_buckets + 1 buckets.
+// For a plane-form source C_A = I - 0.999 n n^T, so  C_B + R C_A R^T = (C_B + I) - 0.999 m m^T  (m = R n)  and, by Sherman-Morrison,
+//   M = (C_B + R C_A R^T)^-1 = A_B + 0.999 (A_B m)(A_B m)^T / (1 - 0.999 m^T A_B m),   A_B = (C_B + I)^-1:
+// the per-point 3x3 inverse of the factor kernel becomes one matrix-vector product, one dot product, one reciprocal and one rank-1 update.
+// A_B depends on the voxel alone, so it is inverted HERE, once per voxel, in FP64 (C_B + I has eigenvalues in [1, 2]: perfectly conditioned).
+// r: a finished record of the plain table (FP32 mean | C_B | count); o: the same voxel's record of the plane view.  Always computed from the
+// FP32 record, so the view is the same bits whether finalize_kernel writes it with the map or plane_view_kernel adds it later.
+__device__ __forceinline__ void plane_record(const float* __restrict__ r, float* __restrict__ o) {
+  const double s00 = (double)r[3] + 1.0, s01 = (double)r[4], s02 = (double)r[5], s11 = (double)r[6] + 1.0, s12 = (double)r[7], s22 = (double)r[8] + 1.0;
+  const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
+  const double idet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
+  o[0] = r[0];
+  o[1] = r[1];
+  o[2] = r[2];
+  o[3] = (float)(k00 * idet);
+  o[4] = (float)(k01 * idet);
+  o[5] = (float)(k02 * idet);
+  o[6] = (float)((s00 * s22 - s02 * s02) * idet);
+  o[7] = (float)((s01 * s02 - s00 * s12) * idet);
+  o[8] = (float)((s00 * s11 - s01 * s01) * idet);
+  o[9] = r[9];
+  o[10] = 0.f;
+  o[11] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void plane_view_kernel(const VoxelBucket* __restrict__ src, VoxelBucket* __restrict__ dst, unsigned int num_buckets) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * (num_buckets + 1)) return;
+  const unsigned int b = i >> 1, w = i & 1;
+  float* o = dst[b].rec[w];
+  if (w == 0) {
+    dst[b].pad[0] = dst[b].pad[1] = dst[b].pad[2] = dst[b].pad[3] = 0;
+  }
+  const unsigned long long key = b < num_buckets ? src[b].key[w] : EMPTY_KEY;
+  dst[b].key[w] = key;
+  if (key == EMPTY_KEY) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[k] = 0.f;
+    return;
+  }
+  plane_record(src[b].rec[w], o);
+}
+
 // one thread per (bucket, way)
 // stats / host_stats (direct build): the voxel count and the range flag of the key insertion, handed to the host through mapped pinned
 // memory by this last launch -- the call then needs a stream synchronise only, no device-to-host copy
+// view (optional; launch 2 * (num_buckets + 1) threads then): the plane view of the table (plane_record), written with the map -- every way
+// of every bucket, so it needs no clearing, plus the all-zero bucket behind the table.
 __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
                                                        const long long* __restrict__ acc, double res, const int* __restrict__ stats,
-                                                       int* __restrict__ host_stats) {
+                                                       int* __restrict__ host_stats, VoxelBucket* __restrict__ view) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && host_stats) {
     host_stats[0] = stats[0];
     host_stats[1] = stats[1];
   }
-  if (i >= 2 * num_buckets) return;
+  if (i >= 2 * num_buckets + (view ? 2u : 0u)) return;
   const unsigned int b = i >> 1, w = i & 1;
-  const unsigned long long key = buckets[b].key[w];
+  const unsigned long long key = b < num_buckets ? buckets[b].key[w] : EMPTY_KEY;
+  if (view) {
+    view[b].key[w] = key;
+    if (w == 0) view[b].pad[0] = view[b].pad[1] = view[b].pad[2] = view[b].pad[3] = 0;
+    if (key == EMPTY_KEY) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) view[b].rec[w][k] = 0.f;
+    }
+  }
   if (key == EMPTY_KEY) return;
   const long long* a = acc + (size_t)i * ACC_STRIDE;
   const long long cnt = a[9];
@@ -331,6 +384,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__
   r[9] = __int_as_float((int)cnt);
   r[10] = 0.f;
   r[11] = 0.f;
+  if (view) plane_record(r, view[b].rec[w]);
 }
 
 // voxels-per-point ratio of the last map built at a resolution class (sizes the direct build of the next one)
@@ -473,6 +527,29 @@ void voxelmap_drop_cleared_tables(int device) {
 }
 }  // namespace glim_amd
 
+namespace glim_amd {
+int ensure_plane_view(glim_amd_voxelmap* m, hipStream_t st) {
+  if (!m->buckets || m->num_buckets == 0) return GLIM_AMD_ERR_STATE;
+  // a map may be reached from factor sets of several contexts at once (GLIM's modules share them): one builder, and the view is COMPLETE
+  // before anybody sees its pointer
+  std::lock_guard<std::mutex> lock(m->view_mu);
+  if (m->buckets_sm) return GLIM_AMD_OK;
+  VoxelBucket* v = nullptr;
+  GA_HIP(pool_malloc(&v, ((size_t)m->num_buckets + 1) * sizeof(VoxelBucket)));
+  const unsigned int threads = 2 * (m->num_buckets + 1);
+  plane_view_kernel<<<(threads + 255) / 256, 256, 0, st>>>(m->buckets, v, m->num_buckets);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    (void)pool_free(v);
+    set_hip_error(e, "ensure_plane_view");
+    return GLIM_AMD_ERR_HIP;
+  }
+  m->buckets_sm = v;
+  return GLIM_AMD_OK;
+}
+}  // namespace glim_amd
+
 extern "C" {
 
 int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int /*init_num_buckets*/, int /*max_bucket_scan_count*/,
@@ -490,9 +567,10 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (!m) return GLIM_AMD_OK;
   if (m->ctx) {
     (void)hipSetDevice(m->ctx->device);
-    quiesce_device(m->ctx->device);  // asynchronous factor launches (of any context) may still be reading this table
+    quiesce_device(m->ctx->device, m->uid);  // asynchronous factor launches (of any context) may still be reading this table
   }
   global_mutation_epoch()++;  // factor sets re-validate their plans
+  if (m->buckets_sm) (void)pool_free(m->buckets_sm);
   if (m->buckets) {
     if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
     else (void)pool_free(m->buckets);
@@ -516,7 +594,12 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   constexpr int DIRECT_MAX_POINTS = 32768;
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
-  if (old) quiesce_device(ctx->device);  // asynchronous factor launches may still be reading the table that is about to be replaced
+  if (old) quiesce_device(ctx->device, m->uid);  // asynchronous factor launches may still be reading the table that is about to be replaced
+  if (m->buckets_sm) {  // the plane view follows the table: rebuilt on the next use (the map's uid changes below, so no plan keeps the old pointer)
+    std::lock_guard<std::mutex> vlock(m->view_mu);
+    (void)pool_free(m->buckets_sm);
+    m->buckets_sm = nullptr;
+  }
   // Direct build (keys straight into the final table, ONE synchronise: build_direct_kernel) needs the table size before the voxels are
   // counted.  Small clouds: 2 buckets per point (4 ways per point: load factor below 1/2 whatever the cloud).  Larger clouds: 6 buckets per
   // EXPECTED voxel, from the voxels-per-point ratio of the last map this context built at (about) this resolution -- consecutive frames of a
@@ -553,10 +636,14 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     int *h_view = nullptr, *d_view = nullptr;
     const bool mapped = pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view));
     int h_stats[2] = {0, 0};
+    // a map built from a plane-form cloud (a frame with kNN covariances) will be matched against plane-form frames: its plane view is written
+    // with the map (no launch, no synchronise on the first factor that uses it); any other map gets the view on first use (ensure_plane_view)
+    VoxelBucket* view = nullptr;
+    if (cloud->plane_form && ctx->diag.view_fused) GA_HIP(pool_malloc(&view, ((size_t)nb + 1) * sizeof(VoxelBucket)));
     if (!have_cleared)
       init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
     build_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, m->inv_resolution, buckets, nb, (long long*)acc.p, (int*)stats.p);
-    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr);
+    finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr, view);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && mapped) {
       e = hipStreamSynchronize(st);
@@ -569,11 +656,13 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       set_hip_error(e, "voxelmap_insert");
       (void)hipStreamSynchronize(st);  // (whatever did get enqueued must not outlive the table)
       (void)pool_free(buckets);
+      if (view) (void)pool_free(view);
       return GLIM_AMD_ERR_HIP;
     }
     in_flight.dismiss();  // synchronised
     if (h_stats[1] != 0) {
       (void)pool_free(buckets);
+      if (view) (void)pool_free(view);
       return GLIM_AMD_ERR_RANGE;
     }
     remember_voxel_ratio(ctx, res_class, (double)h_stats[0] / (double)n);
@@ -582,6 +671,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     // the whole life of the map.  Above 0.35 keys per way the table is rebuilt by the counting path (6 buckets per voxel actually present).
     if (direct_large && (double)h_stats[0] > 0.35 * 2.0 * (double)nb) {
       (void)pool_free(buckets);
+      if (view) (void)pool_free(view);
       (void)pool_free(stats.p);
       stats.p = nullptr;
       (void)pool_free(acc.p);
@@ -590,6 +680,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       break;
     }
     m->buckets = buckets;
+    m->buckets_sm = view;
     m->num_buckets = nb;
     m->num_voxels = h_stats[0];
     m->uid = next_uid();
@@ -627,7 +718,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (nb64 > (1ull << 25)) return GLIM_AMD_ERR_NOMEM;
   if (ctx->diag.bucket_factor == 0) nb64 = round_buckets(nb64);
   const unsigned int nb = (unsigned int)nb64;
-  VoxelBucket* buckets = nullptr;
+  VoxelBucket *buckets = nullptr, *view2 = nullptr;
   GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
   hipError_t e = pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
   if (e == hipSuccess) e = hipMemsetAsync(acc.p, 0, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long), st);
@@ -638,7 +729,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (n > 0)
       accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets,
                                                           nb, (long long*)acc.p);
-    finalize_kernel<<<(2 * nb + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, nullptr, nullptr);
+    if (cloud->plane_form && ctx->diag.view_fused && pool_malloc(&view2, ((size_t)nb + 1) * sizeof(VoxelBucket)) != hipSuccess) {
+      (void)hipGetLastError();
+      view2 = nullptr;  // (the view is a cache: it is built on first use then)
+    }
+    finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, nullptr, nullptr, view2);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -646,9 +741,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     set_hip_error(e, "voxelmap_insert");
     (void)hipStreamSynchronize(st);
     (void)pool_free(buckets);
+    if (view2) (void)pool_free(view2);
     return GLIM_AMD_ERR_HIP;
   }
   in_flight.dismiss();
+  m->buckets_sm = view2;
   if (old) (void)pool_free(old);
   else if (n > 0) remember_voxel_ratio(ctx, res_class, (double)num_voxels / (double)n);
   m->buckets = buckets;

@@ -90,8 +90,11 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair|qgroup,
  * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
- * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1 + resident_idle_us=<n> (repeated synchronous linearisations of a small set
- * served by a resident kernel that leaves after <n> us without a request), pp_fast=0|1 (random-grid preprocessing without sorts),
+ * view_fused=0|1 (a voxel map built from a plane-form cloud gets its plane view -- the (C_B + I)^-1 records the plane-form factor kernel reads --
+ * from the map's own finalise kernel; 0: on the first factor that needs it),
+ * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
+ * served by a resident kernel that leaves after <n> us without a request; auto, the default: only in a context created with priority 1 -- the
+ * session costs whatever else runs on the device 1.3-1.4x while it is alive, so it is opt-in), pp_fast=0|1 (random-grid preprocessing without sorts),
  * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,
  * multi_host_gather=0|1.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and nothing changes.  get_diag prints the current state in the
  * same syntax. */
@@ -324,10 +327,10 @@ int glim_amd_debug_resident_stop(int device);
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
  * One process, N devices: a context + a host thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per
  * device (device 0 is driven by the CALLING thread).  Clouds and voxel maps are replicated on every device, the factor list is sharded into
- * contiguous cost-balanced chunks, every device linearises its chunk -- as two halves when there is more than one device, so that the
- * ncclAllGather of the first halves' 29-double compact records travels over xGMI while the second halves' kernels run -- and the records
- * are expanded on the host in the original factor order.  One hand-over to the devices' threads per evaluation.  All calls are
- * synchronous and must come from one host thread at a time. */
+ * contiguous cost-balanced chunks, every device linearises its chunk -- in a few pieces, so that the ncclAllGather of one piece's 29-double
+ * compact records travels over xGMI (and this device's own rows to the host over its own PCIe link) while the next piece's kernels run --
+ * and the records are expanded on the host in the original factor order.  One hand-over to the devices' threads per evaluation.  All
+ * calls are synchronous and must come from one host thread at a time. */
 typedef struct glim_amd_multi glim_amd_multi;
 /* devices: distinct HIP device ordinals.  A multi-device handle without a working RCCL is refused (GLIM_AMD_ERR_HIP) rather than
  * silently gathering over PCIe; a single device works either way (GLIM_AMD_DIAG="multi_rccl=0" skips the collective there). */
@@ -347,8 +350,12 @@ int glim_amd_multi_set_factors(glim_amd_multi* multi, int64_t num_factors, const
                                const uint32_t* flags);
 /* device d owns factors [bounds[d], bounds[d + 1]); bounds has num_devices + 1 entries */
 int glim_amd_multi_shard(const glim_amd_multi* multi, int64_t* bounds);
-/* H / b / error of every factor at T_target_source (n x 12); out (n records) and total_error may be NULL */
+/* H / b / error of every factor at T_target_source (n x 12); out (n records) and total_error may be NULL.  With out == NULL the compact
+ * records stay in the handle's pinned host array (glim_amd_multi_records) and total_error is summed by the devices. */
 int glim_amd_multi_linearize(glim_amd_multi* multi, const double* T_target_source, glim_amd_linearized6* out, double* total_error);
+/* the last evaluation's compact 29-double records [num_inliers, error, 21 upper-triangular H_ss entries, 6 b_s] of factors
+ * [first, first + count), in factor order (expand one with glim_amd_expand_compact) */
+int glim_amd_multi_records(const glim_amd_multi* multi, int64_t first, int64_t count, double* compact29);
 /* wall-clock milliseconds per whole-cost evaluation (all devices + collective + host expansion skipped), over `iters` evaluations */
 int glim_amd_multi_profile(glim_amd_multi* multi, const double* T_target_source, int iters, float* ms_per_evaluation);
 /* per device, HIP-event milliseconds of the LAST evaluation: its factor kernels + finalise (kernel_ms[d]) and the collective + copy-out behind
@@ -367,12 +374,18 @@ int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, fl
  *   [9] total       the whole glim_amd_multi_linearize call                                (device 0 only) */
 #define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 10
 int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
-/* how a device's shard is evaluated: 1 = as two halves, the all-gather of the first overlapping the kernels of the second; 0 = as one
- * set and one all-gather; -1 (default) = two halves when the handle has more than one device.  Takes effect with the next
+/* how a device's shard is evaluated: n >= 2 = as n pieces (at most 8), the all-gather and copy-out of one piece overlapping the kernels of
+ * the next; 0 or 1 = as one set and one all-gather; -1 (default) = 2 pieces.  Takes effect with the next
  * glim_amd_multi_set_factors. */
 int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
+/* where every factor's 29-double record sits in the gathered [world x max_rows] array of an evaluation, as a pure host function (the rule
+ * glim_amd_multi_linearize, its collectives and glim_amd_multi_records use): bounds from glim_amd_shard_bounds (world + 1 entries),
+ * split_mode as glim_amd_multi_set_split; rows (bounds[world] entries, may be NULL) receives each factor's row, the other outputs (may be
+ * NULL) the padded shard length, the number of pieces a shard is cut into and the rows of a full piece.  Piece p of every shard forms one
+ * contiguous region of world equal slots -- one in-place ncclAllGather each. */
+int glim_amd_shard_layout(const int64_t* bounds, int32_t world, int32_t split_mode, int64_t* rows, int64_t* max_rows, int32_t* pieces, int64_t* piece_rows);
 
 /* ---- overlap: overlap_gpu / overlap_auto (odometry_estimation_gpu.cpp:231,248,265,279,326; sub_mapping.cpp:252-253;
  *      global_mapping.cpp:322,448).  Fraction of source points that hit an occupied voxel of ANY target under its delta. */

@@ -39,6 +39,16 @@ def build_ref(force=False):
     return _REF_PATH
 
 
+def build_twin():
+    """oracle/_ref/libglim_twin.so: the same C entry points as libglim_ref.so over the HIP-backed twins of the three in-tree translation units
+    (adapters/glim/cloud_*_hip.cpp) -- tests/test_twins.py runs both side by side.  Needs the reference's headers and libglim_amd.so: built where
+    /root/reference exists, the prebuilt .so travels to the GPU box.  Returns the path or None."""
+    path = os.path.join(_HERE, "_ref", "libglim_twin.so")
+    if os.path.isdir(os.path.join(_REFERENCE_ROOT, "include", "glim")):
+        subprocess.check_call(["make", "-C", _HERE, "twin", "-s"], stdout=subprocess.DEVNULL)
+    return path if os.path.exists(path) else None
+
+
 def ref_lib():
     """The compiled reference translation units, or None when neither the prebuilt .so nor /root/reference exists."""
     global _ref

@@ -715,12 +715,18 @@ static void vgicp_run_sv(const orc_voxelmap* map, const double* pts, const doubl
   acc_t* parts = (acc_t*)calloc((size_t)num_threads, sizeof(acc_t));
 #pragma omp parallel num_threads(num_threads)
   {
+    /* thread-local accumulator on the thread's own stack, handed over once at the end: the heap array of per-thread sums packs neighbouring
+     * threads' hot fields (the tail of one acc_t, the head of the next) into one cache line, and with every point updating both the line
+     * bounced between the cores -- two threads were SLOWER than one.  Same additions in the same order. */
+    acc_t A_local;
+    memset(&A_local, 0, sizeof(A_local));
+    acc_t* A = &A_local;
 #ifdef _OPENMP
-    acc_t* A = &parts[omp_get_thread_num()];
+    const int tid = omp_get_thread_num();
 #else
-    acc_t* A = &parts[0];
+    const int tid = 0;
 #endif
-#pragma omp for schedule(guided, 8)
+#pragma omp for schedule(guided, 8) nowait
     for (int i = 0; i < n; i++) {
       const double* p = pts + 4 * (size_t)i;
       double q_lin[3];
@@ -758,6 +764,7 @@ static void vgicp_run_sv(const orc_voxelmap* map, const double* pts, const doubl
       }
       accumulate_point(A, T_eval, p, q, vx->mean, M, need_H);
     }
+    parts[tid] = A_local;
   }
   memset(total, 0, sizeof(*total));
   for (int t = 0; t < num_threads; t++) acc_add(total, &parts[t]);
@@ -837,12 +844,18 @@ static void gicp_run(const double* tpts, const double* tcovs, int nt, const doub
   acc_t* parts = (acc_t*)calloc((size_t)num_threads, sizeof(acc_t));
 #pragma omp parallel num_threads(num_threads)
   {
+    /* thread-local accumulator on the thread's own stack, handed over once at the end: the heap array of per-thread sums packs neighbouring
+     * threads' hot fields (the tail of one acc_t, the head of the next) into one cache line, and with every point updating both the line
+     * bounced between the cores -- two threads were SLOWER than one.  Same additions in the same order. */
+    acc_t A_local;
+    memset(&A_local, 0, sizeof(A_local));
+    acc_t* A = &A_local;
 #ifdef _OPENMP
-    acc_t* A = &parts[omp_get_thread_num()];
+    const int tid = omp_get_thread_num();
 #else
-    acc_t* A = &parts[0];
+    const int tid = 0;
 #endif
-#pragma omp for schedule(guided, 8)
+#pragma omp for schedule(guided, 8) nowait
     for (int i = 0; i < n; i++) {
       const double* p = pts + 4 * (size_t)i;
       double q[3];
@@ -863,6 +876,7 @@ static void gicp_run(const double* tpts, const double* tcovs, int nt, const doub
       fused_mahalanobis(tcovs + 16 * (size_t)best, covs + 16 * (size_t)i, T, M);
       accumulate_point(A, T, p, q, tpts + 4 * (size_t)best, M, need_H);
     }
+    parts[tid] = A_local;
   }
   memset(total, 0, sizeof(*total));
   for (int t = 0; t < num_threads; t++) acc_add(total, &parts[t]);

@@ -1,5 +1,6 @@
 #pragma once
 #include <gtsam_points/types/point_cloud.hpp>
+#include <Eigen/Geometry>
 #include <random>
 #include <vector>
 namespace gtsam_points {

@@ -523,6 +523,50 @@ def test_plane_form_kernel_matches_general_kernel_and_oracle(api, ctx, orc):
     assert np.abs(gn_step(results[("plane", True)]) - gn_step(results[("general", True)])).max() < 1e-5
 
 
+def test_plane_view_written_with_the_map_equals_the_one_built_on_first_use(api, ctx, orc, small_pair):
+    """Plane-form factors read the PLANE VIEW of the target table (records hold (C_B + I)^-1, Sherman-Morrison in the kernel).  A map built from a
+    plane-form cloud gets the view from its own finalise kernel (view_fused=1, default); any other map -- or view_fused=0 -- on the first factor
+    that needs it.  Same table, same bits, by both routes and after an incremental insert; and the general kernel (plane=0: plain table,
+    cofactor inverse) agrees with both within FP32 rounding."""
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float32), ctx=ctx)
+    sg = api.PointCloudGPU.clone(s["points"].astype(np.float32), ctx=ctx)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    values = {0: np.eye(4), 1: small_pair["delta"]}
+
+    def run(vm):
+        fset = api.NonlinearFactorSetGPU(ctx)
+        fset.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        out = fset.linearize(values)[0], fset.error(values)[0]
+        fset.close()
+        return out
+
+    fused = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    with ctx.diag("view_fused=0"):
+        lazy = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+    (La, ea), (Lb, eb) = run(fused), run(lazy)
+    assert La["num_inliers"] == Lb["num_inliers"] > 100 and La["error"] == Lb["error"] and ea == eb
+    for key in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+        np.testing.assert_array_equal(La[key], Lb[key], err_msg=key)
+    # incremental insert: the view follows the rebuilt table
+    for vm in (fused, lazy):
+        vm.insert(sg)
+    with ctx.diag("view_fused=0"):
+        both = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+        both.insert(sg)
+    (Lc, _), (Ld, _), (Le, _) = run(fused), run(lazy), run(both)
+    assert Lc["num_inliers"] == Ld["num_inliers"] == Le["num_inliers"] > La["num_inliers"]
+    np.testing.assert_array_equal(Lc["H_ss"], Ld["H_ss"])
+    np.testing.assert_array_equal(Lc["H_ss"], Le["H_ss"])
+    with ctx.diag("plane=0"):
+        Lg, eg = run(fused)
+    assert Lg["num_inliers"] == Lc["num_inliers"]
+    np.testing.assert_allclose(Lg["H_ss"], Lc["H_ss"], rtol=0, atol=2e-5 * np.abs(Lc["H_ss"]).max())
+    assert np.abs(gn_step(Lg) - gn_step(Lc)).max() < 1e-6
+
+
 def test_knn_chunk_and_grid_paths_agree(api, ctx, orc):
     """The two device kNN implementations (Hilbert-ordered chunks, hashed grid) and the oracle give identical lists, also on a cloud
     with a strongly non-uniform density, exact duplicates and a size that is not a multiple of the chunk length."""

@@ -46,6 +46,86 @@ def test_gather_layout_places_every_factor_once():
         assert np.array_equal(ev1.gather_host(rows).numpy(), rows)
 
 
+def test_world8_record_layout_against_the_unsharded_order():
+    """What an 8-device node does with configs[3]'s 32 640 pairs, on the CPU: glim_amd_shard_bounds cuts the pair list, glim_amd_shard_layout
+    (the very arithmetic glim_amd_multi_linearize, its ncclAllGather calls and glim_amd_multi_records use) places every factor's record.  A
+    stand-in evaluation -- every "device" writes its own rows into ITS gathered array, the all-gather of each piece copies equal slots between
+    them -- must reproduce the unsharded record array on every device, for every number of pieces."""
+    from glim_amd import _lib, api
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    rng = np.random.default_rng(8)
+    S = 256
+    sizes = rng.integers(60000, 66000, size=S)
+    pairs = [(i, j) for j in range(S) for i in range(j)]
+    costs = np.array([sizes[j] for _, j in pairs], dtype=np.float64)
+    n, world = len(pairs), 8
+    truth = rng.normal(size=(n, 29))  # the records an unsharded evaluation would produce, factor order
+    b = api.shard_bounds(costs, world)
+    assert b[0] == 0 and b[-1] == n and all(b[r] < b[r + 1] for r in range(world))
+    loads = [costs[b[r]:b[r + 1]].sum() for r in range(world)]
+    assert max(loads) / np.mean(loads) < 1.005  # 4 080 pairs per shard: a boundary moves a load by one pair at most
+    for split in (-1, 1, 2, 4, 8):
+        rows, max_rows, pieces, piece_rows = api.shard_layout(b, split)
+        assert max_rows == max(b[r + 1] - b[r] for r in range(world))
+        assert pieces == (2 if split < 0 else split) and piece_rows == -(-max_rows // pieces)
+        assert len(np.unique(rows)) == n and rows.min() >= 0 and rows.max() < world * max_rows
+        gathered = [np.full((world * max_rows, 29), np.nan) for _ in range(world)]
+        for d in range(world):  # every device's kernels write its own rows
+            gathered[d][rows[b[d]:b[d + 1]]] = truth[b[d]:b[d + 1]]
+        for p in range(pieces):  # ncclAllGather of piece p: region p is `world` equal slots, device d's at d * slot inside it
+            rows_p = max(0, min(piece_rows, max_rows - p * piece_rows))
+            start = world * p * piece_rows
+            for d in range(world):
+                lo = start + d * rows_p
+                own = rows[b[d]:b[d + 1]]
+                own_p = own[(own >= lo) & (own < lo + rows_p)]
+                # the slot holds exactly this device's factors [p * piece_rows, (p + 1) * piece_rows) of its shard, in order
+                k0 = p * piece_rows
+                want = np.arange(min(max(0, (b[d + 1] - b[d]) - k0), rows_p)) + lo
+                assert np.array_equal(own_p, want), (split, p, d)
+                for e in range(world):
+                    gathered[e][lo:lo + rows_p] = gathered[d][lo:lo + rows_p]
+        for d in range(world):
+            assert np.array_equal(gathered[d][rows], truth), (split, d)
+    # ragged and empty shards (fewer factors than devices; a piece that some shards do not reach)
+    for n2, w2 in [(3, 8), (100, 8), (1000, 3), (129, 2)]:
+        c2 = rng.integers(1, 50, size=n2).astype(np.float64)
+        b2 = api.shard_bounds(c2, w2)
+        for split in (-1, 1, 2, 3):
+            rows, max_rows, pieces, piece_rows = api.shard_layout(b2, split)
+            assert len(np.unique(rows)) == n2 and (n2 == 0 or rows.max() < w2 * max_rows) and pieces * piece_rows >= max_rows > (pieces - 1) * piece_rows
+
+
+def test_shard_bounds_properties():
+    """Property test of glim_amd_shard_bounds (hypothesis): contiguous, covering, monotone; the heaviest shard exceeds the mean by at most one
+    factor's cost (the boundary nearest to r / world of the cumulative cost is never further than half a factor away on either side)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from glim_amd import _lib, api
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=100000), min_size=0, max_size=400), st.integers(min_value=1, max_value=16))
+    def check(costs, world):
+        b = api.shard_bounds(costs, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == len(costs)
+        assert all(b[r] <= b[r + 1] for r in range(world))
+        if costs:
+            c = np.asarray(costs, dtype=np.float64)
+            loads = [c[b[r]:b[r + 1]].sum() for r in range(world)]
+            assert sum(loads) == c.sum()
+            assert max(loads) <= c.sum() / world + c.max() + 1e-9
+        rows, max_rows, pieces, piece_rows = api.shard_layout(b, -1)
+        assert len(np.unique(rows)) == len(costs)
+
+    check()
+
+
 def test_c_abi_shard_bounds_equals_python_rule():
     """The single-process multi-device entry (glim_amd_multi_set_factors) shards with glim_amd_shard_bounds; the one-process-per-GPU harness
     (glim_amd/multi.py) with shard_bounds: same rule, same boundaries."""
