@@ -331,6 +331,12 @@ class GaussianVoxelMapGPU:
         check(lib().glim_amd_voxelmap_insert(self._h, frame._h), "glim_amd_voxelmap_insert")
         return self
 
+    def set_lru_horizon(self, lru_horizon, lru_clear_cycle=10):
+        """GaussianVoxelMapCPU::set_lru_horizon (odometry_estimation_cpu.cpp:67): voxels untouched for more than `lru_horizon` inserts are dropped
+        every `lru_clear_cycle` inserts; <= 0 switches eviction off (default)."""
+        check(lib().glim_amd_voxelmap_set_lru_horizon(self._h, int(lru_horizon), int(lru_clear_cycle)), "glim_amd_voxelmap_set_lru_horizon")
+        return self
+
     def voxelmap_info(self):
         nv, nb, res, by = C.c_int32(), C.c_int32(), C.c_double(), C.c_size_t()
         check(lib().glim_amd_voxelmap_info(self._h, C.byref(nv), C.byref(nb), C.byref(res), C.byref(by)), "glim_amd_voxelmap_info")
@@ -356,6 +362,23 @@ class GaussianVoxelMapGPU:
             self.close()
         except Exception:
             pass
+
+
+def frame_create(points4, covs16, normals4, resolutions, ctx=None):
+    """glim_amd_frame_create: PointCloudGPU::clone + one GaussianVoxelMapGPU per resolution as ONE submission with one synchronise (create_frame of
+    the GPU odometry).  Arrays in the reference's layout (n x Vector4d, n x column-major Matrix4d, n x Vector4d).  Returns (cloud, [maps])."""
+    ctx = ctx or default_context()
+    res = np.ascontiguousarray(resolutions, dtype=np.float64)
+    hc = C.c_void_p()
+    hm = (C.c_void_p * len(res))()
+    check(lib().glim_amd_frame_create(ctx._h, len(points4), _dp(points4), _dp(covs16), _dp(normals4), len(res), _dp(res), C.byref(hc),
+                                      C.cast(hm, C.POINTER(C.c_void_p))), "glim_amd_frame_create")
+    maps = []
+    for h in hm:
+        m = GaussianVoxelMapGPU.__new__(GaussianVoxelMapGPU)
+        m.ctx, m._h, m._frame = ctx, C.c_void_p(h), None
+        maps.append(m)
+    return PointCloudGPU(hc, ctx), maps
 
 
 def _lin_to_dict(L):
@@ -662,7 +685,7 @@ class MultiDeviceCost:
         return dict(zip(self.BREAKDOWN_FIELDS, us.tolist()))
 
     def set_split(self, mode):
-        """-1: 2 pieces per shard (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
+        """-1: pieces of >= 2048 factors, at most 8 (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
         check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
 
     def evaluate(self, T_target_source):

@@ -183,7 +183,12 @@ void drop_plane_streams(glim_amd_cloud* c) {
 }
 
 // upload of a small cloud through the pinned staging block; GLIM_AMD_ERR_UNSUPPORTED: no device view of pinned memory here (caller takes the general path)
-int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4) {
+}  // namespace
+namespace glim_amd {
+// The small upload in two halves (glim_amd_frame_create enqueues the frame's voxel maps between them and synchronises ONCE): enqueue = host
+// conversion into the pinned staging block + the pull kernel on ctx->stream(); finish (after the caller has synchronised that stream) = the
+// plane-form verdict, the unused stream copy back to the pool, the staging block back to its pool.
+int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up) {
   const int64_t n = c->n;
   float* stage = nullptr;
   if (pinned_malloc(&stage, (size_t)n * 14 * sizeof(float) + 16) != hipSuccess) {
@@ -218,18 +223,40 @@ int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4
                                                         reinterpret_cast<const float2*>(dev + 12 * n), normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr,
                                                         c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n), c->pn4, c->n2, c->gs0,
                                                         c->gs1, c->gs2, c->gsn);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  else (void)hipStreamSynchronize(s);
-  const bool plane = covs16 && normals4 && *violations == 0u;
-  (void)pinned_free(stage);
+  const hipError_t e = hipGetLastError();
+  up->stage = stage;
+  up->violations = violations;
+  up->maybe_plane = covs16 && normals4;
   if (e != hipSuccess) {
+    (void)hipStreamSynchronize(s);
+    (void)pinned_free(stage);
+    up->stage = nullptr;
     set_hip_error(e, "cloud_create small upload");
     return GLIM_AMD_ERR_HIP;
   }
+  return GLIM_AMD_OK;
+}
+void cloud_small_finish(glim_amd_cloud* c, SmallUpload* up) {
+  const bool plane = up->maybe_plane && *up->violations == 0u;
+  (void)pinned_free(up->stage);
+  up->stage = nullptr;
   c->plane_form = plane;
   if (plane && c->pn4) drop_general_streams(c);  // the factor kernel reads the form the cloud has; the other copy goes back to the pool
   else drop_plane_streams(c);
+}
+}  // namespace glim_amd
+namespace {
+int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4) {
+  SmallUpload up;
+  const int rc = cloud_small_enqueue(ctx, c, points4, covs16, normals4, &up);
+  if (rc != GLIM_AMD_OK) return rc;
+  const hipError_t e = hipStreamSynchronize(ctx->stream());
+  if (e != hipSuccess) {
+    (void)pinned_free(up.stage);
+    set_hip_error(e, "cloud_create small upload");
+    return GLIM_AMD_ERR_HIP;
+  }
+  cloud_small_finish(c, &up);
   return GLIM_AMD_OK;
 }
 
@@ -282,6 +309,8 @@ int alloc_cloud(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_
 }  // namespace
 
 namespace glim_amd {
+
+int alloc_cloud_for_frame(glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, glim_amd_cloud** out) { return alloc_cloud(ctx, n, covs, normals, out); }
 
 int detect_plane_form(glim_amd_cloud* c, hipStream_t st) {
   c->plane_form = false;

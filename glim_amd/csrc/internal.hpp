@@ -58,6 +58,16 @@ int cloud_curve_rank(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
 // switches and its read-back scratch are the ones used (a cloud may be reached from a factor set of ANOTHER context than its owner's, whose
 // mutex the caller does not hold: ADVICE r4).  Same for cloud_curve_rank.
 int ensure_factor_streams(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
+// the host-packed upload of a small cloud (<= HOST_PACK_MAX_POINTS) in two halves around ONE synchronise of ctx->stream() (cloud.hip)
+struct SmallUpload {
+  float* stage = nullptr;
+  volatile unsigned int* violations = nullptr;
+  bool maybe_plane = false;
+};
+int cloud_small_enqueue(::glim_amd_ctx* ctx, ::glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up);
+void cloud_small_finish(::glim_amd_cloud* c, SmallUpload* up);
+int alloc_cloud_for_frame(::glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, ::glim_amd_cloud** out);  // cloud.hip alloc_cloud
+constexpr int64_t HOST_PACK_MAX_POINTS_FRAME = 32768;
 // plane-form test of a freshly uploaded cloud with covariances and normals (cloud.hip): sets c->plane_form
 int detect_plane_form(::glim_amd_cloud* c, hipStream_t st);
 // Diagnostic / tuning switches.  None is needed in production; they exist for A/B measurements and for the cross-checks of the parity
@@ -329,6 +339,9 @@ struct glim_amd_voxelmap {
   // num_buckets that lanes without a correspondence read.  Built on first use (ensure_plane_view), dropped whenever the table is rebuilt.
   glim_amd::VoxelBucket* buckets_sm = nullptr;
   std::mutex view_mu;
+  // least-recently-used eviction of an incrementally built map (glim_amd_voxelmap_set_lru_horizon; GaussianVoxelMapCPU::set_lru_horizon of the
+  // CPU odometry, odometry_estimation_cpu.cpp:63-68): slot 10 of a record holds the insert counter of the last insert that touched the voxel
+  int32_t lru_horizon = 0, lru_clear_cycle = 10, lru_counter = 0;
 };
 namespace glim_amd {
 int ensure_plane_view(::glim_amd_voxelmap* m, hipStream_t st);  // voxelmap.hip; complete (synchronised) before it returns

@@ -87,7 +87,10 @@ inline int64_t layout_row(int ndev, int64_t piece_rows, int64_t max_rows, int d,
 }
 inline void layout_pieces(int64_t max_rows, int ndev, int split_mode, int* pieces, int64_t* piece_rows) {
   (void)ndev;
-  int want = split_mode < 0 ? 2 : std::max(1, split_mode);
+  // default: pieces of >= 2048 factors (16 rounds of resident blocks on configs[3]'s submaps: the launch tail stays a few per cent of the piece), at
+  // most MAX_PIECES -- 8 on one device for the 32 640 pairs of configs[3] (the exposed exchange is then the last eighth: measured 11.53 / 11.33 /
+  // 11.27 ms per evaluation with 1 / 2 / 4 pieces), 1-2 per device on an 8-device node
+  int want = split_mode < 0 ? (int)std::max<int64_t>(1, max_rows / 2048) : std::max(1, split_mode);
   want = (int)std::min<int64_t>(std::min(want, MAX_PIECES), std::max<int64_t>(1, max_rows / 64));  // (a piece of a few rows is all launch tail)
   *piece_rows = (max_rows + want - 1) / want;
   *pieces = (int)((max_rows + *piece_rows - 1) / *piece_rows);
@@ -134,7 +137,7 @@ struct glim_amd_multi {
   // ncclAllGather of equal slots, issued as soon as that piece's kernels are done while the next piece's kernels run.
   int pieces = 1;
   int64_t piece_rows = 0;
-  int split_mode = -1;            // -1: default (2 pieces); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
+  int split_mode = -1;            // -1: default (pieces of >= 2048 factors, at most 8); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
   std::vector<double*> d_gather;  // [device]: ndev x max_rows x COMPACT
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
@@ -557,7 +560,7 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   // Several pieces per shard: the all-gather and the copy-out of piece p (the collective's stream) run beside the kernels of piece p + 1, and
   // the pose upload of piece p + 1 beside the kernels of piece p; only the LAST piece's exchange is exposed.  glim_amd/multi.py
   // `gather_device_halves` is the two-piece form of the same exchange for one process per GPU.  More pieces = a shorter exposed tail but one
-  // more launch tail each (every further launch cost the one-GPU shard simulation 40-60 us): 2 by default.
+  // more launch tail each: pieces of >= 2048 factors by default (layout_pieces).
   int pieces = 1;
   int64_t piece_rows = max_rows;
   layout_pieces(max_rows, m->ndev, m->split_mode, &pieces, &piece_rows);

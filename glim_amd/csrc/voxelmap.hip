@@ -255,12 +255,15 @@ __global__ __launch_bounds__(256) void build_direct_kernel(int n, const float4* 
 // odometry_estimation_cpu.cpp:66-67,189).  The map is rebuilt: the keys of the old voxels and of the new cloud go into one scratch table (counts
 // the voxels of the union), the old voxels are re-opened into the new table's fixed-point accumulators, then the new points accumulate as usual.
 // one thread per (old bucket, way): the key of every old voxel into the scratch table
+// expire_before (LRU eviction, 0 = none): an old voxel whose last-touch stamp is below it is NOT re-inserted -- if this insert's points touch it, their
+// own key insertion (insert_keys_kernel, earlier on the stream) has put the key there already and the voxel survives with its contents
 __global__ __launch_bounds__(256) void reinsert_old_keys_kernel(const VoxelBucket* __restrict__ old, unsigned int old_buckets, unsigned long long* __restrict__ tkeys,
-                                                                unsigned int tmask, int* __restrict__ stats) {
+                                                                unsigned int tmask, int* __restrict__ stats, int expire_before) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * old_buckets) return;
   const unsigned long long key = old[i >> 1].key[i & 1];
   if (key == EMPTY_KEY) return;
+  if (expire_before > 0 && __float_as_int(old[i >> 1].rec[i & 1][10]) < expire_before) return;
   unsigned int s = hash_key(key) & tmask;
   for (;;) {
     const unsigned long long prev = atomicCAS(&tkeys[s], EMPTY_KEY, key);
@@ -274,8 +277,11 @@ __global__ __launch_bounds__(256) void reinsert_old_keys_kernel(const VoxelBucke
 }
 
 // one thread per (old bucket, way): count x (mean, covariance) of the old voxel, as fixed-point sums, into its slot of the new table
+// lru (optional, 2 ints per slot of the new table, zeroed): the old voxel's count and last-touch stamp -- finalize_kernel tells a voxel that this
+// insert's points touched (count grew) from one that was only carried over
 __global__ __launch_bounds__(256) void reopen_old_voxels_kernel(const VoxelBucket* __restrict__ old, unsigned int old_buckets, double res,
-                                                                const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, long long* __restrict__ acc) {
+                                                                const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, long long* __restrict__ acc,
+                                                                int2* __restrict__ lru) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * old_buckets) return;
   const unsigned long long key = old[i >> 1].key[i & 1];
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256) void reopen_old_voxels_kernel(const VoxelBucke
   unpack_key(key, cx, cy, cz);
   const double c = (double)cnt;
   const int s = find_slot(buckets, num_buckets, key);
-  if (s < 0) return;
+  if (s < 0) return;  // (an evicted voxel: its key was not carried over)
+  if (lru) lru[s] = make_int2((int)cnt, __float_as_int(r[10]));
   long long* dst = acc + (size_t)s * ACC_STRIDE;
   const double m[3] = {(double)r[0] + ((double)cx + 0.5) * res, (double)r[1] + ((double)cy + 0.5) * res, (double)r[2] + ((double)cz + 0.5) * res};
 #pragma unroll
@@ -346,7 +353,8 @@ __global__ __launch_bounds__(256) void plane_view_kernel(const VoxelBucket* __re
 // of every bucket, so it needs no clearing, plus the all-zero bucket behind the table.
 __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
                                                        const long long* __restrict__ acc, double res, const int* __restrict__ stats,
-                                                       int* __restrict__ host_stats, VoxelBucket* __restrict__ view) {
+                                                       int* __restrict__ host_stats, VoxelBucket* __restrict__ view, const int2* __restrict__ lru = nullptr,
+                                                       int lru_stamp = 0) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && host_stats) {
     host_stats[0] = stats[0];
@@ -382,7 +390,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__
   r[7] = (float)((double)a[7] * ic);  // c12
   r[8] = (float)((double)a[8] * ic);  // c22
   r[9] = __int_as_float((int)cnt);
-  r[10] = 0.f;
+  // slot 10: the insert counter of the last insert that touched the voxel (LRU maps; 0 = the first insert, which is also what every other map holds)
+  int stamp = lru_stamp;
+  if (lru) {
+    const int2 o = lru[i];
+    if ((long long)o.x == cnt) stamp = o.y;  // carried over untouched: keeps its stamp
+  }
+  r[10] = __int_as_float(stamp);
   r[11] = 0.f;
   if (view) plane_record(r, view[b].rec[w]);
 }
@@ -589,7 +603,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   hipStream_t st = ctx->stream();
   const int n = (int)cloud->n;
 
-  DeviceTemp tkeys, pkeys, stats, acc;
+  DeviceTemp tkeys, pkeys, stats, acc, lru;
   SyncOnExit in_flight(st);  // every exit that has not synchronised itself waits for the stream before the scratch above goes back to the pool
   constexpr int DIRECT_MAX_POINTS = 32768;
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
@@ -683,6 +697,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     m->buckets_sm = view;
     m->num_buckets = nb;
     m->num_voxels = h_stats[0];
+    m->lru_counter += 1;  // (a first insert: every voxel carries stamp 0 = this insert's counter)
     m->uid = next_uid();
     global_mutation_epoch()++;
     return GLIM_AMD_OK;
@@ -700,7 +715,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     GA_HIP(hipGetLastError());
   }
   if (old) {
-    reinsert_old_keys_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, (unsigned long long*)tkeys.p, tsize0 - 1, (int*)stats.p);
+    // LRU eviction (glim_amd_voxelmap_set_lru_horizon): this insert carries counter c = lru_counter; when (c + 1) % clear_cycle == 0 every voxel with
+    // stamp + horizon < c + 1 that the new points do not touch is dropped, i.e. not carried over into the rebuilt table
+    const int c_after = m->lru_counter + 1;
+    const int expire_before = (m->lru_horizon > 0 && c_after % std::max(1, m->lru_clear_cycle) == 0) ? std::max(0, c_after - m->lru_horizon) : 0;
+    reinsert_old_keys_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, (unsigned long long*)tkeys.p, tsize0 - 1, (int*)stats.p, expire_before);
     GA_HIP(hipGetLastError());
   }
   int h_stats[2] = {0, 0};
@@ -725,7 +744,12 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   if (e == hipSuccess) {
     init_buckets_kernel<<<(unsigned int)(((size_t)nb * 8 + 255) / 256), 256, 0, st>>>(buckets, nb);
     move_keys_kernel<<<(tsize0 + 255) / 256, 256, 0, st>>>((const unsigned long long*)tkeys.p, tsize0, buckets, nb);
-    if (old) reopen_old_voxels_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, m->resolution, buckets, nb, (long long*)acc.p);
+    if (old && m->lru_horizon > 0) {
+      e = pool_malloc(&lru.p, (size_t)nb * 2 * sizeof(int2));
+      if (e == hipSuccess) e = hipMemsetAsync(lru.p, 0, (size_t)nb * 2 * sizeof(int2), st);
+    }
+    if (old && e == hipSuccess)
+      reopen_old_voxels_kernel<<<(2 * old_buckets + 255) / 256, 256, 0, st>>>(old, old_buckets, m->resolution, buckets, nb, (long long*)acc.p, lru.as<int2>());
     if (n > 0)
       accumulate_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, (const unsigned long long*)pkeys.p, buckets,
                                                           nb, (long long*)acc.p);
@@ -733,8 +757,10 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       (void)hipGetLastError();
       view2 = nullptr;  // (the view is a cache: it is built on first use then)
     }
-    finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, nullptr, nullptr, view2);
-    e = hipGetLastError();
+    if (e == hipSuccess)
+      finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, nullptr, nullptr, view2, lru.as<int2>(),
+                                                                    m->lru_horizon > 0 ? m->lru_counter : 0);
+    if (e == hipSuccess) e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
@@ -751,8 +777,163 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   m->buckets = buckets;
   m->num_buckets = nb;
   m->num_voxels = num_voxels;
+  m->lru_counter += 1;
   m->uid = next_uid();  // plans built from the previous table are rebuilt (factor_set_prepare)
   global_mutation_epoch()++;
+  return GLIM_AMD_OK;
+}
+
+// create_frame of GLIM's GPU odometry (odometry_estimation_gpu.cpp:86-107) as ONE submission: PointCloudGPU::clone of a frame that arrives with CPU
+// covariances + normals and the GaussianVoxelMapGPU of every level (voxelmap_levels = 2 in the shipped configuration) are enqueued back to back on
+// the context's stream -- pull kernel, then per map: tables, keys + sums, records -- and the host synchronises ONCE; the plane-form verdict of the
+// cloud and every map's voxel count come back with that one completion (host-mapped words).  As three separate calls the same work pays three
+// synchronises (58 + 2 x 24-29 us per 10 000-pt frame).  Frames that do not fit the small-cloud paths take the separate calls.
+int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* covs16, const double* normals4, int32_t num_levels,
+                          const double* resolutions, glim_amd_cloud** cloud_out, glim_amd_voxelmap** maps_out) {
+  constexpr int MAX_LEVELS = 8;
+  if (!ctx || !cloud_out || !maps_out || n < 0 || (n > 0 && !points4) || num_levels < 0 || num_levels > MAX_LEVELS || (num_levels > 0 && !resolutions))
+    return GLIM_AMD_ERR_INVALID;
+  for (int lv = 0; lv < num_levels; lv++)
+    if (!(resolutions[lv] > 0.0)) return GLIM_AMD_ERR_INVALID;
+  *cloud_out = nullptr;
+  for (int lv = 0; lv < num_levels; lv++) maps_out[lv] = nullptr;
+  const bool one_submission = n > 0 && n <= HOST_PACK_MAX_POINTS_FRAME && covs16 && ctx->diag.host_pack && ctx->diag.bucket_factor == 0;
+  if (!one_submission) {
+    GA_TRY(glim_amd_cloud_create(ctx, n, points4, covs16, normals4, cloud_out));
+    int rc = GLIM_AMD_OK;
+    for (int lv = 0; lv < num_levels && rc == GLIM_AMD_OK; lv++) {
+      rc = glim_amd_voxelmap_create(ctx, resolutions[lv], 8192 * 2, 10, 1e-3, &maps_out[lv]);
+      if (rc == GLIM_AMD_OK) rc = glim_amd_voxelmap_insert(maps_out[lv], *cloud_out);
+    }
+    if (rc != GLIM_AMD_OK) {
+      for (int lv = 0; lv < num_levels; lv++) {
+        (void)glim_amd_voxelmap_destroy(maps_out[lv]);
+        maps_out[lv] = nullptr;
+      }
+      (void)glim_amd_cloud_destroy(*cloud_out);
+      *cloud_out = nullptr;
+    }
+    return rc;
+  }
+  struct Build {
+    glim_amd_voxelmap* m = nullptr;
+    VoxelBucket *buckets = nullptr, *view = nullptr;
+    void *acc = nullptr, *stats = nullptr;
+    unsigned int nb = 0;
+  } b[MAX_LEVELS];
+  glim_amd_cloud* c = nullptr;
+  SmallUpload up;
+  int rc = GLIM_AMD_OK;
+  bool enqueued = false;
+  int *h_view = nullptr, *d_view = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GA_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream();
+    rc = alloc_cloud_for_frame(ctx, n, true, normals4 != nullptr, &c);
+    if (rc == GLIM_AMD_OK && !pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view))) rc = GLIM_AMD_ERR_UNSUPPORTED;
+    if (rc == GLIM_AMD_OK) rc = cloud_small_enqueue(ctx, c, points4, covs16, normals4, &up);
+    enqueued = rc == GLIM_AMD_OK;
+    const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, 2ull * (unsigned long long)n));  // (the small direct build of insert)
+    for (int lv = 0; lv < num_levels && rc == GLIM_AMD_OK; lv++) {
+      Build& B = b[lv];
+      B.nb = nb;
+      B.m = new glim_amd_voxelmap();
+      B.m->ctx = ctx;
+      B.m->resolution = resolutions[lv];
+      B.m->inv_resolution = 1.0 / resolutions[lv];
+      ClearedTable cleared;
+      const bool have_cleared = take_cleared_table(ctx->device, nb, &cleared);
+      hipError_t e = hipSuccess;
+      if (have_cleared) {
+        B.buckets = cleared.buckets;
+        B.acc = cleared.acc;
+        B.stats = cleared.stats;
+      } else {
+        e = pool_malloc(&B.stats, 2 * sizeof(int));
+        if (e == hipSuccess) e = pool_malloc(&B.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
+        if (e == hipSuccess) e = pool_malloc(&B.buckets, (size_t)nb * sizeof(VoxelBucket));
+      }
+      // the frame arrives with covariances AND normals of the kNN estimator: its maps will be matched against plane-form frames (view written here)
+      if (e == hipSuccess && normals4 && ctx->diag.view_fused) e = pool_malloc(&B.view, ((size_t)nb + 1) * sizeof(VoxelBucket));
+      if (e != hipSuccess) {
+        set_hip_error(e, "glim_amd_frame_create");
+        rc = e == hipErrorOutOfMemory ? GLIM_AMD_ERR_NOMEM : GLIM_AMD_ERR_HIP;
+        break;
+      }
+      const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
+      if (!have_cleared)
+        init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(B.buckets, nb, (uint4*)B.acc, acc_words, (int*)B.stats);
+      build_direct_kernel<<<((int)n + 255) / 256, 256, 0, st>>>((int)n, c->pts, c->covA, c->covB, B.m->inv_resolution, B.buckets, nb, (long long*)B.acc, (int*)B.stats);
+      finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(B.buckets, nb, (const long long*)B.acc, B.m->resolution, (const int*)B.stats, d_view + 2 * lv, B.view);
+      e = hipGetLastError();
+      if (e != hipSuccess) {
+        set_hip_error(e, "glim_amd_frame_create");
+        rc = GLIM_AMD_ERR_HIP;
+      }
+    }
+    // ---- the one synchronise ----
+    const hipError_t es = hipStreamSynchronize(st);
+    if (rc == GLIM_AMD_OK && es != hipSuccess) {
+      set_hip_error(es, "glim_amd_frame_create: synchronise");
+      rc = GLIM_AMD_ERR_HIP;
+    }
+    if (enqueued) {
+      if (rc == GLIM_AMD_OK) cloud_small_finish(c, &up);
+      else if (up.stage) (void)pinned_free(up.stage);
+    }
+    for (int lv = 0; lv < num_levels; lv++) {
+      Build& B = b[lv];
+      if (B.acc) (void)pool_free(B.acc);
+      if (B.stats) (void)pool_free(B.stats);
+      if (rc == GLIM_AMD_OK && h_view[2 * lv + 1] != 0) rc = GLIM_AMD_ERR_RANGE;
+    }
+    if (rc == GLIM_AMD_OK) {
+      for (int lv = 0; lv < num_levels; lv++) {
+        Build& B = b[lv];
+        B.m->buckets = B.buckets;
+        B.m->buckets_sm = B.view;
+        B.m->num_buckets = B.nb;
+        B.m->num_voxels = h_view[2 * lv];
+        B.m->lru_counter = 1;
+        B.m->uid = next_uid();
+        const int res_class = (int)lround(8.0 * log2(B.m->resolution));
+        remember_voxel_ratio(ctx, res_class, (double)B.m->num_voxels / (double)n);
+      }
+      global_mutation_epoch()++;
+    }
+  }
+  if (rc != GLIM_AMD_OK) {
+    for (int lv = 0; lv < num_levels; lv++) {
+      Build& B = b[lv];
+      if (B.buckets) (void)pool_free(B.buckets);
+      if (B.view) (void)pool_free(B.view);
+      if (B.m) {
+        B.m->ctx = nullptr;
+        delete B.m;
+      }
+    }
+    if (c) (void)glim_amd_cloud_destroy(c);
+    if (rc == GLIM_AMD_ERR_UNSUPPORTED) {  // no device view of pinned memory here: the separate calls
+      GA_TRY(glim_amd_cloud_create(ctx, n, points4, covs16, normals4, cloud_out));
+      for (int lv = 0; lv < num_levels; lv++) {
+        GA_TRY(glim_amd_voxelmap_create(ctx, resolutions[lv], 8192 * 2, 10, 1e-3, &maps_out[lv]));
+        GA_TRY(glim_amd_voxelmap_insert(maps_out[lv], *cloud_out));
+      }
+      return GLIM_AMD_OK;
+    }
+    return rc;
+  }
+  *cloud_out = c;
+  for (int lv = 0; lv < num_levels; lv++) maps_out[lv] = b[lv].m;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_voxelmap_set_lru_horizon(glim_amd_voxelmap* m, int32_t lru_horizon, int32_t lru_clear_cycle) {
+  if (!m || lru_clear_cycle < 0) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(m->ctx->mu);
+  m->lru_horizon = lru_horizon > 0 ? lru_horizon : 0;
+  m->lru_clear_cycle = lru_clear_cycle > 0 ? lru_clear_cycle : 10;
   return GLIM_AMD_OK;
 }
 

@@ -246,7 +246,18 @@ int glim_amd_voxelmap_create(glim_amd_ctx* ctx, double resolution, int init_num_
  * cov * n), i.e. each further insert adds a rounding of 1 FP32 ulp to the old voxels' statistics
  * (tests/test_gpu_parity.py::test_voxelmap_incremental_insert_matches_oracle bounds it against the FP64 oracle's merged map). */
 int glim_amd_voxelmap_insert(glim_amd_voxelmap* vmap, const glim_amd_cloud* cloud);
+/* create_frame of the GPU odometry as ONE submission (src/glim/odometry/odometry_estimation_gpu.cpp:86-107): PointCloudGPU::clone of a frame that
+ * arrives with CPU covariances (+ normals) and GaussianVoxelMapGPU(resolutions[lv]).insert(frame) for lv < num_levels (<= 8; voxelmap_levels, 2 in the
+ * shipped configuration) are enqueued back to back and the host synchronises once.  Same arguments as glim_amd_cloud_create; the results are what the
+ * separate calls return (same bits), *cloud and maps[lv] are owned by the caller.  On failure nothing is created. */
+int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* covs16, const double* normals4, int32_t num_levels,
+                          const double* resolutions, glim_amd_cloud** cloud, glim_amd_voxelmap** maps);
 int glim_amd_voxelmap_destroy(glim_amd_voxelmap* vmap);
+/* GaussianVoxelMapCPU::set_lru_horizon of the CPU odometry's incremental target map (src/glim/odometry/odometry_estimation_cpu.cpp:63-68,
+ * update_target :177-191; config_odometry_cpu.json "lru_thresh": 100): every insert carries a counter; every `lru_clear_cycle` inserts (<= 0: 10,
+ * gtsam_points' default) the voxels that no insert has touched for more than `lru_horizon` inserts are dropped.  lru_horizon <= 0 (the default):
+ * no eviction -- the GPU callers of the reference never set one.  Applies to the inserts that follow. */
+int glim_amd_voxelmap_set_lru_horizon(glim_amd_voxelmap* vmap, int32_t lru_horizon, int32_t lru_clear_cycle);
 /* VoxelMapInfo (standard_viewer_mem.cpp:76-77): num_voxels, num_buckets, resolution, device bytes. */
 int glim_amd_voxelmap_info(const glim_amd_voxelmap* vmap, int32_t* num_voxels, int32_t* num_buckets, double* resolution,
                            size_t* bytes);
@@ -375,7 +386,7 @@ int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, fl
 #define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 10
 int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
 /* how a device's shard is evaluated: n >= 2 = as n pieces (at most 8), the all-gather and copy-out of one piece overlapping the kernels of
- * the next; 0 or 1 = as one set and one all-gather; -1 (default) = 2 pieces.  Takes effect with the next
+ * the next; 0 or 1 = as one set and one all-gather; -1 (default) = pieces of at least 2048 factors, at most 8.  Takes effect with the next
  * glim_amd_multi_set_factors. */
 int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */

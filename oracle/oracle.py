@@ -153,6 +153,7 @@ def lib():
         L.orc_voxelmap_insert.argtypes = [vp, dp, dp, C.c_int]
         L.orc_voxelmap_num_voxels.restype = C.c_int
         L.orc_voxelmap_num_voxels.argtypes = [vp]
+        L.orc_voxelmap_set_lru.argtypes = [vp, C.c_int, C.c_int]
         L.orc_voxelmap_resolution.restype = C.c_double
         L.orc_voxelmap_resolution.argtypes = [vp]
         L.orc_voxelmap_get.argtypes = [vp, C.c_int, ip, ip, dp, dp]
@@ -366,6 +367,11 @@ class VoxelMap:
         p4 = points4(points_xyz)
         c16 = covs16(covs_33)
         lib().orc_voxelmap_insert(self._h, _dp(p4), _dp(c16), p4.shape[0])
+        return self
+
+    def set_lru_horizon(self, horizon, clear_cycle=10):
+        """GaussianVoxelMapCPU::set_lru_horizon (odometry_estimation_cpu.cpp:67) + lru_clear_cycle; horizon <= 0: no eviction."""
+        lib().orc_voxelmap_set_lru(self._h, int(horizon), int(clear_cycle))
         return self
 
     @property

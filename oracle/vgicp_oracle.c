@@ -454,6 +454,7 @@ typedef struct {
   int32_t coord[3];
   int32_t num_points;
   int finalized;
+  int lru; /* insert() counter of the last insert that touched the voxel (IncrementalVoxelMap VoxelInfo::lru, upstream-recall) */
   double mean[4];
   double cov[16];
 } orc_voxel;
@@ -465,6 +466,8 @@ struct orc_voxelmap {
   orc_voxel* voxels;
   size_t table_size; /* power of two */
   int32_t* table;    /* voxel index or -1 */
+  /* least-recently-used eviction of the incremental map (orc_voxelmap_set_lru; 0 = never evict, the default here) */
+  int lru_horizon, lru_clear_cycle, lru_counter;
 };
 
 /* XOR-prime spatial hash (gtsam_points util/vector3i_hash.hpp, upstream-recall; informative only). */
@@ -490,6 +493,18 @@ void orc_voxelmap_destroy(orc_voxelmap* m) {
   free(m->table);
   free(m);
 }
+
+/* (!) upstream-recall: gtsam_points::IncrementalVoxelMap<GaussianVoxel> (ann/impl/incremental_voxelmap_impl.hpp), which GaussianVoxelMapCPU is.
+ * insert(): every point's voxel gets `lru = lru_counter`; after the points, `if ((++lru_counter) % lru_clear_cycle == 0)` every voxel with
+ * `lru + lru_horizon < lru_counter` is removed (std::remove_if: the survivors keep their order, so voxel indices are renumbered) and the
+ * coordinate index is rebuilt; then every voxel is finalised.  Upstream's defaults are lru_horizon = 10, lru_clear_cycle = 10; GLIM's CPU
+ * odometry sets the horizon to lru_thresh = 100 (src/glim/odometry/odometry_estimation_cpu.cpp:63-68, config_odometry_cpu.json:24) and inserts
+ * one downsampled frame per update_target (:177-191).  horizon <= 0 switches eviction off (the restatement's default: the GPU maps have none). */
+void orc_voxelmap_set_lru(orc_voxelmap* m, int horizon, int clear_cycle) {
+  m->lru_horizon = horizon;
+  m->lru_clear_cycle = clear_cycle > 0 ? clear_cycle : 10;
+}
+int orc_voxelmap_lru_counter(const orc_voxelmap* m) { return m->lru_counter; }
 
 int orc_voxelmap_num_voxels(const orc_voxelmap* m) { return m->num_voxels; }
 double orc_voxelmap_resolution(const orc_voxelmap* m) { return m->resolution; }
@@ -554,9 +569,23 @@ void orc_voxelmap_insert(orc_voxelmap* m, const double* pts, const double* covs,
       for (int a = 0; a < 4; a++) vx->mean[a] *= (double)vx->num_points;
       for (int a = 0; a < 16; a++) vx->cov[a] *= (double)vx->num_points;
     }
+    vx->lru = m->lru_counter;
     vx->num_points++;
     for (int a = 0; a < 4; a++) vx->mean[a] += pts[4 * (size_t)i + a];
     for (int a = 0; a < 16; a++) vx->cov[a] += covs[16 * (size_t)i + a];
+  }
+  m->lru_counter++;
+  if (m->lru_horizon > 0 && m->lru_counter % m->lru_clear_cycle == 0) {
+    int kept = 0;
+    for (int v = 0; v < m->num_voxels; v++) {
+      if (m->voxels[v].lru + m->lru_horizon < m->lru_counter) continue; /* least recently used: dropped */
+      if (kept != v) m->voxels[kept] = m->voxels[v];
+      kept++;
+    }
+    if (kept != m->num_voxels) {
+      m->num_voxels = kept;
+      voxelmap_rehash(m, m->table_size);
+    }
   }
   /* GaussianVoxel::finalize: mean /= n, cov /= n */
   for (int v = 0; v < m->num_voxels; v++) {

@@ -79,6 +79,10 @@ void orc_voxelmap_destroy(orc_voxelmap* m);
  * re-opens finalized voxels exactly like the reference: mean*=n, cov*=n, accumulate, divide again). */
 void orc_voxelmap_insert(orc_voxelmap* m, const double* points4, const double* covs16, int n);
 int orc_voxelmap_num_voxels(const orc_voxelmap* m);
+/* least-recently-used eviction of the incremental map (GaussianVoxelMapCPU::set_lru_horizon, odometry_estimation_cpu.cpp:67): voxels that no
+ * insert has touched for more than `horizon` inserts are removed every `clear_cycle` inserts (<= 0: 10, upstream's default).  horizon <= 0: off. */
+void orc_voxelmap_set_lru(orc_voxelmap* m, int horizon, int clear_cycle);
+int orc_voxelmap_lru_counter(const orc_voxelmap* m);
 double orc_voxelmap_resolution(const orc_voxelmap* m);
 /* copy out voxel i: coord[3], num_points, mean[4], cov[16]. */
 void orc_voxelmap_get(const orc_voxelmap* m, int i, int32_t* coord3, int32_t* num_points, double* mean4, double* cov16);

@@ -440,6 +440,78 @@ def test_overlap_batch_equals_single_calls_and_oracle(api, ctx, orc, small_pair)
     assert api.overlap_gpu_batch([queries[4]], ctx=ctx) == [want[4]]
 
 
+def test_frame_create_equals_the_separate_calls(api, orc, small_pair):
+    """glim_amd_frame_create (create_frame of the GPU odometry as one submission, one synchronise): the cloud, its plane-form verdict, both voxel maps
+    and a factor over them are bit for bit what PointCloudGPU::clone + two GaussianVoxelMapGPU::insert give; frames that do not fit the small-cloud
+    path (no covariances, > 32 768 points) take the separate calls inside the same entry point."""
+    ctx = api.Context(0, 1)
+    t, s = small_pair["target"], small_pair["source"]
+
+    def packed(d, covs=True, normals=True):
+        n = len(d["points"])
+        p4 = np.ones((n, 4))
+        p4[:, :3] = d["points"][:, :3]
+        c16 = n4 = None
+        if covs:
+            m = np.zeros((n, 4, 4))
+            m[:, :3, :3] = d["covs"][:, :3, :3]
+            c16 = np.ascontiguousarray(np.transpose(m, (0, 2, 1))).reshape(n, 16)
+        if normals:
+            n4 = np.zeros((n, 4))
+            n4[:, :3] = d["normals"][:, :3]
+        return p4, c16, n4
+
+    levels = [0.5, 1.0]
+    sg = api.PointCloudGPU.clone_packed(*packed(s), ctx=ctx)
+    for reps in range(3):  # (the second and third round take pre-cleared tables from the maps the first one dropped)
+        p4, c16, n4 = packed(t)
+        cloud, maps = api.frame_create(p4, c16, n4, levels, ctx=ctx)
+        ref_cloud = api.PointCloudGPU.clone_packed(p4, c16, n4, ctx=ctx)
+        ref_maps = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(ref_cloud) for r in levels]
+        for a, b in zip(cloud.download(), ref_cloud.download()):
+            np.testing.assert_array_equal(a, b)
+        for m, r in zip(maps, ref_maps):
+            assert m.voxelmap_info() == r.voxelmap_info()
+            (ca, na, ma, va), (cb, nb, mb, vb) = m.voxels(), r.voxels()
+            oa, ob = np.lexsort(ca.T[::-1]), np.lexsort(cb.T[::-1])
+            np.testing.assert_array_equal(ca[oa], cb[ob])
+            np.testing.assert_array_equal(na[oa], nb[ob])
+            np.testing.assert_array_equal(ma[oa], mb[ob])
+            np.testing.assert_array_equal(va[oa], vb[ob])
+            out = []
+            for vm in (m, r):
+                fs = api.NonlinearFactorSetGPU(ctx)
+                fs.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+                out.append(fs.linearize({0: np.eye(4), 1: small_pair["delta"]})[0])
+                fs.close()
+            assert out[0]["num_inliers"] == out[1]["num_inliers"] > 100 and out[0]["error"] == out[1]["error"]
+            np.testing.assert_array_equal(out[0]["H_ss"], out[1]["H_ss"])
+        for x in maps + ref_maps:
+            x.close()
+        cloud.close()
+        ref_cloud.close()
+    # the other routes of the same entry point
+    p4, c16, n4 = packed(t, covs=True, normals=False)
+    cloud, maps = api.frame_create(p4, c16, None, levels, ctx=ctx)
+    assert [m.voxelmap_info()["num_voxels"] for m in maps] == [orc.VoxelMap(r).insert(t["points"], t["covs"]).num_voxels() for r in levels]
+    big = np.tile(p4, (5, 1))[:40000]
+    bigc = np.tile(c16, (5, 1))[:40000]
+    cloud2, maps2 = api.frame_create(big, bigc, None, levels[:1], ctx=ctx)
+    assert cloud2.size() == 40000 and maps2[0].voxelmap_info()["num_voxels"] == maps[0].voxelmap_info()["num_voxels"]
+    with pytest.raises(api.GlimAmdError):
+        api.frame_create(p4, c16, None, [0.5, -1.0], ctx=ctx)
+    far = p4.copy()
+    far[0, 0] = 1e9  # a voxel coordinate outside the key range: nothing is created
+    with pytest.raises(api.GlimAmdError):
+        api.frame_create(far, c16, None, levels, ctx=ctx)
+    for x in maps + maps2:
+        x.close()
+    cloud.close()
+    cloud2.close()
+    sg.close()
+    ctx.close()  # (refused if the failed calls had left anything behind)
+
+
 def test_stale_density_hint_does_not_leave_an_overfull_table(api, orc):
     """the direct build of a > 32 768-point cloud sizes its table from the voxels-per-point ratio of the PREVIOUS map at that resolution.
     A dense scan (ratio ~0.1) followed by a cloud that was already downsampled at about the voxel size (ratio ~1) would leave the floor table of

@@ -523,6 +523,45 @@ def test_plane_form_kernel_matches_general_kernel_and_oracle(api, ctx, orc):
     assert np.abs(gn_step(results[("plane", True)]) - gn_step(results[("general", True)])).max() < 1e-5
 
 
+def test_voxelmap_lru_horizon_matches_oracle_over_an_insert_sequence(api, ctx, orc):
+    """GaussianVoxelMapCPU::set_lru_horizon as the CPU odometry uses it (odometry_estimation_cpu.cpp:63-68, update_target :177-191: one insert per frame
+    into ONE incremental map): 14 inserts of a sensor moving down a corridor, horizon 3, clear cycle 2 -- after EVERY insert the device map holds
+    exactly the oracle's voxels (coordinates, counts; means / covariances within FP32), a factor over it has the oracle's correspondences, and the
+    map without a horizon keeps everything."""
+    rng = np.random.default_rng(2)
+    res = 0.5
+    vm = api.GaussianVoxelMapGPU(res, ctx=ctx).set_lru_horizon(3, 2)
+    keep = api.GaussianVoxelMapGPU(res, ctx=ctx)
+    ref = orc.VoxelMap(res).set_lru_horizon(3, 2)
+    evicted_any = False
+    for step in range(14):
+        pts = (rng.uniform([-1.0, -2.0, 0.0], [1.0, 2.0, 2.0], size=(400, 3)) + [1.5 * step, 0.0, 0.0]).astype(np.float32)
+        covs = np.tile((np.eye(3) * 0.01).astype(np.float32), (len(pts), 1, 1))
+        g = api.PointCloudGPU.clone(pts, covs, ctx=ctx)
+        vm.insert(g)
+        keep.insert(g)
+        ref.insert(pts.astype(np.float64), covs.astype(np.float64))
+        gc, gn, gm, gC = vm.voxels()
+        rc, rn, rm, rC = ref.voxels()
+        og, orr = np.lexsort(gc.T[::-1]), np.lexsort(rc.T[::-1])
+        np.testing.assert_array_equal(gc[og], rc[orr], err_msg=f"insert {step}")
+        np.testing.assert_array_equal(gn[og], rn[orr], err_msg=f"insert {step}")
+        np.testing.assert_allclose(gm[og], rm[orr][:, :3], atol=2e-6)
+        np.testing.assert_allclose(gC[og], rC[orr][:, :3, :3], atol=1e-7)
+        evicted_any = evicted_any or vm.voxelmap_info()["num_voxels"] < keep.voxelmap_info()["num_voxels"]
+    assert evicted_any and keep.voxelmap_info()["num_voxels"] > vm.voxelmap_info()["num_voxels"] == ref.num_voxels()
+    # a factor over the evicting map: the dropped voxels give no correspondences any more
+    src = (rng.uniform([-1.0, -2.0, 0.0], [1.0, 2.0, 2.0], size=(600, 3)) + [1.5 * 2, 0.0, 0.0]).astype(np.float32)   # where the sensor was 11 inserts ago
+    sc = np.tile((np.eye(3) * 0.01).astype(np.float32), (len(src), 1, 1))
+    sg = api.PointCloudGPU.clone(src, sc, ctx=ctx)
+    fs = api.NonlinearFactorSetGPU(ctx)
+    fs.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, vm, sg))
+    fs.add(api.IntegratedVGICPFactorGPU(np.eye(4), 1, keep, sg))
+    got = fs.linearize({1: np.eye(4)})
+    want = orc.vgicp_linearize(ref, src.astype(np.float64), sc.astype(np.float64), np.eye(4))
+    assert got[0]["num_inliers"] == want["num_inliers"] < got[1]["num_inliers"]
+
+
 def test_plane_view_written_with_the_map_equals_the_one_built_on_first_use(api, ctx, orc, small_pair):
     """Plane-form factors read the PLANE VIEW of the target table (records hold (C_B + I)^-1, Sherman-Morrison in the kernel).  A map built from a
     plane-form cloud gets the view from its own finalise kernel (view_fused=1, default); any other map -- or view_fused=0 -- on the first factor

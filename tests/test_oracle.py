@@ -472,3 +472,35 @@ def test_vgicp_surface_validation_leg(orc, small_pair):
     assert nothing["num_inliers"] == 0 and not np.any(nothing["H_ss"])
     e, inl = orc.vgicp_error_frozen_sv(vm, src, covs, nrm, delta, delta)
     assert inl == sv["num_inliers"] and abs(e - sv["error"]) <= 1e-12 * abs(sv["error"])
+
+
+def test_voxelmap_lru_eviction_follows_the_incremental_map_rule(orc):
+    """GaussianVoxelMapCPU::set_lru_horizon (odometry_estimation_cpu.cpp:63-68): the restatement against an independent dict model of
+    IncrementalVoxelMap::insert -- stamp = insert counter of the last touch; every clear_cycle inserts the voxels with stamp + horizon < counter
+    go, survivors keep their first-touch order.  A sensor moving along x in a corridor: old voxels fall out of the window."""
+    rng = np.random.default_rng(2)
+    res, horizon, cycle = 0.5, 3, 2
+    vm = orc.VoxelMap(res).set_lru_horizon(horizon, cycle)
+    plain = orc.VoxelMap(res)  # no eviction: the default
+    model, order, counter = {}, [], 0
+    for step in range(14):
+        pts = rng.uniform([-1.0, -2.0, 0.0], [1.0, 2.0, 2.0], size=(400, 3)) + [1.5 * step, 0.0, 0.0]
+        pts = pts.astype(np.float32).astype(np.float64)
+        covs = np.tile(np.eye(3) * 0.01, (len(pts), 1, 1))
+        vm.insert(pts, covs)
+        plain.insert(pts, covs)
+        for c in map(tuple, np.floor(pts / res).astype(np.int64)):
+            if c not in model:
+                model[c] = [0, counter]
+                order.append(c)
+            model[c][0] += 1
+            model[c][1] = counter
+        counter += 1
+        if counter % cycle == 0:
+            order = [c for c in order if not (model[c][1] + horizon < counter)]
+            model = {c: model[c] for c in order}
+        coords, counts, _, _ = vm.voxels()
+        assert [tuple(c) for c in coords] == order, step
+        assert list(counts) == [model[c][0] for c in order], step
+    assert vm.num_voxels() < plain.num_voxels()  # something WAS evicted
+    assert vm.num_voxels() == len(order)

@@ -178,8 +178,14 @@ def test_twins_run_like_the_compiled_reference(orc):
 
     r, t = covs(ref), covs(twin)
     np.testing.assert_array_equal(r[2], t[2], err_msg="front end: IMU-frame points")
-    for (rn, rcv), (tn, tcv), what in (((r[0], r[1]), (t[0], t[1]), "estimate"), ((r[3], r[4]), (t[3], t[4]), "front end")):
-        assert np.abs(rn - tn).max() < 1e-5, what
+    for (rn, rcv, pp), (tn, tcv), what in (((r[0], r[1], q4), (t[0], t[1]), "estimate"), ((r[3], r[4], r[2]), (t[3], t[4]), "front end")):
+        # normals: equal within the FP32 storage of the device; the SIGN is `p . n <= 0` (cloud_covariance_estimation.cpp:98-101), which a point seen
+        # at grazing incidence (|p . n| below FP32 resolution) may resolve either way -- the covariance I - 0.999 n n^T does not depend on it
+        same, flipped = np.abs(rn - tn).max(axis=1), np.abs(rn + tn).max(axis=1)
+        assert np.minimum(same, flipped).max() < 1e-5, what
+        flips = flipped < same
+        grazing = np.abs(np.einsum("ij,ij->i", pp[:, :3], rn[:, :3])) <= 1e-5 * np.linalg.norm(pp[:, :3], axis=1)
+        assert not (flips & ~grazing).any(), (what, int(flips.sum()))
         rel = np.abs(rcv - tcv).max(axis=1) / np.abs(rcv).max(axis=1)
         assert (rel > 1e-5).sum() == 0, (what, float(rel.max()))
     print(f"twins vs compiled reference on {n} raw -> {m} points: preprocess equal, deskew bit-exact, covariance max rel "

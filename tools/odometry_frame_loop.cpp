@@ -1,0 +1,189 @@
+// odometry_frame_loop.cpp -- GLIM's LIVE GPU odometry frame, timed end to end as ONE unit through the plain C ABI (include/glim_amd.h), from C++ as a
+// GLIM module would drive it.  Per frame, the sequence of src/glim/odometry/odometry_estimation_gpu.cpp (shipped config_odometry_gpu.json):
+//   create_frame (:86-107)        a NEW 10 000-pt frame arrives with CPU covariances: PointCloudGPU::clone + voxelmap_levels (2) GaussianVoxelMapGPU::insert
+//   create_factors (:128-206)     (full_connection_window_size 2 + max_num_keyframes 15) x 2 levels = 34 IntegratedVGICPFactorGPU with the new frame as
+//                                 source, surface validation ON: window frames binary, keyframes unary against their fixed poses
+//   optimiser                     ITERS iterations, each a FRESH NonlinearFactorSetGPU: add(34 factors); linearize (:383-385 + the linearisation hook)
+//   update_keyframes_overlap      one 15-target overlap_gpu (:224-231)
+//   marginalisation               the frame that leaves the window gives up its cloud and its two voxel maps
+// Input: a binary scene written by bench.py (`--workload odometry_frame`): header {int32 frames, int32 points, int32 keyframes, int32 window, double res0},
+// then per frame points4 | covs16 | normals4 | pose (row-major 3x4 T_world_frame).  Frames [0, keyframes + window) seed the keyframes and the window;
+// the rest arrive one by one, forwards then backwards along the trajectory (consecutive arrivals are always neighbours).
+// Output: one JSON line -- microseconds per frame (p50 / p99 / mean over the timed frames) and the p50 of every stage.
+// Build: g++ -O2 -std=c++17 -Iinclude tools/odometry_frame_loop.cpp -Lglim_amd -lglim_amd -Wl,-rpath,$PWD/glim_amd -o odometry_frame_loop
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "glim_amd.h"
+
+#define CHECK(call)                                                                                          \
+  do {                                                                                                       \
+    const int rc_ = (call);                                                                                  \
+    if (rc_ != GLIM_AMD_OK) {                                                                                \
+      fprintf(stderr, "%s failed: %s (%s)\n", #call, glim_amd_error_string(rc_), glim_amd_last_hip_error()); \
+      return 1;                                                                                              \
+    }                                                                                                        \
+  } while (0)
+
+namespace {
+struct HostFrame {
+  std::vector<double> points4, covs16, normals4;
+  double pose[12];
+};
+struct DeviceFrame {
+  glim_amd_cloud* cloud = nullptr;
+  glim_amd_voxelmap* maps[2] = {nullptr, nullptr};
+  int host = -1;
+};
+// inv(A) * B for row-major 3x4 rigid transforms
+void relative(const double* A, const double* B, double* out) {
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) out[4 * r + c] = A[0 + r] * B[0 + c] + A[4 + r] * B[4 + c] + A[8 + r] * B[8 + c];
+    out[4 * r + 3] = A[0 + r] * (B[3] - A[3]) + A[4 + r] * (B[7] - A[7]) + A[8 + r] * (B[11] - A[11]);
+  }
+}
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double pct(std::vector<double> v, double p) {
+  std::sort(v.begin(), v.end());
+  return v[(size_t)std::min<double>(v.size() - 1, p * (v.size() - 1) + 0.5)];
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1]\n", argv[0]);
+    return 2;
+  }
+  const int timed = argc > 2 ? atoi(argv[2]) : 300, iters = argc > 3 ? atoi(argv[3]) : 3, fused = argc > 4 ? atoi(argv[4]) : 0;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  int32_t hdr[4];
+  double res0 = 0.0;
+  if (fread(hdr, sizeof(int32_t), 4, f) != 4 || fread(&res0, sizeof(double), 1, f) != 1) return 2;
+  const int F = hdr[0], n = hdr[1], K = hdr[2], WIN = hdr[3];
+  std::vector<HostFrame> host((size_t)F);
+  for (auto& h : host) {
+    h.points4.resize((size_t)n * 4);
+    h.covs16.resize((size_t)n * 16);
+    h.normals4.resize((size_t)n * 4);
+    if (fread(h.points4.data(), sizeof(double), h.points4.size(), f) != h.points4.size() || fread(h.covs16.data(), sizeof(double), h.covs16.size(), f) != h.covs16.size() ||
+        fread(h.normals4.data(), sizeof(double), h.normals4.size(), f) != h.normals4.size() || fread(h.pose, sizeof(double), 12, f) != 12)
+      return 2;
+  }
+  fclose(f);
+  if (glim_amd_device_count() <= 0) {
+    printf("{\"skipped\": \"no HIP device\"}\n");
+    return 0;
+  }
+  glim_amd_ctx* ctx = nullptr;
+  CHECK(glim_amd_ctx_create_ex(0, 4, nullptr, /*priority=*/1, &ctx));  // as adapters/glim/odometry_estimation_hip_create.cpp creates the odometry's pool
+  const double levels[2] = {res0, 2.0 * res0};
+
+  auto make_frame = [&](int h, DeviceFrame* out) -> int {
+    out->host = h;
+    if (fused) {
+      CHECK(glim_amd_frame_create(ctx, n, host[h].points4.data(), host[h].covs16.data(), host[h].normals4.data(), 2, levels, &out->cloud, out->maps));
+      return 0;
+    }
+    CHECK(glim_amd_cloud_create(ctx, n, host[h].points4.data(), host[h].covs16.data(), host[h].normals4.data(), &out->cloud));
+    for (int lv = 0; lv < 2; lv++) {
+      CHECK(glim_amd_voxelmap_create(ctx, levels[lv], 8192 * 2, 10, 1e-3, &out->maps[lv]));
+      CHECK(glim_amd_voxelmap_insert(out->maps[lv], out->cloud));
+    }
+    return 0;
+  };
+  auto drop_frame = [&](DeviceFrame* d) {
+    for (int lv = 0; lv < 2; lv++) (void)glim_amd_voxelmap_destroy(d->maps[lv]);
+    (void)glim_amd_cloud_destroy(d->cloud);
+    *d = DeviceFrame();
+  };
+
+  std::vector<DeviceFrame> keyframes((size_t)K), window((size_t)WIN);
+  for (int k = 0; k < K; k++)
+    if (make_frame(k, &keyframes[(size_t)k])) return 1;
+  for (int w = 0; w < WIN; w++)
+    if (make_frame(K + w, &window[(size_t)w])) return 1;
+
+  const int first = K + WIN, arrivals = F - first;
+  if (arrivals < 2) return 2;
+  const int NF = (WIN + K) * 2;
+  std::vector<double> T((size_t)NF * 12), Tov((size_t)K * 12);
+  std::vector<glim_amd_linearized6> lin((size_t)NF);
+  std::vector<const glim_amd_voxelmap*> ov_maps((size_t)K);
+  enum { S_CLONE_MAPS = 0, S_LIN_FIRST, S_LIN_REST, S_OVERLAP, S_RETIRE, S_COUNT };
+  std::vector<double> total, stage[S_COUNT];
+  double checksum = 0.0;
+  const int warm = 20;
+  for (int it = 0; it < warm + timed; it++) {
+    // forwards then backwards along the arriving part of the trajectory
+    const int period = 2 * (arrivals - 1), ph = it % period, h = first + (ph < arrivals ? ph : period - ph);
+    const double t0 = now_us();
+    DeviceFrame cur;
+    if (make_frame(h, &cur)) return 1;
+    const double t1 = now_us();
+    // the 34 factors of this frame: (window + keyframes) x levels, the new frame as source
+    int nf = 0;
+    struct Item { const glim_amd_voxelmap* map; uint32_t flags; } items[64];
+    for (int w = 0; w < WIN; w++)
+      for (int lv = 0; lv < 2; lv++) {
+        items[nf] = {window[(size_t)w].maps[lv], GLIM_AMD_FACTOR_BINARY | GLIM_AMD_FACTOR_SURFACE_VALIDATION};
+        relative(host[(size_t)window[(size_t)w].host].pose, host[(size_t)h].pose, &T[(size_t)nf * 12]);
+        nf++;
+      }
+    for (int k = 0; k < K; k++)
+      for (int lv = 0; lv < 2; lv++) {
+        items[nf] = {keyframes[(size_t)k].maps[lv], GLIM_AMD_FACTOR_SURFACE_VALIDATION};
+        relative(host[(size_t)k].pose, host[(size_t)h].pose, &T[(size_t)nf * 12]);
+        nf++;
+      }
+    double t_first = 0.0;
+    for (int i = 0; i < iters; i++) {  // the optimiser: a FRESH set per iteration (odometry_estimation_gpu.cpp:383-385)
+      glim_amd_factor_set* set = nullptr;
+      CHECK(glim_amd_factor_set_create(ctx, &set));
+      for (int j = 0; j < nf; j++) CHECK(glim_amd_factor_set_add(set, items[j].map, cur.cloud, items[j].flags, nullptr));
+      T[3] += 1e-4 * (i + 1);  // (the optimiser moves the pose between iterations)
+      CHECK(glim_amd_factor_set_linearize(set, T.data(), lin.data()));
+      CHECK(glim_amd_factor_set_destroy(set));
+      checksum += lin[0].error;
+      if (i == 0) t_first = now_us();
+    }
+    const double t2 = now_us();
+    for (int k = 0; k < K; k++) {
+      ov_maps[(size_t)k] = keyframes[(size_t)k].maps[1];
+      relative(host[(size_t)k].pose, host[(size_t)h].pose, &Tov[(size_t)k * 12]);
+    }
+    double ov = 0.0;
+    CHECK(glim_amd_overlap(ctx, K, ov_maps.data(), Tov.data(), cur.cloud, &ov));
+    checksum += ov;
+    const double t3 = now_us();
+    drop_frame(&window[0]);  // the oldest window frame is marginalised
+    for (int w = 0; w + 1 < WIN; w++) window[(size_t)w] = window[(size_t)w + 1];
+    window[(size_t)WIN - 1] = cur;
+    const double t4 = now_us();
+    if (it >= warm) {
+      total.push_back(t4 - t0);
+      stage[S_CLONE_MAPS].push_back(t1 - t0);
+      stage[S_LIN_FIRST].push_back(t_first - t1);
+      stage[S_LIN_REST].push_back(iters > 1 ? (t2 - t_first) / (iters - 1) : 0.0);
+      stage[S_OVERLAP].push_back(t3 - t2);
+      stage[S_RETIRE].push_back(t4 - t3);
+    }
+  }
+  double mean = 0.0;
+  for (double v : total) mean += v / (double)total.size();
+  printf("{\"frames\": %d, \"points_per_frame\": %d, \"factors_per_frame\": %d, \"optimiser_iterations\": %d, \"one_submission_create_frame\": %d, "
+         "\"frame_us\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"min\": %.2f}, "
+         "\"stage_p50_us\": {\"clone_and_two_voxelmaps\": %.2f, \"first_linearisation_new_factor_list\": %.2f, \"each_further_linearisation\": %.2f, "
+         "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"checksum\": %.6g}\n",
+         (int)total.size(), n, NF, iters, fused, pct(total, 0.5), pct(total, 0.99), mean, pct(total, 0.0), pct(stage[S_CLONE_MAPS], 0.5), pct(stage[S_LIN_FIRST], 0.5),
+         pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), checksum);
+  for (auto& d : keyframes) drop_frame(&d);
+  for (auto& d : window) drop_frame(&d);
+  CHECK(glim_amd_ctx_destroy(ctx));
+  return 0;
+}
