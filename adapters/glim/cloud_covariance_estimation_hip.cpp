@@ -2,7 +2,7 @@
 //
 // Same header (include/glim/common/cloud_covariance_estimation.hpp), same class, same members: a HIP build of libglim compiles THIS file in place
 // of the reference's translation unit, and every call site -- odometry_estimation_imu.cpp:189,320, sub_mapping.cpp:374, the CPU odometry -- reaches
-// the device kernel (covariance.hip, K1) without an edit.  Per call: the points go up as they are (FP64 Vector4d), the neighbour lists the caller
+// the device kernel (covariance.hip, K1) without an edit.  Per call: the points go up as they are (FP64 Vector4d, kept exact), the neighbour lists the caller
 // already holds are attached (glim_amd_cloud_set_neighbors), one kernel forms the population covariance of the first k_neighbors neighbours, its
 // closed-form eigen-decomposition, the PLANE regularisation V diag(1e-3, 1, 1) V^T and the sensor-facing normal in FP64
 // (cloud_covariance_estimation.cpp:76-101,181-196), and normals + covariances come back (FP32 storage on the device: the parity gate is 1e-5 relative,
@@ -33,7 +33,8 @@ void estimate_on_device(const std::vector<Eigen::Vector4d>& points, const std::v
     throw std::runtime_error("CloudCovarianceEstimation: neighbors must hold N * m indices with k_neighbors <= m");
   glim_amd::Context ctx = glim_amd::StreamTempBufferRoundRobin::default_instance();
   glim_amd_cloud* cloud = nullptr;
-  glim_amd::check(glim_amd_cloud_create(ctx->context(), n, reinterpret_cast<const double*>(points.data()), nullptr, nullptr, &cloud), "CloudCovarianceEstimation: upload");
+  // (the exact FP64 points stay with the cloud: the callers pass deskewed IMU-frame points, which no FP32 image represents)
+  glim_amd::check(glim_amd_cloud_create_exact(ctx->context(), n, reinterpret_cast<const double*>(points.data()), &cloud), "CloudCovarianceEstimation: upload");
   std::vector<float> cov33((std::size_t)n * 9), nrm3((std::size_t)n * 3);
   int rc = glim_amd_cloud_set_neighbors(cloud, k_correspondences, reinterpret_cast<const std::int32_t*>(neighbors.data()));
   if (rc == GLIM_AMD_OK) rc = glim_amd_cloud_estimate_covariances(cloud, k_neighbors);

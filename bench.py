@@ -1089,6 +1089,18 @@ def run_global256(args, D, api, ctx, extra_only=False):
             exchange["form"] = "one all-gather of the whole shard"
     elapsed = timed_steps(D, step, steps, max(args.warmup, 3))
     host = result["blocks"].cpu().numpy()
+    # The timed loop above never waits for an evaluation: the K evaluations queue up behind one another on the stream and nothing returns to the
+    # host (what `value` has meant since round 1).  An optimiser needs the records ON THE HOST before it can choose the next linearisation point, which
+    # is what the native C-ABI path (glim_amd_multi_linearize: synchronous, records in pinned host memory) delivers -- so the like-for-like partner of
+    # `native_c_abi_world1` is THIS loop with a copy-out and a synchronise per evaluation:
+    pinned = torch.empty(result["blocks"].shape, dtype=torch.float64, pin_memory=True)
+
+    def step_sync(_):
+        step(_)
+        pinned.copy_(result["blocks"], non_blocking=True)
+        torch.cuda.synchronize()
+
+    elapsed_sync = timed_steps(D, step_sync, steps, 2)
     # where the time of one evaluation goes on THIS rank (HIP events on our stream, outside the timed region): kernels + finalise, the
     # all-gather, the index_select into factor order -- and the same exchange with the shard split in two so that the gather of the first
     # half overlaps the kernels of the second (what the N > 1 timed loop would gain from it)
@@ -1153,6 +1165,11 @@ def run_global256(args, D, api, ctx, extra_only=False):
             native = {"error": repr(e)}
     return {
         "native_c_abi_world1": native,
+        "synchronous_per_evaluation": {"ms_per_evaluation": elapsed_sync / steps * 1e3,
+                                       "what": "the same torch-driven evaluation with the records copied to pinned host memory and a synchronise after EVERY evaluation -- "
+                                               "the form an optimiser needs and the like-for-like partner of native_c_abi_world1 (`value` queues the evaluations "
+                                               "back to back and never returns to the host)",
+                                       "native_minus_this_ms": (native["ms_per_evaluation"] - elapsed_sync / steps * 1e3) if native and "ms_per_evaluation" in native else None},
         "parity": parity, "predicted_scaling": predicted, "rank_breakdown": per_rank if per_rank else [breakdown], "exchange": exchange,
         "metric": "multi_scan_cost_eval_s", "value": sec, "unit": "s", "n_gpus": D.world, "steps": steps, "warmup": max(args.warmup, 3),
         "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -1233,10 +1250,10 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
                                          "(the device working); join = the other threads; scan = total error over the records"},
            "replication_and_setup_s": setup_s}
     out["total_error"] = tot.value
-    out["pieces_per_shard"] = "default: pieces of >= 2048 factors, at most 8 (glim_amd_multi_set_split)"
+    out["pieces_per_shard"] = "default: pieces of >= 2048 factors, at most 4 (glim_amd_multi_set_split)"
     # the same evaluation with the shard in 1 / 2 / 4 pieces (the exchange and the pose upload of one piece overlap the kernels of the next)
     sweep = {}
-    for pieces in (1, 2, 4):
+    for pieces in (1, 2, 8):
         M.set_split(pieces)
         M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
         sec2, bd2, k2, g2 = measure()
@@ -1491,7 +1508,7 @@ def main():
         m2 = run_global256(args, D, api, ctx, extra_only=True)
         if result is not None and m2 is not None:
             result["m2_global256"] = {k: m2[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline", "parity", "predicted_scaling",
-                                                         "rank_breakdown", "exchange", "native_c_abi_world1") if k in m2}
+                                                         "rank_breakdown", "exchange", "native_c_abi_world1", "synchronous_per_evaluation") if k in m2}
     D.finish()
     sys.stdout.flush()
     if D.rank == 0 and result is not None:

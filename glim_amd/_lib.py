@@ -104,6 +104,7 @@ SYMBOLS = {
     "glim_amd_multi_set_split": (_i, [_vp, _i32]),
     "glim_amd_multi_records": (_i, [_vp, _i64, _i64, _dp]),
     "glim_amd_voxelmap_set_lru_horizon": (_i, [_vp, _i32, _i32]),
+    "glim_amd_cloud_create_exact": (_i, [_vp, _i64, _dp, _pp]),
     "glim_amd_frame_create": (_i, [_vp, _i64, _dp, _dp, _dp, _i32, _dp, _pp, _pp]),
     "glim_amd_shard_layout": (_i, [_lp, _i32, _i32, _lp, _lp, _ip, _lp]),
     "glim_amd_debug_resident_stop": (_i, [_i]),

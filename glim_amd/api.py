@@ -685,7 +685,7 @@ class MultiDeviceCost:
         return dict(zip(self.BREAKDOWN_FIELDS, us.tolist()))
 
     def set_split(self, mode):
-        """-1: pieces of >= 2048 factors, at most 8 (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
+        """-1: pieces of >= 2048 factors, at most 4 (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
         check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
 
     def evaluate(self, T_target_source):

@@ -291,6 +291,20 @@ int run_deskew(glim_amd_ctx* ctx, int64_t n, const double* h_points4, const doub
 
 extern "C" {
 
+int glim_amd_cloud_create_exact(glim_amd_ctx* ctx, int64_t n, const double* points4, glim_amd_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !points4)) return GLIM_AMD_ERR_INVALID;
+  *out = nullptr;
+  if (n > (int64_t)(1 << 28)) return GLIM_AMD_ERR_INVALID;
+  // the deskewing path with ONE table entry, the identity: q = 1 * x + 0 * y + 0 * z + 0 is exact, so the cloud's FP64 points are the caller's
+  const std::vector<int> entry((size_t)n, 0);
+  std::vector<Pose> TT(1);
+  memset(TT[0].m, 0, sizeof(TT[0].m));
+  TT[0].m[0] = TT[0].m[5] = TT[0].m[10] = 1.0;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  GA_HIP(hipSetDevice(ctx->device));
+  return run_deskew(ctx, n, points4, nullptr, entry, TT, nullptr, nullptr, out);
+}
+
 int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
                                    int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
                                    const double* angular_vel3, int32_t to_imu_frame, glim_amd_cloud** out) {

@@ -236,6 +236,7 @@ struct glim_amd_ctx {
   unsigned int* ov_host = nullptr;            // pinned: [0] completion word, [1 + q] hits of query q
   unsigned int* ov_host_dev = nullptr;
   unsigned int ov_seq = 0;
+  unsigned int map_seq = 0;  // sequence number of the polled voxel-map builds of this context (voxelmap.hip; guarded by mu)
   std::vector<std::pair<int, double>> voxel_ratio_hints;  // (resolution class, voxels per point of the last map built there): voxelmap.hip
   void* pinned_scratch = nullptr;  // 1 KiB of pinned host memory for small read-backs (read_back_sync; guarded by mu)
   void* pinned_scratch_dev = nullptr;  // its device view (kernels that hand a few words to the host themselves)
@@ -342,9 +343,18 @@ struct glim_amd_voxelmap {
   // least-recently-used eviction of an incrementally built map (glim_amd_voxelmap_set_lru_horizon; GaussianVoxelMapCPU::set_lru_horizon of the
   // CPU odometry, odometry_estimation_cpu.cpp:63-68): slot 10 of a record holds the insert counter of the last insert that touched the voxel
   int32_t lru_horizon = 0, lru_clear_cycle = 10, lru_counter = 0;
+  // A direct build returns to its caller as soon as the voxel count is on the host (a polled, host-mapped word the LAST kernel of the build writes
+  // when it starts), i.e. while that kernel is still writing records: `ready_event` (recorded behind it) is what every later reader of the table
+  // on another stream waits for (voxelmap_wait_ready), and the build's scratch stays with the map until the event has been seen complete.
+  hipEvent_t ready_event = nullptr;
+  std::atomic<bool> ready_pending{false};
+  void *pending_acc = nullptr, *pending_stats = nullptr;
 };
 namespace glim_amd {
 int ensure_plane_view(::glim_amd_voxelmap* m, hipStream_t st);  // voxelmap.hip; complete (synchronised) before it returns
+// Before anything reads m->buckets / buckets_sm: no-op for a finished map; otherwise `consumer` (a stream) is made to wait for the build, or -- consumer
+// == nullptr -- the host waits.  Any thread, any context.
+int voxelmap_wait_ready(const ::glim_amd_voxelmap* m, hipStream_t consumer);
 }
 
 // Device plan of a factor list: descriptors, the block -> (factor, chunk) map, partial rows, pose / result staging.  Building one costs

@@ -88,9 +88,9 @@ inline int64_t layout_row(int ndev, int64_t piece_rows, int64_t max_rows, int d,
 inline void layout_pieces(int64_t max_rows, int ndev, int split_mode, int* pieces, int64_t* piece_rows) {
   (void)ndev;
   // default: pieces of >= 2048 factors (16 rounds of resident blocks on configs[3]'s submaps: the launch tail stays a few per cent of the piece), at
-  // most MAX_PIECES -- 8 on one device for the 32 640 pairs of configs[3] (the exposed exchange is then the last eighth: measured 11.53 / 11.33 /
-  // 11.27 ms per evaluation with 1 / 2 / 4 pieces), 1-2 per device on an 8-device node
-  int want = split_mode < 0 ? (int)std::max<int64_t>(1, max_rows / 2048) : std::max(1, split_mode);
+  // most 4 -- measured on one device for the 32 640 pairs of configs[3]: 10.92 / 10.74 / 10.66 / 10.73 ms per evaluation with 1 / 2 / 4 / 8 pieces
+  // (the exposed exchange shrinks with the last piece, every further launch adds its tail) --, 1-2 per device on an 8-device node
+  int want = split_mode < 0 ? (int)std::min<int64_t>(4, std::max<int64_t>(1, max_rows / 2048)) : std::max(1, split_mode);
   want = (int)std::min<int64_t>(std::min(want, MAX_PIECES), std::max<int64_t>(1, max_rows / 64));  // (a piece of a few rows is all launch tail)
   *piece_rows = (max_rows + want - 1) / want;
   *pieces = (int)((max_rows + *piece_rows - 1) / *piece_rows);
@@ -137,7 +137,7 @@ struct glim_amd_multi {
   // ncclAllGather of equal slots, issued as soon as that piece's kernels are done while the next piece's kernels run.
   int pieces = 1;
   int64_t piece_rows = 0;
-  int split_mode = -1;            // -1: default (pieces of >= 2048 factors, at most 8); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
+  int split_mode = -1;            // -1: default (pieces of >= 2048 factors, at most 4); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
   std::vector<double*> d_gather;  // [device]: ndev x max_rows x COMPACT
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
@@ -708,9 +708,9 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
               set_hip_error(hipErrorUnknown, "ncclAllGather");
               return (int)GLIM_AMD_ERR_HIP;
             }
-          } else if (m->use_rccl && h == P - 1) {
-            // one device: the collective is a copy onto itself; it is issued ONCE per evaluation (over the last piece) so that the library call
-            // the N-device node makes is made on a 1-GPU box as well
+          } else if (m->use_rccl && h == 0) {
+            // one device: the collective is a copy onto itself; it is issued ONCE per evaluation (over the FIRST piece, so that it runs beside the
+            // later pieces' kernels instead of behind the last one) so that the library call the N-device node makes is made on a 1-GPU box as well
             const ncclResult_t r = rccl().AllGather(region, region, slot, ncclDouble, m->comms[d], cst);
             if (r != ncclSuccess) {
               set_hip_error(hipErrorUnknown, "ncclAllGather");

@@ -1059,7 +1059,7 @@ struct OverlapQuery {
   int n;
   int first_target, num_targets;
   int first_block, num_blocks;  // blocks [first_block, first_block + num_blocks) of the launch walk this query's points
-  int pad;
+  int lanes_shift;              // 2^lanes_shift consecutive lanes share a point and split its targets (overlap_kernel)
 };
 constexpr int OVERLAP_INLINE_TARGETS = 16;
 struct OverlapInline {  // single-query call: everything in the kernel arguments, nothing to upload
@@ -1080,18 +1080,34 @@ __global__ __launch_bounds__(BLOCK) void overlap_kernel(const OverlapInline in, 
   const int qi = INLINE ? 0 : block_query[blockIdx.x];
   const OverlapQuery q = INLINE ? in.q : queries[qi];
   const OverlapTarget* tg = INLINE ? in.t : targets + q.first_target;
+  // A point's targets are looked up by G = 2^lanes_shift CONSECUTIVE LANES at once (G = 16 for the odometry's 15-keyframe query) instead of one
+  // lane walking them one after the other: a lookup is a dependent chain of memory latencies (key line, perhaps a spill), and fifteen of them in
+  // sequence made the 15-target call of a 10 000-pt frame a 30 us kernel -- latency, not work.  Lane l of a group takes targets l, l + G, ...; the
+  // group's verdict is a slice of the wavefront's ballot; the group's first lane counts the point.  Same count: "any target contains the point".
   int mine = 0;
   const int chunk = (int)blockIdx.x - q.first_block;
-  for (int i = chunk * BLOCK + (int)threadIdx.x; i < q.n; i += q.num_blocks * BLOCK) {
+  const int shift = q.lanes_shift, G = 1 << shift, sub_lane = (int)threadIdx.x & (G - 1);
+  const int lane = (int)threadIdx.x & 63, group_base = lane & ~(G - 1);
+  const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << group_base;
+  const long long items = (long long)q.n << shift;  // (point, lane-of-group) pairs
+  const int rounds = (q.num_targets + G - 1) >> shift;
+  for (long long base = (long long)chunk * BLOCK; base < items; base += (long long)q.num_blocks * BLOCK) {  // (block-uniform trip count: ballots stay whole)
+    const long long idx = base + (long long)threadIdx.x;
+    const bool live = idx < items;
+    const int i = live ? (int)(idx >> shift) : 0;
     const float4 p4 = q.pts[i];
-    for (int t = 0; t < q.num_targets; t++) {
-      double qx, qy, qz;
-      transform_point_d(tg[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
-      if (find_slot(tg[t].buckets, tg[t].num_buckets, voxel_key(qx, qy, qz, tg[t].inv_res)) >= 0) {
-        mine++;
-        break;
+    bool group_hit = false;
+    for (int r = 0; r < rounds; r++) {
+      const int t = (r << shift) + sub_lane;
+      bool hit = false;
+      if (live && !group_hit && t < q.num_targets) {
+        double qx, qy, qz;
+        transform_point_d(tg[t].T, (double)p4.x, (double)p4.y, (double)p4.z, qx, qy, qz);
+        hit = find_slot(tg[t].buckets, tg[t].num_buckets, voxel_key(qx, qy, qz, tg[t].inv_res)) >= 0;
       }
+      group_hit = group_hit || (__ballot(hit) & group_mask) != 0ull;
     }
+    if (live && group_hit && sub_lane == 0) mine++;
   }
   const int block_hits = block_reduce_i<2>(mine, s_tmp);
   if (threadIdx.x == 0) {
@@ -1488,6 +1504,9 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     }
     set->plan = p;
   }
+  // target maps whose build returned to its caller before its last kernel had finished (voxelmap.hip: polled voxel count): this set's stream waits
+  // for them.  One relaxed load per entry once the build has been seen complete.
+  for (const auto& e : set->entries) GA_TRY(voxelmap_wait_ready(e.target, set->stream));
   set->inline_args.valid = 0;
   set->poses_dev = set->plan->d_poses;
   if (set->entries.size() == 1) set->inline_args.d = set->plan->h_descs[0];
@@ -2020,8 +2039,16 @@ void fill_overlap_target(OverlapTarget& o, const glim_amd_voxelmap* m, const dou
 }
 
 // blocks a query's points are spread over: one atomic per block ends the query, so few fat blocks (at most one per CU)
-int overlap_blocks(const glim_amd_ctx* ctx, int64_t n) {
-  return (int)std::max<int64_t>(1, std::min<int64_t>((n + 2 * BLOCK - 1) / (2 * BLOCK), std::max(1, ctx->num_cus)));
+// lanes that share a point: the smallest power of two >= the number of targets, at most 16 (more targets take further rounds)
+int overlap_lanes_shift(int num_targets) {
+  int s = 0;
+  while ((1 << s) < num_targets && s < 4) s++;
+  return s;
+}
+int overlap_blocks(const glim_amd_ctx* ctx, int64_t n, int lanes_shift) {
+  // two (point, lane) items per thread, at most two blocks per CU: one returning atomic per block ends the query
+  const int64_t items = n << lanes_shift;
+  return (int)std::max<int64_t>(1, std::min<int64_t>((items + 2 * BLOCK - 1) / (2 * BLOCK), 2 * std::max(1, ctx->num_cus)));
 }
 
 }  // namespace
@@ -2306,6 +2333,7 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream();
+  for (int64_t t = 0; t < total_targets; t++) GA_TRY(voxelmap_wait_ready(targets[t], st));  // (maps whose build the host has not seen complete)
   GA_TRY(overlap_scratch(ctx, st));
   // queries with an empty source are answered here (0.0) and take no part in the launch
   std::vector<int> live;
@@ -2332,7 +2360,8 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
     in.q.first_target = 0;
     in.q.num_targets = num_targets[q];
     in.q.first_block = 0;
-    in.q.num_blocks = overlap_blocks(ctx, sources[q]->n);
+    in.q.lanes_shift = overlap_lanes_shift(num_targets[q]);
+    in.q.num_blocks = overlap_blocks(ctx, sources[q]->n, in.q.lanes_shift);
     for (int t = 0; t < num_targets[q]; t++) fill_overlap_target(in.t[t], targets[first_target[(size_t)q] + t], T + 12 * (first_target[(size_t)q] + t));
     overlap_kernel<true><<<in.q.num_blocks, BLOCK, 0, st>>>(in, nullptr, nullptr, nullptr, 1, ctx->ov_counters, nullptr, ctx->ov_host_dev + 1, ctx->ov_host_dev, seq);
     hipError_t e = hipGetLastError();
@@ -2356,8 +2385,8 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
     hq[i].first_target = (int)live_targets;
     hq[i].num_targets = num_targets[q];
     hq[i].first_block = total_blocks;
-    hq[i].num_blocks = overlap_blocks(ctx, sources[q]->n);
-    hq[i].pad = 0;
+    hq[i].lanes_shift = overlap_lanes_shift(num_targets[q]);
+    hq[i].num_blocks = overlap_blocks(ctx, sources[q]->n, hq[i].lanes_shift);
     total_blocks += hq[i].num_blocks;
     live_targets += num_targets[q];
   }

@@ -13,6 +13,7 @@
 //                      addition is associative, so the sums (and the map) are bit-reproducible whatever the atomic order
 //   4. finalise      : sums / count in FP64, stored as FP32 in the bucket (keys + statistics share one 128-byte line)
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -354,11 +355,14 @@ __global__ __launch_bounds__(256) void plane_view_kernel(const VoxelBucket* __re
 __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
                                                        const long long* __restrict__ acc, double res, const int* __restrict__ stats,
                                                        int* __restrict__ host_stats, VoxelBucket* __restrict__ view, const int2* __restrict__ lru = nullptr,
-                                                       int lru_stamp = 0) {
+                                                       int lru_stamp = 0, unsigned int poll_seq = 0u) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && host_stats) {
     host_stats[0] = stats[0];
     host_stats[1] = stats[1];
+    // poll_seq: the host spins on word 2 and returns to its caller while this kernel is still writing records (system-scope release: the two
+    // words above are visible with it); 0: the host synchronises the stream instead
+    if (poll_seq) __hip_atomic_store(reinterpret_cast<unsigned int*>(host_stats) + 2, poll_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (i >= 2 * num_buckets + (view ? 2u : 0u)) return;
   const unsigned int b = i >> 1, w = i & 1;
@@ -541,9 +545,57 @@ void voxelmap_drop_cleared_tables(int device) {
 }
 }  // namespace glim_amd
 
+namespace {
+bool spin_word(const volatile unsigned int* word, unsigned int value) {  // acquire; false after ~100 ms
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long spins = 0;; spins++) {
+    if (*word == value) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return false;
+  }
+}
+// the build of `m` has been seen complete: its scratch goes back to the pool
+void reap_build(glim_amd_voxelmap* m) {
+  if (m->pending_acc) (void)pool_free(m->pending_acc);
+  if (m->pending_stats) (void)pool_free(m->pending_stats);
+  m->pending_acc = m->pending_stats = nullptr;
+  m->ready_pending.store(false, std::memory_order_release);
+}
+}  // namespace
+
 namespace glim_amd {
+int voxelmap_wait_ready(const glim_amd_voxelmap* cm, hipStream_t consumer) {
+  glim_amd_voxelmap* m = const_cast<glim_amd_voxelmap*>(cm);  // (the bookkeeping of a finished build is not a change of the map)
+  if (!m->ready_pending.load(std::memory_order_acquire)) return GLIM_AMD_OK;
+  std::lock_guard<std::mutex> lock(m->view_mu);
+  if (!m->ready_pending.load(std::memory_order_relaxed)) return GLIM_AMD_OK;
+  const hipError_t q = hipEventQuery(m->ready_event);
+  if (q == hipSuccess) {
+    reap_build(m);
+    return GLIM_AMD_OK;
+  }
+  (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+  if (q != hipErrorNotReady) {
+    set_hip_error(q, "voxelmap_wait_ready");
+    return GLIM_AMD_ERR_HIP;
+  }
+  if (consumer) {
+    GA_HIP(hipStreamWaitEvent(consumer, m->ready_event, 0));  // (stays pending: a consumer on another stream waits as well)
+  } else {
+    GA_HIP(hipEventSynchronize(m->ready_event));
+    reap_build(m);
+  }
+  return GLIM_AMD_OK;
+}
+
 int ensure_plane_view(glim_amd_voxelmap* m, hipStream_t st) {
   if (!m->buckets || m->num_buckets == 0) return GLIM_AMD_ERR_STATE;
+  GA_TRY(voxelmap_wait_ready(m, st));
   // a map may be reached from factor sets of several contexts at once (GLIM's modules share them): one builder, and the view is COMPLETE
   // before anybody sees its pointer
   std::lock_guard<std::mutex> lock(m->view_mu);
@@ -584,6 +636,10 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
     quiesce_device(m->ctx->device, m->uid);  // asynchronous factor launches (of any context) may still be reading this table
   }
   global_mutation_epoch()++;  // factor sets re-validate their plans
+  (void)voxelmap_wait_ready(m, nullptr);  // (a build the host has not seen complete: its last kernel may still be writing the table)
+  if (m->pending_acc) (void)pool_free(m->pending_acc);
+  if (m->pending_stats) (void)pool_free(m->pending_stats);
+  if (m->ready_event) (void)hipEventDestroy(m->ready_event);
   if (m->buckets_sm) (void)pool_free(m->buckets_sm);
   if (m->buckets) {
     if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
@@ -606,6 +662,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   DeviceTemp tkeys, pkeys, stats, acc, lru;
   SyncOnExit in_flight(st);  // every exit that has not synchronised itself waits for the stream before the scratch above goes back to the pool
   constexpr int DIRECT_MAX_POINTS = 32768;
+  GA_TRY(voxelmap_wait_ready(m, nullptr));
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
   if (old) quiesce_device(ctx->device, m->uid);  // asynchronous factor launches may still be reading the table that is about to be replaced
@@ -657,9 +714,24 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     if (!have_cleared)
       init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(buckets, nb, (uint4*)acc.p, acc_words, (int*)stats.p);
     build_direct_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, cloud->pts, cloud->covA, cloud->covB, m->inv_resolution, buckets, nb, (long long*)acc.p, (int*)stats.p);
-    finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr, view);
+    // The host needs the voxel count (the reference's insert returns it through voxelmap_info) and nothing else from this build: the last kernel
+    // hands it over when it STARTS (word 2 of the mapped scratch = this build's sequence number) and the call returns while that kernel writes
+    // the records; readers on other streams wait for `ready_event` (voxelmap_wait_ready).  40-45 -> 3x us per 131 072-pt map.
+    const bool polled = mapped && (m->ready_event || hipEventCreateWithFlags(&m->ready_event, hipEventDisableTiming) == hipSuccess);
+    const unsigned int seq = polled ? (++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq) : 0u;
+    finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr, view,
+                                                                 nullptr, 0, seq);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && mapped) {
+    bool running = false;  // the last kernel may still be running when this call returns
+    if (e == hipSuccess && polled) {
+      e = hipEventRecord(m->ready_event, st);
+      if (e == hipSuccess) {
+        if (spin_word(reinterpret_cast<volatile unsigned int*>(h_view) + 2, seq)) running = true;
+        else e = hipStreamSynchronize(st);
+      }
+      h_stats[0] = h_view[0];
+      h_stats[1] = h_view[1];
+    } else if (e == hipSuccess && mapped) {
       e = hipStreamSynchronize(st);
       h_stats[0] = h_view[0];
       h_stats[1] = h_view[1];
@@ -673,7 +745,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       if (view) (void)pool_free(view);
       return GLIM_AMD_ERR_HIP;
     }
-    in_flight.dismiss();  // synchronised
+    if (running && (h_stats[1] != 0 || (direct_large && (double)h_stats[0] > 0.35 * 2.0 * (double)nb))) {
+      (void)hipStreamSynchronize(st);  // the rare exits below hand memory back: the build has to be over first
+      running = false;
+    }
+    in_flight.dismiss();  // synchronised, or the scratch stays with the map until its event has been seen complete (below)
     if (h_stats[1] != 0) {
       (void)pool_free(buckets);
       if (view) (void)pool_free(view);
@@ -692,6 +768,12 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       acc.p = nullptr;
       in_flight.armed = true;  // the counting path enqueues again
       break;
+    }
+    if (running) {
+      m->pending_acc = acc.p;
+      m->pending_stats = stats.p;
+      acc.p = stats.p = nullptr;
+      m->ready_pending.store(true, std::memory_order_release);
     }
     m->buckets = buckets;
     m->buckets_sm = view;
@@ -826,6 +908,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
   int rc = GLIM_AMD_OK;
   bool enqueued = false;
   int *h_view = nullptr, *d_view = nullptr;
+  unsigned int poll_seq = 0u;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     GA_HIP(hipSetDevice(ctx->device));
@@ -865,18 +948,32 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       if (!have_cleared)
         init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(B.buckets, nb, (uint4*)B.acc, acc_words, (int*)B.stats);
       build_direct_kernel<<<((int)n + 255) / 256, 256, 0, st>>>((int)n, c->pts, c->covA, c->covB, B.m->inv_resolution, B.buckets, nb, (long long*)B.acc, (int*)B.stats);
-      finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(B.buckets, nb, (const long long*)B.acc, B.m->resolution, (const int*)B.stats, d_view + 2 * lv, B.view);
+      // the LAST level's records kernel hands the host the completion word when it starts (the stream runs in order: everything before it -- the
+      // pull kernel's plane-form verdict, the earlier levels' counts -- is complete and visible by then); it may still be writing its own
+      // records when this call returns, which is what ready_event is for (voxelmap_wait_ready)
+      const bool last = lv == num_levels - 1;
+      if (last && hipEventCreateWithFlags(&B.m->ready_event, hipEventDisableTiming) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
+      finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(B.buckets, nb, (const long long*)B.acc, B.m->resolution, (const int*)B.stats, d_view + 4 * lv, B.view,
+                                                                   nullptr, 0, last ? poll_seq : 0u);
       e = hipGetLastError();
+      if (e == hipSuccess && last && poll_seq) e = hipEventRecord(B.m->ready_event, st);
       if (e != hipSuccess) {
         set_hip_error(e, "glim_amd_frame_create");
         rc = GLIM_AMD_ERR_HIP;
       }
     }
-    // ---- the one synchronise ----
-    const hipError_t es = hipStreamSynchronize(st);
-    if (rc == GLIM_AMD_OK && es != hipSuccess) {
-      set_hip_error(es, "glim_amd_frame_create: synchronise");
-      rc = GLIM_AMD_ERR_HIP;
+    // ---- the one wait: the polled word, or a synchronise ----
+    bool running = false;
+    if (rc == GLIM_AMD_OK && num_levels > 0 && poll_seq && spin_word(reinterpret_cast<volatile unsigned int*>(h_view) + 4 * (num_levels - 1) + 2, poll_seq)) {
+      running = true;
+      for (int lv = 0; lv < num_levels; lv++) running = running && h_view[4 * lv + 1] == 0;  // (a range error hands memory back: synchronise first)
+    }
+    if (!running) {
+      const hipError_t es = hipStreamSynchronize(st);
+      if (rc == GLIM_AMD_OK && es != hipSuccess) {
+        set_hip_error(es, "glim_amd_frame_create: synchronise");
+        rc = GLIM_AMD_ERR_HIP;
+      }
     }
     if (enqueued) {
       if (rc == GLIM_AMD_OK) cloud_small_finish(c, &up);
@@ -884,9 +981,16 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     }
     for (int lv = 0; lv < num_levels; lv++) {
       Build& B = b[lv];
-      if (B.acc) (void)pool_free(B.acc);
-      if (B.stats) (void)pool_free(B.stats);
-      if (rc == GLIM_AMD_OK && h_view[2 * lv + 1] != 0) rc = GLIM_AMD_ERR_RANGE;
+      if (running && lv == num_levels - 1) {  // its records kernel may still be reading the accumulators: they stay with the map until the event has been seen
+        B.m->pending_acc = B.acc;
+        B.m->pending_stats = B.stats;
+        B.m->ready_pending.store(true, std::memory_order_release);
+      } else {
+        if (B.acc) (void)pool_free(B.acc);
+        if (B.stats) (void)pool_free(B.stats);
+      }
+      B.acc = B.stats = nullptr;
+      if (rc == GLIM_AMD_OK && h_view[4 * lv + 1] != 0) rc = GLIM_AMD_ERR_RANGE;
     }
     if (rc == GLIM_AMD_OK) {
       for (int lv = 0; lv < num_levels; lv++) {
@@ -894,7 +998,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
         B.m->buckets = B.buckets;
         B.m->buckets_sm = B.view;
         B.m->num_buckets = B.nb;
-        B.m->num_voxels = h_view[2 * lv];
+        B.m->num_voxels = h_view[4 * lv];
         B.m->lru_counter = 1;
         B.m->uid = next_uid();
         const int res_class = (int)lround(8.0 * log2(B.m->resolution));
@@ -909,6 +1013,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       if (B.buckets) (void)pool_free(B.buckets);
       if (B.view) (void)pool_free(B.view);
       if (B.m) {
+        if (B.m->ready_event) (void)hipEventDestroy(B.m->ready_event);
         B.m->ctx = nullptr;
         delete B.m;
       }
@@ -949,6 +1054,7 @@ int glim_amd_voxelmap_info(const glim_amd_voxelmap* m, int32_t* num_voxels, int3
 int glim_amd_voxelmap_download(const glim_amd_voxelmap* m, int32_t* coords, int32_t* counts, float* means, float* cov33) {
   if (!m) return GLIM_AMD_ERR_INVALID;
   if (!m->buckets) return GLIM_AMD_ERR_STATE;
+  GA_TRY(voxelmap_wait_ready(m, nullptr));
   glim_amd_ctx* ctx = m->ctx;
   std::lock_guard<std::mutex> lock(ctx->mu);
   GA_HIP(hipSetDevice(ctx->device));

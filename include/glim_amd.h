@@ -137,6 +137,11 @@ int glim_amd_cloud_load_compact(glim_amd_ctx* ctx, const char* dir, glim_amd_clo
  * to_imu_frame == 0 returns exactly CloudDeskewing::deskew's value (LiDAR frame).
  * The result is a device cloud of the deskewed points -- the exact FP64 values (what glim_amd_cloud_estimate_covariances reads and
  * glim_amd_cloud_download_frame returns) and their FP32 image for the factor path; no covariances yet. */
+/* PointCloudGPU::clone of points only that KEEPS the exact FP64 values beside their FP32 image (what a preprocessed / deskewed cloud does): for
+ * points that are not FP32-representable -- deskewed, IMU-frame points handed to CloudCovarianceEstimation::estimate by a caller that holds them on
+ * the host (src/glim/odometry/odometry_estimation_imu.cpp:320; adapters/glim/cloud_covariance_estimation_hip.cpp) -- so that
+ * glim_amd_cloud_estimate_covariances reads what the reference reads (the 1e-5 covariance gate is then met on every point). */
+int glim_amd_cloud_create_exact(glim_amd_ctx* ctx, int64_t n, const double* points4, glim_amd_cloud** out);
 int glim_amd_cloud_create_deskewed(glim_amd_ctx* ctx, int64_t n, const double* points4, const double* times, const double* T_imu_lidar12,
                                    int32_t n_imu, const double* imu_times, const double* imu_poses12, double stamp, const double* linear_vel3,
                                    const double* angular_vel3, int32_t to_imu_frame, glim_amd_cloud** out);
@@ -386,7 +391,7 @@ int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, fl
 #define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 10
 int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
 /* how a device's shard is evaluated: n >= 2 = as n pieces (at most 8), the all-gather and copy-out of one piece overlapping the kernels of
- * the next; 0 or 1 = as one set and one all-gather; -1 (default) = pieces of at least 2048 factors, at most 8.  Takes effect with the next
+ * the next; 0 or 1 = as one set and one all-gather; -1 (default) = pieces of at least 2048 factors, at most 4.  Takes effect with the next
  * glim_amd_multi_set_factors. */
 int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */

@@ -494,10 +494,10 @@ def test_frame_create_equals_the_separate_calls(api, orc, small_pair):
     p4, c16, n4 = packed(t, covs=True, normals=False)
     cloud, maps = api.frame_create(p4, c16, None, levels, ctx=ctx)
     assert [m.voxelmap_info()["num_voxels"] for m in maps] == [orc.VoxelMap(r).insert(t["points"], t["covs"]).num_voxels() for r in levels]
-    big = np.tile(p4, (5, 1))[:40000]
-    bigc = np.tile(c16, (5, 1))[:40000]
+    reps = -(-40000 // len(p4))
+    big, bigc = np.tile(p4, (reps, 1)), np.tile(c16, (reps, 1))  # > 32 768 points: the separate calls inside the same entry point
     cloud2, maps2 = api.frame_create(big, bigc, None, levels[:1], ctx=ctx)
-    assert cloud2.size() == 40000 and maps2[0].voxelmap_info()["num_voxels"] == maps[0].voxelmap_info()["num_voxels"]
+    assert cloud2.size() == len(big) > 32768 and maps2[0].voxelmap_info()["num_voxels"] == maps[0].voxelmap_info()["num_voxels"]
     with pytest.raises(api.GlimAmdError):
         api.frame_create(p4, c16, None, [0.5, -1.0], ctx=ctx)
     far = p4.copy()

@@ -184,3 +184,60 @@ def test_odometry_latency_is_isolated_from_a_mapping_thread(small_pair):
     p99i, p99l = float(np.percentile(idle, 99)), min(attempts)
     print(f"odometry linearise p99: idle {p99i:.1f} us, beside a mapping thread {p99l:.1f} us ({p99l / p99i:.2f}x; takes: {attempts})")
     assert p99l <= 3.0 * p99i + 10.0, (p99i, attempts)
+
+
+@pytest.mark.gpu
+def test_a_map_is_usable_the_moment_insert_returns(small_pair):
+    """GaussianVoxelMapGPU::insert returns as soon as the voxel count is on the host -- its last kernel may still be writing records (voxelmap.hip:
+    polled completion word).  Whoever reads the table next -- a factor set on ANOTHER stream of the context, a set or an overlap query of another
+    context, a download, an incremental insert, the destructor -- must wait for that kernel on its own: 60 rounds of insert-then-use-at-once on full
+    scans against the same calls made after a context synchronise."""
+    from glim_amd import api, synth
+
+    scene = synth.Scene.default()
+    poses = synth.arc_trajectory(2)
+    dirs = synth.lidar_directions(128, 1024)
+    a, b = api.Context(0, 4), api.Context(0, 2, priority=1)
+    tg = api.PointCloudGPU.clone(synth.scan(scene, poses[0], dirs, 0), ctx=a)
+    sg = api.PointCloudGPU.clone(synth.scan(scene, poses[1], dirs, 1), ctx=b)
+    for g in (tg, sg):
+        g.find_neighbors(10, download=False)
+        g.estimate_covariances(10)
+    T = synth.relative_pose(poses[0], poses[1])
+    values = {0: np.eye(4), 1: T}
+    api.GaussianVoxelMapGPU(0.5, ctx=a).insert(tg).close()  # (the first map at a resolution takes the counting path; the rounds below the direct one)
+
+    def use(vm, ctx):
+        fs = api.NonlinearFactorSetGPU(ctx)
+        fs.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        out = fs.linearize(values)[0]
+        fs.close()
+        return out
+
+    ref_map = api.GaussianVoxelMapGPU(0.5, ctx=a).insert(tg)
+    a.synchronize()
+    want, want_ov = use(ref_map, a), api.overlap_gpu([ref_map], sg, [T], ctx=b)
+    want_voxels = ref_map.voxelmap_info()["num_voxels"]
+    for rep in range(60):
+        vm = api.GaussianVoxelMapGPU(0.5, ctx=a).insert(tg)
+        assert vm.voxelmap_info()["num_voxels"] == want_voxels
+        kind = rep % 4
+        if kind == 0:
+            got = use(vm, a)            # another stream of the map's own context (round robin)
+        elif kind == 1:
+            got = use(vm, b)            # another context
+        elif kind == 2:
+            assert api.overlap_gpu([vm], sg, [T], ctx=b) == want_ov
+            got = use(vm, b)
+        else:
+            assert len(vm.voxels()[0]) == want_voxels  # download right behind the insert
+            got = use(vm, a)
+        assert got["num_inliers"] == want["num_inliers"] and got["error"] == want["error"], (rep, kind)
+        np.testing.assert_array_equal(got["H_ss"], want["H_ss"])
+        vm.close()                      # (and the destructor right behind a use)
+    vm = api.GaussianVoxelMapGPU(0.5, ctx=a).insert(tg)
+    vm.insert(sg)                       # an incremental insert right behind the first
+    both = api.GaussianVoxelMapGPU(0.5, ctx=a).insert(tg)
+    a.synchronize()
+    both.insert(sg)
+    assert vm.voxelmap_info() == both.voxelmap_info()

@@ -69,7 +69,7 @@ def test_world8_record_layout_against_the_unsharded_order():
     for split in (-1, 1, 2, 4, 8):
         rows, max_rows, pieces, piece_rows = api.shard_layout(b, split)
         assert max_rows == max(b[r + 1] - b[r] for r in range(world))
-        assert pieces == (max(1, min(8, max_rows // 2048)) if split < 0 else split) and piece_rows == -(-max_rows // pieces)
+        assert pieces == (max(1, min(4, max_rows // 2048)) if split < 0 else split) and piece_rows == -(-max_rows // pieces)
         assert len(np.unique(rows)) == n and rows.min() >= 0 and rows.max() < world * max_rows
         gathered = [np.full((world * max_rows, 29), np.nan) for _ in range(world)]
         for d in range(world):  # every device's kernels write its own rows

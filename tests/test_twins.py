@@ -34,7 +34,7 @@ def _nm(obj):
 @pytest.mark.parametrize("unit, defines, needs", [
     ("cloud_covariance_estimation_hip.cpp",
      ["T glim::CloudCovarianceEstimation::estimate(", "T glim::CloudCovarianceEstimation::regularize(", "T glim::CloudCovarianceEstimation::CloudCovarianceEstimation(int)"],
-     ["U glim_amd_cloud_estimate_covariances", "U glim_amd_cloud_set_neighbors", "U glim_amd_cloud_create"]),
+     ["U glim_amd_cloud_estimate_covariances", "U glim_amd_cloud_set_neighbors", "U glim_amd_cloud_create_exact"]),
     ("cloud_deskewing_hip.cpp", ["T glim::CloudDeskewing::deskew(Eigen::Isometry3d const&, Eigen::Matrix<double, 3, 1> const&", "T glim::CloudDeskewing::deskew(Eigen::Isometry3d const&, std::vector<double"],
      ["U glim_amd_cloud_create_deskewed", "U glim_amd_cloud_download_frame"]),
     ("cloud_preprocessor_hip.cpp",
