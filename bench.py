@@ -384,6 +384,17 @@ def run_odometry128k(args, D, api, ctx):
     # {set pose, linearize, read back the record} per call, one factor of 131 072 points, issued from C (glim_amd_factor_set_linearize_repeat),
     # on a context of the kind the odometry module creates (adapters/glim/odometry_estimation_hip_create.cpp: own stream pool, priority 1 --
     # which is also what switches the resident session on; every other context leaves it off).  Clouds and maps cross contexts by design.
+    if args.sync_calls <= 0:
+        # profiling runs (tools/profile.sh: --sync-calls 0): only the batched launches, so that the rocprofv3 passes see the dominant kernel alone (a
+        # resident session must not be alive under serialised counter collection)
+        if rank != 0:
+            return None
+        return {"metric": "vgicp_linearize_calls_per_s", "value": value_batched, "unit": "calls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed_batched / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "headline_form": f"profiling form (--sync-calls 0): batched only, {F} factors per NonlinearFactorSetGPU::linearize",
+                "batched_calls_per_s": value_batched, "config": {"workload": "configs[1] odometry128k, batched form only (profiling run)", "factors_per_gpu_batched": F,
+                                                                 "points_per_factor": int(np.mean(n_pts)), "voxels_per_factor": int(np.mean(n_vox))},
+                "roofline": roofline}
     odo = api.Context(D.local_rank, 4, priority=1)
     single = api.NonlinearFactorSetGPU(odo)
     single.add(api.IntegratedVGICPFactorGPU(0, 1, vmaps[0], clouds[1]))
@@ -1158,7 +1169,7 @@ def run_global256(args, D, api, ctx, extra_only=False):
     if D.world == 1 and not args.no_predict:
         predicted = predict_scaling(api, ctx, multi, pairs, deltas, clouds, vmaps, costs, host, sec * 1e3, torch)
     native = None
-    if D.world == 1:
+    if D.world == 1 and not args.no_native:
         try:  # the same cost through the native C-ABI multi-device path, as world 1 (what an N-device node runs with `--gpus N --native`)
             native = native_global256(args, api, submaps, pairs, deltas, 1, 5, 3)
         except Exception as e:  # noqa: BLE001 -- reported, not fatal for the headline
@@ -1474,6 +1485,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="global256 on several GPUs: do not try the two-halves form of the exchange")
     ap.add_argument("--no-predict", action="store_true", help="global256 on one GPU: skip the per-shard timing behind `predicted_scaling`")
+    ap.add_argument("--no-native", action="store_true", help="global256 on one GPU: skip the run through the native C-ABI multi-device path (profiling passes)")
     ap.add_argument("--native", action="store_true", help="configs[3] through the native multi-device C-ABI path (glim_amd_multi_*: ONE process drives --gpus "
                                                          "devices, ncclAllGather) instead of one torch.distributed rank per GPU; run it as a plain `python bench.py`")
     args = ap.parse_args()

@@ -874,14 +874,22 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
       for (int base_w = 0; base_w < words; base_w += LEAD_WORDS) {
         const int w = base_w + (int)threadIdx.x;
         unsigned long long v = w0;
+        bool stale = false;
         if (base_w > 0 && w < words && req != RES_EXIT) {
           // later lines: read until their own tag is the request's (bounded: the host wrote every tag before it wrote line 0's)
+          stale = true;
           for (int tries = 0; tries < 1000; tries++) {
             v = __hip_atomic_load(ra.h_lines + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const unsigned int t = (unsigned int)__shfl((unsigned int)v, (int)((threadIdx.x & 63) | 7), 64);
-            if (__all(t == req)) break;
+            if (__all(t == req)) {
+              stale = false;
+              break;
+            }
           }
         }
+        // a line that never showed this request's tag is not part of a request: nothing of it is published under the tag -- the session ends
+        // (exit tag) and the host's call is answered by the launch-per-call path
+        if (base_w > 0 && __syncthreads_or(stale ? 1 : 0)) req = RES_EXIT;
         const int line = w >> 3, slot = w & 7, i = line * 7 + slot;  // index into the pose array
         if (w < words && slot < 7 && i < nd) {
           const long long bits = req != RES_EXIT ? (long long)v : 0ll;

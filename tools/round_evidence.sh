@@ -4,7 +4,7 @@
 #  3. PMC passes of the global256 workload (general kernel)
 #  4. the default bench line (with cpu_baseline and m2_global256) and the other workloads; tools/batch_sweep.py
 # The raw rocprofv3 output is summarised HERE (tools/summarize_profile.py) and deleted: gpurun copies at most 64 MiB back.
-TAG=${1:-r03}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/evidence_$TAG
 mkdir -p $OUT
@@ -18,7 +18,7 @@ rm -rf gpurun_out/prof_$TAG
 # carry traffic measured on exactly the kernels they time (`traffic_measured_on_this_kernel_version`)
 mkdir -p profiles/$TAG && cp $OUT/traffic.json profiles/$TAG/traffic.json 2>/dev/null
 if [ -z "$SKIP_GLOBAL256_PMC" ]; then
-  SKIP_FETCH_PASS=1 BENCH_ARGS="--workload global256 --steps 3 --warmup 1 --no-cpu-baseline" timeout 600 bash $REPO/tools/profile.sh ${TAG}_g > $OUT/profile_g.log 2>&1 < /dev/null
+  SKIP_FETCH_PASS=1 BENCH_ARGS="--workload global256 --steps 3 --warmup 1 --no-cpu-baseline --no-predict --no-native" timeout 600 bash $REPO/tools/profile.sh ${TAG}_g > $OUT/profile_g.log 2>&1 < /dev/null
   cd $REPO
   mkdir -p $OUT/global256
   python tools/summarize_profile.py gpurun_out/prof_${TAG}_g $OUT/global256 32640 global256 36 2029810471 >> $OUT/summarize.log 2>&1

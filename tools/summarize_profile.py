@@ -32,7 +32,7 @@ def by_kernel_grid(path, value_col, scale=1.0):
     return acc
 
 
-summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --inner 16 --no-cpu-baseline --no-m2   "
+summary = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --inner 16 --sync-calls 0 --no-cpu-baseline --no-m2 --no-resident-cost   "
                       "(tools/profile.sh; PMC passes, each its own run: --pmc FETCH_SIZE; --pmc WRITE_SIZE; --pmc TCC_EA0_RDREQ_{32,64,128}B_sum)"}
 trace = one("stats/**/*kernel_trace.csv")
 rows = []
