@@ -2386,6 +2386,9 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
   int total_blocks = 0;
   std::vector<OverlapQuery> hq(live.size());
   int64_t live_targets = 0;
+  long long walking_blocks = 0;
+  for (const int q : live) walking_blocks += overlap_blocks(ctx, sources[q]->n, 0);
+  const bool batch_fills_device = walking_blocks >= (long long)std::max(1, ctx->num_cus);
   for (size_t i = 0; i < live.size(); i++) {
     const int q = live[i];
     hq[i].pts = sources[q]->pts;
@@ -2393,7 +2396,11 @@ int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t
     hq[i].first_target = (int)live_targets;
     hq[i].num_targets = num_targets[q];
     hq[i].first_block = total_blocks;
-    hq[i].lanes_shift = overlap_lanes_shift(num_targets[q]);
+    // Spreading a point's targets over lanes trades work for latency: every target is looked up, where one lane walking them stops at the first
+    // hit (keyframes overlap: two or three lookups per point on average).  A batch that fills the chip by itself (the 43-query keyframe elimination
+    // loop: 860 blocks) is bound by that work, not by one query's latency -- 55-59 us walking, 92 us spread -- so only batches too small to fill
+    // the device spread.
+    hq[i].lanes_shift = batch_fills_device ? 0 : overlap_lanes_shift(num_targets[q]);
     hq[i].num_blocks = overlap_blocks(ctx, sources[q]->n, hq[i].lanes_shift);
     total_blocks += hq[i].num_blocks;
     live_targets += num_targets[q];
