@@ -700,8 +700,10 @@ def live_odometry_loop(api, host, poses, c32_of, frames, K, WIN, res0, iters, ti
         try:
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "odometry_frame_loop.cpp"),
                                    "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
-            for name, fused in (("separate_calls", 0), ("one_submission_create_frame", 1)):
-                res = subprocess.run([exe, scene, str(timed), str(iters), str(fused)], capture_output=True, text=True, timeout=300)
+            for name, fused, diag in (("separate_calls", 0, ""), ("one_submission_create_frame", 1, ""),
+                                      ("one_submission_without_gated_pull_and_plan_recycling", 1, "pull_gated=0,plan_recycle=0"),
+                                      ("one_submission_without_gated_pull", 1, "pull_gated=0"), ("one_submission_without_plan_recycling", 1, "plan_recycle=0")):
+                res = subprocess.run([exe, scene, str(timed), str(iters), str(fused), diag], capture_output=True, text=True, timeout=300)
                 out[name] = json.loads(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else {"error": (res.stderr or res.stdout)[-400:]}
         except Exception as e:  # noqa: BLE001 -- reported, the pieces above stand on their own
             out["error"] = repr(e)
@@ -1248,7 +1250,7 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
     b0 = bd[0]
     accounted = b0["pose_stage"] + b0["enqueue"] + b0["barrier"] + b0["collective"] + b0["wait"] + b0["join"] + b0["scan"] + b0["post"]
     out = {"form": "C ABI glim_amd_multi_*: one process; the caller's thread drives device 0, one more thread per further device; ONE hand-over per evaluation; "
-                   "ncclAllGather of the owned rows (two halves per shard on several devices: the gather of the first overlaps the kernels of the second)",
+                   "ncclAllGather of the owned rows, piece by piece on several devices (the gather of one piece overlaps the kernels of the next); one device: no library call per evaluation",
            "n_devices": info["num_devices"], "rccl_ranks": info["num_devices"] if info["uses_rccl"] else 0, "uses_rccl": info["uses_rccl"],
            "seconds_per_evaluation": sec, "ms_per_evaluation": sec * 1e3, "steps": steps,
            "per_device": [{"device": d, "pairs": int(b1 - b0_), "kernels_ms": k, "collective_and_copy_out_after_the_kernels_ms": g}
@@ -1258,9 +1260,20 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
                                  "what": "steady_clock inside glim_amd_multi_linearize, averaged over the timed evaluations: post = handing work to the other "
                                          "devices' threads; pose_stage = this shard's poses into the pinned ring; enqueue = plan check + H2D + kernel launches; "
                                          "barrier = until every device has enqueued; collective = ncclAllGather + copy-out enqueue; wait = hipStreamSynchronize "
-                                         "(the device working); join = the other threads; scan = total error over the records"},
+                                         "(the device working); join = the other threads; scan = total error over the records; library_calls = inside ncclAllGather (part of "
+                                         "collective); device_gather / device_copy_out = HIP events after the last kernel: up to the end of the last all-gather, then the "
+                                         "copy-out + error sum"},
            "replication_and_setup_s": setup_s}
     out["total_error"] = tot.value
+    if len(devices) == 1 and info["uses_rccl"]:
+        # one device has nothing to gather and makes no library call per evaluation (the binding is exercised at create); what the no-op
+        # ncclAllGather would cost if it were made every time -- round 5's evidence box: 0.3 ms of host time inside a process with torch's librccl
+        M.set_one_rank_collective(True)
+        sec1, bd1, k1, g1 = measure()
+        M.set_one_rank_collective(False)
+        out["with_the_one_rank_library_call_every_evaluation"] = {
+            "ms_per_evaluation": sec1 * 1e3, "kernels_ms": k1, "collective_and_copy_out_after_the_kernels_ms": g1,
+            "library_calls_host_us": bd1[0]["library_calls"], "device_gather_us": bd1[0]["device_gather"], "device_copy_out_us": bd1[0]["device_copy_out"]}
     out["pieces_per_shard"] = "default: pieces of >= 2048 factors, at most 4 (glim_amd_multi_set_split)"
     # the same evaluation with the shard in 1 / 2 / 4 pieces (the exchange and the pose upload of one piece overlap the kernels of the next)
     sweep = {}

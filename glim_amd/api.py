@@ -676,7 +676,8 @@ class MultiDeviceCost:
         check(lib().glim_amd_multi_last_timing(self._h, k.ctypes.data_as(C.POINTER(C.c_float)), g.ctypes.data_as(C.POINTER(C.c_float))), "glim_amd_multi_last_timing")
         return k.tolist(), g.tolist()
 
-    BREAKDOWN_FIELDS = ("post", "wake", "pose_stage", "enqueue", "barrier", "collective", "wait", "join", "scan", "total")
+    BREAKDOWN_FIELDS = ("post", "wake", "pose_stage", "enqueue", "barrier", "collective", "wait", "join", "scan", "total", "library_calls",
+                        "device_gather", "device_copy_out")
 
     def last_breakdown(self, device=0):
         """Host-side account of the last evaluation on one device's thread, microseconds (glim_amd_multi_last_breakdown)."""
@@ -687,6 +688,10 @@ class MultiDeviceCost:
     def set_split(self, mode):
         """-1: pieces of >= 2048 factors, at most 4 (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
         check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
+
+    def set_one_rank_collective(self, on):
+        """One device: make the (no-op) ncclAllGather in every evaluation as well (measurement aid; default off)."""
+        check(lib().glim_amd_multi_set_one_rank_collective(self._h, int(bool(on))), "glim_amd_multi_set_one_rank_collective")
 
     def evaluate(self, T_target_source):
         """One evaluation that leaves the records in the handle (records()) and returns the total error, summed by the devices."""
@@ -720,6 +725,14 @@ def resident_stats(ctx=None):
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
     check(lib().glim_amd_debug_resident_stats(int(getattr(ctx, "device", 0)), C.byref(a), C.byref(b), C.byref(c)), "glim_amd_debug_resident_stats")
     return {"launches": a.value, "requests": b.value, "alive": bool(c.value)}
+
+
+def plan_stats(ctx=None):
+    """Debug: factor plans built for new lists, how many of them in the buffers of an evicted plan, idle plans cached (glim_amd_debug_plan_stats)."""
+    ctx = ctx or default_context()
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
+    check(lib().glim_amd_debug_plan_stats(ctx._h, C.byref(a), C.byref(b), C.byref(c)), "glim_amd_debug_plan_stats")
+    return {"built": a.value, "recycled": b.value, "cached": c.value}
 
 
 def resident_stop(ctx=None):

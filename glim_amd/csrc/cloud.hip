@@ -102,11 +102,35 @@ __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4
 // cloud's arrays and evaluates the plane-form predicate on the way (violations land in a word of the same block): one launch, one
 // synchronise, 58 us (odometry_frame bench).  Above HOST_PACK_MAX_POINTS the runtime's pageable copy path (43 GB/s measured at 25 MB) beats a single host thread.
 constexpr int64_t HOST_PACK_MAX_POINTS = 32768;
+std::atomic<unsigned int> g_pull_gate_seq{1u};
+std::atomic<bool> g_pull_gate_broken{false};  // a gated pull kernel once gave up waiting for this process' host side: no more gating
 __global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __restrict__ s_pts, const float4* __restrict__ s_covA,
                                                       const float2* __restrict__ s_covB, const float4* __restrict__ s_nrm, float4* __restrict__ pts,
                                                       float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm,
                                                       unsigned int* __restrict__ host_violations, float4* __restrict__ pn4, float2* __restrict__ n2,
-                                                      float4* __restrict__ gs0, float4* __restrict__ gs1, float* __restrict__ gs2, float4* __restrict__ gsn) {
+                                                      float4* __restrict__ gs0, float4* __restrict__ gs1, float* __restrict__ gs2, float4* __restrict__ gsn,
+                                                      const unsigned int* __restrict__ gate, unsigned int gate_seq, int piece_len) {
+  if (gate) {
+    // Launched BEFORE the host has converted anything (cloud_small_enqueue): the block waits until the host has published its piece of the
+    // staging block -- gate word of the piece == this upload's sequence number, host-mapped memory, polled over PCIe by ONE lane.  Every block
+    // of the grid is resident at once (<= 128 blocks), so waiting blocks keep nobody out.  The wait is bounded (seconds): a host that never
+    // comes back ends in PULL_GAVE_UP in the word behind the violations word, not in a hung device.
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+      const unsigned int* g = gate + (blockIdx.x * 256) / piece_len;
+      bool ok = false;
+      for (unsigned int spins = 0; spins < (1u << 21) && !ok; spins++) {
+        ok = __hip_atomic_load(g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == gate_seq;
+        if (!ok) __builtin_amdgcn_s_sleep(16);
+      }
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) {
+      if (threadIdx.x == 0) __hip_atomic_store(host_violations + 1, PULL_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool bad = false;
   if (i < n) {
@@ -138,8 +162,9 @@ __global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __res
 }
 
 // host half: the reference layouts (Vector4d, column-major Matrix4d) -> the FP32 sections of the staging block
-void host_pack_f64(int64_t n, const double* points4, const double* covs16, const double* normals4, float* pts, float* covA, float* covB, float* nrm) {
-  for (int64_t i = 0; i < n; i++) {
+// points [lo, hi) of every section
+void host_pack_f64(int64_t lo, int64_t hi, const double* points4, const double* covs16, const double* normals4, float* pts, float* covA, float* covB, float* nrm) {
+  for (int64_t i = lo; i < hi; i++) {
     const double* p = points4 + 4 * i;
     pts[4 * i + 0] = (float)p[0];
     pts[4 * i + 1] = (float)p[1];
@@ -147,7 +172,7 @@ void host_pack_f64(int64_t n, const double* points4, const double* covs16, const
     pts[4 * i + 3] = 1.0f;
   }
   if (covs16)
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = lo; i < hi; i++) {
       const double* c = covs16 + 16 * i;  // column-major 4x4: (r,c) at c*4 + r
       covA[4 * i + 0] = (float)c[0];
       covA[4 * i + 1] = (float)c[4];
@@ -157,7 +182,7 @@ void host_pack_f64(int64_t n, const double* points4, const double* covs16, const
       covB[2 * i + 1] = (float)c[10];
     }
   if (normals4)
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = lo; i < hi; i++) {
       const double* v = normals4 + 4 * i;
       nrm[4 * i + 0] = (float)v[0];
       nrm[4 * i + 1] = (float)v[1];
@@ -191,7 +216,7 @@ namespace glim_amd {
 int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up) {
   const int64_t n = c->n;
   float* stage = nullptr;
-  if (pinned_malloc(&stage, (size_t)n * 14 * sizeof(float) + 16) != hipSuccess) {
+  if (pinned_malloc(&stage, (size_t)n * 14 * sizeof(float) + 64) != hipSuccess) {
     (void)hipGetLastError();
     return GLIM_AMD_ERR_UNSUPPORTED;
   }
@@ -202,10 +227,10 @@ int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* poin
     return GLIM_AMD_ERR_UNSUPPORTED;
   }
   // sections: pts [0, 4n), covA [4n, 8n), nrm [8n, 12n), covB [12n, 14n) -- the float4 sections first, so that every section is 16-byte
-  // aligned -- then the violation word of the plane-form test
-  host_pack_f64(n, points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
-  volatile unsigned int* violations = reinterpret_cast<unsigned int*>(stage + 14 * n);
-  *violations = 0u;
+  // aligned -- then the tail words: [0] violations of the plane-form test, [1] PULL_GAVE_UP, [4 .. 7] the gate words of the pieces
+  volatile unsigned int* tail = reinterpret_cast<unsigned int*>(stage + 14 * n);
+  tail[0] = 0u;
+  tail[1] = 0u;
   hipStream_t s = ctx->stream();
   // factor streams written by the same kernel (see unstage_kernel); an allocation that fails only means they are built on first use instead
   if (covs16) {
@@ -219,13 +244,33 @@ int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* poin
       drop_plane_streams(c);
     }
   }
+  // Gated form (default): the pull kernel goes out FIRST and the host converts while the launch travels; the cloud is cut into up to four pieces
+  // and the blocks of a piece start pulling the moment the host has published it, so the conversion of piece k + 1 runs beside the pull of
+  // piece k and only the last piece's pull is exposed (round 5, 10 000-pt frame: 35 us of conversion FOLLOWED by a launch and 22 us of pull
+  // before).  Cutting the cloud into four LAUNCHES instead was measured and rejected (+23 us: profiles/r05/probe/upload_in_pieces_rejected.json).
+  const bool gated = ctx->diag.pull_gated && !g_pull_gate_broken.load(std::memory_order_relaxed);
+  unsigned int seq = 0u;
+  while (gated && (seq == 0u || seq == PULL_GAVE_UP)) seq = g_pull_gate_seq.fetch_add(1u, std::memory_order_relaxed);
+  const int64_t pieces_wanted = n >= 4096 ? 4 : 1, piece_len = ((n + pieces_wanted - 1) / pieces_wanted + 255) / 256 * 256;
+  if (!gated) host_pack_f64(0, n, points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
   unstage_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((int)n, reinterpret_cast<const float4*>(dev), covs16 ? reinterpret_cast<const float4*>(dev + 4 * n) : nullptr,
                                                         reinterpret_cast<const float2*>(dev + 12 * n), normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr,
                                                         c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n), c->pn4, c->n2, c->gs0,
-                                                        c->gs1, c->gs2, c->gsn);
+                                                        c->gs1, c->gs2, c->gsn, gated ? reinterpret_cast<const unsigned int*>(dev + 14 * n) + 4 : nullptr, seq,
+                                                        (int)piece_len);
   const hipError_t e = hipGetLastError();
+  if (gated) {
+    // (also when the launch failed: nothing waits then, and the staging block is simply dropped below)
+    int piece = 0;
+    for (int64_t lo = 0; lo < n; lo += piece_len, piece++) {
+      host_pack_f64(lo, std::min(n, lo + piece_len), points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
+      std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
+      tail[4 + piece] = seq;
+    }
+    std::atomic_thread_fence(std::memory_order_release);
+  }
   up->stage = stage;
-  up->violations = violations;
+  up->violations = tail;
   up->maybe_plane = covs16 && normals4;
   if (e != hipSuccess) {
     (void)hipStreamSynchronize(s);
@@ -236,13 +281,20 @@ int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* poin
   }
   return GLIM_AMD_OK;
 }
-void cloud_small_finish(glim_amd_cloud* c, SmallUpload* up) {
-  const bool plane = up->maybe_plane && *up->violations == 0u;
+int cloud_small_finish(glim_amd_cloud* c, SmallUpload* up) {
+  const bool gave_up = up->violations[1] == PULL_GAVE_UP;
+  const bool plane = !gave_up && up->maybe_plane && up->violations[0] == 0u;
   (void)pinned_free(up->stage);
   up->stage = nullptr;
   c->plane_form = plane;
   if (plane && c->pn4) drop_general_streams(c);  // the factor kernel reads the form the cloud has; the other copy goes back to the pool
   else drop_plane_streams(c);
+  if (gave_up) {  // (the host was held up for seconds between the launch and its conversion: the cloud holds nothing; callers repeat the upload ungated)
+    g_pull_gate_broken.store(true);
+    set_hip_error(hipErrorUnknown, "small-cloud upload: the gated pull kernel gave up waiting for the host; gating is off from now on");
+    return GLIM_AMD_ERR_UNSUPPORTED;
+  }
+  return GLIM_AMD_OK;
 }
 }  // namespace glim_amd
 namespace {
@@ -256,8 +308,13 @@ int create_small_f64(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4
     set_hip_error(e, "cloud_create small upload");
     return GLIM_AMD_ERR_HIP;
   }
-  cloud_small_finish(c, &up);
-  return GLIM_AMD_OK;
+  if (cloud_small_finish(c, &up) == GLIM_AMD_OK) return GLIM_AMD_OK;
+  // the gated pull gave up (gating is off now): once more, conversion first
+  drop_general_streams(c);
+  drop_plane_streams(c);
+  GA_TRY(cloud_small_enqueue(ctx, c, points4, covs16, normals4, &up));
+  GA_HIP(hipStreamSynchronize(ctx->stream()));
+  return cloud_small_finish(c, &up);
 }
 
 // factor streams in the Hilbert order of the cloud (rank == null: arrival order)

@@ -52,8 +52,10 @@ const DiagKey kDiagKeys[] = {
   {"inline_pose", &Diag::inline_pose, nullptr, 0, 1},
   {"bucket_factor", &Diag::bucket_factor, nullptr, 0, 64},
   {"plan_cache", &Diag::plan_cache, nullptr, 0, 1},
+  {"plan_recycle", &Diag::plan_recycle, nullptr, 0, 1},
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
+  {"pull_gated", &Diag::pull_gated, nullptr, 0, 1},
   {"view_fused", &Diag::view_fused, nullptr, 0, 1},
   {"fuse", &Diag::fuse, nullptr, 0, 1},
   {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},

@@ -64,8 +64,9 @@ struct SmallUpload {
   volatile unsigned int* violations = nullptr;
   bool maybe_plane = false;
 };
+constexpr unsigned int PULL_GAVE_UP = 0xffffffffu;  // violations word: the gated pull kernel stopped waiting for the host's conversion (cloud.hip)
 int cloud_small_enqueue(::glim_amd_ctx* ctx, ::glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up);
-void cloud_small_finish(::glim_amd_cloud* c, SmallUpload* up);
+int cloud_small_finish(::glim_amd_cloud* c, SmallUpload* up);  // GLIM_AMD_ERR_UNSUPPORTED: the gated pull gave up (the cloud holds nothing; gating is off from now on)
 int alloc_cloud_for_frame(::glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, ::glim_amd_cloud** out);  // cloud.hip alloc_cloud
 constexpr int64_t HOST_PACK_MAX_POINTS_FRAME = 32768;
 // plane-form test of a freshly uploaded cloud with covariances and normals (cloud.hip): sets c->plane_form
@@ -85,6 +86,7 @@ struct Diag {
   int inline_pose = 1;    // inline_pose=0|1                     pose of a single-factor set in the kernel arguments
   int bucket_factor = 0;  // bucket_factor=<n>                   buckets per voxel of a map table (0: default 6)
   int plan_cache = 1;     // plan_cache=0|1                      factor-set plans cached per context, keyed on the (map, cloud, flags) list
+  int plan_recycle = 1;   // plan_recycle=0|1                    a new list of the shape of the plan a full cache is about to evict takes over its buffers
   int host_poses = 1;     // host_poses=0|1                      small synchronous sets: kernels read the poses from host-mapped memory (no H2D copy)
   int resident = 2;       // resident=0|1|auto                  repeated synchronous linearisations of a small set go through a resident kernel (no launch per
                           //                                    call); auto (default): only in a context created with priority 1 (the odometry module's)
@@ -93,6 +95,7 @@ struct Diag {
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int view_fused = 1;     // view_fused=0|1                      a map built from a plane-form cloud gets its plane view (A_B records) from the finalise kernel; 0: on first use
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
+  int pull_gated = 1;     // pull_gated=0|1                      ... and that kernel is launched BEFORE the conversion: its blocks wait for their piece of the staging block
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
@@ -230,6 +233,7 @@ struct glim_amd_ctx {
   std::atomic<bool> async_pending{false};
   int priority = 0;  // 1: its streams were created with the device's greatest priority (glim_amd_ctx_create_ex)
   std::vector<FactorPlan*> plan_cache;  // idle factor plans, most recently released first (vgicp.hip; guarded by mu)
+  uint64_t plans_built = 0, plans_recycled = 0;  // plans built for new factor lists; how many of them in the buffers of an evicted plan (guarded by mu)
   // overlap scratch (vgicp.hip), allocated on first use: per-query arrival counters on the device, results + completion word in host-mapped memory
   static constexpr int OV_MAX_QUERIES = 1024;
   unsigned long long* ov_counters = nullptr;  // [OV_MAX_QUERIES] packed (arrived blocks << 32 | hits), then the queries-done word
@@ -403,6 +407,8 @@ struct FactorPlan {
   unsigned int* h_flag_dev = nullptr;
   unsigned int poll_seq = 0;
   size_t cap_factors = 0, cap_blocks = 0;
+  long long alloc_rows = -1;         // partial rows the buffers were sized for (plan_build re-uses the buffers of an evicted plan of the same shape)
+  bool fused_alloc = false, recycled = false;
   int sync_linearize_calls = 0;      // synchronous linearisations this plan has served (a resident session starts after a few)
   std::vector<glim_amd::FactorDesc> h_descs;
   std::vector<int2> h_blockmap;

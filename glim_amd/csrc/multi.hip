@@ -76,6 +76,7 @@ struct Worker {
   int rc = 0;
 };
 constexpr int WORKER_SPIN_US = 3000;
+constexpr int EV_PER_DEVICE = 4;
 constexpr int MAX_PIECES = 8;  // a device's shard is evaluated as up to this many factor sets (glim_amd_multi_set_split)
 
 // Where a shard's records sit in the gathered array (see glim_amd_multi: one region per piece, equal slots per device inside a region).
@@ -119,6 +120,9 @@ enum {
   BD_JOIN,            // caller: waiting for the other devices' threads after its own device is done
   BD_SCAN,            // caller: total error + expansion of the records in factor order
   BD_TOTAL,           // caller: the whole call
+  BD_LIBRARY_CALLS,   // inside the ncclAllGather calls (part of BD_COLLECTIVE)
+  BD_DEVICE_GATHER,   // HIP events: from the last kernel to the end of the last all-gather on the collective's stream
+  BD_DEVICE_COPY_OUT, // HIP events: from there to the end of the copy-out and the error sum
   BD_FIELDS
 };
 
@@ -142,6 +146,7 @@ struct glim_amd_multi {
   double* h_gather = nullptr;     // pinned
   std::vector<ncclComm_t> comms;
   bool use_rccl = false;
+  bool one_rank_collective = false;  // ONE device: make the (no-op) library call in every evaluation all the same (glim_amd_multi_set_one_rank_collective)
   bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
   std::mutex abort_mu;
   std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
@@ -150,7 +155,7 @@ struct glim_amd_multi {
   std::vector<hipEvent_t> piece_ev;  // [device * MAX_PIECES + piece]: "this piece's records are written", recorded on the factor sets' stream
   std::vector<double*> h_total, h_total_dev;  // [device]: this shard's error sum, written by the device into host-mapped memory (sum_error_kernel)
   // HIP events per device around the two phases of the LAST evaluation (kernels, then what is left of collective + copy-out): glim_amd_multi_last_timing
-  std::vector<hipEvent_t> ev;  // 3 per device: start (sets' stream), kernels done (sets' stream), end (collective stream)
+  std::vector<hipEvent_t> ev;  // 4 per device: start (sets' stream), kernels done (sets' stream), last all-gather done, end (both: collective stream)
   std::vector<float> kernel_ms, gather_ms;
   std::vector<double> breakdown;  // [device][BD_FIELDS]
   // host barrier of one evaluation: every device's thread arrives after it has enqueued its kernels
@@ -287,6 +292,28 @@ void sum_error_launch(hipStream_t st, const double* gathered, int d, int64_t own
 
 }  // namespace
 
+namespace {
+// ONE device: the evaluation makes no library call (nothing to gather), so the binding is exercised here, once: the in-place all-gather of a
+// record-sized buffer on the collective's stream must come back unchanged.  (On several devices every evaluation is the test.)
+bool rccl_self_test(glim_amd_multi* m) {
+  if (m->comms.empty() || !m->comms[0] || m->cstream.empty() || !m->cstream[0]) return false;
+  double host[COMPACT], back[COMPACT];
+  for (int i = 0; i < COMPACT; i++) host[i] = 1.0 + i, back[i] = 0.0;
+  double* dev = nullptr;
+  if (hipMalloc(&dev, sizeof(host)) != hipSuccess) return false;
+  bool ok = hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice) == hipSuccess &&
+            rccl().AllGather(dev, dev, COMPACT, ncclDouble, m->comms[0], m->cstream[0]) == ncclSuccess && hipStreamSynchronize(m->cstream[0]) == hipSuccess &&
+            hipMemcpy(back, dev, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(dev);
+  for (int i = 0; ok && i < COMPACT; i++) ok = back[i] == host[i];
+  if (!ok) {
+    (void)hipGetLastError();
+    set_hip_error(hipErrorUnknown, "glim_amd_multi_create: one-rank ncclAllGather self-test failed; evaluating without the library");
+  }
+  return ok;
+}
+}  // namespace
+
 extern "C" {
 
 // Contiguous, cost-balanced split of a factor list (pure host arithmetic; also what glim_amd/multi.py computes for the one-process-per-GPU
@@ -412,7 +439,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   }
   for (int d = 0; d < num_devices; d++) {
     (void)hipSetDevice(devices[d]);
-    for (int e = 0; e < 3; e++) {
+    for (int e = 0; e < EV_PER_DEVICE; e++) {
       hipEvent_t ev = nullptr;
       if (hipEventCreate(&ev) != hipSuccess) {
         (void)hipGetLastError();
@@ -428,6 +455,11 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
       m->ev.clear();
       break;
     }
+  if (num_devices == 1 && m->use_rccl && !rccl_self_test(m)) {  // (one device has nothing to gather: the library is not needed to evaluate)
+    (void)rccl().CommDestroy(m->comms[0]);
+    m->comms.clear();
+    m->use_rccl = false;
+  }
   if (prev_device >= 0) (void)hipSetDevice(prev_device);
   *out = m;
   return GLIM_AMD_OK;
@@ -608,6 +640,12 @@ int glim_amd_multi_set_split(glim_amd_multi* m, int32_t mode) {
   return GLIM_AMD_OK;
 }
 
+int glim_amd_multi_set_one_rank_collective(glim_amd_multi* m, int32_t on) {
+  if (!m) return GLIM_AMD_ERR_INVALID;
+  m->one_rank_collective = on != 0;
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
   if (!m || !bounds || m->bounds.empty()) return GLIM_AMD_ERR_INVALID;
   for (int d = 0; d <= m->ndev; d++) bounds[d] = m->bounds[d];
@@ -636,7 +674,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   if (m->broken) return GLIM_AMD_ERR_STATE;
   const auto t_call = std::chrono::steady_clock::now();
   const int ndev = m->ndev, P = m->pieces;
-  const bool timed = m->ev.size() == (size_t)3 * ndev;
+  const bool timed = m->ev.size() == (size_t)EV_PER_DEVICE * ndev;
   m->generation += 1;
   const uint64_t all_arrived = m->generation * (uint64_t)ndev;
   m->failed.store(0);
@@ -657,7 +695,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
             sst = m->sets[MAX_PIECES * d + h]->stream;
             break;
           }
-        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d], sst));
+        if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d], sst));
         hipStream_t last = sst;
         for (int h = 0; h < P; h++) {
           glim_amd_factor_set* set = m->sets[MAX_PIECES * d + h];
@@ -671,7 +709,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           }
           GA_HIP(hipEventRecord(m->piece_ev[MAX_PIECES * d + h], last));
         }
-        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 1], last));
+        if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 1], last));
         return (int)GLIM_AMD_OK;
       };
       rc_d = enqueue_kernels();
@@ -697,26 +735,35 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       auto collective = [&]() -> int {
         for (int h = 0; h < P; h++) {
           const int64_t rows = m->rows_of_piece(h);
-          if (rows == 0) continue;
+          if (rows == 0) {
+            if (timed && h == P - 1) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 2], cst));
+            continue;
+          }
           const size_t start = (size_t)m->region_start(h) * COMPACT, slot = (size_t)rows * COMPACT;
           double* region = m->d_gather[d] + start;
           GA_HIP(hipStreamWaitEvent(cst, m->piece_ev[MAX_PIECES * d + h], 0));
           if (m->use_rccl && ndev > 1) {
             // in place: this device's slot is both the send buffer and its own segment of the receive buffer
+            const auto t_lib = std::chrono::steady_clock::now();
             const ncclResult_t r = rccl().AllGather(region + (size_t)d * slot, region, slot, ncclDouble, m->comms[d], cst);
+            bd[BD_LIBRARY_CALLS] += us_since(t_lib);
             if (r != ncclSuccess) {
               set_hip_error(hipErrorUnknown, "ncclAllGather");
               return (int)GLIM_AMD_ERR_HIP;
             }
-          } else if (m->use_rccl && h == 0) {
-            // one device: the collective is a copy onto itself; it is issued ONCE per evaluation (over the FIRST piece, so that it runs beside the
-            // later pieces' kernels instead of behind the last one) so that the library call the N-device node makes is made on a 1-GPU box as well
+          } else if (m->use_rccl && m->one_rank_collective && h == 0) {
+            // ONE device has nothing to gather: its records are where they belong.  The library is exercised once, when the handle is created
+            // (rccl_self_test); with glim_amd_multi_set_one_rank_collective the no-op call is ALSO made in every evaluation, over the first
+            // piece -- round 5 measured what it costs inside a process that has torch's librccl loaded: 0.3 ms of host time per call.
+            const auto t_lib = std::chrono::steady_clock::now();
             const ncclResult_t r = rccl().AllGather(region, region, slot, ncclDouble, m->comms[d], cst);
+            bd[BD_LIBRARY_CALLS] += us_since(t_lib);
             if (r != ncclSuccess) {
               set_hip_error(hipErrorUnknown, "ncclAllGather");
               return (int)GLIM_AMD_ERR_HIP;
             }
           }
+          if (timed && h == P - 1) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 2], cst));
           // copy-out: every device hands ITS OWN rows of the piece to the host over its own PCIe link (round 4: device 0 copied the whole
           // gathered array, 7.6 MB behind the collective; the devices' links work in parallel and need not wait for xGMI)
           const int64_t own = std::max<int64_t>(0, std::min(rows, (hi - lo) - (int64_t)h * m->piece_rows));
@@ -731,7 +778,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           if (hi > lo) sum_error_launch(cst, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->h_total_dev[d]);
           GA_HIP(hipGetLastError());
         }
-        if (timed) GA_HIP(hipEventRecord(m->ev[3 * d + 2], cst));
+        if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 3], cst));
         return (int)GLIM_AMD_OK;
       };
       rc_d = collective();
@@ -749,8 +796,12 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
         return (int)GLIM_AMD_ERR_HIP;
       }
       if (timed) {
-        (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[3 * d], m->ev[3 * d + 1]);
-        (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[3 * d + 1], m->ev[3 * d + 2]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[EV_PER_DEVICE * d], m->ev[EV_PER_DEVICE * d + 1]);
+        (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 3]);
+        if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 2]) == hipSuccess) bd[BD_DEVICE_GATHER] = 1e3 * std::max(ms, 0.f);
+        if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 2], m->ev[EV_PER_DEVICE * d + 3]) == hipSuccess) bd[BD_DEVICE_COPY_OUT] = 1e3 * ms;
+        (void)hipGetLastError();
       }
       return (int)GLIM_AMD_OK;
     },

@@ -1156,11 +1156,9 @@ constexpr int RESIDENT_MAX_FACTORS = 64;  // sets a resident session may serve (
 constexpr int FUSED_MAX_FACTORS = 1024, FUSED_MAX_ROWS = 16384;  // sets that may take the single-dispatch form (2.6 MB of tagged rows at most)
 constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many factors: poses read by the kernels from host-mapped memory (96 B per factor over PCIe)
 
-void plan_free(FactorPlan* p) {
-  if (!p) return;
-  resident_release(nullptr, p);  // a resident session that serves this plan ends first
-  // nothing enqueued earlier (asynchronous entry points included) may still be using the buffers that go back to the pool
-  if (p->maybe_busy && p->last_stream) (void)hipStreamSynchronize(p->last_stream);
+// The plan's device blocks, pinned blocks and events go back where they came from; the plan object stays (plan_build fills it again).
+// Caller: no session serves the plan and nothing enqueued is still using the buffers (plan_idle).
+void plan_release_buffers(FactorPlan* p) {
   if (p->d_upload) (void)pool_free(p->d_upload);  // d_descs | d_blockmap | d_finmap
   if (p->h_upload) (void)pinned_free(p->h_upload);
   if (p->d_zeroed) (void)pool_free(p->d_zeroed);  // d_done | d_trip_stats | d_rows16
@@ -1171,9 +1169,40 @@ void plan_free(FactorPlan* p) {
   if (p->h_compact) (void)pinned_free(p->h_compact);
   if (p->h_flag) (void)pinned_free(p->h_flag);
   if (p->h_rec16) (void)pinned_free(p->h_rec16);
-  for (int i = 0; i < FactorPlan::POSE_RING; i++)
+  p->d_upload = p->h_upload = p->d_zeroed = nullptr;
+  p->d_partials = nullptr;
+  p->d_poses = p->d_compact = p->h_poses = p->h_poses_dev = p->h_compact = p->h_compact_dev = nullptr;
+  p->h_flag = p->h_flag_dev = nullptr;
+  p->h_rec16 = p->h_rec16_dev = nullptr;
+  p->d_descs = nullptr;
+  p->d_blockmap = nullptr;
+  p->d_finmap = nullptr;
+  p->d_done = nullptr;
+  p->d_trip_stats = nullptr;
+  p->d_rows16 = nullptr;
+  for (int i = 0; i < FactorPlan::POSE_RING; i++) {
     if (p->pose_events[i]) (void)hipEventDestroy(p->pose_events[i]);
+    p->pose_events[i] = nullptr;
+    p->pose_pending[i] = false;
+  }
   if (p->poses_free_event) (void)hipEventDestroy(p->poses_free_event);
+  p->poses_free_event = nullptr;
+  p->poses_free_pending = false;
+  p->cap_factors = p->cap_blocks = 0;
+  p->alloc_rows = -1;
+}
+
+// a resident session that serves this plan ends; nothing enqueued earlier (asynchronous entry points included) is still using its buffers
+void plan_idle(FactorPlan* p) {
+  resident_release(nullptr, p);
+  if (p->maybe_busy && p->last_stream) (void)hipStreamSynchronize(p->last_stream);
+  p->maybe_busy = false;
+}
+
+void plan_free(FactorPlan* p) {
+  if (!p) return;
+  plan_idle(p);
+  plan_release_buffers(p);
   delete p;
 }
 
@@ -1408,55 +1437,73 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   // single-dispatch form (small synchronous sets only): tagged rows, every tag 0 = "no call yet" (sequence numbers start at 1)
   const bool fused_form = nf >= 1 && nf <= FUSED_MAX_FACTORS && total_blocks <= FUSED_MAX_ROWS;
   auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  {  // descriptors | block map | finaliser map: one device block, one pinned image, one copy (plan_upload)
-    const size_t o_map = up16(nfa * sizeof(FactorDesc)), o_fin = o_map + up16(nba * sizeof(int2));
-    plan->upload_bytes = o_fin + (fused_form ? up16((size_t)nf * sizeof(int)) : 0);
-    GA_HIP(pool_malloc(&plan->d_upload, plan->upload_bytes));
-    GA_HIP(pinned_malloc(&plan->h_upload, plan->upload_bytes));
-    memset(plan->h_upload, 0, plan->upload_bytes);
-    plan->d_descs = reinterpret_cast<FactorDesc*>(plan->d_upload);
-    plan->d_blockmap = reinterpret_cast<int2*>(plan->d_upload + o_map);
-    plan->d_finmap = fused_form ? reinterpret_cast<int*>(plan->d_upload + o_fin) : nullptr;
-  }
-  {  // completion counter | skipped-trip counters | tagged rows: one block, one memset
-    const size_t o_trip = 64, o_rows = o_trip + 64 * sizeof(unsigned long long);
-    const size_t zero_bytes = o_rows + (fused_form ? (size_t)total_blocks * TAG_ROW_BYTES : 0);
-    GA_HIP(pool_malloc(&plan->d_zeroed, zero_bytes));
-    GA_HIP(hipMemsetAsync(plan->d_zeroed, 0, zero_bytes, set->stream));
-    plan->d_done = reinterpret_cast<int*>(plan->d_zeroed);
-    plan->d_trip_stats = reinterpret_cast<unsigned long long*>(plan->d_zeroed + o_trip);
-    plan->d_rows16 = fused_form ? plan->d_zeroed + o_rows : nullptr;
-  }
-  GA_HIP(pool_malloc(&plan->d_partials, (size_t)std::max(1ll, total_blocks) * PARTIAL_STRIDE * sizeof(float)));
-  GA_HIP(pool_malloc(&plan->d_poses, nfa * 24 * sizeof(double)));
-  GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
-  if (fused_form) {
-    const size_t rec_bytes = (size_t)nf * COMPACT * 16;
-    if (pinned_malloc(&plan->h_rec16, rec_bytes) == hipSuccess) {
-      memset(plan->h_rec16, 0, rec_bytes);
-      if (!host_device_view(plan->h_rec16, &plan->h_rec16_dev)) {
-        (void)pinned_free(plan->h_rec16);
+  const size_t o_map = up16(nfa * sizeof(FactorDesc)), o_fin = o_map + up16(nba * sizeof(int2));
+  const size_t upload_bytes = o_fin + (fused_form ? up16((size_t)nf * sizeof(int)) : 0);
+  const size_t o_trip = 64, o_rows = o_trip + 64 * sizeof(unsigned long long);
+  // A plan object that comes with buffers is the one the cache was about to evict (factor_set_prepare): GLIM's odometry asks for a NEW list with
+  // every frame -- the new cloud against the same number of window frames and keyframes --, so the evicted plan has exactly the shape of the
+  // one being built and its ten blocks, four host views and events serve again (round 5: 12 us of a live frame's first linearisation were
+  // allocation, views and the clearing memset).  Tags keep counting (poll_seq is not reset), so the tagged rows and record granules of the
+  // previous life can never read as this one's and nothing needs clearing; the skipped-trip counters are cleared when the plan has general rows.
+  const bool reuse = plan->d_upload && plan->cap_factors == nfa && plan->cap_blocks == nba && plan->alloc_rows == total_blocks && plan->fused_alloc == fused_form &&
+                     plan->upload_bytes == upload_bytes && plan->h_flag && plan->h_poses_dev && plan->h_compact_dev && (!fused_form || plan->h_rec16);
+  if (plan->d_upload && !reuse) plan_release_buffers(plan);
+  if (reuse) {
+    if (seg_rows[1] > 0) GA_HIP(hipMemsetAsync(plan->d_trip_stats, 0, 64 * sizeof(unsigned long long), set->stream));
+  } else {
+    {  // descriptors | block map | finaliser map: one device block, one pinned image, one copy (plan_upload)
+      plan->upload_bytes = upload_bytes;
+      GA_HIP(pool_malloc(&plan->d_upload, plan->upload_bytes));
+      GA_HIP(pinned_malloc(&plan->h_upload, plan->upload_bytes));
+      memset(plan->h_upload, 0, plan->upload_bytes);
+    }
+    {  // completion counter | skipped-trip counters | tagged rows: one block, one memset
+      const size_t zero_bytes = o_rows + (fused_form ? (size_t)total_blocks * TAG_ROW_BYTES : 0);
+      GA_HIP(pool_malloc(&plan->d_zeroed, zero_bytes));
+      GA_HIP(hipMemsetAsync(plan->d_zeroed, 0, zero_bytes, set->stream));
+    }
+    GA_HIP(pool_malloc(&plan->d_partials, (size_t)std::max(1ll, total_blocks) * PARTIAL_STRIDE * sizeof(float)));
+    GA_HIP(pool_malloc(&plan->d_poses, nfa * 24 * sizeof(double)));
+    GA_HIP(pool_malloc(&plan->d_compact, nfa * COMPACT * sizeof(double)));
+    if (fused_form) {
+      const size_t rec_bytes = (size_t)nf * COMPACT * 16;
+      if (pinned_malloc(&plan->h_rec16, rec_bytes) == hipSuccess) {
+        memset(plan->h_rec16, 0, rec_bytes);
+        if (!host_device_view(plan->h_rec16, &plan->h_rec16_dev)) {
+          (void)pinned_free(plan->h_rec16);
+          plan->h_rec16 = nullptr;
+        }
+      } else {
+        (void)hipGetLastError();
         plan->h_rec16 = nullptr;
+      }
+    }
+    if (pinned_malloc(&plan->h_flag, 64) == hipSuccess) {
+      *plan->h_flag = 0;
+      if (!host_device_view(plan->h_flag, &plan->h_flag_dev)) {
+        (void)pinned_free(plan->h_flag);
+        plan->h_flag = nullptr;
       }
     } else {
       (void)hipGetLastError();
-      plan->h_rec16 = nullptr;
-    }
-  }
-  if (pinned_malloc(&plan->h_flag, 64) == hipSuccess) {
-    *plan->h_flag = 0;
-    if (!host_device_view(plan->h_flag, &plan->h_flag_dev)) {
-      (void)pinned_free(plan->h_flag);
       plan->h_flag = nullptr;
     }
-  } else {
-    (void)hipGetLastError();
-    plan->h_flag = nullptr;
+    GA_HIP(pinned_malloc(&plan->h_poses, (size_t)FactorPlan::POSE_RING * nfa * 24 * sizeof(double)));
+    (void)host_device_view(plan->h_poses, &plan->h_poses_dev);
+    GA_HIP(pinned_malloc(&plan->h_compact, nfa * COMPACT * sizeof(double)));
+    (void)host_device_view(plan->h_compact, &plan->h_compact_dev);
+    plan->poll_seq = 0;
   }
-  GA_HIP(pinned_malloc(&plan->h_poses, (size_t)FactorPlan::POSE_RING * nfa * 24 * sizeof(double)));
-  (void)host_device_view(plan->h_poses, &plan->h_poses_dev);
-  GA_HIP(pinned_malloc(&plan->h_compact, nfa * COMPACT * sizeof(double)));
-  (void)host_device_view(plan->h_compact, &plan->h_compact_dev);
+  plan->d_descs = reinterpret_cast<FactorDesc*>(plan->d_upload);
+  plan->d_blockmap = reinterpret_cast<int2*>(plan->d_upload + o_map);
+  plan->d_finmap = fused_form ? reinterpret_cast<int*>(plan->d_upload + o_fin) : nullptr;
+  plan->d_done = reinterpret_cast<int*>(plan->d_zeroed);
+  plan->d_trip_stats = reinterpret_cast<unsigned long long*>(plan->d_zeroed + o_trip);
+  plan->d_rows16 = fused_form ? plan->d_zeroed + o_rows : nullptr;
+  plan->alloc_rows = total_blocks;
+  plan->fused_alloc = fused_form;
+  plan->recycled = reuse;
+  plan->sync_linearize_calls = 0;
   plan->cap_factors = nfa;
   plan->cap_blocks = nba;
   plan->h_blockmap = std::move(blockmap);
@@ -1503,13 +1550,23 @@ int factor_set_prepare(glim_amd_factor_set* set) {
     }
   }
   if (!set->plan) {
-    FactorPlan* p = new FactorPlan();
+    // a full cache: the plan the next park would evict is taken now, buffers and all -- plan_build keeps them when the new list has its shape
+    FactorPlan* p = nullptr;
+    if (diag.plan_cache && diag.plan_recycle && ctx->plan_cache.size() >= PLAN_CACHE_MAX) {
+      p = ctx->plan_cache.back();
+      ctx->plan_cache.pop_back();
+      plan_idle(p);
+    } else {
+      p = new FactorPlan();
+    }
     p->key = key;
     const int rc = plan_build(set, p);
     if (rc != GLIM_AMD_OK) {
       plan_free(p);
       return rc;
     }
+    ctx->plans_built++;
+    if (p->recycled) ctx->plans_recycled++;
     set->plan = p;
   }
   // target maps whose build returned to its caller before its last kernel had finished (voxelmap.hip: polled voxel count): this set's stream waits
@@ -1920,6 +1977,15 @@ extern "C" int glim_amd_debug_resident_stats(int device, uint64_t* launches, uin
   return GLIM_AMD_OK;
 }
 
+extern "C" int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached) {
+  if (!ctx) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (built) *built = ctx->plans_built;
+  if (recycled) *recycled = ctx->plans_recycled;
+  if (cached) *cached = (int32_t)ctx->plan_cache.size();
+  return GLIM_AMD_OK;
+}
+
 extern "C" int glim_amd_debug_resident_stop(int device) {
   if (device < 0 || device >= 16) return GLIM_AMD_ERR_INVALID;
   ResidentSession& S = g_resident[device];
@@ -1978,6 +2044,15 @@ namespace {
 //  * large sets: device records + one copy + stream synchronise.
 // The context mutex is held only while the work is enqueued, so factor sets of one context (different streams of its pool) overlap on
 // the device when driven from different host threads, like the reference's StreamTempBufferRoundRobin factors.
+// The host has seen the results of a call enqueued on the set's stream: whatever was enqueued there before (the plan's descriptor upload
+// included) is done, and work of an earlier owner on another stream was waited for when the plan was adopted -- whoever frees, adopts or
+// recycles the plan next need not synchronise.
+inline void plan_seen_complete(const glim_amd_factor_set* set, FactorPlan* plan) {
+  if (set->plan != plan) return;
+  plan->last_stream = set->stream;
+  plan->maybe_busy = false;
+}
+
 int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const double* T_eval, bool allow_fast = true) {
   const size_t nf = set->entries.size();
   if (allow_fast && mode == MODE_LINEARIZE && !T_eval && nf <= (size_t)RESIDENT_MAX_FACTORS && resident_enabled(set->ctx)) {
@@ -2011,9 +2086,11 @@ int run_sync(glim_amd_factor_set* set, int mode, const double* T_lin, const doub
     if (!got) return GLIM_AMD_ERR_STATE;
     // a lost row (the finaliser's bounded spin ran out) arrives as a NaN record under a valid tag: answer with the two-dispatch form
     if (records_lost(plan, nf)) return run_sync(set, mode, T_lin, T_eval, false);
+    plan_seen_complete(set, plan);
     return GLIM_AMD_OK;
   }
   if (!(poll && spin_until(plan->h_flag, seq))) GA_HIP(hipStreamSynchronize(set->stream));
+  plan_seen_complete(set, plan);
   return GLIM_AMD_OK;
 }
 

@@ -976,8 +976,15 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       }
     }
     if (enqueued) {
-      if (rc == GLIM_AMD_OK) cloud_small_finish(c, &up);
-      else if (up.stage) (void)pinned_free(up.stage);
+      if (rc == GLIM_AMD_OK) {
+        rc = cloud_small_finish(c, &up);  // GLIM_AMD_ERR_UNSUPPORTED: the gated pull gave up -- the maps were built from nothing; the separate calls below
+        if (rc != GLIM_AMD_OK && running) {
+          (void)hipStreamSynchronize(st);  // (the last level's records kernel may still be writing the table that is about to be handed back)
+          running = false;
+        }
+      } else if (up.stage) {
+        (void)pinned_free(up.stage);
+      }
     }
     for (int lv = 0; lv < num_levels; lv++) {
       Build& B = b[lv];

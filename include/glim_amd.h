@@ -89,7 +89,7 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair|qgroup,
- * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, host_poses=0|1, host_pack=0|1,
+ * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, plan_recycle=0|1, host_poses=0|1, host_pack=0|1, pull_gated=0|1,
  * view_fused=0|1 (a voxel map built from a plane-form cloud gets its plane view -- the (C_B + I)^-1 records the plane-form factor kernel reads --
  * from the map's own finalise kernel; 0: on the first factor that needs it),
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
@@ -338,6 +338,9 @@ int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_tar
 int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive);
 /* ends the device's resident session now instead of letting it idle out (GLIM_AMD_ERR_STATE while a request is in flight). */
 int glim_amd_debug_resident_stop(int device);
+/* parity / debug only: factor plans this context has built for new factor lists, how many of them took over the buffers of the plan its full
+ * cache was about to evict (a new list of the same shape: GLIM's odometry brings one per frame), idle plans cached right now. */
+int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached);
 
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
@@ -387,13 +390,20 @@ int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, fl
  *   [6] wait        hipStreamSynchronize: the device working
  *   [7] join        caller: waiting for the other devices' threads                        (device 0 only)
  *   [8] scan        caller: total error + expansion of the records in factor order        (device 0 only)
- *   [9] total       the whole glim_amd_multi_linearize call                                (device 0 only) */
-#define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 10
+ *   [9] total       the whole glim_amd_multi_linearize call                                (device 0 only)
+ *   [10] library_calls   inside the ncclAllGather calls (part of [5])
+ *   [11] device_gather   HIP events: from this device's last kernel to the end of its last all-gather
+ *   [12] device_copy_out HIP events: from there to the end of the copy-out and the error sum  ([11] + [12] = gather_ms of last_timing) */
+#define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 13
 int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
 /* how a device's shard is evaluated: n >= 2 = as n pieces (at most 8), the all-gather and copy-out of one piece overlapping the kernels of
  * the next; 0 or 1 = as one set and one all-gather; -1 (default) = pieces of at least 2048 factors, at most 4.  Takes effect with the next
  * glim_amd_multi_set_factors. */
 int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
+/* ONE device has nothing to gather, so its evaluations make no library call; the binding is exercised when the handle is created (an in-place
+ * one-rank all-gather that must come back unchanged; glim_amd_multi_info uses_rccl says whether it did).  on != 0: make the no-op
+ * ncclAllGather in every evaluation as well (measurement aid: bench.py prices it).  No effect on several devices. */
+int glim_amd_multi_set_one_rank_collective(glim_amd_multi* multi, int32_t on);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
 /* where every factor's 29-double record sits in the gathered [world x max_rows] array of an evaluation, as a pure host function (the rule

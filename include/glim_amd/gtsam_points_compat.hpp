@@ -190,11 +190,39 @@ public:
   }
   glim_amd_voxelmap* handle() const { return h_; }
   const Context& context() const { return ctx_; }
+  // GaussianVoxelMapCPU::set_lru_horizon (odometry_estimation_cpu.cpp:67) for an incrementally built map; <= 0: no eviction (default)
+  void set_lru_horizon(int lru_horizon, int lru_clear_cycle = 10) { check(glim_amd_voxelmap_set_lru_horizon(h_, lru_horizon, lru_clear_cycle), "set_lru_horizon"); }
+  // takes ownership of a map created by another C-ABI call (glim_amd_frame_create)
+  static Ptr adopt(glim_amd_voxelmap* h, Context ctx) {
+    Ptr m(new GaussianVoxelMapGPU(std::move(ctx), h));
+    return m;
+  }
 
 private:
+  GaussianVoxelMapGPU(Context ctx, glim_amd_voxelmap* h) : ctx_(ctx ? ctx : StreamTempBufferRoundRobin::default_instance()), h_(h) {}
   Context ctx_;
   glim_amd_voxelmap* h_ = nullptr;
 };
+
+// OdometryEstimationGPU::create_frame (odometry_estimation_gpu.cpp:86-107) as ONE submission: PointCloudGPU::clone of a frame that arrives with CPU
+// covariances (+ normals) and one GaussianVoxelMapGPU per level, enqueued back to back with one completion (glim_amd_frame_create) -- what the three
+// statements of create_frame (:96, :103-104) cost as separate calls minus two synchronises.  points4 / covs16 / normals4: the raw arrays of
+// gtsam_points::PointCloud (Vector4d / column-major Matrix4d / Vector4d).  GLIM's unmodified source calls clone and insert one at a time.
+struct FrameGPU {
+  PointCloudGPU::Ptr frame;
+  std::vector<GaussianVoxelMapGPU::Ptr> voxelmaps;
+};
+inline FrameGPU create_frame(std::int64_t n, const double* points4, const double* covs16, const double* normals4, const std::vector<double>& resolutions,
+                             Context ctx = nullptr) {
+  ctx = ctx ? ctx : StreamTempBufferRoundRobin::default_instance();
+  glim_amd_cloud* c = nullptr;
+  std::vector<glim_amd_voxelmap*> m(resolutions.size(), nullptr);
+  check(glim_amd_frame_create(ctx->context(), n, points4, covs16, normals4, (std::int32_t)resolutions.size(), resolutions.data(), &c, m.data()), "create_frame");
+  FrameGPU out;
+  out.frame = PointCloudGPU::adopt(c, ctx);
+  for (glim_amd_voxelmap* h : m) out.voxelmaps.push_back(GaussianVoxelMapGPU::adopt(h, ctx));
+  return out;
+}
 
 // Result of linearize(): the ingredients of gtsam::HessianFactor(k_t, k_s, H_tt, H_ts, -b_t, H_ss, -b_s, error).
 using LinearizedSystem6 = glim_amd_linearized6;

@@ -292,6 +292,25 @@ int main() {
       vm2->insert(*merged.gpu);
       REQUIRE(vm2->voxelmap_info().num_voxels > 20);
       std::printf("merge OK: %d + %d -> %d points\n", na, nb2, mm);
+      // create_frame as one submission (glim_amd::create_frame): the same maps as clone + insert, level by level
+      {
+        const std::vector<double> levels = {0.5, 1.0};
+        const FrameGPU fr = create_frame(na, A.data(), CA.data(), nullptr, levels);
+        REQUIRE((int)fr.frame->size() == na && fr.voxelmaps.size() == 2);
+        auto host_cloud = PointCloudGPU::clone(A.data(), CA.data(), nullptr, na);
+        for (size_t lv = 0; lv < levels.size(); lv++) {
+          GaussianVoxelMapGPU ref((float)levels[lv]);
+          ref.insert(*host_cloud);
+          REQUIRE(ref.voxelmap_info().num_voxels == fr.voxelmaps[lv]->voxelmap_info().num_voxels);
+          REQUIRE(ref.voxelmap_info().num_buckets == fr.voxelmaps[lv]->voxelmap_info().num_buckets);
+        }
+        // an incremental map with an LRU horizon (GaussianVoxelMapCPU::set_lru_horizon): re-inserting the same frame keeps every voxel alive
+        GaussianVoxelMapGPU inc(0.5f);
+        inc.set_lru_horizon(2, 2);
+        for (int k = 0; k < 5; k++) inc.insert(*host_cloud);
+        REQUIRE(inc.voxelmap_info().num_voxels == fr.voxelmaps[0]->voxelmap_info().num_voxels);
+        std::printf("create_frame / lru OK\n");
+      }
     }
   }
   std::printf("test_compat OK: %d points, inliers level0 = %lld\n", n, (long long)factors[0]->linearized().num_inliers);

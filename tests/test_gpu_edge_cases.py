@@ -389,6 +389,53 @@ def test_plan_cache_serves_fresh_sets_and_follows_object_identity(api, ctx, orc,
     assert np.abs(gn(got) - gn(ref)).max() < 1e-4
 
 
+def test_a_new_list_of_the_evicted_plans_shape_takes_over_its_buffers(api, orc, small_pair):
+    """GLIM's odometry brings a NEW factor list with every frame (the new cloud against the same number of targets).  Once the context's
+    plan cache is full, the plan it would evict next hands its buffers to the new list when the shape is the same: same bits as a context
+    that never recycles, lists of another shape in between included, three linearisations per list (tags keep counting across lives)."""
+    t, s = small_pair["target"], small_pair["source"]
+    a_ctx, b_ctx = api.Context(0, 2), api.Context(0, 2)
+    b_ctx.set_diag("plan_recycle=0")
+    n = 1500
+    frames = [(s["points"][k:k + n].astype(np.float64), s["covs"][k:k + n]) for k in range(0, 40 * 7, 7)]  # 40 different clouds of one size
+    results = {}
+    for name, c in (("recycle", a_ctx), ("plain", b_ctx)):
+        tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=c)
+        vms = [api.GaussianVoxelMapGPU(r, ctx=c).insert(tg) for r in (0.5, 1.0)]
+        out = []
+        for k, (p, cv) in enumerate(frames):
+            g = api.PointCloudGPU.clone(p if k % 9 != 4 else p[:700], cv if k % 9 != 4 else cv[:700], ctx=c)  # (every ninth list has another shape)
+            values = {0: np.eye(4), 1: small_pair["delta"]}
+            for it in range(3):  # a fresh set per optimiser iteration, as odometry_estimation_gpu.cpp:383-385 drives it
+                fs = api.NonlinearFactorSetGPU(c)
+                for vm in vms:
+                    fs.add(api.IntegratedVGICPFactorGPU(0, 1, vm, g))
+                if k % 5 == 3:
+                    fs.add(api.IntegratedVGICPFactorGPU(0, 1, vms[0], g))  # (and every fifth one more factor)
+                values[1] = small_pair["delta"] @ np.block([[np.eye(3), np.full((3, 1), 1e-3 * it)], [np.zeros((1, 3)), np.ones((1, 1))]])
+                out.append(fs.linearize(values))
+                fs.close()
+            g.close()
+        results[name] = out
+        stats = api.plan_stats(c)
+        assert stats["built"] == len(frames)
+        if name == "recycle":
+            assert stats["recycled"] >= 10, stats
+        else:
+            assert stats["recycled"] == 0
+    for a, b in zip(results["recycle"], results["plain"]):
+        for x, y in zip(a, b):
+            assert x["num_inliers"] == y["num_inliers"]
+            np.testing.assert_array_equal(x["H_ss"], y["H_ss"])
+            np.testing.assert_array_equal(x["b_s"], y["b_s"])
+            assert x["error"] == y["error"]
+    # one of them against the oracle
+    ref = orc.vgicp_linearize(orc.VoxelMap(0.5).insert(t["points"], t["covs"]), frames[-1][0], frames[-1][1], small_pair["delta"])
+    got = results["recycle"][-3][0]
+    assert got["num_inliers"] == ref["num_inliers"]
+    assert np.abs(gn(got) - gn(ref)).max() < 1e-4
+
+
 def test_reestimating_covariances_rebuilds_plans_that_streamed_the_old_ones(api, ctx, orc):
     """A cloud uploaded with general covariances sits in a LIVE factor set (its plan holds the addresses of the 36 B/pt streams); then
     glim_amd_cloud_estimate_covariances replaces the covariances (plane form, streams freed).  The next linearise of the same set must run

@@ -84,6 +84,33 @@ def test_cloud_roundtrip_f64_and_f32_layouts(api, ctx, small_pair):
     assert g64.memory_usage_gpu() in (len(s["points"]) * (16 + 24 + 16 + 24), len(s["points"]) * (16 + 24 + 16 + 36 + 16))
 
 
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 4095, 4096, 4097, 10000, 32768])
+def test_gated_pull_equals_the_conversion_first_form(api, ctx, n):
+    """The pull kernel of a small cloud is launched BEFORE the host converts the arrays and its blocks wait for their piece (pull_gated=1, the
+    default); pull_gated=0 converts everything first.  Same arrays, same plane-form decision, whatever the piece boundaries."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-40, 40, (n, 3))
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = nrm.astype(np.float32).astype(np.float64)
+    covs = np.eye(3)[None] - 0.999 * nrm[:, :, None] * nrm[:, None, :]
+    if n % 2 == 0:
+        covs[n // 2] += 0.05 * np.eye(3)  # (one point that is not in plane form: the verdict must flip in both forms)
+    got = {}
+    for mode in ("pull_gated=1", "pull_gated=0"):
+        with ctx.diag(mode):
+            for rep in range(3):  # (staging blocks are recycled: an earlier upload's gate words must never open this one's)
+                g = api.PointCloudGPU.clone(pts, covs, nrm, ctx=ctx)
+                got[mode, rep] = (g.download(), g.memory_usage_gpu())
+                g.close()
+    for rep in range(3):
+        (a, ma), (b, mb) = got["pull_gated=1", rep], got["pull_gated=0", rep]
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        assert ma == mb
+        np.testing.assert_array_equal(a[0], pts.astype(np.float32))
+
+
 def test_small_cloud_host_pack_equals_the_device_pack(api, ctx, orc, small_pair):
     """Clouds of up to 32 768 points are converted to the device layout on the host and pulled over by one kernel (host_pack=1, the default);
     the general path uploads the FP64 arrays and packs on the device.  Same arrays, same plane-form decision (a factor over either cloud runs

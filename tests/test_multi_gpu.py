@@ -1,5 +1,6 @@
 """Single-process multi-device cost evaluation (glim_amd_multi_*) on the GPU box: a plain C program through the C ABI, and the Python mirror.
-With one visible device the RCCL all-gather is a one-rank collective -- it is still the code path that runs (uses_rccl must be true)."""
+With one visible device there is nothing to gather: the library is exercised when the handle is created (a one-rank in-place all-gather that must
+come back unchanged: uses_rccl must be true) and, on request, in every evaluation (set_one_rank_collective) -- with identical records."""
 import os
 import subprocess
 
@@ -57,6 +58,16 @@ def test_multi_device_python_mirror_matches_oracle(orc):
     deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
     out, total = md.linearize(deltas)
     assert total == pytest.approx(sum(o["error"] for o in out), rel=1e-12)
+    if info["num_devices"] == 1:  # the no-op library call inside the evaluation changes nothing but the host's account of it
+        rec0 = md.records().copy()
+        assert md.last_breakdown(0)["library_calls"] == 0.0
+        md.set_one_rank_collective(True)
+        assert md.evaluate(deltas) == pytest.approx(total, rel=1e-15)
+        assert md.last_breakdown(0)["library_calls"] > 0.0
+        np.testing.assert_array_equal(md.records(), rec0)
+        md.set_one_rank_collective(False)
+    bd = md.last_breakdown(0)
+    assert bd["total"] > 0 and bd["device_gather"] >= 0 and bd["device_copy_out"] >= 0
     # oracle on the same inputs (covariances as the device estimated them)
     ctx = api.Context(0, 1)
     covs = []

@@ -56,7 +56,7 @@ double pct(std::vector<double> v, double p) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1]\n", argv[0]);
+    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1] [diag switches]\n", argv[0]);
     return 2;
   }
   const int timed = argc > 2 ? atoi(argv[2]) : 300, iters = argc > 3 ? atoi(argv[3]) : 3, fused = argc > 4 ? atoi(argv[4]) : 0;
@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
   }
   glim_amd_ctx* ctx = nullptr;
   CHECK(glim_amd_ctx_create_ex(0, 4, nullptr, /*priority=*/1, &ctx));  // as adapters/glim/odometry_estimation_hip_create.cpp creates the odometry's pool
+  if (argc > 5 && argv[5][0]) CHECK(glim_amd_ctx_set_diag(ctx, argv[5]));  // (A/B of a diagnostic switch on the same box, e.g. "pull_gated=0,plan_recycle=0")
   const double levels[2] = {res0, 2.0 * res0};
 
   auto make_frame = [&](int h, DeviceFrame* out) -> int {
@@ -174,14 +175,17 @@ int main(int argc, char** argv) {
       stage[S_RETIRE].push_back(t4 - t3);
     }
   }
+  uint64_t plans_built = 0, plans_recycled = 0;
+  (void)glim_amd_debug_plan_stats(ctx, &plans_built, &plans_recycled, nullptr);
   double mean = 0.0;
   for (double v : total) mean += v / (double)total.size();
   printf("{\"frames\": %d, \"points_per_frame\": %d, \"factors_per_frame\": %d, \"optimiser_iterations\": %d, \"one_submission_create_frame\": %d, "
          "\"frame_us\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"min\": %.2f}, "
          "\"stage_p50_us\": {\"clone_and_two_voxelmaps\": %.2f, \"first_linearisation_new_factor_list\": %.2f, \"each_further_linearisation\": %.2f, "
-         "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"checksum\": %.6g}\n",
+         "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"factor_plans_built\": %llu, \"of_them_in_the_buffers_of_an_evicted_plan\": %llu, "
+         "\"checksum\": %.6g}\n",
          (int)total.size(), n, NF, iters, fused, pct(total, 0.5), pct(total, 0.99), mean, pct(total, 0.0), pct(stage[S_CLONE_MAPS], 0.5), pct(stage[S_LIN_FIRST], 0.5),
-         pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), checksum);
+         pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), (unsigned long long)plans_built, (unsigned long long)plans_recycled, checksum);
   for (auto& d : keyframes) drop_frame(&d);
   for (auto& d : window) drop_frame(&d);
   CHECK(glim_amd_ctx_destroy(ctx));
