@@ -701,7 +701,8 @@ def live_odometry_loop(api, host, poses, c32_of, frames, K, WIN, res0, iters, ti
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "odometry_frame_loop.cpp"),
                                    "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
             for name, fused, diag in (("separate_calls", 0, ""), ("one_submission_create_frame", 1, ""),
-                                      ("one_submission_without_gated_pull_and_plan_recycling", 1, "pull_gated=0,plan_recycle=0"),
+                                      ("one_submission_as_round5_take2", 1, "frame_fused=0,pull_gated=0,plan_recycle=0"),
+                                      ("one_submission_without_fused_frame_kernels", 1, "frame_fused=0"),
                                       ("one_submission_without_gated_pull", 1, "pull_gated=0"), ("one_submission_without_plan_recycling", 1, "plan_recycle=0")):
                 res = subprocess.run([exe, scene, str(timed), str(iters), str(fused), diag], capture_output=True, text=True, timeout=300)
                 out[name] = json.loads(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else {"error": (res.stderr or res.stdout)[-400:]}
@@ -1274,6 +1275,14 @@ def native_global256(args, api, submaps, pairs, deltas, n_gpus, steps, warmup):
         out["with_the_one_rank_library_call_every_evaluation"] = {
             "ms_per_evaluation": sec1 * 1e3, "kernels_ms": k1, "collective_and_copy_out_after_the_kernels_ms": g1,
             "library_calls_host_us": bd1[0]["library_calls"], "device_gather_us": bd1[0]["device_gather"], "device_copy_out_us": bd1[0]["device_copy_out"]}
+    # the records' way to the host: stored by the finalising kernels into the host array as well (default) against copies behind every piece
+    M.set_host_records(0)
+    M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
+    sec0, bd0_, k0, g0 = measure()
+    out["with_device_to_host_copies_behind_the_pieces"] = {"ms_per_evaluation": sec0 * 1e3, "kernels_ms": k0, "collective_and_copy_out_after_the_kernels_ms": g0,
+                                                           "device_copy_out_us": bd0_[0]["device_copy_out"]}
+    M.set_host_records(1)
+    M.set_factors([map_ids[i] for i, _ in pairs], [cloud_ids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
     out["pieces_per_shard"] = "default: pieces of >= 2048 factors, at most 4 (glim_amd_multi_set_split)"
     # the same evaluation with the shard in 1 / 2 / 4 pieces (the exchange and the pose upload of one piece overlap the kernels of the next)
     sweep = {}

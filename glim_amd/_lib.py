@@ -101,7 +101,9 @@ SYMBOLS = {
     "glim_amd_multi_last_timing": (_i, [_vp, _fp, _fp]),
     "glim_amd_multi_last_breakdown": (_i, [_vp, _i32, _dp, _i32]),
     "glim_amd_debug_plan_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
+    "glim_amd_debug_frame_stages": (_i, [_dp, _i32]),
     "glim_amd_multi_set_one_rank_collective": (_i, [_vp, _i32]),
+    "glim_amd_multi_set_host_records": (_i, [_vp, _i32]),
     "glim_amd_factor_set_linearize_repeat": (_i, [_vp, _dp, _i, _i, _vp]),
     "glim_amd_multi_set_split": (_i, [_vp, _i32]),
     "glim_amd_multi_records": (_i, [_vp, _i64, _i64, _dp]),

@@ -689,6 +689,11 @@ class MultiDeviceCost:
         """-1: pieces of >= 2048 factors, at most 4 (default); 0 / 1: one piece; n: n pieces.  Applies to the next set_factors."""
         check(lib().glim_amd_multi_set_split(self._h, int(mode)), "glim_amd_multi_set_split")
 
+    def set_host_records(self, mode):
+        """1 (default): the finalising kernels store every record into the host array as well; 0: device-to-host copies behind each piece.
+        Applies to the next set_factors."""
+        check(lib().glim_amd_multi_set_host_records(self._h, int(mode)), "glim_amd_multi_set_host_records")
+
     def set_one_rank_collective(self, on):
         """One device: make the (no-op) ncclAllGather in every evaluation as well (measurement aid; default off)."""
         check(lib().glim_amd_multi_set_one_rank_collective(self._h, int(bool(on))), "glim_amd_multi_set_one_rank_collective")

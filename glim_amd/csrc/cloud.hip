@@ -4,6 +4,7 @@
 #include <string>
 
 #include "internal.hpp"
+#include "pull.hpp"
 #include "scope_sync.hpp"
 
 using namespace glim_amd;
@@ -71,17 +72,6 @@ __global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const float4* __
   }
 }
 
-// Plane-form test: does every stored covariance equal I - (1 - 1e-3) n n^T for the stored unit normal, within FP32 rounding of the two
-// uploads?  (GLIM's CloudCovarianceEstimation only emits this form, cloud_covariance_estimation.cpp:20,:181-196, together with the
-// eigenvector it is built from as the normal, :98-101; a frame that keeps the CPU estimator and is uploaded with
-// PointCloudGPU::clone(frame) therefore qualifies for the 24 B/pt factor kernel.)  Tolerance: C and n are each rounded to FP32
-// independently (<= 6e-8 per coefficient), n n^T then differs by <= 1.3e-7 per entry; 4e-7 leaves margin and is far below any covariance a
-// merged / averaged cloud would show (those differ from the form by 1e-3 or more).
-__device__ __forceinline__ bool off_plane_form(float c00, float c01, float c02, float c11, float c12, float c22, float nx, float ny, float nz) {
-  const float w = 0.999f, tol = 4e-7f;
-  return !(fabsf(c00 - (1.f - w * nx * nx)) <= tol && fabsf(c01 + w * nx * ny) <= tol && fabsf(c02 + w * nx * nz) <= tol &&
-           fabsf(c11 - (1.f - w * ny * ny)) <= tol && fabsf(c12 + w * ny * nz) <= tol && fabsf(c22 - (1.f - w * nz * nz)) <= tol);
-}
 __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4* __restrict__ covA, const float2* __restrict__ covB,
                                                          const float4* __restrict__ nrm, unsigned int* __restrict__ violations) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,61 +94,17 @@ __global__ __launch_bounds__(256) void plane_form_kernel(int64_t n, const float4
 constexpr int64_t HOST_PACK_MAX_POINTS = 32768;
 std::atomic<unsigned int> g_pull_gate_seq{1u};
 std::atomic<bool> g_pull_gate_broken{false};  // a gated pull kernel once gave up waiting for this process' host side: no more gating
-__global__ __launch_bounds__(256) void unstage_kernel(int n, const float4* __restrict__ s_pts, const float4* __restrict__ s_covA,
-                                                      const float2* __restrict__ s_covB, const float4* __restrict__ s_nrm, float4* __restrict__ pts,
-                                                      float4* __restrict__ covA, float2* __restrict__ covB, float4* __restrict__ nrm,
-                                                      unsigned int* __restrict__ host_violations, float4* __restrict__ pn4, float2* __restrict__ n2,
-                                                      float4* __restrict__ gs0, float4* __restrict__ gs1, float* __restrict__ gs2, float4* __restrict__ gsn,
-                                                      const unsigned int* __restrict__ gate, unsigned int gate_seq, int piece_len) {
-  if (gate) {
-    // Launched BEFORE the host has converted anything (cloud_small_enqueue): the block waits until the host has published its piece of the
-    // staging block -- gate word of the piece == this upload's sequence number, host-mapped memory, polled over PCIe by ONE lane.  Every block
-    // of the grid is resident at once (<= 128 blocks), so waiting blocks keep nobody out.  The wait is bounded (seconds): a host that never
-    // comes back ends in PULL_GAVE_UP in the word behind the violations word, not in a hung device.
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-      const unsigned int* g = gate + (blockIdx.x * 256) / piece_len;
-      bool ok = false;
-      for (unsigned int spins = 0; spins < (1u << 21) && !ok; spins++) {
-        ok = __hip_atomic_load(g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == gate_seq;
-        if (!ok) __builtin_amdgcn_s_sleep(16);
-      }
-      s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_ok) {
-      if (threadIdx.x == 0) __hip_atomic_store(host_violations + 1, PULL_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
+__global__ __launch_bounds__(256) void unstage_kernel(const PullArgs pa) {
+  __shared__ int s_ok;
+  if (!pull_wait(pa, &s_ok)) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool bad = false;
-  if (i < n) {
-    const float4 p = s_pts[i];
-    pts[i] = p;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), v = a;
-    float2 b = make_float2(0.f, 0.f);
-    if (s_covA) {
-      covA[i] = a = s_covA[i];
-      covB[i] = b = s_covB[i];
-    }
-    if (s_nrm) nrm[i] = v = s_nrm[i];
-    bad = s_covA && s_nrm && off_plane_form(a.x, a.y, a.z, a.w, b.x, b.y, v.x, v.y, v.z);
-    // The factor streams of the cloud (plane_stream_kernel / general_stream_kernel; arrival order: clouds of this size carry no Hilbert rank), in
-    // BOTH forms while the values are in registers -- which form the factor kernel reads is only known when every block has tested its points;
-    // the host drops the other.  The first factor that streams the cloud then finds them in place (no kernel, no synchronise at first use).
-    if (pn4) {
-      pn4[i] = make_float4(p.x, p.y, p.z, v.x);
-      n2[i] = make_float2(v.y, v.z);
-    }
-    if (gs0) {
-      gs0[i] = make_float4(p.x, p.y, p.z, a.x);
-      gs1[i] = make_float4(a.y, a.z, a.w, b.x);
-      gs2[i] = b.y;
-      if (gsn) gsn[i] = v;
-    }
+  if (i < pa.n) {
+    float4 p, a, v;
+    float2 b;
+    bad = pull_point(pa, i, p, a, b, v);
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_violations, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  pull_report(pa, bad);
 }
 
 // host half: the reference layouts (Vector4d, column-major Matrix4d) -> the FP32 sections of the staging block
@@ -210,10 +156,12 @@ void drop_plane_streams(glim_amd_cloud* c) {
 // upload of a small cloud through the pinned staging block; GLIM_AMD_ERR_UNSUPPORTED: no device view of pinned memory here (caller takes the general path)
 }  // namespace
 namespace glim_amd {
+thread_local double g_frame_stage_us[FRAME_STAGES] = {0, 0, 0, 0, 0, 0, 0};
+thread_local double g_frame_t0_us = 0.0;
 // The small upload in two halves (glim_amd_frame_create enqueues the frame's voxel maps between them and synchronises ONCE): enqueue = host
 // conversion into the pinned staging block + the pull kernel on ctx->stream(); finish (after the caller has synchronised that stream) = the
 // plane-form verdict, the unused stream copy back to the pool, the staging block back to its pool.
-int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up) {
+int cloud_small_prepare(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up) {
   const int64_t n = c->n;
   float* stage = nullptr;
   if (pinned_malloc(&stage, (size_t)n * 14 * sizeof(float) + 64) != hipSuccess) {
@@ -231,8 +179,7 @@ int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* poin
   volatile unsigned int* tail = reinterpret_cast<unsigned int*>(stage + 14 * n);
   tail[0] = 0u;
   tail[1] = 0u;
-  hipStream_t s = ctx->stream();
-  // factor streams written by the same kernel (see unstage_kernel); an allocation that fails only means they are built on first use instead
+  // factor streams written by the same kernel (pull_point); an allocation that fails only means they are built on first use instead
   if (covs16) {
     const size_t nn = (size_t)n;
     bool ok = pool_malloc(&c->gs0, nn * sizeof(float4)) == hipSuccess && pool_malloc(&c->gs1, nn * sizeof(float4)) == hipSuccess &&
@@ -244,41 +191,86 @@ int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* poin
       drop_plane_streams(c);
     }
   }
+  frame_stamp(1);
   // Gated form (default): the pull kernel goes out FIRST and the host converts while the launch travels; the cloud is cut into up to four pieces
-  // and the blocks of a piece start pulling the moment the host has published it, so the conversion of piece k + 1 runs beside the pull of
-  // piece k and only the last piece's pull is exposed (round 5, 10 000-pt frame: 35 us of conversion FOLLOWED by a launch and 22 us of pull
-  // before).  Cutting the cloud into four LAUNCHES instead was measured and rejected (+23 us: profiles/r05/probe/upload_in_pieces_rejected.json).
+  // and the blocks of a piece start pulling the moment the host has published it.  (Cutting the cloud into four LAUNCHES instead was measured
+  // and rejected, +23 us: profiles/r05/probe/upload_in_pieces_rejected.json.)
   const bool gated = ctx->diag.pull_gated && !g_pull_gate_broken.load(std::memory_order_relaxed);
   unsigned int seq = 0u;
   while (gated && (seq == 0u || seq == PULL_GAVE_UP)) seq = g_pull_gate_seq.fetch_add(1u, std::memory_order_relaxed);
   const int64_t pieces_wanted = n >= 4096 ? 4 : 1, piece_len = ((n + pieces_wanted - 1) / pieces_wanted + 255) / 256 * 256;
-  if (!gated) host_pack_f64(0, n, points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
-  unstage_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((int)n, reinterpret_cast<const float4*>(dev), covs16 ? reinterpret_cast<const float4*>(dev + 4 * n) : nullptr,
-                                                        reinterpret_cast<const float2*>(dev + 12 * n), normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr,
-                                                        c->pts, c->covA, c->covB, c->normals, reinterpret_cast<unsigned int*>(dev + 14 * n), c->pn4, c->n2, c->gs0,
-                                                        c->gs1, c->gs2, c->gsn, gated ? reinterpret_cast<const unsigned int*>(dev + 14 * n) + 4 : nullptr, seq,
-                                                        (int)piece_len);
-  const hipError_t e = hipGetLastError();
-  if (gated) {
-    // (also when the launch failed: nothing waits then, and the staging block is simply dropped below)
-    int piece = 0;
-    for (int64_t lo = 0; lo < n; lo += piece_len, piece++) {
-      host_pack_f64(lo, std::min(n, lo + piece_len), points4, covs16, normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
-      std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
-      tail[4 + piece] = seq;
-    }
-    std::atomic_thread_fence(std::memory_order_release);
-  }
+  PullArgs& pa = up->args;
+  pa = PullArgs();
+  pa.n = (int)n;
+  pa.s_pts = reinterpret_cast<const float4*>(dev);
+  pa.s_covA = covs16 ? reinterpret_cast<const float4*>(dev + 4 * n) : nullptr;
+  pa.s_covB = reinterpret_cast<const float2*>(dev + 12 * n);
+  pa.s_nrm = normals4 ? reinterpret_cast<const float4*>(dev + 8 * n) : nullptr;
+  pa.pts = c->pts;
+  pa.covA = c->covA;
+  pa.covB = c->covB;
+  pa.nrm = c->normals;
+  pa.host_tail = reinterpret_cast<unsigned int*>(dev + 14 * n);
+  pa.pn4 = c->pn4;
+  pa.n2 = c->n2;
+  pa.gs0 = c->gs0;
+  pa.gs1 = c->gs1;
+  pa.gs2 = c->gs2;
+  pa.gsn = c->gsn;
+  pa.gate = gated ? reinterpret_cast<const unsigned int*>(dev + 14 * n) + 4 : nullptr;
+  pa.gate_seq = seq;
+  pa.piece_len = (int)piece_len;
   up->stage = stage;
   up->violations = tail;
   up->maybe_plane = covs16 && normals4;
+  up->gated = gated;
+  up->packed = false;
+  up->points4 = points4;
+  up->covs16 = covs16;
+  up->normals4 = normals4;
+  return GLIM_AMD_OK;
+}
+
+// host conversion into the staging block; gated form: piece by piece, every piece published through its gate word the moment it is complete
+void cloud_small_pack(SmallUpload* up) {
+  if (up->packed || !up->stage) return;
+  const int64_t n = up->args.n, piece_len = up->gated ? up->args.piece_len : std::max<int64_t>(n, 1);
+  float* stage = up->stage;
+  int piece = 0;
+  for (int64_t lo = 0; lo < n; lo += piece_len, piece++) {
+    host_pack_f64(lo, std::min(n, lo + piece_len), up->points4, up->covs16, up->normals4, stage, stage + 4 * n, stage + 12 * n, stage + 8 * n);
+    if (up->gated) {
+      std::atomic_thread_fence(std::memory_order_release);  // (x86: stores stay in program order; the fence keeps the compiler from moving them)
+      up->violations[4 + piece] = up->args.gate_seq;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_release);
+  up->packed = true;
+  frame_stamp(3);
+}
+
+int cloud_small_launch(SmallUpload* up, hipStream_t st) {
+  unstage_kernel<<<(up->args.n + 255) / 256, 256, 0, st>>>(up->args);
+  const hipError_t e = hipGetLastError();
+  frame_stamp(2);
   if (e != hipSuccess) {
-    (void)hipStreamSynchronize(s);
-    (void)pinned_free(stage);
-    up->stage = nullptr;
     set_hip_error(e, "cloud_create small upload");
     return GLIM_AMD_ERR_HIP;
   }
+  return GLIM_AMD_OK;
+}
+
+int cloud_small_enqueue(glim_amd_ctx* ctx, glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up) {
+  GA_TRY(cloud_small_prepare(ctx, c, points4, covs16, normals4, up));
+  if (!up->gated) cloud_small_pack(up);
+  const int rc = cloud_small_launch(up, ctx->stream());
+  if (rc != GLIM_AMD_OK) {  // (nothing waits for the gate then)
+    (void)hipStreamSynchronize(ctx->stream());
+    (void)pinned_free(up->stage);
+    up->stage = nullptr;
+    return rc;
+  }
+  cloud_small_pack(up);
   return GLIM_AMD_OK;
 }
 int cloud_small_finish(glim_amd_cloud* c, SmallUpload* up) {

@@ -56,6 +56,7 @@ const DiagKey kDiagKeys[] = {
   {"host_poses", &Diag::host_poses, nullptr, 0, 1},
   {"host_pack", &Diag::host_pack, nullptr, 0, 1},
   {"pull_gated", &Diag::pull_gated, nullptr, 0, 1},
+  {"frame_fused", &Diag::frame_fused, nullptr, 0, 1},
   {"view_fused", &Diag::view_fused, nullptr, 0, 1},
   {"fuse", &Diag::fuse, nullptr, 0, 1},
   {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -59,13 +60,52 @@ int cloud_curve_rank(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
 // mutex the caller does not hold: ADVICE r4).  Same for cloud_curve_rank.
 int ensure_factor_streams(::glim_amd_cloud* c, ::glim_amd_ctx* held, hipStream_t st);
 // the host-packed upload of a small cloud (<= HOST_PACK_MAX_POINTS) in two halves around ONE synchronise of ctx->stream() (cloud.hip)
+// what the pull kernels take (pull.hpp): the staging block's sections (device view of pinned host memory; s_covA / s_nrm may be null), the cloud's
+// arrays and factor streams, the tail words of the staging block ([0] violations of the plane-form test, [1] PULL_GAVE_UP) and the gate
+struct PullArgs {
+  int n = 0;
+  const float4* s_pts = nullptr;
+  const float4* s_covA = nullptr;
+  const float2* s_covB = nullptr;
+  const float4* s_nrm = nullptr;
+  float4* pts = nullptr;
+  float4* covA = nullptr;
+  float2* covB = nullptr;
+  float4* nrm = nullptr;
+  unsigned int* host_tail = nullptr;
+  float4* pn4 = nullptr;
+  float2* n2 = nullptr;
+  float4* gs0 = nullptr;
+  float4* gs1 = nullptr;
+  float* gs2 = nullptr;
+  float4* gsn = nullptr;
+  const unsigned int* gate = nullptr;  // null: the staging block was complete before the launch
+  unsigned int gate_seq = 0u;
+  int piece_len = 256;
+};
 struct SmallUpload {
   float* stage = nullptr;
-  volatile unsigned int* violations = nullptr;
+  volatile unsigned int* violations = nullptr;  // the tail words of the staging block, host side
   bool maybe_plane = false;
+  bool gated = false, packed = false;
+  PullArgs args;
+  const double *points4 = nullptr, *covs16 = nullptr, *normals4 = nullptr;  // the caller's arrays (cloud_small_pack)
 };
+// debug account of the LAST glim_amd_frame_create of this thread, microseconds from its entry (glim_amd_debug_frame_stages): [0] cloud allocated,
+// [1] staging block + stream allocations, [2] pull kernel launched, [3] host conversion done, [4] voxel-map kernels enqueued, [5] completion
+// word seen, [6] return
+constexpr int FRAME_STAGES = 7;
+extern thread_local double g_frame_stage_us[FRAME_STAGES];
+extern thread_local double g_frame_t0_us;
+inline double frame_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline void frame_stamp(int i) { g_frame_stage_us[i] = frame_now_us() - g_frame_t0_us; }
 constexpr unsigned int PULL_GAVE_UP = 0xffffffffu;  // violations word: the gated pull kernel stopped waiting for the host's conversion (cloud.hip)
 int cloud_small_enqueue(::glim_amd_ctx* ctx, ::glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up);
+// its three steps, for a caller that launches its own pull kernel (glim_amd_frame_create): allocations + kernel arguments; the host conversion
+// into the staging block (gated form: AFTER the launch, publishing piece by piece); the plain pull kernel on `st`
+int cloud_small_prepare(::glim_amd_ctx* ctx, ::glim_amd_cloud* c, const double* points4, const double* covs16, const double* normals4, SmallUpload* up);
+void cloud_small_pack(SmallUpload* up);
+int cloud_small_launch(SmallUpload* up, hipStream_t st);
 int cloud_small_finish(::glim_amd_cloud* c, SmallUpload* up);  // GLIM_AMD_ERR_UNSUPPORTED: the gated pull gave up (the cloud holds nothing; gating is off from now on)
 int alloc_cloud_for_frame(::glim_amd_ctx* ctx, int64_t n, bool covs, bool normals, ::glim_amd_cloud** out);  // cloud.hip alloc_cloud
 constexpr int64_t HOST_PACK_MAX_POINTS_FRAME = 32768;
@@ -95,6 +135,7 @@ struct Diag {
   int fuse = 1;           // fuse=0|1                           small synchronous sets: ONE dispatch (factors finalised inside the factor kernel)
   int view_fused = 1;     // view_fused=0|1                      a map built from a plane-form cloud gets its plane view (A_B records) from the finalise kernel; 0: on first use
   int host_pack = 1;      // host_pack=0|1                       small clouds (<= 32 768 pts) are converted to the device layout on the host, one kernel pulls them over
+  int frame_fused = 1;    // frame_fused=0|1                     glim_amd_frame_create: one launch pulls the cloud and builds every level, one writes every level's records
   int pull_gated = 1;     // pull_gated=0|1                      ... and that kernel is launched BEFORE the conversion: its blocks wait for their piece of the staging block
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
@@ -441,6 +482,9 @@ struct glim_amd_factor_set {
   // asynchronous calls only (glim_amd_multi: one per device): the pose copy goes to THIS stream and the set's stream waits for it, so that the
   // upload of one piece of a shard runs beside the kernels of the piece before it instead of queueing behind them
   hipStream_t upload_stream = nullptr;
+  // asynchronous calls with caller-owned device records (glim_amd_factor_set_linearize_device_async): when set, the finalising blocks store every
+  // record here as well, at the same row offset (device view of host-mapped memory)
+  double* record_mirror = nullptr;
 };
 
 namespace glim_amd {

@@ -144,6 +144,10 @@ struct glim_amd_multi {
   int split_mode = -1;            // -1: default (pieces of >= 2048 factors, at most 4); 0 / 1: one piece; n >= 2: n pieces (glim_amd_multi_set_split)
   std::vector<double*> d_gather;  // [device]: ndev x max_rows x COMPACT
   double* h_gather = nullptr;     // pinned
+  // [device]: device view of h_gather when the finalising kernels of that device store their records THERE as well (no device-to-host copy behind
+  // the kernels), or null: copy-out by hipMemcpyAsync on the collective's stream (glim_amd_multi_set_host_records)
+  std::vector<double*> h_gather_dev;
+  bool mirror_records = true;
   std::vector<ncclComm_t> comms;
   bool use_rccl = false;
   bool one_rank_collective = false;  // ONE device: make the (no-op) library call in every evaluation all the same (glim_amd_multi_set_one_rank_collective)
@@ -237,6 +241,7 @@ void release_factors(glim_amd_multi* m) {
   m->d_gather.assign(m->ndev, nullptr);
   if (m->h_gather) (void)pinned_free(m->h_gather);
   m->h_gather = nullptr;
+  m->h_gather_dev.assign((size_t)m->ndev, nullptr);
   m->nf = m->max_rows = m->piece_rows = 0;
   m->pieces = 1;
 }
@@ -609,14 +614,20 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
   m->max_rows = max_rows;
   m->piece_rows = piece_rows;
   m->pieces = pieces;
+  m->h_gather_dev.assign((size_t)m->ndev, nullptr);
   const int rc = m->run_all([&](int d) -> int {
     GA_HIP(hipSetDevice(m->devices[d]));
+    if (m->mirror_records && hipHostGetDevicePointer(reinterpret_cast<void**>(&m->h_gather_dev[d]), m->h_gather, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      m->h_gather_dev[d] = nullptr;  // (no device view of the pinned array here: copies behind the kernels)
+    }
     const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
     for (int h = 0; h < m->pieces; h++) {
       const int64_t f0 = std::min(lo + (int64_t)h * piece_rows, hi), f1 = std::min(f0 + piece_rows, hi);
       if (f1 <= f0) continue;
       GA_TRY(glim_amd_factor_set_create(m->ctxs[d], &m->sets[MAX_PIECES * d + h]));
       m->sets[MAX_PIECES * d + h]->upload_stream = m->ustream[d];
+      m->sets[MAX_PIECES * d + h]->record_mirror = m->h_gather_dev[d];
       for (int64_t f = f0; f < f1; f++)
         GA_TRY(glim_amd_factor_set_add(m->sets[MAX_PIECES * d + h], m->maps[d][target_map_ids[f]], m->clouds[d][source_cloud_ids[f]], m->flags[(size_t)f], nullptr));
     }
@@ -637,6 +648,12 @@ int glim_amd_multi_set_factors(glim_amd_multi* m, int64_t num_factors, const int
 int glim_amd_multi_set_split(glim_amd_multi* m, int32_t mode) {
   if (!m || mode < -1 || mode > MAX_PIECES) return GLIM_AMD_ERR_INVALID;
   m->split_mode = mode;  // takes effect with the next glim_amd_multi_set_factors
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_set_host_records(glim_amd_multi* m, int32_t mode) {
+  if (!m || mode < 0 || mode > 1) return GLIM_AMD_ERR_INVALID;
+  m->mirror_records = mode == 1;  // takes effect with the next glim_amd_multi_set_factors
   return GLIM_AMD_OK;
 }
 
@@ -767,7 +784,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           // copy-out: every device hands ITS OWN rows of the piece to the host over its own PCIe link (round 4: device 0 copied the whole
           // gathered array, 7.6 MB behind the collective; the devices' links work in parallel and need not wait for xGMI)
           const int64_t own = std::max<int64_t>(0, std::min(rows, (hi - lo) - (int64_t)h * m->piece_rows));
-          if (own > 0)
+          if (own > 0 && !m->h_gather_dev[d])  // (otherwise the finalising kernels have stored the rows there themselves)
             GA_HIP(hipMemcpyAsync(m->h_gather + start + (size_t)d * slot, region + (size_t)d * slot, (size_t)own * COMPACT * sizeof(double),
                                   hipMemcpyDeviceToHost, cst));
         }

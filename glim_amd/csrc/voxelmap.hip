@@ -20,6 +20,7 @@
 
 #include "device_math.hpp"
 #include "internal.hpp"
+#include "pull.hpp"
 #include "scope_sync.hpp"
 
 using namespace glim_amd;
@@ -187,68 +188,111 @@ __global__ __launch_bounds__(256) void accumulate_kernel(int n, const float4* __
 // 131 072 points).
 // stats[0] = distinct keys, stats[1] = points whose coordinate does not fit the 21-bit key range
 constexpr int LDS_SLOTS = 512;
-__global__ __launch_bounds__(256) void build_direct_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
-                                                           const float2* __restrict__ covB, double inv_res, VoxelBucket* __restrict__ buckets,
-                                                           unsigned int num_buckets, long long* __restrict__ acc, int* __restrict__ stats) {
-  __shared__ unsigned long long s_key[LDS_SLOTS];
-  __shared__ unsigned long long s_acc[ACC_STRIDE][LDS_SLOTS];  // value-major: the lanes of a wavefront that add value j to different slots hit different banks
-  __shared__ int s_claimed;  // voxels this block was the first to put into the global table: ONE atomic per block on the shared counter
-  if (threadIdx.x == 0) s_claimed = 0;
+struct BuildLds {
+  unsigned long long key[LDS_SLOTS];
+  unsigned long long acc[ACC_STRIDE][LDS_SLOTS];  // value-major: the lanes of a wavefront that add value j to different slots hit different banks
+  int claimed;                                    // voxels this block was the first to put into the global table: ONE atomic per block on the shared counter
+};
+// one block's (up to) 256 points into one map's table; all lanes of the block must call (valid = this lane holds a point)
+__device__ __forceinline__ void build_block(BuildLds& L, bool valid, const float4& p, const float4& a, const float2& b, double inv_res,
+                                            VoxelBucket* __restrict__ buckets, unsigned int num_buckets, long long* __restrict__ acc, int* __restrict__ stats) {
+  if (threadIdx.x == 0) L.claimed = 0;
   for (int s = threadIdx.x; s < LDS_SLOTS; s += 256) {
-    s_key[s] = EMPTY_KEY;
+    L.key[s] = EMPTY_KEY;
 #pragma unroll
-    for (int j = 0; j < ACC_STRIDE; j++) s_acc[j][s] = 0ull;
+    for (int j = 0; j < ACC_STRIDE; j++) L.acc[j][s] = 0ull;
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const float4 p = pts[i];
-    const float4 a = covA[i];
-    const float2 b = covB[i];
+  if (valid) {
     const unsigned long long key = voxel_key((double)p.x, (double)p.y, (double)p.z, inv_res);
     if (key == EMPTY_KEY) {
       atomicAdd(&stats[1], 1);
     } else {
       unsigned int s = hash_key(key) & (LDS_SLOTS - 1);
       for (;;) {  // at most 256 of the 512 slots are ever taken
-        const unsigned long long prev = atomicCAS(&s_key[s], EMPTY_KEY, key);
+        const unsigned long long prev = atomicCAS(&L.key[s], EMPTY_KEY, key);
         if (prev == EMPTY_KEY || prev == key) break;
         s = (s + 1) & (LDS_SLOTS - 1);
       }
-      atomicAdd(&s_acc[0][s], (unsigned long long)__double2ll_rn((double)p.x * MEAN_SCALE));
-      atomicAdd(&s_acc[1][s], (unsigned long long)__double2ll_rn((double)p.y * MEAN_SCALE));
-      atomicAdd(&s_acc[2][s], (unsigned long long)__double2ll_rn((double)p.z * MEAN_SCALE));
-      atomicAdd(&s_acc[3][s], (unsigned long long)__double2ll_rn((double)a.x * COV_SCALE));
-      atomicAdd(&s_acc[4][s], (unsigned long long)__double2ll_rn((double)a.y * COV_SCALE));
-      atomicAdd(&s_acc[5][s], (unsigned long long)__double2ll_rn((double)a.z * COV_SCALE));
-      atomicAdd(&s_acc[6][s], (unsigned long long)__double2ll_rn((double)a.w * COV_SCALE));
-      atomicAdd(&s_acc[7][s], (unsigned long long)__double2ll_rn((double)b.x * COV_SCALE));
-      atomicAdd(&s_acc[8][s], (unsigned long long)__double2ll_rn((double)b.y * COV_SCALE));
-      atomicAdd(&s_acc[9][s], 1ull);
+      atomicAdd(&L.acc[0][s], (unsigned long long)__double2ll_rn((double)p.x * MEAN_SCALE));
+      atomicAdd(&L.acc[1][s], (unsigned long long)__double2ll_rn((double)p.y * MEAN_SCALE));
+      atomicAdd(&L.acc[2][s], (unsigned long long)__double2ll_rn((double)p.z * MEAN_SCALE));
+      atomicAdd(&L.acc[3][s], (unsigned long long)__double2ll_rn((double)a.x * COV_SCALE));
+      atomicAdd(&L.acc[4][s], (unsigned long long)__double2ll_rn((double)a.y * COV_SCALE));
+      atomicAdd(&L.acc[5][s], (unsigned long long)__double2ll_rn((double)a.z * COV_SCALE));
+      atomicAdd(&L.acc[6][s], (unsigned long long)__double2ll_rn((double)a.w * COV_SCALE));
+      atomicAdd(&L.acc[7][s], (unsigned long long)__double2ll_rn((double)b.x * COV_SCALE));
+      atomicAdd(&L.acc[8][s], (unsigned long long)__double2ll_rn((double)b.y * COV_SCALE));
+      atomicAdd(&L.acc[9][s], 1ull);
     }
   }
   __syncthreads();
   for (int s = threadIdx.x; s < LDS_SLOTS; s += 256) {
-    const unsigned long long key = s_key[s];
+    const unsigned long long key = L.key[s];
     if (key == EMPTY_KEY) continue;
-    unsigned int b = bucket_of(key, num_buckets);
+    unsigned int bk = bucket_of(key, num_buckets);
     int slot = -1;
     while (slot < 0) {
 #pragma unroll
       for (int w = 0; w < 2; w++) {
         if (slot >= 0) continue;
-        const unsigned long long prev = atomicCAS(&buckets[b].key[w], EMPTY_KEY, key);
-        if (prev == EMPTY_KEY) atomicAdd(&s_claimed, 1);
-        if (prev == EMPTY_KEY || prev == key) slot = (int)(2u * b + (unsigned int)w);
+        const unsigned long long prev = atomicCAS(&buckets[bk].key[w], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY) atomicAdd(&L.claimed, 1);
+        if (prev == EMPTY_KEY || prev == key) slot = (int)(2u * bk + (unsigned int)w);
       }
-      b = (b + 1 == num_buckets) ? 0u : b + 1;
+      bk = (bk + 1 == num_buckets) ? 0u : bk + 1;
     }
     long long* dst = acc + (size_t)slot * ACC_STRIDE;
 #pragma unroll
-    for (int j = 0; j < ACC_STRIDE; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), s_acc[j][s]);
+    for (int j = 0; j < ACC_STRIDE; j++) atomicAdd(reinterpret_cast<unsigned long long*>(dst + j), L.acc[j][s]);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && s_claimed) atomicAdd(&stats[0], s_claimed);
+  if (threadIdx.x == 0 && L.claimed) atomicAdd(&stats[0], L.claimed);
+}
+
+__global__ __launch_bounds__(256) void build_direct_kernel(int n, const float4* __restrict__ pts, const float4* __restrict__ covA,
+                                                           const float2* __restrict__ covB, double inv_res, VoxelBucket* __restrict__ buckets,
+                                                           unsigned int num_buckets, long long* __restrict__ acc, int* __restrict__ stats) {
+  __shared__ BuildLds L;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f), a = p;
+  float2 b = make_float2(0.f, 0.f);
+  if (i < n) {
+    p = pts[i];
+    a = covA[i];
+    b = covB[i];
+  }
+  build_block(L, i < n, p, a, b, inv_res, buckets, num_buckets, acc, stats);
+}
+
+// The maps of a FRAME in the launch that pulls the frame's cloud over (glim_amd_frame_create): a block waits for its piece of the staging block
+// (pull.hpp), pulls its 256 points into the cloud's arrays and streams, and -- the values are in its registers -- sums them into every level's
+// table straight away.  Pull kernel + one build kernel per level were 1 + L dependent launches in a row; a dependent launch costs the stream
+// ~5 us before its first wavefront runs, more than any of these kernels computes on a 10 000-pt frame.
+constexpr int FRAME_MAX_LEVELS = 8;
+struct FrameLevels {
+  int count = 0;
+  double inv_res[FRAME_MAX_LEVELS], res[FRAME_MAX_LEVELS];
+  VoxelBucket* buckets[FRAME_MAX_LEVELS];
+  VoxelBucket* view[FRAME_MAX_LEVELS];
+  long long* acc[FRAME_MAX_LEVELS];
+  int* stats[FRAME_MAX_LEVELS];
+  unsigned int nb[FRAME_MAX_LEVELS];
+};
+__global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, const FrameLevels lv) {
+  __shared__ BuildLds L;
+  __shared__ int s_ok;
+  if (!pull_wait(pa, &s_ok)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f), a = p, v = p;
+  float2 b = make_float2(0.f, 0.f);
+  bool bad = false;
+  if (i < pa.n) bad = pull_point(pa, i, p, a, b, v);
+  pull_report(pa, bad);
+  for (int k = 0; k < lv.count; k++) {
+    build_block(L, i < pa.n, p, a, b, lv.inv_res[k], lv.buckets[k], lv.nb[k], lv.acc[k], lv.stats[k]);
+    __syncthreads();  // (the next level re-initialises the LDS table)
+  }
 }
 
 // ---- incremental insert (a second insert() into a map: GaussianVoxelMapCPU semantics, gtsam_points GaussianVoxel::add re-opens a finalised voxel
@@ -352,18 +396,9 @@ __global__ __launch_bounds__(256) void plane_view_kernel(const VoxelBucket* __re
 // memory by this last launch -- the call then needs a stream synchronise only, no device-to-host copy
 // view (optional; launch 2 * (num_buckets + 1) threads then): the plane view of the table (plane_record), written with the map -- every way
 // of every bucket, so it needs no clearing, plus the all-zero bucket behind the table.
-__global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
-                                                       const long long* __restrict__ acc, double res, const int* __restrict__ stats,
-                                                       int* __restrict__ host_stats, VoxelBucket* __restrict__ view, const int2* __restrict__ lru = nullptr,
-                                                       int lru_stamp = 0, unsigned int poll_seq = 0u) {
-  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && host_stats) {
-    host_stats[0] = stats[0];
-    host_stats[1] = stats[1];
-    // poll_seq: the host spins on word 2 and returns to its caller while this kernel is still writing records (system-scope release: the two
-    // words above are visible with it); 0: the host synchronises the stream instead
-    if (poll_seq) __hip_atomic_store(reinterpret_cast<unsigned int*>(host_stats) + 2, poll_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+// slot i (= 2 * bucket + way) of a table: sums -> record (and the plane view's record)
+__device__ __forceinline__ void finalize_slot(unsigned int i, VoxelBucket* __restrict__ buckets, unsigned int num_buckets, const long long* __restrict__ acc, double res,
+                                              VoxelBucket* __restrict__ view, const int2* __restrict__ lru, int lru_stamp) {
   if (i >= 2 * num_buckets + (view ? 2u : 0u)) return;
   const unsigned int b = i >> 1, w = i & 1;
   const unsigned long long key = b < num_buckets ? buckets[b].key[w] : EMPTY_KEY;
@@ -403,6 +438,38 @@ __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__
   r[10] = __int_as_float(stamp);
   r[11] = 0.f;
   if (view) plane_record(r, view[b].rec[w]);
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__ buckets, unsigned int num_buckets,
+                                                       const long long* __restrict__ acc, double res, const int* __restrict__ stats,
+                                                       int* __restrict__ host_stats, VoxelBucket* __restrict__ view, const int2* __restrict__ lru = nullptr,
+                                                       int lru_stamp = 0, unsigned int poll_seq = 0u) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && host_stats) {
+    host_stats[0] = stats[0];
+    host_stats[1] = stats[1];
+    // poll_seq: the host spins on word 2 and returns to its caller while this kernel is still writing records (system-scope release: the two
+    // words above are visible with it); 0: the host synchronises the stream instead
+    if (poll_seq) __hip_atomic_store(reinterpret_cast<unsigned int*>(host_stats) + 2, poll_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  finalize_slot(i, buckets, num_buckets, acc, res, view, lru, lru_stamp);
+}
+
+// every level of a frame in ONE launch (blockIdx.y = level).  host_view: 4 words per level -- voxels, points out of range, (last level only)
+// the completion word.  The first thread of the grid writes EVERY level's counts and then the completion word (system-scope release): the
+// build kernel is complete when this one starts (the stream runs in order), so the counts are final, and the host returns while the
+// records are still being written (ready_event).
+__global__ __launch_bounds__(256) void frame_finalize_kernel(const FrameLevels lv, int* __restrict__ host_view, unsigned int poll_seq) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = (int)blockIdx.y;
+  if (i == 0 && k == 0) {
+    for (int j = 0; j < lv.count; j++) {
+      host_view[4 * j] = lv.stats[j][0];
+      host_view[4 * j + 1] = lv.stats[j][1];
+    }
+    if (poll_seq) __hip_atomic_store(reinterpret_cast<unsigned int*>(host_view) + 4 * (lv.count - 1) + 2, poll_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  finalize_slot(i, lv.buckets[k], lv.nb[k], lv.acc[k], lv.res[k], lv.view[k], nullptr, 0);
 }
 
 // voxels-per-point ratio of the last map built at a resolution class (sizes the direct build of the next one)
@@ -913,10 +980,17 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     std::lock_guard<std::mutex> lock(ctx->mu);
     GA_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream();
+    g_frame_t0_us = frame_now_us();
     rc = alloc_cloud_for_frame(ctx, n, true, normals4 != nullptr, &c);
+    frame_stamp(0);
     if (rc == GLIM_AMD_OK && !pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view))) rc = GLIM_AMD_ERR_UNSUPPORTED;
-    if (rc == GLIM_AMD_OK) rc = cloud_small_enqueue(ctx, c, points4, covs16, normals4, &up);
+    // frame_fused (default): ONE launch pulls the cloud and builds every level (frame_build_kernel), one more writes every level's records
+    // (frame_finalize_kernel) -- 2 dependent launches instead of 1 + 2 per level; with the gated pull both go out BEFORE the host converts
+    const bool fused = ctx->diag.frame_fused && num_levels >= 1 && num_levels <= FRAME_MAX_LEVELS;
+    if (rc == GLIM_AMD_OK) rc = fused ? cloud_small_prepare(ctx, c, points4, covs16, normals4, &up) : cloud_small_enqueue(ctx, c, points4, covs16, normals4, &up);
     enqueued = rc == GLIM_AMD_OK;
+    if (enqueued && fused && !up.gated) cloud_small_pack(&up);
+    FrameLevels FL;
     const unsigned int nb = (unsigned int)round_buckets(std::max<unsigned long long>(16, 2ull * (unsigned long long)n));  // (the small direct build of insert)
     for (int lv = 0; lv < num_levels && rc == GLIM_AMD_OK; lv++) {
       Build& B = b[lv];
@@ -947,6 +1021,22 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
       if (!have_cleared)
         init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, st>>>(B.buckets, nb, (uint4*)B.acc, acc_words, (int*)B.stats);
+      if (fused) {
+        FL.count = lv + 1;
+        FL.inv_res[lv] = B.m->inv_resolution;
+        FL.res[lv] = B.m->resolution;
+        FL.buckets[lv] = B.buckets;
+        FL.view[lv] = B.view;
+        FL.acc[lv] = (long long*)B.acc;
+        FL.stats[lv] = (int*)B.stats;
+        FL.nb[lv] = nb;
+        const hipError_t ei = hipGetLastError();
+        if (ei != hipSuccess) {
+          set_hip_error(ei, "glim_amd_frame_create");
+          rc = GLIM_AMD_ERR_HIP;
+        }
+        continue;
+      }
       build_direct_kernel<<<((int)n + 255) / 256, 256, 0, st>>>((int)n, c->pts, c->covA, c->covB, B.m->inv_resolution, B.buckets, nb, (long long*)B.acc, (int*)B.stats);
       // the LAST level's records kernel hands the host the completion word when it starts (the stream runs in order: everything before it -- the
       // pull kernel's plane-form verdict, the earlier levels' counts -- is complete and visible by then); it may still be writing its own
@@ -962,6 +1052,30 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
         rc = GLIM_AMD_ERR_HIP;
       }
     }
+    if (fused && enqueued) {
+      bool launched = false;
+      if (rc == GLIM_AMD_OK) {
+        glim_amd_voxelmap* last_map = b[num_levels - 1].m;
+        frame_build_kernel<<<((int)n + 255) / 256, 256, 0, st>>>(up.args, FL);
+        hipError_t e = hipGetLastError();
+        launched = e == hipSuccess;
+        frame_stamp(2);
+        if (e == hipSuccess && hipEventCreateWithFlags(&last_map->ready_event, hipEventDisableTiming) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
+        if (e == hipSuccess) {
+          frame_finalize_kernel<<<dim3((2 * (nb + 1) + 255) / 256, (unsigned int)num_levels), 256, 0, st>>>(FL, d_view, poll_seq);
+          e = hipGetLastError();
+        }
+        if (e == hipSuccess && poll_seq) e = hipEventRecord(last_map->ready_event, st);
+        if (e != hipSuccess) {
+          set_hip_error(e, "glim_amd_frame_create");
+          rc = GLIM_AMD_ERR_HIP;
+        }
+      }
+      // the host conversion, piece by piece, behind the launches (gated form).  Also after a failed step IF the pull kernel is out: its blocks wait
+      // for the gate words
+      if (launched) cloud_small_pack(&up);
+    }
+    frame_stamp(4);
     // ---- the one wait: the polled word, or a synchronise ----
     bool running = false;
     if (rc == GLIM_AMD_OK && num_levels > 0 && poll_seq && spin_word(reinterpret_cast<volatile unsigned int*>(h_view) + 4 * (num_levels - 1) + 2, poll_seq)) {
@@ -975,6 +1089,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
         rc = GLIM_AMD_ERR_HIP;
       }
     }
+    frame_stamp(5);
     if (enqueued) {
       if (rc == GLIM_AMD_OK) {
         rc = cloud_small_finish(c, &up);  // GLIM_AMD_ERR_UNSUPPORTED: the gated pull gave up -- the maps were built from nothing; the separate calls below
@@ -1038,6 +1153,13 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
   }
   *cloud_out = c;
   for (int lv = 0; lv < num_levels; lv++) maps_out[lv] = b[lv].m;
+  frame_stamp(6);
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_debug_frame_stages(double* microseconds, int32_t num_fields) {
+  if (!microseconds || num_fields < 0) return GLIM_AMD_ERR_INVALID;
+  for (int i = 0; i < num_fields; i++) microseconds[i] = i < FRAME_STAGES ? g_frame_stage_us[i] : 0.0;
   return GLIM_AMD_OK;
 }
 

@@ -89,7 +89,7 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
 /* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
  * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
  * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair|qgroup,
- * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, plan_recycle=0|1, host_poses=0|1, host_pack=0|1, pull_gated=0|1,
+ * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, plan_recycle=0|1, host_poses=0|1, host_pack=0|1, pull_gated=0|1, frame_fused=0|1,
  * view_fused=0|1 (a voxel map built from a plane-form cloud gets its plane view -- the (C_B + I)^-1 records the plane-form factor kernel reads --
  * from the map's own finalise kernel; 0: on the first factor that needs it),
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
@@ -341,6 +341,10 @@ int glim_amd_debug_resident_stop(int device);
 /* parity / debug only: factor plans this context has built for new factor lists, how many of them took over the buffers of the plan its full
  * cache was about to evict (a new list of the same shape: GLIM's odometry brings one per frame), idle plans cached right now. */
 int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached);
+/* parity / debug only: host-side account of the calling thread's LAST one-submission glim_amd_frame_create, microseconds since its entry:
+ * [0] cloud allocated, [1] staging block + stream allocations, [2] pull kernel launched, [3] host conversion done, [4] voxel-map kernels
+ * enqueued, [5] completion word seen, [6] return (tools/odometry_frame_loop.cpp prints the medians). */
+int glim_amd_debug_frame_stages(double* microseconds, int32_t num_fields);
 
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
@@ -404,6 +408,11 @@ int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
  * one-rank all-gather that must come back unchanged; glim_amd_multi_info uses_rccl says whether it did).  on != 0: make the no-op
  * ncclAllGather in every evaluation as well (measurement aid: bench.py prices it).  No effect on several devices. */
 int glim_amd_multi_set_one_rank_collective(glim_amd_multi* multi, int32_t on);
+/* how every device's own records reach the host array (glim_amd_multi_records, the `out` of glim_amd_multi_linearize): 1 (default) = its
+ * finalising kernels store them there as well (host-mapped memory, 232 B per factor over the device's PCIe link while the launch runs: nothing
+ * is copied behind the kernels); 0 = device-to-host copies on the collective's stream behind each piece.  Takes effect with the next
+ * glim_amd_multi_set_factors. */
+int glim_amd_multi_set_host_records(glim_amd_multi* multi, int32_t mode);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
 /* where every factor's 29-double record sits in the gathered [world x max_rows] array of an evaluation, as a pure host function (the rule

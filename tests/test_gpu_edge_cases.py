@@ -510,7 +510,12 @@ def test_frame_create_equals_the_separate_calls(api, orc, small_pair):
 
     levels = [0.5, 1.0]
     sg = api.PointCloudGPU.clone_packed(*packed(s), ctx=ctx)
-    for reps in range(3):  # (the second and third round take pre-cleared tables from the maps the first one dropped)
+    # (the second and later rounds take pre-cleared tables from the maps the first one dropped; the switches: one launch for the pull and every
+    # level's build + one for every level's records against 1 + 2 per level; the pull kernel launched before / after the host conversion)
+    for reps, switches in enumerate(("", "", "", "frame_fused=0", "pull_gated=0", "frame_fused=0,pull_gated=0", "")):
+        ctx.set_diag("")  # (set_diag adds to the switches in force: back to the defaults first)
+        if switches:
+            ctx.set_diag(switches)
         p4, c16, n4 = packed(t)
         cloud, maps = api.frame_create(p4, c16, n4, levels, ctx=ctx)
         ref_cloud = api.PointCloudGPU.clone_packed(p4, c16, n4, ctx=ctx)
@@ -537,6 +542,7 @@ def test_frame_create_equals_the_separate_calls(api, orc, small_pair):
             x.close()
         cloud.close()
         ref_cloud.close()
+    ctx.set_diag("")
     # the other routes of the same entry point
     p4, c16, n4 = packed(t, covs=True, normals=False)
     cloud, maps = api.frame_create(p4, c16, None, levels, ctx=ctx)

@@ -68,6 +68,17 @@ def test_multi_device_python_mirror_matches_oracle(orc):
         md.set_one_rank_collective(False)
     bd = md.last_breakdown(0)
     assert bd["total"] > 0 and bd["device_gather"] >= 0 and bd["device_copy_out"] >= 0
+    # the records reach the host by a second store of the finalising kernels (default) or by copies behind the pieces: the same bytes
+    rec_mirrored = md.records().copy()
+    md.set_host_records(0)
+    md.set_factors([mids[i] for i, _ in pairs], [cids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
+    assert md.evaluate(deltas) == pytest.approx(total, rel=1e-15)
+    np.testing.assert_array_equal(md.records(), rec_mirrored)
+    md.set_host_records(1)
+    md.set_factors([mids[i] for i, _ in pairs], [cids[j] for _, j in pairs], [api.FACTOR_BINARY] * len(pairs))
+    out2, total2 = md.linearize(deltas)
+    assert total2 == total
+    np.testing.assert_array_equal(out2[3]["H_ss"], out[3]["H_ss"])
     # oracle on the same inputs (covariances as the device estimated them)
     ctx = api.Context(0, 1)
     covs = []

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
   std::vector<glim_amd_linearized6> lin((size_t)NF);
   std::vector<const glim_amd_voxelmap*> ov_maps((size_t)K);
   enum { S_CLONE_MAPS = 0, S_LIN_FIRST, S_LIN_REST, S_OVERLAP, S_RETIRE, S_COUNT };
-  std::vector<double> total, stage[S_COUNT];
+  std::vector<double> total, stage[S_COUNT], inside[7];
   double checksum = 0.0;
   const int warm = 20;
   for (int it = 0; it < warm + timed; it++) {
@@ -127,6 +127,8 @@ int main(int argc, char** argv) {
     DeviceFrame cur;
     if (make_frame(h, &cur)) return 1;
     const double t1 = now_us();
+    double fs[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (fused) (void)glim_amd_debug_frame_stages(fs, 7);
     // the 34 factors of this frame: (window + keyframes) x levels, the new frame as source
     int nf = 0;
     struct Item { const glim_amd_voxelmap* map; uint32_t flags; } items[64];
@@ -173,6 +175,7 @@ int main(int argc, char** argv) {
       stage[S_LIN_REST].push_back(iters > 1 ? (t2 - t_first) / (iters - 1) : 0.0);
       stage[S_OVERLAP].push_back(t3 - t2);
       stage[S_RETIRE].push_back(t4 - t3);
+      for (int k = 0; k < 7; k++) inside[k].push_back(fs[k]);
     }
   }
   uint64_t plans_built = 0, plans_recycled = 0;
@@ -183,9 +186,11 @@ int main(int argc, char** argv) {
          "\"frame_us\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"min\": %.2f}, "
          "\"stage_p50_us\": {\"clone_and_two_voxelmaps\": %.2f, \"first_linearisation_new_factor_list\": %.2f, \"each_further_linearisation\": %.2f, "
          "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"factor_plans_built\": %llu, \"of_them_in_the_buffers_of_an_evicted_plan\": %llu, "
-         "\"checksum\": %.6g}\n",
+         "\"inside_frame_create_p50_us_since_entry\": {\"cloud_allocated\": %.2f, \"staging_and_stream_allocations\": %.2f, \"pull_kernel_launched\": %.2f, "
+         "\"host_conversion_done\": %.2f, \"map_kernels_enqueued\": %.2f, \"completion_word_seen\": %.2f, \"return\": %.2f}, \"checksum\": %.6g}\n",
          (int)total.size(), n, NF, iters, fused, pct(total, 0.5), pct(total, 0.99), mean, pct(total, 0.0), pct(stage[S_CLONE_MAPS], 0.5), pct(stage[S_LIN_FIRST], 0.5),
-         pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), (unsigned long long)plans_built, (unsigned long long)plans_recycled, checksum);
+         pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), (unsigned long long)plans_built, (unsigned long long)plans_recycled, pct(inside[0], 0.5), pct(inside[1], 0.5), pct(inside[2], 0.5), pct(inside[3], 0.5),
+         pct(inside[4], 0.5), pct(inside[5], 0.5), pct(inside[6], 0.5), checksum);
   for (auto& d : keyframes) drop_frame(&d);
   for (auto& d : window) drop_frame(&d);
   CHECK(glim_amd_ctx_destroy(ctx));
