@@ -156,6 +156,7 @@ struct glim_amd_multi {
   std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
   std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next piece run beside it)
   std::vector<hipStream_t> ustream;  // [device]: pose uploads (the upload of the next piece runs beside the kernels of this one)
+  std::vector<hipEvent_t> sum_ev;    // [device]: "this shard's error sum is in host memory", recorded on the factor sets' stream
   std::vector<hipEvent_t> piece_ev;  // [device * MAX_PIECES + piece]: "this piece's records are written", recorded on the factor sets' stream
   std::vector<double*> h_total, h_total_dev;  // [device]: this shard's error sum, written by the device into host-mapped memory (sum_error_kernel)
   // HIP events per device around the two phases of the LAST evaluation (kernels, then what is left of collective + copy-out): glim_amd_multi_last_timing
@@ -422,6 +423,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->cstream.assign(num_devices, nullptr);
   m->ustream.assign(num_devices, nullptr);
   m->piece_ev.assign((size_t)MAX_PIECES * num_devices, nullptr);
+  m->sum_ev.assign(num_devices, nullptr);
   m->h_total.assign(num_devices, nullptr);
   m->h_total_dev.assign(num_devices, nullptr);
   int prev_device = -1;
@@ -433,6 +435,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
     if (hipStreamCreateWithFlags(&m->ustream[d], hipStreamNonBlocking) != hipSuccess) streams_ok = false;
     for (int h = 0; h < MAX_PIECES; h++)
       if (hipEventCreateWithFlags(&m->piece_ev[MAX_PIECES * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+    if (hipEventCreateWithFlags(&m->sum_ev[d], hipEventDisableTiming) != hipSuccess) streams_ok = false;
     if (pinned_malloc(&m->h_total[d], 64) != hipSuccess || hipHostGetDevicePointer(reinterpret_cast<void**>(&m->h_total_dev[d]), m->h_total[d], 0) != hipSuccess)
       streams_ok = false;
   }
@@ -504,6 +507,7 @@ int glim_amd_multi_destroy(glim_amd_multi* m) {
     if (d < (int)m->ustream.size() && m->ustream[d]) (void)hipStreamDestroy(m->ustream[d]);
     for (int h = 0; h < MAX_PIECES; h++)
       if ((size_t)(MAX_PIECES * d + h) < m->piece_ev.size() && m->piece_ev[MAX_PIECES * d + h]) (void)hipEventDestroy(m->piece_ev[MAX_PIECES * d + h]);
+    if (d < (int)m->sum_ev.size() && m->sum_ev[d]) (void)hipEventDestroy(m->sum_ev[d]);
     if (d < (int)m->h_total.size() && m->h_total[d]) (void)pinned_free(m->h_total[d]);
   }
   for (int d = 0; d < m->ndev; d++) {
@@ -703,6 +707,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       bd[BD_WAKE] = d ? us_since(t_call) : 0.0;
       int rc_d = GLIM_AMD_OK;
       hipStream_t sst = nullptr;  // the factor sets' stream
+      bool summed = false;
       const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
       auto enqueue_kernels = [&]() -> int {
         GA_HIP(hipSetDevice(m->devices[d]));
@@ -727,6 +732,19 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           GA_HIP(hipEventRecord(m->piece_ev[MAX_PIECES * d + h], last));
         }
         if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 1], last));
+        // the shard's error sum, by the device (the host would stream the whole 232-B-per-factor array through its caches for it: 190 us for
+        // 32 640 factors on the round's boxes), on the stream of the kernels whose rows it reads: it needs neither the gather nor a second stream
+        // (round 5 take 2 launched it on the collective's stream, behind a cross-stream wait: 68 us after the last kernel on one device)
+        summed = false;
+        if (total_error && !out) {
+          *m->h_total[d] = 0.0;
+          if (hi > lo) {
+            sum_error_launch(last, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->h_total_dev[d]);
+            GA_HIP(hipGetLastError());
+            GA_HIP(hipEventRecord(m->sum_ev[d], last));
+            summed = true;
+          }
+        }
         return (int)GLIM_AMD_OK;
       };
       rc_d = enqueue_kernels();
@@ -788,13 +806,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
             GA_HIP(hipMemcpyAsync(m->h_gather + start + (size_t)d * slot, region + (size_t)d * slot, (size_t)own * COMPACT * sizeof(double),
                                   hipMemcpyDeviceToHost, cst));
         }
-        // the shard's error sum, by the device (the host would stream the whole 232-B-per-factor array through its caches for it: 190 us for
-        // 32 640 factors on the round's boxes)
-        if (total_error && !out) {
-          *m->h_total[d] = 0.0;
-          if (hi > lo) sum_error_launch(cst, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->h_total_dev[d]);
-          GA_HIP(hipGetLastError());
-        }
+        if (summed) GA_HIP(hipStreamWaitEvent(cst, m->sum_ev[d], 0));
         if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 3], cst));
         return (int)GLIM_AMD_OK;
       };
