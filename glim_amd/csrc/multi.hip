@@ -156,6 +156,7 @@ struct glim_amd_multi {
   std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
   std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next piece run beside it)
   std::vector<hipStream_t> ustream;  // [device]: pose uploads (the upload of the next piece runs beside the kernels of this one)
+  std::vector<double*> d_sum_scratch;  // [device]: the blocks' partial sums + the arrival counter of sum_error_kernel
   std::vector<hipEvent_t> sum_ev;    // [device]: "this shard's error sum is in host memory", recorded on the factor sets' stream
   std::vector<hipEvent_t> piece_ev;  // [device * MAX_PIECES + piece]: "this piece's records are written", recorded on the factor sets' stream
   std::vector<double*> h_total, h_total_dev;  // [device]: this shard's error sum, written by the device into host-mapped memory (sum_error_kernel)
@@ -261,39 +262,52 @@ void abort_collectives(glim_amd_multi* m) {
 }
 
 
-// error sum of device d's own rows of the gathered array (column 1 of the 29-double records), fixed order: thread t of ONE 1024-thread block adds
-// rows t, t + 1024, ... in FP64 -- eight independent loads in flight at a time: the first version, a 256-thread dependent chain of 128 uncached
-// loads, took 0.2 ms for 32 640 rows -- and the 1024 partial sums are added in a fixed tree: bit-reproducible.
-__global__ __launch_bounds__(1024) void sum_error_kernel(const double* __restrict__ gathered, int d, long long own_rows, long long piece_rows, long long max_rows,
-                                                         int ndev, double* __restrict__ host_total) {
-  __shared__ double s_part[1024];
+// error sum of device d's own rows of the gathered array (column 1 of the 29-double records), bit-reproducible: thread g of the grid adds rows
+// g, g + G, ... in FP64 (G = threads of the grid: ONE row each for configs[3]'s 32 640), a block adds its 256 values in a fixed tree, and the block
+// that arrives last at the counter adds the blocks' sums in block order.  Many blocks because the rows are 232 B apart -- every load its own cache
+// line, and ONE compute unit pulls lines at ~100 GB/s: the one-block form of the earlier takes (1 024 threads, eight loads in flight) kept the
+// stream busy for 70 us behind the last kernel, the first version (a 256-thread dependent chain) for 0.2 ms.
+constexpr int SUM_BLOCKS_MAX = 128;
+__global__ __launch_bounds__(256) void sum_error_kernel(const double* __restrict__ gathered, int d, long long own_rows, long long piece_rows, long long max_rows,
+                                                        int ndev, double* __restrict__ partials, unsigned int* __restrict__ counter, double* __restrict__ host_total) {
+  __shared__ double s_part[256];
+  __shared__ int s_last;
   double acc = 0.0;
-  for (long long k0 = threadIdx.x; k0 < own_rows; k0 += 8 * 1024) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const long long k = k0 + (long long)u * 1024;
-      v[u] = 0.0;
-      if (k < own_rows) {
-        const long long p = k / piece_rows;
-        const long long rows_p = min(piece_rows, max_rows - p * piece_rows);
-        const long long row = (long long)ndev * p * piece_rows + (long long)d * rows_p + (k - p * piece_rows);
-        v[u] = gathered[(size_t)row * COMPACT + 1];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) acc += v[u];
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < own_rows; k += (long long)gridDim.x * 256) {
+    const long long p = k / piece_rows;
+    const long long rows_p = min(piece_rows, max_rows - p * piece_rows);
+    const long long row = (long long)ndev * p * piece_rows + (long long)d * rows_p + (k - p * piece_rows);
+    acc += gathered[(size_t)row * COMPACT + 1];
   }
   s_part[threadIdx.x] = acc;
   __syncthreads();
-  for (int w = 512; w >= 1; w >>= 1) {
+  for (int w = 128; w >= 1; w >>= 1) {
     if ((int)threadIdx.x < w) s_part[threadIdx.x] += s_part[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) __hip_atomic_store(host_total, s_part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], s_part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  s_part[threadIdx.x] = (threadIdx.x < gridDim.x) ? __hip_atomic_load(&partials[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) s_part[threadIdx.x] += s_part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next evaluation's launch comes behind this one on the stream)
+    __hip_atomic_store(host_total, s_part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
-void sum_error_launch(hipStream_t st, const double* gathered, int d, int64_t own_rows, int64_t piece_rows, int64_t max_rows, int ndev, double* host_total) {
-  sum_error_kernel<<<1, 1024, 0, st>>>(gathered, d, (long long)own_rows, (long long)piece_rows, (long long)max_rows, ndev, host_total);
+// scratch: SUM_BLOCKS_MAX doubles, then the arrival counter (zero between launches)
+void sum_error_launch(hipStream_t st, const double* gathered, int d, int64_t own_rows, int64_t piece_rows, int64_t max_rows, int ndev, double* scratch, double* host_total) {
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(SUM_BLOCKS_MAX, (own_rows + 255) / 256));
+  sum_error_kernel<<<blocks, 256, 0, st>>>(gathered, d, (long long)own_rows, (long long)piece_rows, (long long)max_rows, ndev, scratch,
+                                           reinterpret_cast<unsigned int*>(scratch + SUM_BLOCKS_MAX), host_total);
 }
 
 }  // namespace
@@ -424,6 +438,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->ustream.assign(num_devices, nullptr);
   m->piece_ev.assign((size_t)MAX_PIECES * num_devices, nullptr);
   m->sum_ev.assign(num_devices, nullptr);
+  m->d_sum_scratch.assign(num_devices, nullptr);
   m->h_total.assign(num_devices, nullptr);
   m->h_total_dev.assign(num_devices, nullptr);
   int prev_device = -1;
@@ -436,6 +451,9 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
     for (int h = 0; h < MAX_PIECES; h++)
       if (hipEventCreateWithFlags(&m->piece_ev[MAX_PIECES * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
     if (hipEventCreateWithFlags(&m->sum_ev[d], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+    if (hipMalloc(reinterpret_cast<void**>(&m->d_sum_scratch[d]), (SUM_BLOCKS_MAX + 1) * sizeof(double)) != hipSuccess ||
+        hipMemset(m->d_sum_scratch[d], 0, (SUM_BLOCKS_MAX + 1) * sizeof(double)) != hipSuccess)
+      streams_ok = false;
     if (pinned_malloc(&m->h_total[d], 64) != hipSuccess || hipHostGetDevicePointer(reinterpret_cast<void**>(&m->h_total_dev[d]), m->h_total[d], 0) != hipSuccess)
       streams_ok = false;
   }
@@ -508,6 +526,7 @@ int glim_amd_multi_destroy(glim_amd_multi* m) {
     for (int h = 0; h < MAX_PIECES; h++)
       if ((size_t)(MAX_PIECES * d + h) < m->piece_ev.size() && m->piece_ev[MAX_PIECES * d + h]) (void)hipEventDestroy(m->piece_ev[MAX_PIECES * d + h]);
     if (d < (int)m->sum_ev.size() && m->sum_ev[d]) (void)hipEventDestroy(m->sum_ev[d]);
+    if (d < (int)m->d_sum_scratch.size() && m->d_sum_scratch[d]) (void)hipFree(m->d_sum_scratch[d]);
     if (d < (int)m->h_total.size() && m->h_total[d]) (void)pinned_free(m->h_total[d]);
   }
   for (int d = 0; d < m->ndev; d++) {
@@ -739,7 +758,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
         if (total_error && !out) {
           *m->h_total[d] = 0.0;
           if (hi > lo) {
-            sum_error_launch(last, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->h_total_dev[d]);
+            sum_error_launch(last, m->d_gather[d], d, hi - lo, m->piece_rows, m->max_rows, ndev, m->d_sum_scratch[d], m->h_total_dev[d]);
             GA_HIP(hipGetLastError());
             GA_HIP(hipEventRecord(m->sum_ev[d], last));
             summed = true;

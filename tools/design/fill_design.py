@@ -19,7 +19,19 @@ st=one['stage_p50_us']
 sw=n['pieces_sweep']
 f=lambda x,nd=2: f"{x:.{nd}f}"
 sp=lambda x: f"{int(round(x)):,}".replace(',',' ')
+nat_alone=json.load(open(d+'bench_global256_native.json'))['native']
+cop=n.get('with_device_to_host_copies_behind_the_pieces',{}); onerank=n.get('with_the_one_rank_library_call_every_evaluation',{})
+take2=ll['one_submission_as_round5_take2']; nofused=ll['one_submission_without_fused_frame_kernels']; nogate=ll['one_submission_without_gated_pull']; norec=ll['one_submission_without_plan_recycling']
+fc=one['inside_frame_create_p50_us_since_entry']
 vals={
+ 'NATIVE_COPIES': f(cop['ms_per_evaluation'],2), 'NATIVE_COPIES_DELTA': f"{cop['ms_per_evaluation']-n['ms_per_evaluation']:.2f}", 'NATIVE_COPIES_AFTER': f(cop['collective_and_copy_out_after_the_kernels_ms'][0]*1e3,0),
+ 'NATIVE_AFTER': f(n['per_device'][0]['collective_and_copy_out_after_the_kernels_ms']*1e3,0), 'NATIVE_KERNELS': f(n['per_device'][0]['kernels_ms'],2),
+ 'NATIVE_MINUS_M2': f"{n['ms_per_evaluation']-m2['ms_per_step']:+.2f}", 'ONE_RANK_HOST': f(onerank['library_calls_host_us'],1),
+ 'FRAME_TAKE2': f(take2['frame_us']['p50'],0), 'FRAME_NOFUSED': f(nofused['frame_us']['p50'],0), 'FRAME_NOGATE': f(nogate['frame_us']['p50'],0), 'FRAME_NORECYCLE': f(norec['frame_us']['p50'],0),
+ 'LIN_FIRST': f(st['first_linearisation_new_factor_list'],0), 'LIN_FIRST_NORECYCLE': f(norec['stage_p50_us']['first_linearisation_new_factor_list'],0),
+ 'PLANS_BUILT': str(one['factor_plans_built']), 'PLANS_RECYCLED': str(one['of_them_in_the_buffers_of_an_evicted_plan']),
+ 'FC_LAUNCHED': f(fc['pull_kernel_launched'],1), 'FC_PACKED': f(fc['host_conversion_done'],1), 'FC_SEEN': f(fc['completion_word_seen'],1), 'FC_TAIL': f(fc['completion_word_seen']-fc['host_conversion_done'],0),
+ 'FC_PACK_US': f(fc['host_conversion_done']-fc['pull_kernel_launched'],0),
  'ACHIEVED': f(r['achieved']/1000,2), 'ALGO_RATIO': f(r['algorithmic_48B_ratio_to_peak'],2), 'BATCHED': f(b['batched_calls_per_s']/1e6,2),
  'BOUND2': f(src['2']['compute_only_speedup_bound'],2), 'BOUND4': f(src['4']['compute_only_speedup_bound'],2), 'BOUND8': f(src['8']['compute_only_speedup_bound'],2),
  'BOUNDT8': f(tgt['8']['compute_only_speedup_bound'],2), 'BSPEEDUP': sp(b['batched_speedup_vs_cpu_baseline']), 'CPU': sp(cb['value']),
