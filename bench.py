@@ -1396,6 +1396,9 @@ def run_frontend128k(args, D, api, ctx):
     dk = dict(imu_times=imu_times, imu_poses=imu_poses, stamp=stamp, to_imu_frame=True)
     n_frames = args.frames
     prev_map, prev_pose, lat, kept, stage = None, None, [], [], np.zeros(5)
+    fine = [] if os.environ.get("BENCH_FRONTEND_FINE") else None
+    fine_prev, fine_destroy = [None, None], []
+    fs = None
     D.barrier_sync()
     t_all = time.perf_counter()
     for fidx in range(n_frames + 3):
@@ -1414,9 +1417,28 @@ def run_frontend128k(args, D, api, ctx):
         vm = api.GaussianVoxelMapGPU(args.resolution, ctx=ctx).insert(g)
         t4 = time.perf_counter()
         if prev_map is not None:
-            fs = api.NonlinearFactorSetGPU(ctx)
-            fs.add(api.IntegratedVGICPFactorGPU(prev_pose, 1, prev_map, g))
-            fs.linearize({1: T})
+            if fine is not None:  # BENCH_FRONTEND_FINE=1: where the linearise stage's time goes, call by call (diagnostic)
+                ta = time.perf_counter()
+                fs = None  # (the previous set, and with it the previous frame's cloud and the map before it, are released HERE)
+                ta1 = time.perf_counter()
+                if fine_prev[0] is not None:
+                    fine_prev[0].close()
+                ta2 = time.perf_counter()
+                if fine_prev[1] is not None:
+                    fine_prev[1].close()
+                ta3 = time.perf_counter()
+                fine_prev[0], fine_prev[1] = g, prev_map
+                fine_destroy.append((fidx, (ta1 - ta) * 1e6, (ta2 - ta1) * 1e6, (ta3 - ta2) * 1e6))
+                tb = time.perf_counter()
+                fs = api.NonlinearFactorSetGPU(ctx)
+                fs.add(api.IntegratedVGICPFactorGPU(prev_pose, 1, prev_map, g))
+                tc = time.perf_counter()
+                fs.linearize({1: T})
+                fine.append((fidx, (tb - ta) * 1e6, (tc - tb) * 1e6, (time.perf_counter() - tc) * 1e6))
+            else:
+                fs = api.NonlinearFactorSetGPU(ctx)
+                fs.add(api.IntegratedVGICPFactorGPU(prev_pose, 1, prev_map, g))
+                fs.linearize({1: T})
         t5 = time.perf_counter()
         prev_map, prev_pose = vm, T
         lat.append(t5 - t0)
@@ -1424,6 +1446,16 @@ def run_frontend128k(args, D, api, ctx):
         kept.append(g.size())
     D.torch.cuda.synchronize()
     total = time.perf_counter() - t_all
+    if fine:
+        arr = np.array(fine)
+        sys.stderr.write("linearise stage, us: release of the previous set / new set + add / linearize: mean %s, p50 %s, max %s\n" %
+                         (arr[:, 1:].mean(0).round(1), np.percentile(arr[:, 1:], 50, axis=0).round(1), arr[:, 1:].max(0).round(1)))
+        dd = np.array(fine_destroy)[3:]
+        sys.stderr.write("release, us: set / previous cloud / previous-previous map: mean %s, p50 %s, p99 %s, max %s\n" %
+                         (dd[:, 1:].mean(0).round(1), np.percentile(dd[:, 1:], 50, axis=0).round(1), np.percentile(dd[:, 1:], 99, axis=0).round(1), dd[:, 1:].max(0).round(1)))
+        sys.stderr.write("slowest releases: %s\n" % dd[np.argsort(-dd[:, 1:].sum(1))[:10]].round(1).tolist())
+        worst = arr[np.argsort(-arr[:, 1:].sum(1))[:12]]
+        sys.stderr.write("slowest frames (index, release, new set, linearize): %s\n" % worst.round(1).tolist())
     lat = np.array(lat) * 1e3
     result = {
         "metric": "lidar_frontend_frames_per_s", "value": n_frames / total, "unit": "frames/s", "n_gpus": 1, "steps": n_frames, "warmup": 3,
