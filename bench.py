@@ -703,6 +703,7 @@ def live_odometry_loop(api, host, poses, c32_of, frames, K, WIN, res0, iters, ti
             for name, fused, diag in (("separate_calls", 0, ""), ("one_submission_create_frame", 1, ""),
                                       ("one_submission_as_round5_take2", 1, "frame_fused=0,pull_gated=0,plan_recycle=0"),
                                       ("one_submission_without_fused_frame_kernels", 1, "frame_fused=0"),
+                                      ("one_submission_without_fused_frame_kernels_and_gated_pull", 1, "frame_fused=0,pull_gated=0"),
                                       ("one_submission_without_gated_pull", 1, "pull_gated=0"), ("one_submission_without_plan_recycling", 1, "plan_recycle=0")):
                 res = subprocess.run([exe, scene, str(timed), str(iters), str(fused), diag], capture_output=True, text=True, timeout=300)
                 out[name] = json.loads(res.stdout.strip().splitlines()[-1]) if res.returncode == 0 and res.stdout.strip() else {"error": (res.stderr or res.stdout)[-400:]}

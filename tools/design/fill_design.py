@@ -27,6 +27,7 @@ vals={
  'NATIVE_COPIES': f(cop['ms_per_evaluation'],2), 'NATIVE_COPIES_DELTA': f"{cop['ms_per_evaluation']-n['ms_per_evaluation']:.2f}", 'NATIVE_COPIES_AFTER': f(cop['collective_and_copy_out_after_the_kernels_ms'][0]*1e3,0),
  'NATIVE_AFTER': f(n['per_device'][0]['collective_and_copy_out_after_the_kernels_ms']*1e3,0), 'NATIVE_KERNELS': f(n['per_device'][0]['kernels_ms'],2),
  'NATIVE_MINUS_M2': f"{n['ms_per_evaluation']-m2['ms_per_step']:+.2f}", 'ONE_RANK_HOST': f(onerank['library_calls_host_us'],1),
+ 'FRAME_NOFUSED_NOGATE': f(ll['one_submission_without_fused_frame_kernels_and_gated_pull']['frame_us']['p50'],0),
  'FRAME_TAKE2': f(take2['frame_us']['p50'],0), 'FRAME_NOFUSED': f(nofused['frame_us']['p50'],0), 'FRAME_NOGATE': f(nogate['frame_us']['p50'],0), 'FRAME_NORECYCLE': f(norec['frame_us']['p50'],0),
  'LIN_FIRST': f(st['first_linearisation_new_factor_list'],0), 'LIN_FIRST_NORECYCLE': f(norec['stage_p50_us']['first_linearisation_new_factor_list'],0),
  'PLANS_BUILT': str(one['factor_plans_built']), 'PLANS_RECYCLED': str(one['of_them_in_the_buffers_of_an_evicted_plan']),
