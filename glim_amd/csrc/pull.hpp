@@ -67,7 +67,10 @@ __device__ __forceinline__ bool pull_point(const PullArgs& pa, int i, float4& p,
 
 // (one lane per wavefront that saw a point off the form)
 __device__ __forceinline__ void pull_report(const PullArgs& pa, bool bad) {
-  if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(pa.host_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (__any(bad) && (threadIdx.x & 63) == 0) {
+    __hip_atomic_store(pa.host_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();  // (visible before anything this block publishes later: frame_build_kernel's arrival)
+  }
 }
 
 }  // namespace glim_amd

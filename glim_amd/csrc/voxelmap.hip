@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void init_buckets_kernel(VoxelBucket* __restri
 __global__ __launch_bounds__(256) void init_tables_kernel(VoxelBucket* __restrict__ buckets, unsigned int n, uint4* __restrict__ acc16, size_t acc_words,
                                                           int* __restrict__ stats) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) stats[0] = stats[1] = 0;
+  if (i == 0) stats[0] = stats[1] = stats[2] = stats[3] = 0;  // ([2]: arrival counter of frame_build_kernel's blocks; every stats block holds 4 ints)
   if (i < (size_t)n * 8) {
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if ((i & 7) == 0) v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // key[0] = key[1] = EMPTY_KEY
@@ -279,10 +279,10 @@ struct FrameLevels {
   int* stats[FRAME_MAX_LEVELS];
   unsigned int nb[FRAME_MAX_LEVELS];
 };
-__global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, const FrameLevels lv) {
+__global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, const FrameLevels lv, int* __restrict__ host_view, unsigned int poll_seq) {
   __shared__ BuildLds L;
   __shared__ int s_ok;
-  if (!pull_wait(pa, &s_ok)) return;
+  if (!pull_wait(pa, &s_ok)) return;  // (gave up: no arrival either -- the completion word is never written, the host falls back to a synchronise)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f), a = p, v = p;
   float2 b = make_float2(0.f, 0.f);
@@ -292,6 +292,23 @@ __global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, con
   for (int k = 0; k < lv.count; k++) {
     build_block(L, i < pa.n, p, a, b, lv.inv_res[k], lv.buckets[k], lv.nb[k], lv.acc[k], lv.stats[k]);
     __syncthreads();  // (the next level re-initialises the LDS table)
+  }
+  // The block that arrives LAST hands the host what it waits for -- every level's voxel count and range flag, then the completion word
+  // (system-scope release) -- instead of the first thread of the records kernel behind this one: the counts are final when every block has
+  // added its share, and a dependent launch starts ~8 us after its predecessor ends.  (Every block's counter updates, and its report of a
+  // point off the plane form, are ordered before its arrival by the fence; the arrival counter is left at zero for the table's next life.)
+  if (poll_seq && threadIdx.x == 0) {
+    __threadfence_system();
+    int* counter = lv.stats[0] + 2;
+    const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (int)gridDim.x - 1) {
+      for (int j = 0; j < lv.count; j++) {
+        host_view[4 * j] = __hip_atomic_load(lv.stats[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        host_view[4 * j + 1] = __hip_atomic_load(lv.stats[j] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned int*>(host_view) + 4 * (lv.count - 1) + 2, poll_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(VoxelBucket* __restrict__
 __global__ __launch_bounds__(256) void frame_finalize_kernel(const FrameLevels lv, int* __restrict__ host_view, unsigned int poll_seq) {
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = (int)blockIdx.y;
-  if (i == 0 && k == 0) {
+  if (i == 0 && k == 0 && host_view) {  // (null: the build kernel's last block has written them, and the completion word)
     for (int j = 0; j < lv.count; j++) {
       host_view[4 * j] = lv.stats[j][0];
       host_view[4 * j + 1] = lv.stats[j][1];
@@ -504,6 +521,46 @@ unsigned int next_pow2(unsigned long long v) {
 // when a frame leaves its window) in tables of a few recurring sizes (round_buckets), so a table that a destroyed map hands back is cleared on a
 // side stream at once, together with a matching block of accumulators and counters, and kept for the next map of that size: its build then
 // starts with the keys.  The host takes a table only after it has SEEN the clearing kernel's event complete.
+// Events without timing, recycled per device: a frame of the odometry makes and drops four of them (two maps' ready events, two cleared tables'),
+// and create + destroy are runtime calls of about a microsecond each.  An event goes back only when its last record has been seen complete or no
+// longer matters (a later record replaces it; a wait already enqueued keeps the record it was given).
+struct EventPool {
+  std::mutex mu;
+  std::vector<hipEvent_t> free_events[16];
+};
+EventPool& event_pool() {
+  static EventPool* pool = new EventPool();  // leaked on purpose, like the memory pools
+  return *pool;
+}
+hipError_t event_get(hipEvent_t* e) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    EventPool& P = event_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (!P.free_events[dev].empty()) {
+      *e = P.free_events[dev].back();
+      P.free_events[dev].pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+void event_put(hipEvent_t e) {
+  if (!e) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    EventPool& P = event_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (P.free_events[dev].size() < 64) {
+      P.free_events[dev].push_back(e);
+      return;
+    }
+  }
+  (void)hipEventDestroy(e);
+}
+
 struct ClearedTable {
   VoxelBucket* buckets = nullptr;
   long long* acc = nullptr;
@@ -544,14 +601,14 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
     }
     for (ClearedTable& old : evicted) {
       (void)hipEventSynchronize(old.done);  // (its clearing kernel was enqueued at least a cache's worth of maps ago)
-      (void)hipEventDestroy(old.done);
+      event_put(old.done);
       (void)pool_free(old.buckets);
       (void)pool_free(old.acc);
       (void)pool_free(old.stats);
     }
   }
-  if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 2 * sizeof(int)) == hipSuccess &&
-                   hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+  if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 4 * sizeof(int)) == hipSuccess &&
+                   event_get(&t.done) == hipSuccess;
   if (keep) {
     const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
     init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, C.stream>>>(buckets, nb, (uint4*)t.acc, acc_words, t.stats);
@@ -562,7 +619,7 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
     (void)hipGetLastError();
     if (t.acc) (void)pool_free(t.acc);
     if (t.stats) (void)pool_free(t.stats);
-    if (t.done) (void)hipEventDestroy(t.done);
+    if (t.done) event_put(t.done);
     (void)pool_free(buckets);
     return;
   }
@@ -582,7 +639,7 @@ bool take_cleared_table(int device, unsigned int nb, ClearedTable* out) {
     *out = C.tables[i];
     C.tables.erase(C.tables.begin() + (long)i);
     C.bytes -= cleared_bytes(nb);
-    (void)hipEventDestroy(out->done);
+    event_put(out->done);
     out->done = nullptr;
     return true;
   }
@@ -706,7 +763,7 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   (void)voxelmap_wait_ready(m, nullptr);  // (a build the host has not seen complete: its last kernel may still be writing the table)
   if (m->pending_acc) (void)pool_free(m->pending_acc);
   if (m->pending_stats) (void)pool_free(m->pending_stats);
-  if (m->ready_event) (void)hipEventDestroy(m->ready_event);
+  if (m->ready_event) event_put(m->ready_event);  // (voxelmap_wait_ready above has seen it complete)
   if (m->buckets_sm) (void)pool_free(m->buckets_sm);
   if (m->buckets) {
     if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
@@ -764,7 +821,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
       acc.p = cleared.acc;
       stats.p = cleared.stats;
     } else {
-      GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
+      GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
       GA_HIP(pool_malloc(&acc.p, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)));
       GA_HIP(pool_malloc(&buckets, (size_t)nb * sizeof(VoxelBucket)));
     }
@@ -784,7 +841,7 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     // The host needs the voxel count (the reference's insert returns it through voxelmap_info) and nothing else from this build: the last kernel
     // hands it over when it STARTS (word 2 of the mapped scratch = this build's sequence number) and the call returns while that kernel writes
     // the records; readers on other streams wait for `ready_event` (voxelmap_wait_ready).  40-45 -> 3x us per 131 072-pt map.
-    const bool polled = mapped && (m->ready_event || hipEventCreateWithFlags(&m->ready_event, hipEventDisableTiming) == hipSuccess);
+    const bool polled = mapped && (m->ready_event || event_get(&m->ready_event) == hipSuccess);
     const unsigned int seq = polled ? (++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq) : 0u;
     finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr, view,
                                                                  nullptr, 0, seq);
@@ -854,8 +911,8 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   const unsigned int tsize0 = next_pow2((unsigned long long)std::max<long long>(32, (long long)n + (old ? (long long)m->num_voxels : 0ll)) * 2);
   GA_HIP(pool_malloc(&tkeys.p, (size_t)tsize0 * sizeof(unsigned long long)));
   GA_HIP(pool_malloc(&pkeys.p, (size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
-  GA_HIP(pool_malloc(&stats.p, 2 * sizeof(int)));
-  GA_HIP(hipMemsetAsync(stats.p, 0, 2 * sizeof(int), st));
+  GA_HIP(pool_malloc(&stats.p, 4 * sizeof(int)));
+  GA_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(int), st));
   fill_u64_kernel<<<1024, 256, 0, st>>>((unsigned long long*)tkeys.p, tsize0, EMPTY_KEY);
   GA_HIP(hipGetLastError());
   if (n > 0) {
@@ -1007,7 +1064,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
         B.acc = cleared.acc;
         B.stats = cleared.stats;
       } else {
-        e = pool_malloc(&B.stats, 2 * sizeof(int));
+        e = pool_malloc(&B.stats, 4 * sizeof(int));
         if (e == hipSuccess) e = pool_malloc(&B.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long));
         if (e == hipSuccess) e = pool_malloc(&B.buckets, (size_t)nb * sizeof(VoxelBucket));
       }
@@ -1042,7 +1099,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       // pull kernel's plane-form verdict, the earlier levels' counts -- is complete and visible by then); it may still be writing its own
       // records when this call returns, which is what ready_event is for (voxelmap_wait_ready)
       const bool last = lv == num_levels - 1;
-      if (last && hipEventCreateWithFlags(&B.m->ready_event, hipEventDisableTiming) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
+      if (last && event_get(&B.m->ready_event) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
       finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(B.buckets, nb, (const long long*)B.acc, B.m->resolution, (const int*)B.stats, d_view + 4 * lv, B.view,
                                                                    nullptr, 0, last ? poll_seq : 0u);
       e = hipGetLastError();
@@ -1055,17 +1112,21 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     if (fused && enqueued) {
       bool launched = false;
       if (rc == GLIM_AMD_OK) {
-        glim_amd_voxelmap* last_map = b[num_levels - 1].m;
-        frame_build_kernel<<<((int)n + 255) / 256, 256, 0, st>>>(up.args, FL);
+        // The completion word is written by the LAST block of the build kernel: the records kernel behind it only has to be enqueued, and the
+        // host returns before it has started.  EVERY level's table is therefore still being written when this call returns: every map gets its
+        // ready event (readers on other streams wait for it: voxelmap_wait_ready) and keeps its accumulators until that event has been seen.
+        bool events = true;
+        for (int lv = 0; lv < num_levels && events; lv++) events = event_get(&b[lv].m->ready_event) == hipSuccess;
+        if (events) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
+        frame_build_kernel<<<((int)n + 255) / 256, 256, 0, st>>>(up.args, FL, d_view, poll_seq);
         hipError_t e = hipGetLastError();
         launched = e == hipSuccess;
         frame_stamp(2);
-        if (e == hipSuccess && hipEventCreateWithFlags(&last_map->ready_event, hipEventDisableTiming) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
         if (e == hipSuccess) {
-          frame_finalize_kernel<<<dim3((2 * (nb + 1) + 255) / 256, (unsigned int)num_levels), 256, 0, st>>>(FL, d_view, poll_seq);
+          frame_finalize_kernel<<<dim3((2 * (nb + 1) + 255) / 256, (unsigned int)num_levels), 256, 0, st>>>(FL, poll_seq ? nullptr : d_view, 0u);
           e = hipGetLastError();
         }
-        if (e == hipSuccess && poll_seq) e = hipEventRecord(last_map->ready_event, st);
+        for (int lv = 0; lv < num_levels && e == hipSuccess && poll_seq; lv++) e = hipEventRecord(b[lv].m->ready_event, st);
         if (e != hipSuccess) {
           set_hip_error(e, "glim_amd_frame_create");
           rc = GLIM_AMD_ERR_HIP;
@@ -1103,7 +1164,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     }
     for (int lv = 0; lv < num_levels; lv++) {
       Build& B = b[lv];
-      if (running && lv == num_levels - 1) {  // its records kernel may still be reading the accumulators: they stay with the map until the event has been seen
+      if (running && (fused || lv == num_levels - 1)) {  // its records kernel may still be reading the accumulators: they stay with the map until the event has been seen
         B.m->pending_acc = B.acc;
         B.m->pending_stats = B.stats;
         B.m->ready_pending.store(true, std::memory_order_release);
@@ -1135,7 +1196,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       if (B.buckets) (void)pool_free(B.buckets);
       if (B.view) (void)pool_free(B.view);
       if (B.m) {
-        if (B.m->ready_event) (void)hipEventDestroy(B.m->ready_event);
+        if (B.m->ready_event) event_put(B.m->ready_event);  // (every path that gets here has synchronised the stream)
         B.m->ctx = nullptr;
         delete B.m;
       }

@@ -248,3 +248,67 @@ def test_a_map_is_usable_the_moment_insert_returns(small_pair):
     a.synchronize()
     both.insert(sg)
     assert vm.voxelmap_info() == both.voxelmap_info()
+
+
+@pytest.mark.gpu
+def test_a_frames_maps_are_usable_the_moment_frame_create_returns(small_pair):
+    """glim_amd_frame_create returns when the LAST block of its build kernel has handed over the voxel counts -- the kernel that writes EVERY level's
+    records is only enqueued by then.  Whoever reads one of the frame's maps next (a factor set on another stream of the context or of another
+    context, an overlap query, a download, the destructor), and whoever re-uses the memory of its accumulators, must wait for that kernel on its
+    own: 60 rounds of create-then-use-at-once, both levels, against the same maps used after a context synchronise."""
+    from glim_amd import api
+
+    t, s, T = small_pair["target"], small_pair["source"], small_pair["delta"]
+    a, b = api.Context(0, 4, priority=1), api.Context(0, 2)
+    n = len(t["points"])
+    p4 = np.ones((n, 4))
+    p4[:, :3] = t["points"][:, :3]
+    m44 = np.zeros((n, 4, 4))
+    m44[:, :3, :3] = t["covs"][:, :3, :3]
+    c16 = np.ascontiguousarray(np.transpose(m44, (0, 2, 1))).reshape(n, 16)
+    n4 = np.zeros((n, 4))
+    n4[:, :3] = t["normals"][:, :3]
+    reps = -(-20000 // n)  # (a frame of ~20 000 points: the records kernel has 2 x 80 000 slots to write)
+    p4, c16, n4 = np.tile(p4, (reps, 1)), np.tile(c16, (reps, 1)), np.tile(n4, (reps, 1))
+    sg = api.PointCloudGPU.clone(s["points"].astype(np.float64), s["covs"], s["normals"], ctx=b)
+    values = {0: np.eye(4), 1: T}
+    levels = [0.5, 1.0]
+
+    def use(vm, ctx):
+        fs = api.NonlinearFactorSetGPU(ctx)
+        fs.add(api.IntegratedVGICPFactorGPU(0, 1, vm, sg))
+        out = fs.linearize(values)[0]
+        fs.close()
+        return out
+
+    cloud, maps = api.frame_create(p4, c16, n4, levels, ctx=a)
+    a.synchronize()
+    want = [use(m, a) for m in maps]
+    want_ov = [api.overlap_gpu([m], sg, [T], ctx=b) for m in maps]
+    want_info = [m.voxelmap_info() for m in maps]
+    assert all(w["num_inliers"] > 100 for w in want)
+    for m in maps:
+        m.close()
+    cloud.close()
+    for rep in range(60):
+        cloud, maps = api.frame_create(p4, c16, n4, levels, ctx=a)
+        lv = rep % 2
+        kind = (rep // 2) % 4
+        assert maps[lv].voxelmap_info() == want_info[lv]
+        if kind == 0:
+            used, got = lv, use(maps[lv], a)          # another stream of the frame's own context (round robin)
+        elif kind == 1:
+            used, got = lv, use(maps[lv], b)          # another context
+        elif kind == 2:
+            assert api.overlap_gpu([maps[lv]], sg, [T], ctx=b) == want_ov[lv]
+            used, got = 1 - lv, use(maps[1 - lv], b)
+        else:
+            assert len(maps[lv].voxels()[0]) == want_info[lv]["num_voxels"]  # download right behind the create
+            used, got = 1 - lv, use(maps[1 - lv], a)
+        ref = want[used]
+        assert got["num_inliers"] == ref["num_inliers"] and got["error"] == ref["error"], (rep, kind)
+        np.testing.assert_array_equal(got["H_ss"], ref["H_ss"])
+        for m in maps:
+            m.close()                   # (the destructor right behind a use; its accumulators go back to the pool only when the records kernel is done)
+        cloud.close()
+    sg.close()

@@ -32,6 +32,7 @@ vals={
  'LIN_FIRST': f(st['first_linearisation_new_factor_list'],0), 'LIN_FIRST_NORECYCLE': f(norec['stage_p50_us']['first_linearisation_new_factor_list'],0),
  'PLANS_BUILT': str(one['factor_plans_built']), 'PLANS_RECYCLED': str(one['of_them_in_the_buffers_of_an_evicted_plan']),
  'FC_LAUNCHED': f(fc['pull_kernel_launched'],1), 'FC_PACKED': f(fc['host_conversion_done'],1), 'FC_SEEN': f(fc['completion_word_seen'],1), 'FC_TAIL': f(fc['completion_word_seen']-fc['host_conversion_done'],0),
+ 'FC_TAIL_BEFORE': '29',
  'FC_PACK_US': f(fc['host_conversion_done']-fc['pull_kernel_launched'],0),
  'ACHIEVED': f(r['achieved']/1000,2), 'ALGO_RATIO': f(r['algorithmic_48B_ratio_to_peak'],2), 'BATCHED': f(b['batched_calls_per_s']/1e6,2),
  'BOUND2': f(src['2']['compute_only_speedup_bound'],2), 'BOUND4': f(src['4']['compute_only_speedup_bound'],2), 'BOUND8': f(src['8']['compute_only_speedup_bound'],2),
