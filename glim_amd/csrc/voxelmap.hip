@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, con
   }
   // The block that arrives LAST hands the host what it waits for -- every level's voxel count and range flag, then the completion word
   // (system-scope release) -- instead of the first thread of the records kernel behind this one: the counts are final when every block has
-  // added its share, and a dependent launch starts ~8 us after its predecessor ends.  (Every block's counter updates, and its report of a
+  // added its share, and the host need not wait for a dependent launch to start (2 us of a 10 000-pt frame).  (Every block's counter updates, and its report of a
   // point off the plane form, are ordered before its arrival by the fence; the arrival counter is left at zero for the table's next life.)
   if (poll_seq && threadIdx.x == 0) {
     __threadfence_system();
