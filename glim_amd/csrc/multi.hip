@@ -700,9 +700,12 @@ int glim_amd_multi_shard(const glim_amd_multi* m, int64_t* bounds) {
 //   for every piece p of its shard: poses -> pinned ring -> H2D, kernels, event p          (the factor sets' stream; the pose staging of
 //                                                                                          piece p + 1 overlaps the kernels of piece p)
 //   host barrier: has EVERY device enqueued its kernels?                                   (a device that failed must keep the others out of the collective)
-//   for every piece p, behind event p: ncclAllGather of the p-th pieces over xGMI, then THIS device's own rows to the host   (the collective's
-//                                                                                          stream: every device copies out over its own PCIe link)
-//   the shard's error sum, by the device, into host-mapped memory; one synchronise.
+//   the shard's error sum, by the device, into host-mapped memory                           (the same stream, behind the last piece)
+//   for every piece p, behind event p: ncclAllGather of the p-th pieces over xGMI          (the collective's stream; a device's OWN rows reach the
+//                                                                                          host array by a second store of its finalising kernels --
+//                                                                                          or, glim_amd_multi_set_host_records(0), by a copy here)
+//   one synchronise                                                                        (of the collective's stream; ONE device that has nothing
+//                                                                                          to exchange waits for the kernels' own stream instead)
 // The host barrier costs no device time: the kernels are running while the threads meet.  glim_amd_multi_last_breakdown names every phase.
 int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linearized6* out, double* total_error) {
   if (!m) return GLIM_AMD_ERR_INVALID;
@@ -786,7 +789,18 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       // ---- collective + copy-out on the collective's stream ----
       const auto t_col = std::chrono::steady_clock::now();
       hipStream_t cst = m->cstream[d];
+      // ONE device whose kernels store their records to the host themselves has nothing for the collective's stream to do: no gather, no copy --
+      // the call waits for the kernels' own stream (a wait across streams costs 6-94 us behind the last kernel on this round's boxes)
+      const bool own_stream_only = !(m->use_rccl && (ndev > 1 || m->one_rank_collective)) && m->h_gather_dev[d] != nullptr && sst != nullptr;
+      if (own_stream_only) cst = sst;
       auto collective = [&]() -> int {
+        if (own_stream_only) {
+          if (timed) {
+            GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 2], cst));
+            GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 3], cst));
+          }
+          return (int)GLIM_AMD_OK;
+        }
         for (int h = 0; h < P; h++) {
           const int64_t rows = m->rows_of_piece(h);
           if (rows == 0) {
