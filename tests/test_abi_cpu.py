@@ -167,3 +167,13 @@ def test_every_diagnostic_key_is_documented():
     for words in re.findall(r'k(?:Path|Kernel)Words\[\] = \{([^}]*)\}', src):
         for w in re.findall(r'"([a-z0-9]+)"', words):
             assert w in header and w in design, w
+
+
+def test_design_md_is_the_template_filled_from_the_committed_evidence():
+    """DESIGN.md is generated: tools/design/DESIGN.tpl.md with every number read from profiles/r05/ (tools/design/fill_design.py).  A number edited
+    by hand in DESIGN.md, or evidence refreshed without refilling it, fails here."""
+    import subprocess
+    import sys
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design", "fill_design.py"), "--check"], cwd=ROOT, capture_output=True, text=True)
+    assert res.returncode == 0, "DESIGN.md differs from the filled template: run `python tools/design/fill_design.py`\n" + res.stderr[-500:]
