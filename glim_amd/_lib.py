@@ -166,6 +166,13 @@ SYMBOLS = {
     "glim_amd_multi_linearize": (_i, [_vp, _dp, C.POINTER(Linearized6), _dp]),
     "glim_amd_multi_profile": (_i, [_vp, _dp, _i, _fp]),
     "glim_amd_shard_bounds": (_i, [_dp, _i64, _i32, _lp]),
+    "glim_amd_multi_set_gather_mode": (_i, [_vp, _i32]),
+    "glim_amd_multi_wait_gather": (_i, [_vp]),
+    "glim_amd_multi_gathered_device": (_i, [_vp, _i32, _pp, _lp]),
+    "glim_amd_debug_multi_create_virtual": (_i, [_ip, _i32, _pp]),
+    "glim_amd_debug_multi_inject_failure": (_i, [_vp, _i32, _i32]),
+    "glim_amd_debug_multi_set_diag": (_i, [_vp, C.c_char_p]),
+    "glim_amd_debug_multi_gathered_download": (_i, [_vp, _i32, _i64, _i64, _dp]),
 }
 
 _lib = None

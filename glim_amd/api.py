@@ -613,12 +613,44 @@ class MultiDeviceCost:
     """Single-process, multi-device evaluation of a multi-scan VGICP cost (glim_amd_multi_*, include/glim_amd.h): clouds and voxel maps
     replicated on every device, the factor list sharded, one RCCL all-gather of the compact records per evaluation."""
 
-    def __init__(self, devices=(0,)):
+    def __init__(self, devices=(0,), virtual=False):
+        """virtual=True (tests / one-GPU boxes only, glim_amd_diag.h): a device ordinal may be listed several times -- every entry is a "virtual
+        device" with its own context, host thread, shard and gathered array; the exchange is a same-device stand-in for ncclAllGather."""
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
-        check(lib().glim_amd_multi_create(_ip(dev), len(dev), C.byref(h)), "glim_amd_multi_create")
+        if virtual:
+            check(lib().glim_amd_debug_multi_create_virtual(_ip(dev), len(dev), C.byref(h)), "glim_amd_debug_multi_create_virtual")
+        else:
+            check(lib().glim_amd_multi_create(_ip(dev), len(dev), C.byref(h)), "glim_amd_multi_create")
         self._h = h
         self.factors = []
+
+    def set_gather_mode(self, mode):
+        """1 (default): the all-gather completes behind the call; 2: the call waits for it; 0: no exchange (glim_amd_multi_set_gather_mode)."""
+        check(lib().glim_amd_multi_set_gather_mode(self._h, int(mode)), "glim_amd_multi_set_gather_mode")
+
+    def wait_gather(self):
+        check(lib().glim_amd_multi_wait_gather(self._h), "glim_amd_multi_wait_gather")
+
+    def gathered_device(self, device=0):
+        """(device pointer, rows) of the complete device-resident record array of one device (glim_amd_multi_gathered_device)."""
+        ptr, rows = C.c_void_p(), C.c_int64()
+        check(lib().glim_amd_multi_gathered_device(self._h, int(device), C.byref(ptr), C.byref(rows)), "glim_amd_multi_gathered_device")
+        return ptr.value, rows.value
+
+    def gathered_records(self, device=0, first=0, count=None):
+        """What a device-side consumer on `device` reads after the exchange, copied back in factor order (glim_amd_debug_multi_gathered_download)."""
+        count = self._n - first if count is None else count
+        out = np.zeros((count, 29), dtype=np.float64)
+        check(lib().glim_amd_debug_multi_gathered_download(self._h, int(device), int(first), int(count), _dp(out)), "glim_amd_debug_multi_gathered_download")
+        return out
+
+    def inject_failure(self, device, where):
+        """One shot: the next evaluation fails on `device` before the barrier (where=1) / inside its exchange (where=2)."""
+        check(lib().glim_amd_debug_multi_inject_failure(self._h, int(device), int(where)), "glim_amd_debug_multi_inject_failure")
+
+    def set_diag(self, key_values):
+        check(lib().glim_amd_debug_multi_set_diag(self._h, key_values.encode()), "glim_amd_debug_multi_set_diag")
 
     def info(self):
         nd, rc, nf = C.c_int32(), C.c_int32(), C.c_int64()

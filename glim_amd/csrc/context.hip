@@ -65,6 +65,7 @@ const DiagKey kDiagKeys[] = {
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},
+  {"multi_virtual", &Diag::multi_virtual, nullptr, 0, 1},
 };
 }  // namespace
 
@@ -179,9 +180,9 @@ int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values) {
     ctx->diag = process_diag();
     return GLIM_AMD_OK;
   }
-  // pool / multi_rccl / multi_host_gather are read from the PROCESS defaults only (pool_disabled, glim_amd_multi_create): setting them on a
-  // context would be accepted and do nothing, so it is refused (they belong in GLIM_AMD_DIAG)
-  for (const char* key : {"pool=", "multi_rccl=", "multi_host_gather="}) {
+  // pool / multi_rccl / multi_host_gather / multi_virtual are read from the PROCESS defaults only (pool_disabled, glim_amd_multi_create): setting
+  // them on a context would be accepted and do nothing, so it is refused (they belong in GLIM_AMD_DIAG)
+  for (const char* key : {"pool=", "multi_rccl=", "multi_host_gather=", "multi_virtual="}) {
     const size_t len = strlen(key);
     for (const char* q = key_values; (q = strstr(q, key)) != nullptr; q += len)
       if (q == key_values || q[-1] == ',') return GLIM_AMD_ERR_INVALID;

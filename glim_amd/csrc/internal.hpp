@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/glim_amd.h"
+#include "../../include/glim_amd_diag.h"  // measurement / test hooks: implemented by the same library, not part of the drop-in boundary
 
 namespace glim_amd {
 
@@ -140,6 +141,8 @@ struct Diag {
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
+  int multi_virtual = 0;  // multi_virtual=0|1                   glim_amd_multi_create accepts one physical device several times ("virtual devices": the N > 1
+                          //                                    code path on a one-GPU box; the exchange is a same-device stand-in for ncclAllGather)
   char knn_debug[256] = "";   // knn_debug=<file>                dump per-wavefront work counters of the 64-query chunk kernel
 };
 enum { RESIDENT_OFF = 0, RESIDENT_ON = 1, RESIDENT_AUTO = 2 };

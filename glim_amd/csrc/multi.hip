@@ -152,6 +152,22 @@ struct glim_amd_multi {
   bool use_rccl = false;
   bool one_rank_collective = false;  // ONE device: make the (no-op) library call in every evaluation all the same (glim_amd_multi_set_one_rank_collective)
   bool broken = false;  // a collective failed and the communicators were aborted: only destroy is valid from here on
+  // "Virtual devices": one physical device listed several times (GLIM_AMD_DIAG multi_virtual=1 or glim_amd_debug_multi_create_virtual).  Every
+  // entry gets its own context, host thread, shard, pieces, streams and gathered array -- the whole N > 1 path of this file -- and the exchange is
+  // a same-device stand-in for the in-place ncclAllGather (RCCL refuses one device twice): every "device" copies its slot of a piece into the
+  // others' arrays on its collective stream, behind the piece's event, exactly where the library call sits for distinct devices.
+  bool virtual_devices = false;
+  // What the exchange is FOR.  The host optimiser (GLIM's ISAM2 / LM run on the host: global_mapping.cpp:501) gets every record through the
+  // finalising kernels' second store into the pinned host array; the gathered DEVICE array serves device-side consumers
+  // (glim_amd_multi_gathered_device).  1 (default): the exchange is enqueued behind the pieces and completes BEHIND the call -- the call waits for
+  // the kernels and the host records only; the next evaluation's kernels wait for it on the device before they overwrite the send slots, and
+  // glim_amd_multi_gathered_device / _wait_gather wait for it on the host.  2: the call waits for the exchange as well (rounds 4-5).  0: no exchange.
+  int gather_mode = 1;
+  std::vector<hipEvent_t> gather_done_ev;  // [device]: the last evaluation's exchange (and copy-out) on the collective's stream is over
+  std::vector<char> gather_pending;        // [device]: gather_done_ev has a record the device's kernels have not waited for yet
+  bool gather_timing_pending = false;      // the last evaluation's collective-stream events have not been read (they complete behind the call)
+  // failure injection (glim_amd_debug_multi_inject_failure): the next evaluation fails on this device before the barrier (1) / inside its exchange (2)
+  int inject_device = -1, inject_where = 0;
   std::mutex abort_mu;
   std::vector<Worker*> workers;   // [device]; workers[0] is null: the CALLER's thread drives device 0 (no hand-over at all on one device)
   std::vector<hipStream_t> cstream;  // [device]: the collective's stream (the factor kernels of the next piece run beside it)
@@ -230,17 +246,22 @@ void worker_loop(Worker* w, int device) {
 }
 
 void release_factors(glim_amd_multi* m) {
-  for (int d = 0; d < m->ndev; d++) {
+  for (int d = 0; d < m->ndev; d++) {  // every stream of every device first: a virtual device's exchange writes into the OTHERS' gathered arrays
     (void)hipSetDevice(m->devices[d]);
     if (d < (int)m->ctxs.size() && m->ctxs[d]) (void)glim_amd_ctx_synchronize(m->ctxs[d]);  // asynchronous linearisations write into d_gather
     if (d < (int)m->cstream.size() && m->cstream[d]) (void)hipStreamSynchronize(m->cstream[d]);
     if (d < (int)m->ustream.size() && m->ustream[d]) (void)hipStreamSynchronize(m->ustream[d]);
+  }
+  for (int d = 0; d < m->ndev; d++) {
+    (void)hipSetDevice(m->devices[d]);
     for (int h = 0; h < MAX_PIECES; h++)
       if ((size_t)(MAX_PIECES * d + h) < m->sets.size() && m->sets[MAX_PIECES * d + h]) (void)glim_amd_factor_set_destroy(m->sets[MAX_PIECES * d + h]);
     if (d < (int)m->d_gather.size() && m->d_gather[d]) (void)pool_free(m->d_gather[d]);
   }
   m->sets.assign((size_t)MAX_PIECES * m->ndev, nullptr);
   m->d_gather.assign(m->ndev, nullptr);
+  m->gather_pending.assign((size_t)m->ndev, 0);  // (every collective stream was synchronised above)
+  m->gather_timing_pending = false;
   if (m->h_gather) (void)pinned_free(m->h_gather);
   m->h_gather = nullptr;
   m->h_gather_dev.assign((size_t)m->ndev, nullptr);
@@ -252,13 +273,47 @@ void release_factors(glim_amd_multi* m) {
 // leave, their streams drain) and retire the handle -- a communicator cannot be used after an abort.  Any device's thread may call it.
 void abort_collectives(glim_amd_multi* m) {
   std::lock_guard<std::mutex> lock(m->abort_mu);
-  if (m->broken || !m->use_rccl || !rccl().CommAbort) return;
-  for (auto& c : m->comms)
-    if (c) {
-      (void)rccl().CommAbort(c);
-      c = nullptr;
+  if (m->broken) return;
+  if (m->use_rccl && rccl().CommAbort)
+    for (auto& c : m->comms)
+      if (c) {
+        (void)rccl().CommAbort(c);
+        c = nullptr;
+      }
+  m->broken = true;  // (virtual devices have no communicator to abort; the handle is retired all the same: its gathered arrays are half-exchanged)
+}
+
+// collective-stream timing of the last evaluation (HIP events 1 -> 2 -> 3 of every device), once those events have completed
+void harvest_gather_timing(glim_amd_multi* m) {
+  if (m->ev.size() != (size_t)EV_PER_DEVICE * m->ndev) return;
+  for (int d = 0; d < m->ndev; d++) {
+    float ms = 0.f;
+    double* bd = &m->breakdown[(size_t)d * BD_FIELDS];
+    if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 3]) == hipSuccess) m->gather_ms[d] = std::max(ms, 0.f);
+    if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 2]) == hipSuccess) bd[BD_DEVICE_GATHER] = 1e3 * std::max(ms, 0.f);
+    if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 2], m->ev[EV_PER_DEVICE * d + 3]) == hipSuccess) bd[BD_DEVICE_COPY_OUT] = 1e3 * std::max(ms, 0.f);
+    (void)hipGetLastError();
+  }
+  m->gather_timing_pending = false;
+}
+
+// host wait for the exchange of the last evaluation on EVERY device (a virtual device's array is written by the others' streams)
+int wait_gather(glim_amd_multi* m) {
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  int rc = GLIM_AMD_OK;
+  for (int d = 0; d < m->ndev; d++) {
+    if (!m->gather_pending[(size_t)d]) continue;
+    (void)hipSetDevice(m->devices[d]);
+    const hipError_t e = hipEventSynchronize(m->gather_done_ev[(size_t)d]);
+    if (e != hipSuccess) {
+      set_hip_error(e, "glim_amd_multi: waiting for the exchange");
+      rc = GLIM_AMD_ERR_HIP;
     }
-  m->broken = true;
+  }
+  if (rc == GLIM_AMD_OK && m->gather_timing_pending) harvest_gather_timing(m);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return rc;
 }
 
 
@@ -378,17 +433,20 @@ int glim_amd_shard_layout(const int64_t* bounds, int32_t world, int32_t split_mo
   return GLIM_AMD_OK;
 }
 
-int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out) {
-  if (!out || num_devices <= 0 || !devices) return GLIM_AMD_ERR_INVALID;
+static int multi_create_impl(const int32_t* devices, int32_t num_devices, bool allow_virtual, glim_amd_multi** out) {
+  if (!out || num_devices <= 0 || num_devices > 64 || !devices) return GLIM_AMD_ERR_INVALID;
   *out = nullptr;
   const int ndev_visible = glim_amd_device_count();
   if (ndev_visible <= 0) return GLIM_AMD_ERR_NO_DEVICE;
+  bool repeated = false;
   for (int i = 0; i < num_devices; i++) {
     if (devices[i] < 0 || devices[i] >= ndev_visible) return GLIM_AMD_ERR_INVALID;
     for (int j = 0; j < i; j++)
-      if (devices[j] == devices[i]) return GLIM_AMD_ERR_INVALID;
+      if (devices[j] == devices[i]) repeated = true;
   }
+  if (repeated && !allow_virtual) return GLIM_AMD_ERR_INVALID;
   glim_amd_multi* m = new glim_amd_multi();
+  m->virtual_devices = repeated;
   m->ndev = num_devices;
   m->devices.assign(devices, devices + num_devices);
   m->clouds.resize(num_devices);
@@ -409,7 +467,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   // RCCL: one communicator per device, created together in this process.  A single device still goes through the collective (it is a
   // copy there) unless diag multi_rccl=0 (GLIM_AMD_DIAG), so that the path the 8-GPU node takes is the path a 1-GPU box tests.
   const Diag& diag = process_diag();
-  if (diag.multi_rccl && rccl().ok()) {
+  if (diag.multi_rccl && rccl().ok() && !m->virtual_devices) {  // (ncclCommInitAll refuses one device twice: virtual devices exchange by copies)
     m->comms.assign(num_devices, nullptr);
     const ncclResult_t r = rccl().CommInitAll(m->comms.data(), num_devices, m->devices.data());
     if (r == ncclSuccess) {
@@ -438,6 +496,8 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   m->ustream.assign(num_devices, nullptr);
   m->piece_ev.assign((size_t)MAX_PIECES * num_devices, nullptr);
   m->sum_ev.assign(num_devices, nullptr);
+  m->gather_done_ev.assign(num_devices, nullptr);
+  m->gather_pending.assign(num_devices, 0);
   m->d_sum_scratch.assign(num_devices, nullptr);
   m->h_total.assign(num_devices, nullptr);
   m->h_total_dev.assign(num_devices, nullptr);
@@ -451,6 +511,7 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
     for (int h = 0; h < MAX_PIECES; h++)
       if (hipEventCreateWithFlags(&m->piece_ev[MAX_PIECES * d + h], hipEventDisableTiming) != hipSuccess) streams_ok = false;
     if (hipEventCreateWithFlags(&m->sum_ev[d], hipEventDisableTiming) != hipSuccess) streams_ok = false;
+    if (hipEventCreateWithFlags(&m->gather_done_ev[d], hipEventDisableTiming) != hipSuccess) streams_ok = false;
     if (hipMalloc(reinterpret_cast<void**>(&m->d_sum_scratch[d]), (SUM_BLOCKS_MAX + 1) * sizeof(double)) != hipSuccess ||
         hipMemset(m->d_sum_scratch[d], 0, (SUM_BLOCKS_MAX + 1) * sizeof(double)) != hipSuccess)
       streams_ok = false;
@@ -491,6 +552,68 @@ int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_
   return GLIM_AMD_OK;
 }
 
+int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out) {
+  return multi_create_impl(devices, num_devices, process_diag().multi_virtual != 0, out);
+}
+
+int glim_amd_debug_multi_create_virtual(const int32_t* devices, int32_t num_devices, glim_amd_multi** out) {
+  return multi_create_impl(devices, num_devices, true, out);
+}
+
+int glim_amd_debug_multi_inject_failure(glim_amd_multi* m, int32_t device, int32_t where) {
+  if (!m || device < -1 || device >= m->ndev || where < 0 || where > 2) return GLIM_AMD_ERR_INVALID;
+  m->inject_device = where ? device : -1;
+  m->inject_where = device >= 0 ? where : 0;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_debug_multi_set_diag(glim_amd_multi* m, const char* key_values) {
+  if (!m) return GLIM_AMD_ERR_INVALID;
+  for (glim_amd_ctx* c : m->ctxs) GA_TRY(glim_amd_ctx_set_diag(c, key_values));
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_set_gather_mode(glim_amd_multi* m, int32_t mode) {
+  if (!m || mode < 0 || mode > 2) return GLIM_AMD_ERR_INVALID;
+  GA_TRY(wait_gather(m));
+  m->gather_mode = mode;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_multi_wait_gather(glim_amd_multi* m) {
+  if (!m) return GLIM_AMD_ERR_INVALID;
+  return wait_gather(m);
+}
+
+int glim_amd_multi_gathered_device(glim_amd_multi* m, int32_t device, const double** gathered, int64_t* rows) {
+  if (!m || device < 0 || device >= m->ndev || !gathered) return GLIM_AMD_ERR_INVALID;
+  if (m->broken || m->nf == 0 || !m->d_gather[(size_t)device]) return GLIM_AMD_ERR_STATE;
+  GA_TRY(wait_gather(m));
+  *gathered = m->d_gather[(size_t)device];
+  if (rows) *rows = (int64_t)m->ndev * m->max_rows;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_debug_multi_gathered_download(glim_amd_multi* m, int32_t device, int64_t first, int64_t count, double* compact29) {
+  if (!m || device < 0 || device >= m->ndev || !compact29 || first < 0 || count < 0 || first + count > m->nf) return GLIM_AMD_ERR_INVALID;
+  const double* dev = nullptr;
+  GA_TRY(glim_amd_multi_gathered_device(m, device, &dev, nullptr));
+  const size_t doubles = (size_t)m->ndev * (size_t)m->max_rows * COMPACT;
+  std::vector<double> host(doubles);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  GA_HIP(hipSetDevice(m->devices[device]));
+  const hipError_t e = hipMemcpy(host.data(), dev, doubles * sizeof(double), hipMemcpyDeviceToHost);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  GA_HIP(e);
+  for (int64_t f = first; f < first + count; f++) {
+    int d = 0;
+    while (d + 1 < m->ndev && f >= m->bounds[d + 1]) d++;
+    memcpy(compact29 + (size_t)(f - first) * COMPACT, host.data() + (size_t)m->row_of(d, f - m->bounds[d]) * COMPACT, COMPACT * sizeof(double));
+  }
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_multi_last_timing(const glim_amd_multi* m, float* kernel_ms, float* gather_ms) {
   if (!m) return GLIM_AMD_ERR_INVALID;
   if (m->ev.empty()) return GLIM_AMD_ERR_UNSUPPORTED;
@@ -526,6 +649,7 @@ int glim_amd_multi_destroy(glim_amd_multi* m) {
     for (int h = 0; h < MAX_PIECES; h++)
       if ((size_t)(MAX_PIECES * d + h) < m->piece_ev.size() && m->piece_ev[MAX_PIECES * d + h]) (void)hipEventDestroy(m->piece_ev[MAX_PIECES * d + h]);
     if (d < (int)m->sum_ev.size() && m->sum_ev[d]) (void)hipEventDestroy(m->sum_ev[d]);
+    if (d < (int)m->gather_done_ev.size() && m->gather_done_ev[d]) (void)hipEventDestroy(m->gather_done_ev[d]);
     if (d < (int)m->d_sum_scratch.size() && m->d_sum_scratch[d]) (void)hipFree(m->d_sum_scratch[d]);
     if (d < (int)m->h_total.size() && m->h_total[d]) (void)pinned_free(m->h_total[d]);
   }
@@ -722,13 +846,19 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   const uint64_t all_arrived = m->generation * (uint64_t)ndev;
   m->failed.store(0);
   std::fill(m->breakdown.begin(), m->breakdown.end(), 0.0);
+  const int inject_device = m->inject_device, inject_where = m->inject_where;  // one shot
+  m->inject_device = -1;
+  m->inject_where = 0;
+  // is there an exchange at all?  Several devices with a communicator (or virtual devices, whose stand-in copies take its place), unless switched
+  // off; ONE device only when the no-op library call was asked for (glim_amd_multi_set_one_rank_collective)
+  const bool exchange = m->gather_mode != 0 && ((ndev > 1 && (m->use_rccl || m->virtual_devices)) || (ndev == 1 && m->use_rccl && m->one_rank_collective));
   double post_us = 0.0, join_us = 0.0;
   const int rc = m->run_all(
     [&](int d) -> int {
       double* bd = &m->breakdown[(size_t)d * BD_FIELDS];
       bd[BD_WAKE] = d ? us_since(t_call) : 0.0;
       int rc_d = GLIM_AMD_OK;
-      hipStream_t sst = nullptr;  // the factor sets' stream
+      hipStream_t sst = nullptr, last = nullptr;  // the factor sets' stream; the stream of the last piece enqueued
       bool summed = false;
       const int64_t lo = m->bounds[d], hi = m->bounds[d + 1];
       auto enqueue_kernels = [&]() -> int {
@@ -739,8 +869,19 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
             sst = m->sets[MAX_PIECES * d + h]->stream;
             break;
           }
+        last = sst;
+        if (inject_device == d && inject_where == 1) {
+          set_hip_error(hipErrorUnknown, "glim_amd_multi_linearize: injected failure before the barrier");
+          return (int)GLIM_AMD_ERR_HIP;
+        }
+        // the previous evaluation's exchange reads this device's slots of the gathered array (they are its send buffer): the kernels that
+        // overwrite them wait for it ON THE DEVICE (it has normally finished long ago: the host has been away choosing the next poses)
+        if (m->gather_pending[(size_t)d]) {
+          for (int h = 0; h < P; h++)
+            if (m->sets[MAX_PIECES * d + h]) GA_HIP(hipStreamWaitEvent(m->sets[MAX_PIECES * d + h]->stream, m->gather_done_ev[(size_t)d], 0));
+          m->gather_pending[(size_t)d] = 0;
+        }
         if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d], sst));
-        hipStream_t last = sst;
         for (int h = 0; h < P; h++) {
           glim_amd_factor_set* set = m->sets[MAX_PIECES * d + h];
           const int64_t f0 = std::min(lo + (int64_t)h * m->piece_rows, hi);
@@ -784,15 +925,18 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
       bd[BD_BARRIER] = us_since(t_bar);
       if (m->failed.load()) {
         if (sst) (void)hipStreamSynchronize(sst);  // what this device did enqueue must not outlive the call
+        if (last && last != sst) (void)hipStreamSynchronize(last);
         return rc_d != GLIM_AMD_OK ? rc_d : m->failed.load();
       }
-      // ---- collective + copy-out on the collective's stream ----
+      // ---- exchange (+ copy-out) on the collective's stream ----
       const auto t_col = std::chrono::steady_clock::now();
       hipStream_t cst = m->cstream[d];
-      // ONE device whose kernels store their records to the host themselves has nothing for the collective's stream to do: no gather, no copy --
-      // the call waits for the kernels' own stream (a wait across streams costs 6-94 us behind the last kernel on this round's boxes)
-      const bool own_stream_only = !(m->use_rccl && (ndev > 1 || m->one_rank_collective)) && m->h_gather_dev[d] != nullptr && sst != nullptr;
-      if (own_stream_only) cst = sst;
+      const bool mirrored = m->h_gather_dev[d] != nullptr;
+      // nothing for the collective's stream to do: no exchange, and the kernels store their records to the host themselves
+      const bool own_stream_only = !exchange && mirrored && sst != nullptr;
+      // the call waits for the exchange only when asked to (gather_mode 2) or when the host records come by copies on its stream
+      const bool wait_for_exchange = !own_stream_only && (m->gather_mode == 2 || !mirrored || !exchange);
+      if (own_stream_only) cst = last;
       auto collective = [&]() -> int {
         if (own_stream_only) {
           if (timed) {
@@ -810,7 +954,11 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           const size_t start = (size_t)m->region_start(h) * COMPACT, slot = (size_t)rows * COMPACT;
           double* region = m->d_gather[d] + start;
           GA_HIP(hipStreamWaitEvent(cst, m->piece_ev[MAX_PIECES * d + h], 0));
-          if (m->use_rccl && ndev > 1) {
+          if (inject_device == d && inject_where == 2 && h == P - 1) {
+            set_hip_error(hipErrorUnknown, "glim_amd_multi_linearize: injected failure inside the exchange");
+            return (int)GLIM_AMD_ERR_HIP;
+          }
+          if (exchange && m->use_rccl && ndev > 1) {
             // in place: this device's slot is both the send buffer and its own segment of the receive buffer
             const auto t_lib = std::chrono::steady_clock::now();
             const ncclResult_t r = rccl().AllGather(region + (size_t)d * slot, region, slot, ncclDouble, m->comms[d], cst);
@@ -819,7 +967,17 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
               set_hip_error(hipErrorUnknown, "ncclAllGather");
               return (int)GLIM_AMD_ERR_HIP;
             }
-          } else if (m->use_rccl && m->one_rank_collective && h == 0) {
+          } else if (exchange && m->virtual_devices && ndev > 1) {
+            // the stand-in (virtual devices share one physical device: plain copies reach every array): this "device" sends its slot of the piece
+            // to the same slot of every other array -- the bytes an all-gather moves, in the place and stream order of the library call.  (Every
+            // device has enqueued its kernels -- the host barrier above -- and a receiver only WRITES its own slot, so no other event is needed;
+            // who READS a gathered array waits for every device's exchange: wait_gather.)
+            const auto t_lib = std::chrono::steady_clock::now();
+            for (int e = 0; e < ndev; e++)
+              if (e != d)
+                GA_HIP(hipMemcpyAsync(m->d_gather[e] + start + (size_t)d * slot, region + (size_t)d * slot, slot * sizeof(double), hipMemcpyDeviceToDevice, cst));
+            bd[BD_LIBRARY_CALLS] += us_since(t_lib);
+          } else if (exchange && m->use_rccl && m->one_rank_collective && h == 0) {
             // ONE device has nothing to gather: its records are where they belong.  The library is exercised once, when the handle is created
             // (rccl_self_test); with glim_amd_multi_set_one_rank_collective the no-op call is ALSO made in every evaluation, over the first
             // piece -- round 5 measured what it costs inside a process that has torch's librccl loaded: 0.3 ms of host time per call.
@@ -835,22 +993,29 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
           // copy-out: every device hands ITS OWN rows of the piece to the host over its own PCIe link (round 4: device 0 copied the whole
           // gathered array, 7.6 MB behind the collective; the devices' links work in parallel and need not wait for xGMI)
           const int64_t own = std::max<int64_t>(0, std::min(rows, (hi - lo) - (int64_t)h * m->piece_rows));
-          if (own > 0 && !m->h_gather_dev[d])  // (otherwise the finalising kernels have stored the rows there themselves)
+          if (own > 0 && !mirrored)  // (otherwise the finalising kernels have stored the rows there themselves)
             GA_HIP(hipMemcpyAsync(m->h_gather + start + (size_t)d * slot, region + (size_t)d * slot, (size_t)own * COMPACT * sizeof(double),
                                   hipMemcpyDeviceToHost, cst));
         }
-        if (summed) GA_HIP(hipStreamWaitEvent(cst, m->sum_ev[d], 0));
+        if (summed && wait_for_exchange) GA_HIP(hipStreamWaitEvent(cst, m->sum_ev[d], 0));
         if (timed) GA_HIP(hipEventRecord(m->ev[EV_PER_DEVICE * d + 3], cst));
+        GA_HIP(hipEventRecord(m->gather_done_ev[(size_t)d], cst));
+        m->gather_pending[(size_t)d] = 1;
         return (int)GLIM_AMD_OK;
       };
       rc_d = collective();
       bd[BD_COLLECTIVE] = us_since(t_col);
       if (rc_d != GLIM_AMD_OK) {
         abort_collectives(m);  // the others are inside (or about to enter) their ncclAllGather
+        if (last) (void)hipStreamSynchronize(last);
+        (void)hipStreamSynchronize(m->cstream[d]);
         return rc_d;
       }
+      // ---- the one wait: the kernels (+ the error sum) whose records the finalising blocks have also stored into the host array; the exchange
+      //      only when the call was asked to wait for it (it completes behind the call otherwise) ----
       const auto t_wait = std::chrono::steady_clock::now();
-      const hipError_t e = hipStreamSynchronize(cst);
+      hipError_t e = hipStreamSynchronize(wait_for_exchange ? cst : last);
+      if (e == hipSuccess && !wait_for_exchange && sst && sst != last) e = hipStreamSynchronize(sst);
       bd[BD_WAIT] = us_since(t_wait);
       if (e != hipSuccess) {
         set_hip_error(e, "glim_amd_multi_linearize: synchronise");
@@ -858,11 +1023,7 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
         return (int)GLIM_AMD_ERR_HIP;
       }
       if (timed) {
-        float ms = 0.f;
         (void)hipEventElapsedTime(&m->kernel_ms[d], m->ev[EV_PER_DEVICE * d], m->ev[EV_PER_DEVICE * d + 1]);
-        (void)hipEventElapsedTime(&m->gather_ms[d], m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 3]);
-        if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 1], m->ev[EV_PER_DEVICE * d + 2]) == hipSuccess) bd[BD_DEVICE_GATHER] = 1e3 * std::max(ms, 0.f);
-        if (hipEventElapsedTime(&ms, m->ev[EV_PER_DEVICE * d + 2], m->ev[EV_PER_DEVICE * d + 3]) == hipSuccess) bd[BD_DEVICE_COPY_OUT] = 1e3 * ms;
         (void)hipGetLastError();
       }
       return (int)GLIM_AMD_OK;
@@ -872,6 +1033,12 @@ int glim_amd_multi_linearize(glim_amd_multi* m, const double* T, glim_amd_linear
   bd0[BD_POST] = post_us;
   bd0[BD_JOIN] = join_us;
   if (rc != GLIM_AMD_OK) return rc;
+  if (timed) {
+    m->gather_timing_pending = true;
+    const bool behind = exchange && m->gather_mode == 1;
+    if (!behind) harvest_gather_timing(m);  // (every collective stream was synchronised above; behind the call: glim_amd_multi_wait_gather reads them)
+    else std::fill(m->gather_ms.begin(), m->gather_ms.end(), 0.f);
+  }
   const auto t_scan = std::chrono::steady_clock::now();
   double total = 0.0;
   if (out) {

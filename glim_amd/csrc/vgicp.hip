@@ -2010,7 +2010,12 @@ namespace glim_amd {
 void resident_stop_device(int device, uint64_t uid) {
   if (device < 0 || device >= 16) return;
   ResidentSession& S = g_resident[device];
-  for (int tries = 0; tries < 20000; tries++) {
+  // This function must not return while the session can still read the object (the caller recycles its memory next): it waits for a request in
+  // flight as long as it takes -- a request is bounded by its own give-up time -- and after FORCE_AFTER_TRIES (2 s: something is wrong) it ends the
+  // kernel under the requester's feet instead of falling through (the earlier 0.2 s time-out returned with the session alive); the
+  // requester then finds its line unanswered, retires the session and repeats the call as a launch.
+  constexpr long FORCE_AFTER_TRIES = 200000;
+  for (long tries = 0;; tries++) {
     {
       std::lock_guard<std::mutex> slock(S.mu);
       if (!S.launched) return;
@@ -2019,7 +2024,8 @@ void resident_stop_device(int device, uint64_t uid) {
         for (const PlanKey& k : S.plan->key) used = used || k.target_uid == uid || k.source_uid == uid;
         if (!used) return;
       }
-      if (!S.busy.load()) {
+      if (!S.busy.load() || tries >= FORCE_AFTER_TRIES) {
+        if (tries >= FORCE_AFTER_TRIES) set_hip_error(hipErrorUnknown, "resident_stop_device: session busy for 2 s, stopped by force");
         int prev = -1;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(device);

@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, con
   // (system-scope release) -- instead of the first thread of the records kernel behind this one: the counts are final when every block has
   // added its share, and the host need not wait for a dependent launch to start (2 us of a 10 000-pt frame).  (Every block's counter updates, and its report of a
   // point off the plane form, are ordered before its arrival by the fence; the arrival counter is left at zero for the table's next life.)
+  if (poll_seq) {  // EVERY wavefront's stores (cloud arrays, factor streams, accumulator atomics) are performed before the block arrives: the
+    __threadfence();  // barrier alone orders the waves, it does not wait for their outstanding stores, and the host frees one stream
+    __syncthreads();  // family and lets readers of other streams in the moment it sees the completion word
+  }
   if (poll_seq && threadIdx.x == 0) {
     __threadfence_system();
     int* counter = lv.stats[0] + 2;
@@ -532,9 +536,9 @@ EventPool& event_pool() {
   static EventPool* pool = new EventPool();  // leaked on purpose, like the memory pools
   return *pool;
 }
-hipError_t event_get(hipEvent_t* e) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
+// `dev` = the device the event belongs to (the owner's, passed explicitly: the CURRENT device of a destroying or worker thread may be another
+// one, and an event parked in the wrong device's list later fails its hipEventRecord there -- ADVICE r5)
+hipError_t event_get(int dev, hipEvent_t* e) {
   if (dev >= 0 && dev < 16) {
     EventPool& P = event_pool();
     std::lock_guard<std::mutex> lock(P.mu);
@@ -546,10 +550,8 @@ hipError_t event_get(hipEvent_t* e) {
   }
   return hipEventCreateWithFlags(e, hipEventDisableTiming);
 }
-void event_put(hipEvent_t e) {
+void event_put(int dev, hipEvent_t e) {
   if (!e) return;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16) {
     EventPool& P = event_pool();
     std::lock_guard<std::mutex> lock(P.mu);
@@ -601,14 +603,14 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
     }
     for (ClearedTable& old : evicted) {
       (void)hipEventSynchronize(old.done);  // (its clearing kernel was enqueued at least a cache's worth of maps ago)
-      event_put(old.done);
+      event_put(device, old.done);
       (void)pool_free(old.buckets);
       (void)pool_free(old.acc);
       (void)pool_free(old.stats);
     }
   }
   if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 4 * sizeof(int)) == hipSuccess &&
-                   event_get(&t.done) == hipSuccess;
+                   event_get(device, &t.done) == hipSuccess;
   if (keep) {
     const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
     init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, C.stream>>>(buckets, nb, (uint4*)t.acc, acc_words, t.stats);
@@ -619,7 +621,7 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
     (void)hipGetLastError();
     if (t.acc) (void)pool_free(t.acc);
     if (t.stats) (void)pool_free(t.stats);
-    if (t.done) event_put(t.done);
+    if (t.done) event_put(device, t.done);
     (void)pool_free(buckets);
     return;
   }
@@ -639,7 +641,7 @@ bool take_cleared_table(int device, unsigned int nb, ClearedTable* out) {
     *out = C.tables[i];
     C.tables.erase(C.tables.begin() + (long)i);
     C.bytes -= cleared_bytes(nb);
-    event_put(out->done);
+    event_put(device, out->done);
     out->done = nullptr;
     return true;
   }
@@ -763,7 +765,7 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   (void)voxelmap_wait_ready(m, nullptr);  // (a build the host has not seen complete: its last kernel may still be writing the table)
   if (m->pending_acc) (void)pool_free(m->pending_acc);
   if (m->pending_stats) (void)pool_free(m->pending_stats);
-  if (m->ready_event) event_put(m->ready_event);  // (voxelmap_wait_ready above has seen it complete)
+  if (m->ready_event) event_put(m->ctx ? m->ctx->device : -1, m->ready_event);  // (voxelmap_wait_ready above has seen it complete; no owner: destroyed)
   if (m->buckets_sm) (void)pool_free(m->buckets_sm);
   if (m->buckets) {
     if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
@@ -790,11 +792,8 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
   VoxelBucket* const old = m->buckets;  // a map that already holds voxels: incremental insert (rebuild with the old voxels re-opened)
   const unsigned int old_buckets = old ? m->num_buckets : 0u;
   if (old) quiesce_device(ctx->device, m->uid);  // asynchronous factor launches may still be reading the table that is about to be replaced
-  if (m->buckets_sm) {  // the plane view follows the table: rebuilt on the next use (the map's uid changes below, so no plan keeps the old pointer)
-    std::lock_guard<std::mutex> vlock(m->view_mu);
-    (void)pool_free(m->buckets_sm);
-    m->buckets_sm = nullptr;
-  }
+  // (the plane view follows the table, but only at the COMMIT below: every failing exit leaves the map -- uid, table AND view -- as it was, so a
+  //  plan that holds the view's pointer keeps reading live memory)
   // Direct build (keys straight into the final table, ONE synchronise: build_direct_kernel) needs the table size before the voxels are
   // counted.  Small clouds: 2 buckets per point (4 ways per point: load factor below 1/2 whatever the cloud).  Larger clouds: 6 buckets per
   // EXPECTED voxel, from the voxels-per-point ratio of the last map this context built at (about) this resolution -- consecutive frames of a
@@ -841,8 +840,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     // The host needs the voxel count (the reference's insert returns it through voxelmap_info) and nothing else from this build: the last kernel
     // hands it over when it STARTS (word 2 of the mapped scratch = this build's sequence number) and the call returns while that kernel writes
     // the records; readers on other streams wait for `ready_event` (voxelmap_wait_ready).  40-45 -> 3x us per 131 072-pt map.
-    const bool polled = mapped && (m->ready_event || event_get(&m->ready_event) == hipSuccess);
+    const bool polled = mapped && (m->ready_event || event_get(ctx->device, &m->ready_event) == hipSuccess);
     const unsigned int seq = polled ? (++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq) : 0u;
+    // the completion word lives in the context's shared pinned scratch, where read_back_sync() leaves arbitrary small integers (kNN counters,
+    // kept points): a leftover equal to this build's sequence number would end the wait before the kernel has written anything
+    if (polled) reinterpret_cast<volatile unsigned int*>(h_view)[2] = 0u;
     finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(buckets, nb, (const long long*)acc.p, m->resolution, (const int*)stats.p, mapped ? d_view : nullptr, view,
                                                                  nullptr, 0, seq);
     hipError_t e = hipGetLastError();
@@ -977,7 +979,11 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     return GLIM_AMD_ERR_HIP;
   }
   in_flight.dismiss();
-  m->buckets_sm = view2;
+  {  // commit: the old view goes with the old table (the uid changes below, so no plan keeps either pointer)
+    std::lock_guard<std::mutex> vlock(m->view_mu);
+    if (m->buckets_sm) (void)pool_free(m->buckets_sm);
+    m->buckets_sm = view2;
+  }
   if (old) (void)pool_free(old);
   else if (n > 0) remember_voxel_ratio(ctx, res_class, (double)num_voxels / (double)n);
   m->buckets = buckets;
@@ -1041,6 +1047,9 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
     rc = alloc_cloud_for_frame(ctx, n, true, normals4 != nullptr, &c);
     frame_stamp(0);
     if (rc == GLIM_AMD_OK && !pinned_scratch_views(ctx, reinterpret_cast<void**>(&h_view), reinterpret_cast<void**>(&d_view))) rc = GLIM_AMD_ERR_UNSUPPORTED;
+    // (the completion word shares the context's pinned scratch with read_back_sync(): whatever a kNN or preprocessing call left there must not read
+    //  as this submission's sequence number -- ADVICE r5)
+    if (rc == GLIM_AMD_OK && num_levels > 0) reinterpret_cast<volatile unsigned int*>(h_view)[4 * (num_levels - 1) + 2] = 0u;
     // frame_fused (default): ONE launch pulls the cloud and builds every level (frame_build_kernel), one more writes every level's records
     // (frame_finalize_kernel) -- 2 dependent launches instead of 1 + 2 per level; with the gated pull both go out BEFORE the host converts
     const bool fused = ctx->diag.frame_fused && num_levels >= 1 && num_levels <= FRAME_MAX_LEVELS;
@@ -1099,7 +1108,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       // pull kernel's plane-form verdict, the earlier levels' counts -- is complete and visible by then); it may still be writing its own
       // records when this call returns, which is what ready_event is for (voxelmap_wait_ready)
       const bool last = lv == num_levels - 1;
-      if (last && event_get(&B.m->ready_event) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
+      if (last && event_get(ctx->device, &B.m->ready_event) == hipSuccess) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
       finalize_kernel<<<(2 * (nb + 1) + 255) / 256, 256, 0, st>>>(B.buckets, nb, (const long long*)B.acc, B.m->resolution, (const int*)B.stats, d_view + 4 * lv, B.view,
                                                                    nullptr, 0, last ? poll_seq : 0u);
       e = hipGetLastError();
@@ -1116,7 +1125,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
         // host returns before it has started.  EVERY level's table is therefore still being written when this call returns: every map gets its
         // ready event (readers on other streams wait for it: voxelmap_wait_ready) and keeps its accumulators until that event has been seen.
         bool events = true;
-        for (int lv = 0; lv < num_levels && events; lv++) events = event_get(&b[lv].m->ready_event) == hipSuccess;
+        for (int lv = 0; lv < num_levels && events; lv++) events = event_get(ctx->device, &b[lv].m->ready_event) == hipSuccess;
         if (events) poll_seq = ++ctx->map_seq ? ctx->map_seq : ++ctx->map_seq;
         frame_build_kernel<<<((int)n + 255) / 256, 256, 0, st>>>(up.args, FL, d_view, poll_seq);
         hipError_t e = hipGetLastError();
@@ -1196,7 +1205,7 @@ int glim_amd_frame_create(glim_amd_ctx* ctx, int64_t n, const double* points4, c
       if (B.buckets) (void)pool_free(B.buckets);
       if (B.view) (void)pool_free(B.view);
       if (B.m) {
-        if (B.m->ready_event) event_put(B.m->ready_event);  // (every path that gets here has synchronised the stream)
+        if (B.m->ready_event) event_put(ctx->device, B.m->ready_event);  // (every path that gets here has synchronised the stream)
         B.m->ctx = nullptr;
         delete B.m;
       }

@@ -86,20 +86,6 @@ int glim_amd_ctx_create_ex(int device, int num_streams, void* external_stream, i
 /* GLIM_AMD_ERR_STATE (and the context stays valid) while clouds, voxel maps, factor sets or search indices created from it are alive. */
 int glim_amd_ctx_destroy(glim_amd_ctx* ctx);
 int glim_amd_ctx_synchronize(glim_amd_ctx* ctx);
-/* Diagnostic / tuning switches of a context (no counterpart in the reference; none is needed in production).  key_values:
- * "key=value,key=value"; NULL or "" restores the process defaults, which come from the ONE environment variable the library reads,
- * GLIM_AMD_DIAG (same syntax, parsed once per process).  Keys: knn_path=auto|grid|chunks|brute, knn_kernel=auto|wave64|pair|qgroup,
- * knn_select=0|1, plane=0|1, curve_order=0|1, ppt=<n>, poll=0|1, inline_pose=0|1, bucket_factor=<n>, plan_cache=0|1, plan_recycle=0|1, host_poses=0|1, host_pack=0|1, pull_gated=0|1, frame_fused=0|1,
- * view_fused=0|1 (a voxel map built from a plane-form cloud gets its plane view -- the (C_B + I)^-1 records the plane-form factor kernel reads --
- * from the map's own finalise kernel; 0: on the first factor that needs it),
- * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
- * served by a resident kernel that leaves after <n> us without a request; auto, the default: only in a context created with priority 1 -- the
- * session costs whatever else runs on the device 1.3-1.4x while it is alive, so it is opt-in), pp_fast=0|1 (random-grid preprocessing without sorts),
- * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,
- * multi_host_gather=0|1.  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and nothing changes.  get_diag prints the current state in the
- * same syntax. */
-int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values);
-int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
 /* gtsam_points::cuda_device_names / cuda_mem_get_info (src/glim/util/debug.cpp:84, viewer/memory_monitor.cpp:39). */
 int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t* free_bytes, size_t* total_bytes, int* num_cus);
 
@@ -182,12 +168,6 @@ int glim_amd_cloud_download_frame(const glim_amd_cloud* cloud, double* points4, 
 int glim_amd_cloud_deskew(const glim_amd_cloud* pre, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times,
                           const double* imu_poses12, double stamp, const double* linear_vel3, const double* angular_vel3, int32_t to_imu_frame,
                           glim_amd_cloud** out);
-/* parity / debug only (host arithmetic, no device needed): the time table CloudDeskewing::deskew builds (cloud_deskewing.cpp:22-45 / :70-124) --
- * entry_out[i] = table entry of point i (n, may be NULL), table12_out = one row-major 3x4 T_lidar0_lidar1 per entry (table_cap entries, may
- * be NULL), *table_size = number of entries.  The deskewing kernels gather from exactly this table. */
-int glim_amd_debug_deskew_table(int64_t n, const double* times, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
-                                double stamp, const double* linear_vel3, const double* angular_vel3, int32_t* entry_out, double* table12_out, int32_t table_cap,
-                                int32_t* table_size);
 /* ---- GICP factor on device: gtsam_points::IntegratedGICPFactor -- nearest-neighbour correspondences instead
  * of a voxel lookup -- as constructed at src/glim/mapping/sub_mapping.cpp:202 (between factors, one linearize, :203),
  * src/glim/mapping/global_mapping.cpp:400-402 (set_max_correspondence_distance(0.5), 10 LM iterations) and
@@ -220,9 +200,6 @@ int glim_amd_merge_frames(glim_amd_ctx* ctx, int32_t num_frames, const double* p
                           glim_amd_cloud** out);
 /* the merged submap back on the host as gtsam_points::PointCloudCPU holds it: points4 n x Vector4d, covs16 n x Matrix4d (exact FP64). */
 int glim_amd_cloud_download_merged(const glim_amd_cloud* cloud, double* points4, double* covs16);
-/* parity / debug only: the stable device radix sort behind the preprocessing (sorts by the low `bits` key bits; vals_in NULL = 0..n-1). */
-int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
-                              uint32_t* vals_out);
 
 /* kNN on device: CloudPreprocessor::find_neighbors (src/glim/preprocess/cloud_preprocessor.cpp:190-221).
  * k nearest among all points including the query itself, ascending (distance, index); fewer than k points -> the tail is 0 (what the
@@ -296,56 +273,6 @@ int glim_amd_factor_set_linearize_device_async(glim_amd_factor_set* set, const d
                                                int64_t out_row_offset);
 int glim_amd_expand_compact(const double* compact, const double* T_target_source, uint32_t flags, glim_amd_linearized6* out);
 
-/* Timing aid used by bench.py: runs `iters` back-to-back launches bracketed by HIP events on the set's stream.
- * ms_vgicp_kernel: average duration of the fused lookup+residual+Jacobian+reduce kernel alone;
- * ms_linearize: average duration of the whole device-resident linearise (kernel + finalise). */
-int glim_amd_factor_set_profile(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_vgicp_kernel,
-                                float* ms_linearize);
-
-/* wall-clock milliseconds per synchronous glim_amd_factor_set_linearize call (pose upload, launches, result in host memory),
- * measured inside the library so that no binding overhead is included. */
-int glim_amd_factor_set_profile_sync(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_per_call);
-/* timing aid: EXACTLY `iters` synchronous glim_amd_factor_set_linearize calls from C, no warm-up, no clock -- the caller times it.  Call i
- * linearises at pose set i % num_pose_sets of T_target_source (num_pose_sets x n x 12: an optimiser moves the poses between its
- * relinearisations); out_last (n records, may be NULL) receives the last call's result. */
-int glim_amd_factor_set_linearize_repeat(glim_amd_factor_set* set, const double* T_target_source, int num_pose_sets, int iters,
-                                         glim_amd_linearized6* out_last);
-
-/* GLIM's live call pattern (odometry_estimation_gpu.cpp:383-385; the optimisers' linearisation hook does clear -> add(graph) -> linearize per
- * iteration): a FRESH factor set per linearisation -- create, add the n factors, synchronous linearize (poses T: n x 12), destroy -- `iters`
- * times; microseconds per iteration, measured inside the library. */
-int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
-                                      const uint32_t* flags, const double* T_target_source, int iters, float* us_per_iteration);
-
-/* Measurement aid: wavefront trips of the general (36 B/pt) factor kernel that found no correspondence in any lane and skipped the record gather
- * and the algebra, summed over every evaluation of the set's current plan since the last reset, and the trips ONE evaluation of the plan makes
- * (blocks x 4 wavefronts x points per thread).  bench.py prices the kernel's instruction floor with the measured share instead of a constant. */
-int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_trips, uint64_t* total_trips_per_evaluation, int reset);
-
-/* The same pattern with every iteration timed on its own (samples_us: `iters` entries) and `gap_us` of host busy-waiting between iterations -- the
- * optimiser's own work between two linearisations --, for latency percentiles while other threads load the device (bench.py
- * --workload odometry_under_load). */
-int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,
-                                              const uint32_t* flags, const double* T_target_source, int iters, double gap_us, float* samples_us);
-
-/* One Levenberg-Marquardt iteration as the optimisers drive it (sub_mapping.cpp:435-443, odometry_estimation_cpu.cpp:116-149): a synchronous
- * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
-int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
-
-/* parity / debug only: the device's resident session (repeated synchronous linearisations of a small factor list are served by a kernel that stays
- * on the device and takes its requests through host-mapped memory; it leaves by itself after `resident_idle_us` without a request): kernel
- * launches and requests served so far, whether one is alive right now. */
-int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive);
-/* ends the device's resident session now instead of letting it idle out (GLIM_AMD_ERR_STATE while a request is in flight). */
-int glim_amd_debug_resident_stop(int device);
-/* parity / debug only: factor plans this context has built for new factor lists, how many of them took over the buffers of the plan its full
- * cache was about to evict (a new list of the same shape: GLIM's odometry brings one per frame), idle plans cached right now. */
-int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached);
-/* parity / debug only: host-side account of the calling thread's LAST one-submission glim_amd_frame_create, microseconds since its entry:
- * [0] cloud allocated, [1] staging block + stream allocations, [2] pull kernel launched, [3] host conversion done, [4] voxel-map kernels
- * enqueued, [5] completion word seen, [6] return (tools/odometry_frame_loop.cpp prints the medians). */
-int glim_amd_debug_frame_stages(double* microseconds, int32_t num_fields);
-
 /* ---- multi-device cost evaluation (BASELINE.json configs[3]; no counterpart in the reference, which is single-device:
  *      src/glim/mapping/global_mapping.cpp:110 one StreamTempBufferRoundRobin(64), :430-484 create_matching_cost_factors) -------------
  * One process, N devices: a context + a host thread + an RCCL communicator (ncclCommInitAll; librccl is dlopen'ed on first use) per
@@ -353,10 +280,16 @@ int glim_amd_debug_frame_stages(double* microseconds, int32_t num_fields);
  * contiguous cost-balanced chunks, every device linearises its chunk -- in a few pieces, so that the ncclAllGather of one piece's 29-double
  * compact records travels over xGMI (and this device's own rows to the host over its own PCIe link) while the next piece's kernels run --
  * and the records are expanded on the host in the original factor order.  One hand-over to the devices' threads per evaluation.  All
- * calls are synchronous and must come from one host thread at a time. */
+ * calls are synchronous and must come from one host thread at a time.
+ * Who reads what: the HOST optimiser (GLIM's ISAM2 / LM, global_mapping.cpp:501) gets every record through a second store of the finalising
+ * kernels into one pinned host array, so a call returns when the kernels are done; the all-gather completes the DEVICE-resident copy of the
+ * record array on every device for device-side consumers (glim_amd_multi_gathered_device) and finishes behind the call
+ * (glim_amd_multi_set_gather_mode). */
 typedef struct glim_amd_multi glim_amd_multi;
 /* devices: distinct HIP device ordinals.  A multi-device handle without a working RCCL is refused (GLIM_AMD_ERR_HIP) rather than
- * silently gathering over PCIe; a single device works either way (GLIM_AMD_DIAG="multi_rccl=0" skips the collective there). */
+ * silently gathering over PCIe; a single device works either way (GLIM_AMD_DIAG="multi_rccl=0" skips the collective there).  (Test boxes with one
+ * GPU run the N > 1 path over "virtual devices" -- one ordinal listed several times -- only when GLIM_AMD_DIAG holds multi_virtual=1:
+ * glim_amd_diag.h.) */
 int glim_amd_multi_create(const int32_t* devices, int32_t num_devices, glim_amd_multi** out);
 int glim_amd_multi_destroy(glim_amd_multi* multi);
 int glim_amd_multi_info(const glim_amd_multi* multi, int32_t* num_devices, int32_t* uses_rccl, int64_t* num_factors);
@@ -379,40 +312,18 @@ int glim_amd_multi_linearize(glim_amd_multi* multi, const double* T_target_sourc
 /* the last evaluation's compact 29-double records [num_inliers, error, 21 upper-triangular H_ss entries, 6 b_s] of factors
  * [first, first + count), in factor order (expand one with glim_amd_expand_compact) */
 int glim_amd_multi_records(const glim_amd_multi* multi, int64_t first, int64_t count, double* compact29);
-/* wall-clock milliseconds per whole-cost evaluation (all devices + collective + host expansion skipped), over `iters` evaluations */
-int glim_amd_multi_profile(glim_amd_multi* multi, const double* T_target_source, int iters, float* ms_per_evaluation);
-/* per device, HIP-event milliseconds of the LAST evaluation: its factor kernels + finalise (kernel_ms[d]) and the collective + copy-out behind
- * them (gather_ms[d]); num_devices entries each, either may be NULL */
-int glim_amd_multi_last_timing(const glim_amd_multi* multi, float* kernel_ms, float* gather_ms);
-/* host-side account of the LAST evaluation on one device's thread, microseconds, GLIM_AMD_MULTI_BREAKDOWN_FIELDS values:
- *   [0] post        caller: handing the evaluation to the other devices' threads          (device 0 only)
- *   [1] wake        from the caller's entry to the start of this device's task            (0 for device 0: the caller's own thread)
- *   [2] pose_stage  this shard's poses copied into the pinned ring
- *   [3] enqueue     plan check + H2D pose copy + kernel launches
- *   [4] barrier     waiting until every device has enqueued (no collective starts before)
- *   [5] collective  ncclAllGather calls + copy-out enqueue
- *   [6] wait        hipStreamSynchronize: the device working
- *   [7] join        caller: waiting for the other devices' threads                        (device 0 only)
- *   [8] scan        caller: total error + expansion of the records in factor order        (device 0 only)
- *   [9] total       the whole glim_amd_multi_linearize call                                (device 0 only)
- *   [10] library_calls   inside the ncclAllGather calls (part of [5])
- *   [11] device_gather   HIP events: from this device's last kernel to the end of its last all-gather
- *   [12] device_copy_out HIP events: from there to the end of the copy-out and the error sum  ([11] + [12] = gather_ms of last_timing) */
-#define GLIM_AMD_MULTI_BREAKDOWN_FIELDS 13
-int glim_amd_multi_last_breakdown(const glim_amd_multi* multi, int32_t device, double* microseconds, int32_t num_fields);
-/* how a device's shard is evaluated: n >= 2 = as n pieces (at most 8), the all-gather and copy-out of one piece overlapping the kernels of
- * the next; 0 or 1 = as one set and one all-gather; -1 (default) = pieces of at least 2048 factors, at most 4.  Takes effect with the next
- * glim_amd_multi_set_factors. */
-int glim_amd_multi_set_split(glim_amd_multi* multi, int32_t mode);
-/* ONE device has nothing to gather, so its evaluations make no library call; the binding is exercised when the handle is created (an in-place
- * one-rank all-gather that must come back unchanged; glim_amd_multi_info uses_rccl says whether it did).  on != 0: make the no-op
- * ncclAllGather in every evaluation as well (measurement aid: bench.py prices it).  No effect on several devices. */
-int glim_amd_multi_set_one_rank_collective(glim_amd_multi* multi, int32_t on);
-/* how every device's own records reach the host array (glim_amd_multi_records, the `out` of glim_amd_multi_linearize): 1 (default) = its
- * finalising kernels store them there as well (host-mapped memory, 232 B per factor over the device's PCIe link while the launch runs: nothing
- * is copied behind the kernels); 0 = device-to-host copies on the collective's stream behind each piece.  Takes effect with the next
- * glim_amd_multi_set_factors. */
-int glim_amd_multi_set_host_records(glim_amd_multi* multi, int32_t mode);
+/* The exchange of an evaluation: 1 (default) = enqueued behind every piece, NOT waited for by glim_amd_multi_linearize (the next evaluation's
+ * kernels wait for it on the device before they overwrite their send slots; glim_amd_multi_gathered_device / _wait_gather wait on the host);
+ * 2 = the call returns only when every device holds every record (the form of versions <= 0.1.0 r5); 0 = no exchange at all (host records only). */
+int glim_amd_multi_set_gather_mode(glim_amd_multi* multi, int32_t mode);
+/* host wait for the last evaluation's exchange on every device (no-op when none is pending) */
+int glim_amd_multi_wait_gather(glim_amd_multi* multi);
+/* The consumer side of the all-gather: the device-resident record array of device `device` (an index into the handle's device list), complete on
+ * return -- *gathered points at num_devices x max_rows records of GLIM_AMD_COMPACT_DOUBLES doubles in DEVICE memory (valid until the next
+ * glim_amd_multi_set_factors / destroy; overwritten by the next evaluation), *rows (may be NULL) = num_devices x max_rows; factor f of the list sits at
+ * the row glim_amd_shard_layout gives for it.  An on-device consumer (cost, gradient or a whole optimiser step built from every factor's blocks)
+ * reads it from any stream of that device without a host trip. */
+int glim_amd_multi_gathered_device(glim_amd_multi* multi, int32_t device, const double** gathered, int64_t* rows);
 /* the sharding rule as a pure host function (no device needed): contiguous chunks whose cumulative cost is nearest to r / world of the total */
 int glim_amd_shard_bounds(const double* costs, int64_t n, int32_t world, int64_t* bounds);
 /* where every factor's 29-double record sits in the gathered [world x max_rows] array of an evaluation, as a pure host function (the rule
@@ -431,9 +342,6 @@ int glim_amd_overlap(glim_amd_ctx* ctx, int32_t num_targets, const glim_amd_voxe
  * `T_target_source` (12 doubles each) in query order, against sources[q]; overlaps[q] receives the fraction.  At most 1024 queries. */
 int glim_amd_overlap_batch(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
                            const double* T_target_source, const glim_amd_cloud* const* sources, double* overlaps);
-/* timing aid: `iters` back-to-back glim_amd_overlap_batch calls with these arguments; microseconds per call, measured inside the library. */
-int glim_amd_overlap_profile(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
-                             const double* T_target_source, const glim_amd_cloud* const* sources, int iters, float* us_per_call);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/glim_amd.h"
+#include "../../include/glim_amd_diag.h" /* glim_amd_multi_profile: a timing loop, not part of the drop-in ABI */
 
 #define REQUIRE(cond)                                                          \
   do {                                                                         \
@@ -49,18 +50,22 @@ static void rel_pose(double xa, double ya, double wa, double xb, double yb, doub
   memcpy(T, R, sizeof(R));
 }
 
-int main(void) {
+int main(int argc, char** argv) {
   const int ndev = glim_amd_device_count();
   REQUIRE(ndev >= 1);
   int32_t devices[16];
-  const int use = ndev < 16 ? ndev : 16;
-  for (int i = 0; i < use; i++) devices[i] = i;
+  /* `test_multi virtual N` (with GLIM_AMD_DIAG=multi_virtual=1 in the environment): device 0 listed N times -- the N > 1 path of multi.hip (threads,
+   * host barrier, per-device shards and pieces, the exchange) on a one-GPU box; the exchange is then the same-device stand-in, not RCCL */
+  const int virtual_n = (argc > 2 && strcmp(argv[1], "virtual") == 0) ? atoi(argv[2]) : 0;
+  const int use = virtual_n > 0 ? (virtual_n < 16 ? virtual_n : 16) : (ndev < 16 ? ndev : 16);
+  for (int i = 0; i < use; i++) devices[i] = virtual_n > 0 ? 0 : i;
   glim_amd_multi* multi = NULL;
   REQUIRE(glim_amd_multi_create(devices, use, &multi) == GLIM_AMD_OK);
   int32_t nd = 0, rccl = 0;
   REQUIRE(glim_amd_multi_info(multi, &nd, &rccl, NULL) == GLIM_AMD_OK && nd == use);
   printf("devices %d, rccl %d\n", nd, rccl);
-  REQUIRE(rccl == 1); /* librccl ships with the ROCm image: the collective path must be the one that runs */
+  if (virtual_n > 1) REQUIRE(rccl == 0);
+  else REQUIRE(rccl == 1); /* librccl ships with the ROCm image: the collective path must be the one that runs */
 
   enum { S = 6, N = 20000 };
   const double px[S] = {1.0, 1.5, 2.1, 2.4, 3.0, 3.3}, py[S] = {1.0, 1.2, 1.1, 1.6, 1.9, 2.4}, pw[S] = {0.0, 0.05, 0.1, 0.12, 0.2, 0.25};

@@ -23,12 +23,43 @@ def L():
 def test_every_declared_symbol_is_exported(L):
     from glim_amd import _lib
 
-    header = open(os.path.join(ROOT, "include", "glim_amd.h")).read()
-    declared = set(re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no declarations parsed"
+    declared = set()
+    for h in ("glim_amd.h", "glim_amd_diag.h"):
+        header = open(os.path.join(ROOT, "include", h)).read()
+        found = set(re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", header))
+        assert found, f"no declarations parsed in {h}"
+        assert not (found & declared), f"declared in both headers: {found & declared}"
+        declared |= found
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
+
+
+def _diag_symbols():
+    header = open(os.path.join(ROOT, "include", "glim_amd_diag.h")).read()
+    return set(re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", header))
+
+
+def test_the_stable_header_holds_no_probe_and_the_drop_in_layers_never_touch_the_diag_header():
+    """include/glim_amd.h is the drop-in boundary; include/glim_amd_diag.h holds every timing loop, counter, switch and debug view.  A GLIM
+    maintainer binding the ABI must be able to tell them apart: no *_profile* / glim_amd_debug_* / *_trip_stats / set_diag name is declared in the
+    stable header, and nothing under adapters/, examples/ or include/glim_amd/ includes the diag header or calls one of its entry points."""
+    stable = open(os.path.join(ROOT, "include", "glim_amd.h")).read()
+    names = set(re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", stable))
+    for n in names:
+        assert not re.search(r"profile|_debug_|trip_stats|_diag$|linearize_repeat|last_timing|last_breakdown|inject", n), n
+    assert "#include \"glim_amd_diag.h\"" not in stable and "#include <glim_amd_diag.h>" not in stable  # (named in a comment only)
+    diag = _diag_symbols()
+    assert len(diag) >= 20
+    for top in ("adapters", "examples", os.path.join("include", "glim_amd")):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".h", ".hpp", ".c", ".cpp", ".cc")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "glim_amd_diag.h" not in text, os.path.join(dirpath, f)
+                used = {n for n in re.findall(r"\b(glim_amd_[a-z0-9_]+)\s*\(", text)} & diag
+                assert not used, (os.path.join(dirpath, f), used)
 
 
 def test_version_and_error_strings(L):
@@ -159,10 +190,10 @@ def test_every_diagnostic_key_is_documented():
     src = open(os.path.join(ROOT, "glim_amd", "csrc", "context.hip")).read()
     keys = re.findall(r'\{"([a-z_0-9]+)", &Diag::', src) + ["knn_debug"]
     assert len(keys) >= 20
-    header = open(os.path.join(ROOT, "include", "glim_amd.h")).read()
+    header = open(os.path.join(ROOT, "include", "glim_amd_diag.h")).read()
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     for k in keys:
-        assert k + "=" in header, f"diag key {k} is not documented in include/glim_amd.h"
+        assert k + "=" in header, f"diag key {k} is not documented in include/glim_amd_diag.h"
         assert k + "=" in design or f"`{k}`" in design, f"diag key {k} is not documented in DESIGN.md"
     for words in re.findall(r'k(?:Path|Kernel)Words\[\] = \{([^}]*)\}', src):
         for w in re.findall(r'"([a-z0-9]+)"', words):

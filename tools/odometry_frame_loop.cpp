@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "glim_amd.h"
+#include "glim_amd_diag.h"  // set_diag A/B switches, frame-stage and plan counters: measurement hooks
 
 #define CHECK(call)                                                                                          \
   do {                                                                                                       \

@@ -21,6 +21,6 @@ for name, pts, res in (("10000 pts, 0.443 m", full[np.sort(rng.choice(len(full),
     for _ in range(40):
         m = api.GaussianVoxelMapGPU(res, ctx=ctx)
         t = time.perf_counter(); m.insert(g); ts.append(time.perf_counter() - t)
-        nv = m.num_voxels() if hasattr(m, "num_voxels") else -1
+        nv = m.voxelmap_info()["num_voxels"]
         m.close()
     print(f"{name}: insert p50 {np.median(ts) * 1e6:.1f} us  min {np.min(ts) * 1e6:.1f} us  voxels {nv}", flush=True)
