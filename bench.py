@@ -1527,7 +1527,7 @@ def main():
     ap.add_argument("--sync-calls", type=int, default=2000, help="odometry128k: synchronous single-factor linearize calls per step (the headline loop)")
     ap.add_argument("--submap-frames", type=int, default=4, help="global256: keyframes merged into one submap")
     ap.add_argument("--submap-rings", type=int, default=40)
-    ap.add_argument("--submap-azimuths", type=int, default=512)
+    ap.add_argument("--submap-azimuths", type=int, default=560, help="global256: 4 x 40 x 560 rays per submap merge to >= 65 536 points on average (BASELINE configs[3]: 256 x 64k; 512 gave 62 187)")
     ap.add_argument("--no-resident-cost", action="store_true", help="skip the interference measurement (factor kernels timed beside an idle resident session)")
     ap.add_argument("--no-m2", action="store_true", help="N = 1 default run: skip the 256-submap cost evaluation that is attached as `m2_global256` (~17 s)")
     ap.add_argument("--factors", type=int, default=128, help="odometry128k: factors per GPU per step")

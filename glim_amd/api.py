@@ -772,6 +772,12 @@ def plan_stats(ctx=None):
     return {"built": a.value, "recycled": b.value, "cached": c.value}
 
 
+def scratch_poke(ctx, word, value=0xFFFFFFFF):
+    """Test hook (glim_amd_debug_scratch_poke): leave `value` in a word of the context's pinned scratch; the default stands for the sequence
+    number the context's next polled voxel-map build waits for."""
+    check(lib().glim_amd_debug_scratch_poke(ctx._h, int(word), int(value)), "glim_amd_debug_scratch_poke")
+
+
 def resident_stop(ctx=None):
     """Debug: end the device's resident session now (it would idle out by itself after `resident_idle_us`)."""
     ctx = ctx or default_context()

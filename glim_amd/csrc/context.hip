@@ -190,6 +190,19 @@ int glim_amd_ctx_set_diag(glim_amd_ctx* ctx, const char* key_values) {
   return diag_parse(ctx->diag, key_values);
 }
 
+// test hook: what an earlier read-back may have left in the context's shared pinned scratch (the polled voxel-map builds keep their completion
+// word there: tests/test_gpu_edge_cases.py poisons it with the NEXT build's sequence number)
+int glim_amd_debug_scratch_poke(glim_amd_ctx* ctx, int32_t word, uint32_t value) {
+  if (!ctx || word < 0 || word >= 256) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  void *h = nullptr, *d = nullptr;
+  GA_HIP(hipSetDevice(ctx->device));
+  if (!pinned_scratch_views(ctx, &h, &d)) return GLIM_AMD_ERR_UNSUPPORTED;
+  if (value == 0xffffffffu) value = (ctx->map_seq + 1u) ? ctx->map_seq + 1u : 1u;  // "the sequence number the next polled build will wait for"
+  reinterpret_cast<volatile uint32_t*>(h)[word] = value;
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len) {
   if (!ctx) return GLIM_AMD_ERR_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -40,6 +40,10 @@ int glim_amd_ctx_get_diag(glim_amd_ctx* ctx, char* buf, size_t len);
 int glim_amd_debug_deskew_table(int64_t n, const double* times, const double* T_imu_lidar12, int32_t n_imu, const double* imu_times, const double* imu_poses12,
                                 double stamp, const double* linear_vel3, const double* angular_vel3, int32_t* entry_out, double* table12_out, int32_t table_cap,
                                 int32_t* table_size);
+/* test hook: writes `value` into 32-bit word `word` (< 256) of the context's pinned scratch block -- what an earlier read-back (kNN counters, kept
+ * points) may have left where the polled voxel-map builds keep their completion word (word 2; 4 * (levels - 1) + 2 for glim_amd_frame_create).
+ * value = 0xffffffff stands for "the sequence number the context's NEXT polled build will wait for". */
+int glim_amd_debug_scratch_poke(glim_amd_ctx* ctx, int32_t word, uint32_t value);
 /* parity / debug only: the stable device radix sort behind the preprocessing (sorts by the low `bits` key bits; vals_in NULL = 0..n-1). */
 int glim_amd_debug_sort_pairs(glim_amd_ctx* ctx, int64_t n, int32_t bits, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
                               uint32_t* vals_out);

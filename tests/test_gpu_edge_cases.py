@@ -674,3 +674,42 @@ def test_resident_session_lifecycle(api, ctx, orc, small_pair):
         assert served["launches"] > before["launches"] and served["requests"] >= before["requests"] + 60, (before, served)
         f2.close(); m2.close(); s2.close(); t2.close()
         c2.close()
+
+
+def test_a_stale_scratch_word_equal_to_the_next_build_number_does_not_end_the_wait(api, orc, small_pair):
+    """the polled completion word of voxelmap_insert (word 2) and of glim_amd_frame_create (word 4 * (levels - 1) + 2) lives in the context's
+    shared pinned scratch, where read_back_sync() leaves small integers (kNN counters, kept points).  A leftover equal to the NEXT build's sequence
+    number used to end the host's wait before the kernel had written anything -- the voxel count then was the previous map's.  The word is cleared
+    before every launch now: with the scratch poisoned the counts are the oracle's."""
+    ctx = api.Context(0, 1)
+    t, s = small_pair["target"], small_pair["source"]
+    tg = api.PointCloudGPU.clone(t["points"].astype(np.float64), t["covs"], ctx=ctx)
+    few = slice(0, 700)
+    sg = api.PointCloudGPU.clone(s["points"][few].astype(np.float64), s["covs"][few], ctx=ctx)
+    want_t = {r: orc.VoxelMap(r).insert(t["points"], t["covs"]).num_voxels() for r in (0.5, 1.0)}
+    want_s = orc.VoxelMap(0.5).insert(s["points"][few], s["covs"][few]).num_voxels()
+    assert want_s != want_t[0.5]
+    first = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)  # leaves its own count in word 0
+    assert first.voxelmap_info()["num_voxels"] == want_t[0.5]
+    for _ in range(3):
+        api.scratch_poke(ctx, 2)  # "the next build is complete"
+        m = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(sg)
+        assert m.voxelmap_info()["num_voxels"] == want_s
+        api.scratch_poke(ctx, 2)
+        m2 = api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(tg)
+        assert m2.voxelmap_info()["num_voxels"] == want_t[0.5]
+    n = len(t["points"])
+    p4 = np.ones((n, 4))
+    p4[:, :3] = t["points"][:, :3]
+    c = np.zeros((n, 4, 4))
+    c[:, :3, :3] = t["covs"][:, :3, :3]
+    c16 = np.ascontiguousarray(np.transpose(c, (0, 2, 1))).reshape(n, 16)
+    n4 = np.zeros((n, 4))
+    n4[:, :3] = t["normals"][:, :3]
+    for switches in ("", "frame_fused=0"):
+        ctx.set_diag(switches)
+        api.GaussianVoxelMapGPU(0.5, ctx=ctx).insert(sg)  # (word 0 / 4 now hold other counts)
+        api.scratch_poke(ctx, 6)
+        cloud, maps = api.frame_create(p4, c16, n4, [0.5, 1.0], ctx=ctx)
+        assert [m.voxelmap_info()["num_voxels"] for m in maps] == [want_t[0.5], want_t[1.0]]
+    ctx.set_diag("")
