@@ -129,8 +129,9 @@ public:
   double error(const gtsam::Values& values) const override {
     const Isometry3d delta = impl_->calc_delta(to_values(values));
     if (err_valid_ && same_pose(delta, err_delta_)) return err_;
-    // after a linearisation the GPU factor evaluates with the correspondences frozen at the linearisation point
-    err_ = impl_->error(to_values(values), lin_valid_ ? &lin_values_ : nullptr);
+    // after a linearisation the GPU factor evaluates with the correspondences frozen at the linearisation point; the
+    // CPU-named factor (gtsam_points/factors/integrated_vgicp_factor.hpp of the shim tree) finds them at `values` (row a6)
+    err_ = impl_->error(to_values(values), (frozen_error_ && lin_valid_) ? &lin_values_ : nullptr);
     err_delta_ = delta;
     err_valid_ = true;
     return err_;
@@ -155,10 +156,17 @@ public:
     err_valid_ = true;
   }
   bool has_linearization_point() const { return lin_valid_; }
+  // false: error() finds its correspondences at the evaluation pose (CPU-factor semantics); true (default): frozen at the last linearisation point
+  bool frozen_error() const { return frozen_error_; }
   const Values& linearization_values() const { return lin_values_; }
+
+protected:
+  void set_frozen_error(bool frozen) { frozen_error_ = frozen; }
+  void reset_impl_clone() { impl_ = impl_->clone(); }  // (a copy-constructed factor shares impl_ with its source until this is called)
 
 private:
   IntegratedVGICPFactorGPU::shared_ptr impl_;
+  bool frozen_error_ = true;
   mutable bool lin_valid_ = false, err_valid_ = false;
   mutable Isometry3d lin_delta_, err_delta_;
   mutable Values lin_values_;
@@ -237,7 +245,7 @@ public:
     bool frozen = true;
     Values lin;
     for (const auto& f : factors_) {
-      frozen = frozen && f->has_linearization_point();
+      frozen = frozen && f->frozen_error() && f->has_linearization_point();  // (a CPU-named factor in the set: correspondences at `values` for all)
       if (!frozen) break;
       for (const auto& kv : f->linearization_values()) {
         auto it = lin.find(kv.first);

@@ -11,7 +11,17 @@
 // (`dynamic_cast<gtsam_points::IntegratedGICPFactor*>` at global_mapping.cpp:584 sees this class: the factors it inspects were made here).
 // The target's search structure: upstream passes a gtsam_points::NearestNeighborSearch (a KdTree of the target); here any such pointer is
 // accepted and ignored -- the device index (glim_amd_nn_index) is built from the target frame itself, once per factor.
+//
+// The REAL header stays reachable (round 6): upstream defines a class TEMPLATE IntegratedGICPFactor_<TargetFrame, SourceFrame> and the alias
+// `using IntegratedGICPFactor = IntegratedGICPFactor_<>`; the CPU odometry instantiates the template over an iVox target
+// (odometry_estimation_cpu.cpp:94-99, registration_type "GICP"), which is not this library's path.  So the real header is pulled in with
+// #include_next under a one-identifier rename of the ALIAS only (`IntegratedGICPFactor_` is a different token and untouched): every
+// `IntegratedGICPFactor_<iVox, PointCloud>` keeps compiling against libgtsam_points, and the plain name `IntegratedGICPFactor` is the device class below.
 #pragma once
+
+#define IntegratedGICPFactor IntegratedGICPFactorUpstreamAlias
+#include_next <gtsam_points/factors/integrated_gicp_factor.hpp>
+#undef IntegratedGICPFactor
 
 #include <memory>
 

@@ -11,6 +11,7 @@
 #include <Eigen/Core>
 #include <Eigen/Geometry>
 #include <gtsam_points/types/gaussian_voxelmap.hpp>
+#include <gtsam_points/types/hip_voxelmap_holder.hpp>
 #include <gtsam_points/types/point_cloud_gpu.hpp>
 
 struct CUstream_st;
@@ -24,7 +25,7 @@ struct VoxelMapInfo {
   float voxel_resolution;
 };
 
-class GaussianVoxelMapGPU : public GaussianVoxelMap {
+class GaussianVoxelMapGPU : public GaussianVoxelMap, public HipVoxelMapHolder {
 public:
   using Ptr = std::shared_ptr<GaussianVoxelMapGPU>;
   using ConstPtr = std::shared_ptr<const GaussianVoxelMapGPU>;
@@ -53,19 +54,13 @@ public:
   }
   void save_compact(const std::string& /*path*/) const { throw std::runtime_error("GaussianVoxelMapGPU::save_compact: not supported (upstream neither)"); }
   size_t memory_usage_gpu() const { return impl_->voxelmap_info().bytes; }
-  const glim_amd::GaussianVoxelMapGPU::ConstPtr device() const { return impl_; }
+  glim_amd::GaussianVoxelMapGPU::ConstPtr device() const override { return impl_; }
 
   VoxelMapInfo voxelmap_info;  // standard_viewer_mem.cpp:77 reads num_voxels / num_buckets
 
 private:
   std::shared_ptr<glim_amd::GaussianVoxelMapGPU> impl_;
 };
-
-inline glim_amd::GaussianVoxelMapGPU::ConstPtr device_map(const GaussianVoxelMap::ConstPtr& voxelmap) {
-  auto gpu = std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(voxelmap);
-  if (!gpu) throw std::runtime_error("a GPU factor / overlap_gpu needs a GaussianVoxelMapGPU target (upstream aborts here too)");
-  return gpu->device();
-}
 
 // (stream: accepted for the signature; the call runs on the context of the target map, which is the calling module's own)
 inline double overlap_gpu(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta, CUstream_st* /*stream*/ = nullptr) {
@@ -77,16 +72,15 @@ inline double overlap_gpu(const std::vector<GaussianVoxelMap::ConstPtr>& targets
   for (const auto& m : targets) t.push_back(device_map(m));
   return glim_amd::overlap_gpu(t, device_cloud(source), deltas);
 }
-// The CPU overlap of the (CPU-only) gtsam_points install this tree is layered over -- upstream declares it in
-// gtsam_points/types/gaussian_voxelmap_cpu.hpp and libgtsam_points defines it; redeclared here so that overlap_auto can reach it without
-// pulling that header into every translation unit that includes this one.
+// The CPU overlap of the (CPU-only) gtsam_points install this tree is layered over -- libgtsam_points defines it; declared here so that
+// overlap_auto can fall back to it for a map that is NOT device-backed (a map of some other GaussianVoxelMap subclass).
 double overlap(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta);
 
-// overlap_auto dispatches on where the map lives, as upstream does: a GaussianVoxelMapGPU target takes the device path, anything else (a
-// libglim built with GTSAM_POINTS_USE_CUDA but run with enable_gpu = false creates GaussianVoxelMapCPU maps: global_mapping.cpp:275, and
-// reaches this call unconditionally at sub_mapping.cpp:253 and global_mapping.cpp:322,448) falls back to the CPU overlap.
+// overlap_auto dispatches on where the map lives, as upstream does: a device-backed target -- GaussianVoxelMapGPU, and the GaussianVoxelMapCPU of
+// this include tree, which a libglim run with enable_gpu = false creates (global_mapping.cpp:275) and hands to this call unconditionally at
+// sub_mapping.cpp:253 and global_mapping.cpp:322,448 -- takes the device path; anything else falls back to the CPU overlap.
 inline double overlap_auto(const GaussianVoxelMap::ConstPtr& target, const PointCloud::ConstPtr& source, const Eigen::Isometry3d& delta) {
-  if (std::dynamic_pointer_cast<const GaussianVoxelMapGPU>(target)) return overlap_gpu(target, source, delta);
+  if (dynamic_cast<const HipVoxelMapHolder*>(target.get())) return overlap_gpu(target, source, delta);
   return overlap(target, source, delta);
 }
 

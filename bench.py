@@ -1122,7 +1122,7 @@ def run_global256(args, D, api, ctx, extra_only=False):
     breakdown = ev.profile_device(fset, deltas, send, gathered, index_t, reps=5)
     n_pts = [costs[f] for f in ev.owned()]
     n_vox = [vmaps[pairs[f][0]].voxelmap_info()["num_voxels"] for f in ev.owned()]
-    traffic = measured_traffic("global256") if (S, args.submap_frames, args.submap_rings, args.submap_azimuths) == (256, 4, 40, 512) else None
+    traffic = measured_traffic("global256") if (S, args.submap_frames, args.submap_rings, args.submap_azimuths) == (256, 4, 40, 560) else None
     if traffic:
         traffic = (traffic[0] * len(n_pts), traffic[1], traffic[2])  # measured per factor (PMC passes over all 32 640 pairs), scaled to this rank's share
     roof = roofline_of(fset, local_poses, n_pts, n_vox, 5, traffic)
@@ -1152,10 +1152,22 @@ def run_global256(args, D, api, ctx, extra_only=False):
     torch.cuda.synchronize()
     skipped, total_trips = fset.trip_stats(reset=True)
     skip_share = skipped / max(1, total_trips)
-    floor_ms = visits * (1.0 - skip_share * 0.6) / pts_per_s * 1e3
+    # pre-cull (round 6): trips the pre-pass marked -- their chunk box misses the target's occupancy mask -- are never walked at all; the in-loop skip
+    # above then only sees the all-miss trips the box test could not prove empty
+    culled = fset.cull_stats(reset=True)
+    fset.cull_stats(reset=True)
+    ev.gather_device(fset, deltas, send, gathered)
+    torch.cuda.synchronize()
+    culled = fset.cull_stats(reset=True)
+    cull_share = (culled[0] / max(1, total_trips)) if culled else 0.0
+    roof["pre_cull"] = ({"culled_trips_per_evaluation": int(culled[0]), "trips_with_points_per_evaluation": int(culled[1]), "trips_per_evaluation": int(total_trips),
+                         "culled_share_of_trips_with_points": culled[0] / max(1, culled[1]), "in_loop_all_miss_skips_left": int(skipped),
+                         "in_loop_skip_share_of_trips_with_points": skipped / max(1, culled[1])}
+                        if culled else {"enabled": False})
+    floor_ms = visits * (1.0 - skip_share * 0.6 - cull_share) / pts_per_s * 1e3
     roof["diagnostic_valu_issue_model"] = {
         "ticks_per_point_trip": ticks, "chip_points_per_s": pts_per_s, "point_visits": visits,
-        "skipped_trips_this_run": int(skipped), "trips_per_evaluation": int(total_trips), "skipped_trip_share": skip_share,
+        "skipped_trips_this_run": int(skipped), "trips_per_evaluation": int(total_trips), "skipped_trip_share": skip_share, "pre_culled_trip_share": cull_share,
         "model_ms": floor_ms, "kernel_ms_over_model_ms": roof["kernel_ms"] / floor_ms,
         "note": "a fitted description of vector-ALU issue, not a hardware limit and not a predictor: see the comment in bench.py",
     }

@@ -551,6 +551,15 @@ class NonlinearFactorSetGPU:
         check(lib().glim_amd_factor_set_correspondences(self._h, int(index), _dp(T), _ip(corr)), "glim_amd_factor_set_correspondences")
         return corr
 
+    def cull_stats(self, reset=False):
+        """(trips culled by the pre-pass, trips that hold points) since the last reset, or None when the plan has no pre-cull (glim_amd_factor_set_cull_stats)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        rc = lib().glim_amd_factor_set_cull_stats(self._h, C.byref(a), C.byref(b), int(bool(reset)))
+        if rc == -6:
+            return None
+        check(rc, "glim_amd_factor_set_cull_stats")
+        return a.value, b.value
+
     def linearize_device_async(self, T_target_source, out_device_ptr, row_offset=0):
         T = T_target_source
         if not (isinstance(T, np.ndarray) and T.dtype == np.float64 and T.flags.c_contiguous and T.size == 12 * len(self.factors)):

@@ -142,9 +142,11 @@ void drop_general_streams(glim_amd_cloud* c) {
   if (c->gs1) (void)pool_free(c->gs1);
   if (c->gs2) (void)pool_free(c->gs2);
   if (c->gsn) (void)pool_free(c->gsn);
+  if (c->gbox) (void)pool_free(c->gbox);
   c->gs0 = c->gs1 = nullptr;
   c->gs2 = nullptr;
   c->gsn = nullptr;
+  c->gbox = nullptr;
 }
 void drop_plane_streams(glim_amd_cloud* c) {
   if (c->pn4) (void)pool_free(c->pn4);
@@ -383,6 +385,43 @@ int detect_plane_form(glim_amd_cloud* c, hipStream_t st) {
   return GLIM_AMD_OK;
 }
 
+// min | max of the xyz of every 64 consecutive points of the general stream: one wavefront per chunk (xor-butterfly over the lanes; min / max of
+// floats are exact, so every point of the chunk lies inside its box bit for bit)
+__global__ __launch_bounds__(256) void chunk_box_kernel(int n, const float4* __restrict__ gs0, float* __restrict__ box) {
+  const int chunk = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+  if (chunk * 64 >= n) return;  // (wave-uniform)
+  const float4 p = gs0[min(chunk * 64 + lane, n - 1)];  // a lane past the end repeats the last point: inside the box of the others
+  float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], m, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m, 64));
+    }
+  const float v = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0] : lane == 4 ? hi[1] : hi[2];
+  if (lane < 6) box[6 * (size_t)chunk + lane] = v;
+}
+
+int ensure_chunk_boxes(glim_amd_cloud* c, hipStream_t st) {
+  if (c->n <= 0 || !c->gs0) return GLIM_AMD_ERR_STATE;
+  std::lock_guard<std::mutex> build_lock(c->build_mu);
+  if (c->gbox) return GLIM_AMD_OK;
+  const int n = (int)c->n, chunks = (n + 63) / 64;
+  float* box = nullptr;
+  GA_HIP(pool_malloc(&box, (size_t)chunks * 6 * sizeof(float)));
+  chunk_box_kernel<<<(chunks * 64 + 255) / 256, 256, 0, st>>>(n, c->gs0, box);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // once per cloud: complete before anybody sees the pointer (any stream, any context)
+  if (e != hipSuccess) {
+    (void)pool_free(box);
+    set_hip_error(e, "ensure_chunk_boxes");
+    return GLIM_AMD_ERR_HIP;
+  }
+  c->gbox = box;
+  return GLIM_AMD_OK;
+}
+
 int ensure_factor_streams(glim_amd_cloud* c, glim_amd_ctx* held, hipStream_t st) {
   if (!c->has_covs || c->n <= 0) return GLIM_AMD_OK;
   // a cloud may be reached from factor sets of several contexts / streams at once (GLIM's modules share frames): one builder, and the streams
@@ -519,6 +558,7 @@ int glim_amd_cloud_destroy(glim_amd_cloud* c) {
   if (c->gs1) (void)pool_free(c->gs1);
   if (c->gs2) (void)pool_free(c->gs2);
   if (c->gsn) (void)pool_free(c->gsn);
+  if (c->gbox) (void)pool_free(c->gbox);
   if (c->pts) (void)pool_free(c->pts);
   if (c->covA) (void)pool_free(c->covA);
   if (c->covB) (void)pool_free(c->covB);

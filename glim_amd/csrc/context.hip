@@ -62,6 +62,7 @@ const DiagKey kDiagKeys[] = {
   {"pp_fast", &Diag::pp_fast, nullptr, 0, 1},
   {"resident", &Diag::resident, kResidentWords, 0, 2},
   {"resident_idle_us", &Diag::resident_idle_us, nullptr, 100, 1000000},
+  {"cull", &Diag::cull, nullptr, 0, 2},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},

@@ -173,6 +173,7 @@ int glim_amd_cloud_estimate_covariances(glim_amd_cloud* c, int k_neighbors) {
   if (c->gs1) { (void)pool_free(c->gs1); c->gs1 = nullptr; }
   if (c->gs2) { (void)pool_free(c->gs2); c->gs2 = nullptr; }
   if (c->gsn) { (void)pool_free(c->gsn); c->gsn = nullptr; }
+  if (c->gbox) { (void)pool_free(c->gbox); c->gbox = nullptr; }
   if (!c->pn4) GA_HIP(pool_malloc(&c->pn4, nn * sizeof(float4)));
   if (!c->n2) GA_HIP(pool_malloc(&c->n2, nn * sizeof(float2)));
   if (c->n > 0) {

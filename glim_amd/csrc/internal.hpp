@@ -139,6 +139,7 @@ struct Diag {
   int frame_fused = 1;    // frame_fused=0|1                     glim_amd_frame_create: one launch pulls the cloud and builds every level, one writes every level's records
   int pull_gated = 1;     // pull_gated=0|1                      ... and that kernel is launched BEFORE the conversion: its blocks wait for their piece of the staging block
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
+  int cull = 1;           // cull=0|1|2                          large general-form sets: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask (2: sets of any size, tests)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
   int multi_virtual = 0;  // multi_virtual=0|1                   glim_amd_multi_create accepts one physical device several times ("virtual devices": the N > 1
@@ -347,6 +348,9 @@ struct glim_amd_cloud {
   float4* gs1 = nullptr;  // c01 c02 c11 c12
   float* gs2 = nullptr;   // c22
   float4* gsn = nullptr;  // normals in stream order
+  // chunk boxes of the general stream (vgicp.hip "pre-cull"): min xyz | max xyz of every 64 consecutive stream points -- what one wavefront trip of
+  // the factor kernel covers --, 6 floats per chunk; built on first use by a large factor set (ensure_chunk_boxes), dropped with the stream
+  float* gbox = nullptr;
   unsigned int* curve_rank = nullptr;  // position of point i on the Hilbert curve through the cloud (knn.hip); orders the factor streams
   bool plane_form = false;
   int32_t* neighbors = nullptr;
@@ -397,9 +401,17 @@ struct glim_amd_voxelmap {
   hipEvent_t ready_event = nullptr;
   std::atomic<bool> ready_pending{false};
   void *pending_acc = nullptr, *pending_stats = nullptr;
+  // Occupancy mask (vgicp.hip "pre-cull"): one bit per cell of (voxel << occ_shift) inside the box of the occupied voxels, x along the bits of a
+  // row of occ_row_words 32-bit words, rows ordered (z, y).  A transformed chunk box that touches no set bit cannot hold a correspondence.  Built on
+  // first use by a large factor set (ensure_occupancy, under view_mu), dropped whenever the table is rebuilt.  occ_state: 0 not built, 1 built,
+  // -1 not available (empty map / box too large for the 64 KiB cap even at the coarsest cell).
+  unsigned int* occ = nullptr;
+  int occ_org[3] = {0, 0, 0}, occ_dim[3] = {0, 0, 0}, occ_shift = 0, occ_row_words = 0, occ_state = 0;
 };
 namespace glim_amd {
 int ensure_plane_view(::glim_amd_voxelmap* m, hipStream_t st);  // voxelmap.hip; complete (synchronised) before it returns
+int ensure_occupancy(::glim_amd_voxelmap* m, hipStream_t st);   // voxelmap.hip; likewise (GLIM_AMD_OK also when no mask can be had: occ stays null)
+int ensure_chunk_boxes(::glim_amd_cloud* c, hipStream_t st);    // cloud.hip; likewise (the general stream must exist)
 // Before anything reads m->buckets / buckets_sm: no-op for a finished map; otherwise `consumer` (a stream) is made to wait for the build, or -- consumer
 // == nullptr -- the host waits.  Any thread, any context.
 int voxelmap_wait_ready(const ::glim_amd_voxelmap* m, hipStream_t consumer);
@@ -417,7 +429,7 @@ struct PlanKey {
 };
 struct FactorPlan {
   std::vector<PlanKey> key;
-  int built_plane = 1, built_ppt = 0;  // plan-time diagnostic switches the plan was built with
+  int built_plane = 1, built_ppt = 0, built_cull = 1;  // plan-time diagnostic switches the plan was built with
   // rows [0, plane_rows) = blocks of factors whose source cloud is plane-form (24 B/pt kernel), rows [plane_rows, total_rows) = blocks of
   // the other factors (36 B/pt kernel); each segment is its own launch
   int points_per_thread = 1;
@@ -427,6 +439,13 @@ struct FactorPlan {
   int2* d_blockmap = nullptr;     // total_rows x int2
   float* d_partials = nullptr;
   unsigned long long* d_trip_stats = nullptr;  // 64 counters of skipped wavefront trips (general kernel; glim_amd_factor_set_trip_stats)
+  // pre-cull of the general segment (vgicp.hip cull_kernel): per (plan row, wavefront) one 64-bit word, bit t = trip t of that wavefront cannot
+  // find a correspondence (its chunk box, moved by this evaluation's pose, touches no occupied cell of the target's mask) or holds no point
+  void* d_cull_descs = nullptr;                 // CullDesc per factor
+  unsigned long long* d_cull_words = nullptr;   // (total_rows - plane_rows) x 4
+  unsigned long long* d_cull_stats = nullptr;   // [0] trips culled by the box test, [1] trips that hold points, summed over the evaluations since the last reset
+  bool cull = false;
+  int cull_log2p = 0;                           // log2 of the pre-pass's lanes per (row, wavefront) pair (the next power of two >= points per thread)
   char* d_rows16 = nullptr;       // tagged partial rows of the single-dispatch synchronous form (vgicp.hip TAG_ROW_BYTES per row), or null
   int* d_finmap = nullptr;        // factor ids the trailing blocks of each segment's single-dispatch launch finalise (plane-form segment first)
   int fin_count[2] = {0, 0};

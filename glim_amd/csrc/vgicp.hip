@@ -123,6 +123,8 @@ struct FinalizeArgs {
   unsigned long long* trip_stats;  // 64 counters: skipped wavefront trips of the factors f with f % 64 == slot (null: not collected)
   char* rec16;               // host-mapped record granules (COMPACT x 16 B per factor) of the single-dispatch form, or null
   const int* finmap;         // factor ids, plane-form segment first (null for a single-factor set: factor 0)
+  // pre-cull (vgicp_kernel<..., CULL>): 4 words per row of the general segment, written by cull_kernel on the same stream just before the launch
+  const unsigned long long* cull_words;
 };
 
 // ---- tagged rows: the hand-off of the single-dispatch synchronous call --------------------------------------------------------------
@@ -559,9 +561,10 @@ struct PipeCtx {  // wave-uniform context of the pipelined loop
 // The first version of the loop issued key gather t, stream t+1, then waited for the key, then for the record, inside one trip: two
 // dependent memory round trips (one of them HBM) exposed per trip per wave, which 5 waves per SIMD could not cover (waves parked on
 // memory 71 % of their cycles; 50 % with this form -- tools/pmc_kexp.sh, profiles/r02/probe/).
+// i1 / ok1: the point this trip probes (stream data in `nxt`) and whether it exists; i2: the point whose stream loads this trip issues.
 template <int MODE, bool FROZEN, bool PLANE>
-__device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers, int& wave_skips) {
-  constexpr int AHEAD = 1;
+__device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int i1, bool ok1, int i2, float (&acc)[NACC], int& wave_inliers,
+                                             int& wave_skips) {
   const FactorDesc& d = pc.d;
   // (1) resolve point `it`
   const Probe<PLANE> cur = pr;
@@ -599,9 +602,9 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
     r2 = gld1(rp + 32);   // c22
   }
   // (2) probe of point it+AHEAD (a lane past its last point probes with EMPTY_KEY at a clamped, valid address)
-  pr = probe_point<FROZEN, PLANE>(d, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
+  pr = probe_point<FROZEN, PLANE>(d, nxt, i1, ok1, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
   // (3) stream loads of point it+AHEAD+1
-  nxt = load_point<PLANE>(d, (unsigned int)min(pc.base + (it + AHEAD + 1) * pc.stride, pc.last));
+  nxt = load_point<PLANE>(d, (unsigned int)min(i2, pc.last));
   // (4) algebra of point `it`
   if (any_hit) accumulate_point<MODE, PLANE>(acc, hit, r0, r1, r2, cur, pc.R);
   // The key gather the NEXT trip resolves is consumed HERE, at the very end of this trip, and nowhere earlier: without this pin the
@@ -611,6 +614,12 @@ __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>
   // Likewise the six FP32 offsets of the point probed in this trip must EXIST here: left alone, the scheduler sinks the FP64 -> FP32
   // conversions into the next trip and carries the six FP64 values (12 VGPRs instead of 6) around the loop.
   asm volatile("" : "+v"(pr.qr0), "+v"(pr.qr1), "+v"(pr.qr2), "+v"(pr.qp0), "+v"(pr.qp1), "+v"(pr.qp2));
+}
+template <int MODE, bool FROZEN, bool PLANE>
+__device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers, int& wave_skips) {
+  constexpr int AHEAD = 1;
+  pipe_trip_at<MODE, FROZEN, PLANE>(pc, pr, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.base + (it + AHEAD + 1) * pc.stride, acc, wave_inliers,
+                                    wave_skips);
 }
 
 // The SIMD's issue arbiter serves the highest user priority first and, among equals, the OLDEST wave: with every wave at priority 0 the
@@ -633,9 +642,13 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // runs the algebra (a lane without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  On return
 // (after a block barrier) s_red[w][j] holds wavefront w's sum of accumulator j, s_red[w][28] its inlier count.
 // first: the stream data of this lane's first point when the caller has loaded it already (a resident worker does, while it waits for its pose).
-template <int MODE, bool FROZEN, bool PLANE>
+// cull (CULL only): this block's four pre-cull words (cull_kernel), one per wavefront: bit t set = trip t of that wavefront has no point or cannot
+// find a correspondence.  The wavefront then walks its LIVE trips only, through the same two-trip pipeline: a culled trip costs nothing at all --
+// no stream load, no FP64 transform, no hash, no key gather (the in-loop skip of an all-miss trip still pays those: 40 % of a trip) -- and since
+// a culled trip would have added exact zeros in every lane, the sums are the same bits.
+template <int MODE, bool FROZEN, bool PLANE, bool CULL = false>
 __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* __restrict__ Tl, const double* __restrict__ Te, int chunk, int prio_phase,
-                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr) {
+                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr, const unsigned long long* cull = nullptr) {
   // rotation of the linearisation pose in FP32 (R[r][c])
   // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
@@ -663,12 +676,34 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
     // Software pipeline over the points of this lane (pipe_trip above): the key gather of a point is issued one trip before its algebra.
     // (Issuing it two trips ahead buys little: loads return in order, so the record gather of the trip in between would wait for it.)
     PipeCtx<PLANE> pc = {d, Tl, Te, R, base, stride, ppt, last, validate};
+    if (CULL) {
+      // wave-uniform throughout: the word comes by a scalar load, the live mask and the three trip numbers of the pipeline live in SGPRs
+      const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      unsigned long long live = (ppt >= 64 ? ~0ull : ((1ull << ppt) - 1ull)) & ~cull[wv];
+      auto pop = [ppt](unsigned long long& m) -> int {  // lowest live trip, ppt ("none") when the mask is empty
+        const int i = m ? (int)__builtin_ctzll(m) : ppt;
+        m &= m - 1ull;
+        return i;
+      };
+      int t0 = pop(live), t1 = pop(live), t2 = pop(live);
+      PointIn nxt = load_point<PLANE>(d, (unsigned int)min(base + t0 * stride, last));
+      Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base + t0 * stride, t0 < ppt, Tl, Te, R, validate, last);
+      nxt = load_point<PLANE>(d, (unsigned int)min(base + t1 * stride, last));
+      for (int step = 0; t0 < ppt; step++) {
+        rotate_priority(step + prio_phase);
+        pipe_trip_at<MODE, FROZEN, PLANE>(pc, pr, nxt, base + t1 * stride, t1 < ppt, base + t2 * stride, acc, wave_inliers, wave_skips);
+        t0 = t1;
+        t1 = t2;
+        t2 = pop(live);
+      }
+    } else {
     PointIn nxt = first ? *first : load_point<PLANE>(d, (unsigned int)min(base, last));
     Probe<PLANE> pr = probe_point<FROZEN, PLANE>(d, nxt, base, ppt > 0, Tl, Te, R, validate, last);
     nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
     for (int it = 0; it < ppt; it++) {
       rotate_priority(it + prio_phase);
       pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers, wave_skips);
+    }
     }
   }
 
@@ -720,7 +755,8 @@ __device__ __forceinline__ void publish_row_tagged(const float (*s_red)[PARTIAL_
 // instead of plain rows: no second dispatch, no kernel boundary, no arrival counter.
 // (FUSED variants serve small latency-bound sets that never fill the chip: they take the general kernel's 128-register budget, which keeps
 //  the finalising branch's sixteen 16-byte loads in flight out of scratch.)
-template <int MODE, bool FROZEN, bool PLANE, bool INLINE, bool FUSED>
+// CULL: the general segment of a large set, with the pre-cull words of cull_kernel (fa.cull_words; compute_row).
+template <int MODE, bool FROZEN, bool PLANE, bool INLINE, bool FUSED, bool CULL = false>
 __global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GLIM_AMD_MINW_GENERAL) void vgicp_kernel(const FactorDesc* __restrict__ descs, const double* __restrict__ poses_lin,
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
                                                           float* __restrict__ partials, const InlineArgs ip, const FinalizeArgs fa, int block_offset,
@@ -745,7 +781,7 @@ __global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GL
   const double* Tl = INLINE ? ip.m : poses_lin + 12 * (size_t)f;
   const double* Te = FROZEN ? poses_eval + 12 * (size_t)f : Tl;
   // prio_phase: which of the CU's resident blocks this one is (dispatch is round robin over the CUs)
-  compute_row<MODE, FROZEN, PLANE>(d, Tl, Te, bm.y, gblock / blocks_per_round, s_red);
+  compute_row<MODE, FROZEN, PLANE, CULL>(d, Tl, Te, bm.y, gblock / blocks_per_round, s_red, nullptr, CULL ? fa.cull_words + 4 * (size_t)blockIdx.x : nullptr);
   // a factor's partial rows are consecutive: row first_block + chunk (the finalisation reads them without an index table)
   const size_t row = (size_t)(d.first_block + bm.y);
   if (FUSED) {
@@ -753,6 +789,94 @@ __global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GL
     return;
   }
   if (threadIdx.x < PARTIAL_STRIDE) partials[row * PARTIAL_STRIDE + threadIdx.x] = row_value<MODE>(s_red, (int)threadIdx.x);
+}
+
+// ---- pre-cull of the general segment -----------------------------------------------------------------------------------
+// 17.8 % of the wavefront trips of the 256-submap all-pairs cost find no correspondence in any lane; the in-loop skip saves them the record
+// gather and the algebra, but only AFTER the stream loads, the FP64 transform, the hash and the key gather (40 % of a trip).  Whether a trip can
+// hit at all is decided by geometry the kernel does not need to look at point by point: the 64 stream-consecutive (Hilbert-ordered) points of a
+// trip lie in a small box (ensure_chunk_boxes: 24 B per chunk, once per cloud), and the target map's occupied voxels are a few-KB bit mask
+// (ensure_occupancy, once per map).  This pre-pass -- one THREAD per (plan row, wavefront), so the 31 M box tests of an evaluation are ordinary
+// data-parallel work, ~60 instructions each, not wave-uniform work inside the hot loop -- moves every chunk box by the evaluation's pose
+// (FP64, conservative: centre + |R| half-extent, padded by 1e-7 voxel against the 1e-13 the two FP64 evaluation orders can differ by) and marks
+// the trips whose box touches no occupied cell.  Conservative by construction: a marked trip has no correspondence in any lane, so it would have
+// added exact zeros -- results are bit-identical with the pre-cull on or off (tests/test_gpu_edge_cases.py).
+struct CullDesc {
+  const float* boxes;       // source cloud's chunk boxes (6 floats per 64 stream points), or null: nothing of this factor is culled
+  const unsigned int* occ;  // target map's occupancy mask, or null
+  int org[3], dim[3], shift, row_words;
+};
+
+__device__ __forceinline__ bool box_misses_mask(const CullDesc& cd, const float* __restrict__ b, const double (&T)[12], double inv_res) {
+  const double cx = 0.5 * ((double)b[0] + (double)b[3]), cy = 0.5 * ((double)b[1] + (double)b[4]), cz = 0.5 * ((double)b[2] + (double)b[5]);
+  const double hx = 0.5 * ((double)b[3] - (double)b[0]), hy = 0.5 * ((double)b[4] - (double)b[1]), hz = 0.5 * ((double)b[5] - (double)b[2]);
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double q = T[4 * a] * cx + T[4 * a + 1] * cy + T[4 * a + 2] * cz + T[4 * a + 3];
+    const double e = fabs(T[4 * a]) * hx + fabs(T[4 * a + 1]) * hy + fabs(T[4 * a + 2]) * hz;
+    const double tl = fmin(fmax(floor((q - e) * inv_res - 1e-7), -2097152.0), 2097152.0), th = fmin(fmax(floor((q + e) * inv_res + 1e-7), -2097152.0), 2097152.0);
+    lo[a] = max(((int)tl - cd.org[a]) >> cd.shift, 0);
+    hi[a] = min(((int)th - cd.org[a]) >> cd.shift, cd.dim[a] - 1);
+    if (lo[a] > hi[a]) return true;  // entirely outside the box of the occupied voxels
+  }
+  const int w0 = lo[0] >> 5, w1 = hi[0] >> 5;
+  if ((long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1) * (w1 - w0 + 1) > 192) return false;  // a box this large (in cells) is not worth walking
+  for (int z = lo[2]; z <= hi[2]; z++)
+    for (int y = lo[1]; y <= hi[1]; y++) {
+      const unsigned int* row = cd.occ + ((size_t)z * cd.dim[1] + y) * cd.row_words;
+      for (int w = w0; w <= w1; w++) {
+        unsigned int m = 0xffffffffu;
+        if (w == w0) m &= 0xffffffffu << (lo[0] & 31);
+        if (w == w1) m &= 0xffffffffu >> (31 - (hi[0] & 31));
+        if (row[w] & m) return false;
+      }
+    }
+  return true;
+}
+
+// One LANE per (plan row, wavefront, trip): lanes [k P2, (k + 1) P2) of a wavefront test the P2 = 2^log2p >= ppt trips of ONE (row, wavefront) pair,
+// so all the box tests of a pair are in flight at once (the first version walked a pair's <= 32 trips one after the other in one thread: two dependent
+// loads per trip, ~1.7 us each, 0.7 ms per evaluation of configs[3] -- more than the cull saved) and the pair's word is one ballot, no atomics.
+__global__ __launch_bounds__(256) void cull_kernel(const FactorDesc* __restrict__ descs, const CullDesc* __restrict__ culls, const double* __restrict__ poses_lin,
+                                                   const int2* __restrict__ blockmap, int row0, int rows, int log2p, unsigned long long* __restrict__ words,
+                                                   unsigned long long* __restrict__ stats) {
+  const int lane = (int)(threadIdx.x & 63);
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int pairs_per_wave = 64 >> log2p, it = lane & ((1 << log2p) - 1);
+  const long long pair = wave * pairs_per_wave + (lane >> log2p);
+  bool cull = false, has_points = false;
+  if (pair < 4ll * rows) {
+    const int r = (int)(pair >> 2), w = (int)(pair & 3);
+    const int2 bm = blockmap[row0 + r];
+    if (bm.x >= 0) {
+      const int n = descs[bm.x].n, nb = descs[bm.x].num_blocks, ppt = descs[bm.x].ppt;
+      const long long chunk = ((long long)it * nb + bm.y) * 4 + w;  // trip `it` of this wavefront covers stream points [64 chunk, 64 chunk + 64)
+      if (it >= ppt || chunk * 64 >= n) {
+        cull = true;  // no such trip / no point at all
+      } else {
+        has_points = true;
+        const CullDesc cd = culls[bm.x];
+        if (cd.boxes && cd.occ) {
+          double T[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) T[i] = poses_lin[12 * (size_t)bm.x + i];
+          cull = box_misses_mask(cd, cd.boxes + 6 * chunk, T, descs[bm.x].inv_res);
+        }
+      }
+    } else {
+      cull = true;  // padding row of the XCD-aware map: its block returns at once
+    }
+  }
+  const unsigned long long culled_lanes = __ballot(cull), point_lanes = __ballot(has_points);
+  if (it == 0 && pair < 4ll * rows) {
+    const unsigned long long field = log2p == 6 ? ~0ull : ((1ull << (1 << log2p)) - 1ull);
+    words[pair] = (culled_lanes >> ((lane >> log2p) << log2p)) & field;
+  }
+  if (lane == 0 && point_lanes) {  // counters (measurement: glim_amd_factor_set_cull_stats)
+    atomicAdd(&stats[0], (unsigned long long)__popcll(culled_lanes & point_lanes));
+    atomicAdd(&stats[1], (unsigned long long)__popcll(point_lanes));
+  }
 }
 
 // ---- resident form of the synchronous call --------------------------------------------------------------------------------------------
@@ -925,6 +1049,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
       fa.trip_stats = nullptr;
       fa.rec16 = ra.rec16;
       fa.finmap = ra.finmap;
+      fa.cull_words = nullptr;
       const FactorDesc d = ra.descs[f];
       fused_finalize<8>(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose);
       __syncthreads();
@@ -1163,7 +1288,17 @@ constexpr size_t HOST_POSES_MAX = 256;   // synchronous sets up to this many fac
 
 // The plan's device blocks, pinned blocks and events go back where they came from; the plan object stays (plan_build fills it again).
 // Caller: no session serves the plan and nothing enqueued is still using the buffers (plan_idle).
+void plan_release_cull(FactorPlan* p) {
+  if (p->d_cull_descs) (void)pool_free(p->d_cull_descs);
+  if (p->d_cull_words) (void)pool_free(p->d_cull_words);
+  if (p->d_cull_stats) (void)pool_free(p->d_cull_stats);
+  p->d_cull_descs = nullptr;
+  p->d_cull_words = nullptr;
+  p->d_cull_stats = nullptr;
+  p->cull = false;
+}
 void plan_release_buffers(FactorPlan* p) {
+  plan_release_cull(p);
   if (p->d_upload) (void)pool_free(p->d_upload);  // d_descs | d_blockmap | d_finmap
   if (p->h_upload) (void)pinned_free(p->h_upload);
   if (p->d_zeroed) (void)pool_free(p->d_zeroed);  // d_done | d_trip_stats | d_rows16
@@ -1298,6 +1433,7 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
 
   plan->built_plane = diag.plane;
   plan->built_ppt = diag.ppt;
+  plan->built_cull = diag.cull;
   plan->h_descs.assign(nf, FactorDesc());
   plan->h_finmap.clear();
   std::vector<int> nblocks(nf);
@@ -1519,6 +1655,53 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   plan->last_stream = set->stream;
   plan->maybe_busy = false;
   if (nf > 1) GA_TRY(plan_upload(set, plan));
+  // pre-cull of the general segment: large asynchronous-sized sets only (the pre-pass is one more launch, ~5 us of stream latency + ~2 ns per
+  // row: a set whose general segment runs for less than ~150 us would pay more than it gets back), every general factor at <= 64 points per thread
+  plan_release_cull(plan);
+  constexpr int CULL_MIN_ROWS = 16384;
+  bool want_cull = diag.cull && !fused_form && seg_rows[1] > 0 && (seg_rows[1] >= CULL_MIN_ROWS || diag.cull == 2);  // (cull=2: any size, for the tests)
+  int cull_ppt = 1;
+  for (int f = 0; f < nf && want_cull; f++)
+    if (!plan->h_descs[f].plane) {
+      if (plan->h_descs[f].ppt > 64) want_cull = false;
+      cull_ppt = std::max(cull_ppt, plan->h_descs[f].ppt);
+    }
+  plan->cull_log2p = 0;
+  while ((1 << plan->cull_log2p) < cull_ppt) plan->cull_log2p++;  // lanes per (row, wavefront) pair of the pre-pass: the next power of two >= ppt
+  if (want_cull) {
+    std::vector<CullDesc> cds((size_t)nf);
+    for (int f = 0; f < nf; f++) {
+      CullDesc& cd = cds[(size_t)f];
+      memset(&cd, 0, sizeof(cd));
+      if (plan->h_descs[f].plane) continue;
+      glim_amd_cloud* src = const_cast<glim_amd_cloud*>(set->entries[f].source);
+      glim_amd_voxelmap* tm = const_cast<glim_amd_voxelmap*>(set->entries[f].target);  // (the mask is a cache, not a change of the map)
+      if (plan->h_descs[f].s0 != src->gs0) continue;  // (not the cloud's own general stream: no boxes for it)
+      GA_TRY(ensure_chunk_boxes(src, set->stream));
+      GA_TRY(ensure_occupancy(tm, set->stream));
+      if (!tm->occ) continue;
+      cd.boxes = src->gbox;
+      cd.occ = tm->occ;
+      for (int a = 0; a < 3; a++) {
+        cd.org[a] = tm->occ_org[a];
+        cd.dim[a] = tm->occ_dim[a];
+      }
+      cd.shift = tm->occ_shift;
+      cd.row_words = tm->occ_row_words;
+    }
+    hipError_t e = pool_malloc(&plan->d_cull_descs, cds.size() * sizeof(CullDesc));
+    if (e == hipSuccess) e = pool_malloc(&plan->d_cull_words, (size_t)seg_rows[1] * 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = pool_malloc(&plan->d_cull_stats, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(plan->d_cull_descs, cds.data(), cds.size() * sizeof(CullDesc), hipMemcpyHostToDevice, set->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(plan->d_cull_stats, 0, 2 * sizeof(unsigned long long), set->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(set->stream);  // (`cds` is pageable and goes out of scope)
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      plan_release_cull(plan);  // a cache of hints, not a requirement: the plain kernel computes the same bits
+    } else {
+      plan->cull = true;
+    }
+  }
   return GLIM_AMD_OK;
 }
 
@@ -1536,10 +1719,10 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   glim_amd_ctx* ctx = set->ctx;
   const uint64_t epoch = global_mutation_epoch().load();
   const Diag& diag = ctx->diag;
-  if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt) return GLIM_AMD_OK;
+  if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt && set->plan->built_cull == diag.cull) return GLIM_AMD_OK;
   std::vector<PlanKey> key;
   make_key(set, key);
-  auto usable = [&](const FactorPlan* p) { return p->key == key && p->built_plane == diag.plane && p->built_ppt == diag.ppt; };
+  auto usable = [&](const FactorPlan* p) { return p->key == key && p->built_plane == diag.plane && p->built_ppt == diag.ppt && p->built_cull == diag.cull; };
   if (set->plan && !usable(set->plan)) factor_set_park_plan(set);
   if (!set->plan && diag.plan_cache) {
     for (size_t i = 0; i < ctx->plan_cache.size(); i++) {
@@ -1603,6 +1786,7 @@ FinalizeArgs finalize_args(const glim_amd_factor_set* set, double* out, long lon
   fa.trip_stats = plan->d_trip_stats;
   fa.rec16 = nullptr;
   fa.finmap = plan->d_finmap;
+  fa.cull_words = plan->cull ? plan->d_cull_words : nullptr;
   return fa;
 }
 
@@ -1617,7 +1801,13 @@ void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa, float* pa
   if (rows0 > 0)
     vgicp_kernel<MODE, FROZEN, true, INLINE, FUSED><<<rows0 + fin0, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, 0,
                                                                                             per_round, rows0, 0);
-  if (rows1 > 0)
+  if (rows1 > 0 && plan->cull && !INLINE && !FUSED) {
+    const long long cull_waves = ((4ll * rows1) + (64 >> plan->cull_log2p) - 1) / (64 >> plan->cull_log2p);
+    cull_kernel<<<(unsigned int)((cull_waves + 3) / 4), 256, 0, set->stream>>>(plan->d_descs, static_cast<const CullDesc*>(plan->d_cull_descs), lin, plan->d_blockmap, rows0,
+                                                                              rows1, plan->cull_log2p, plan->d_cull_words, plan->d_cull_stats);
+    vgicp_kernel<MODE, FROZEN, false, false, false, true><<<rows1, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, rows0,
+                                                                                           per_round, rows1, fin0);
+  } else if (rows1 > 0)
     vgicp_kernel<MODE, FROZEN, false, INLINE, FUSED><<<rows1 + fin1, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa,
                                                                                              rows0, per_round, rows1, fin0);
 }
@@ -2568,6 +2758,23 @@ int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_t
   }
   if (reset) GA_HIP(hipMemset(plan->d_trip_stats, 0, sizeof(h)));
   return GLIM_AMD_OK;
+}
+
+int glim_amd_factor_set_cull_stats(glim_amd_factor_set* set, uint64_t* culled_trips, uint64_t* trips_with_points, int reset) {
+  if (!set) return GLIM_AMD_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(set->ctx->mu);
+  GA_HIP(hipSetDevice(set->ctx->device));
+  GA_TRY(factor_set_prepare(set));
+  FactorPlan* plan = set->plan;
+  unsigned long long h[2] = {0ull, 0ull};
+  if (plan->cull) {
+    GA_HIP(hipStreamSynchronize(set->stream));
+    GA_HIP(hipMemcpy(h, plan->d_cull_stats, sizeof(h), hipMemcpyDeviceToHost));
+    if (reset) GA_HIP(hipMemset(plan->d_cull_stats, 0, sizeof(h)));
+  }
+  if (culled_trips) *culled_trips = h[0];
+  if (trips_with_points) *trips_with_points = h[1];
+  return plan->cull ? GLIM_AMD_OK : GLIM_AMD_ERR_UNSUPPORTED;
 }
 
 int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, const glim_amd_voxelmap* const* targets, const glim_amd_cloud* const* sources,

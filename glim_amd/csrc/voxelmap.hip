@@ -412,6 +412,48 @@ __global__ __launch_bounds__(256) void plane_view_kernel(const VoxelBucket* __re
   plane_record(src[b].rec[w], o);
 }
 
+// ---- occupancy mask (the factor kernel's pre-cull, vgicp.hip) --------------------------------------------------------------------------------
+// bbox[0..2] = min, bbox[3..5] = max voxel coordinate over the occupied (bucket, way) slots (initialised to INT_MAX / INT_MIN by the host)
+__global__ __launch_bounds__(256) void occ_bbox_kernel(const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, int* __restrict__ bbox) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  if (i < 2 * num_buckets) {
+    const unsigned long long key = buckets[i >> 1].key[i & 1];
+    if (key != EMPTY_KEY) {
+      unpack_key(key, lo[0], lo[1], lo[2]);
+      hi[0] = lo[0];
+      hi[1] = lo[1];
+      hi[2] = lo[2];
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], m, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], m, 64));
+    }
+  if ((threadIdx.x & 63) == 0 && lo[0] <= hi[0]) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&bbox[a], lo[a]);
+      atomicMax(&bbox[3 + a], hi[a]);
+    }
+  }
+}
+// bit ((v - org) >> shift) of the mask for every occupied voxel v; x along the bits of a row, rows ordered (z, y)
+__global__ __launch_bounds__(256) void occ_fill_kernel(const VoxelBucket* __restrict__ buckets, unsigned int num_buckets, int ox, int oy, int oz, int shift, int dy,
+                                                       int row_words, unsigned int* __restrict__ occ) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * num_buckets) return;
+  const unsigned long long key = buckets[i >> 1].key[i & 1];
+  if (key == EMPTY_KEY) return;
+  int cx, cy, cz;
+  unpack_key(key, cx, cy, cz);
+  const int x = (cx - ox) >> shift, y = (cy - oy) >> shift, z = (cz - oz) >> shift;
+  atomicOr(&occ[((size_t)z * dy + y) * row_words + (x >> 5)], 1u << (x & 31));
+}
+
 // one thread per (bucket, way)
 // stats / host_stats (direct build): the voxel count and the range flag of the key insertion, handed to the host through mapped pinned
 // memory by this last launch -- the call then needs a stream synchronise only, no device-to-host copy
@@ -740,6 +782,69 @@ int ensure_plane_view(glim_amd_voxelmap* m, hipStream_t st) {
   m->buckets_sm = v;
   return GLIM_AMD_OK;
 }
+// The occupancy mask of a finished map: at most OCC_MAX_WORDS 32-bit words; the cell is the voxel itself when the box of the occupied voxels fits
+// (a 60 x 40 x 8 m room at 1 m voxels: 2.8 KB), otherwise the smallest power-of-two multiple that does.  Two short kernels and two
+// synchronises, once per map and only for maps a LARGE factor set is evaluated against (plan_build).
+int ensure_occupancy(glim_amd_voxelmap* m, hipStream_t st) {
+  if (!m->buckets || m->num_buckets == 0) return GLIM_AMD_ERR_STATE;
+  GA_TRY(voxelmap_wait_ready(m, st));
+  std::lock_guard<std::mutex> lock(m->view_mu);
+  if (m->occ_state != 0) return GLIM_AMD_OK;
+  constexpr long long OCC_MAX_WORDS = 16384;  // 64 KiB
+  int* d_bbox = nullptr;
+  GA_HIP(pool_malloc(&d_bbox, 6 * sizeof(int)));
+  int h_bbox[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  hipError_t e = hipMemcpyAsync(d_bbox, h_bbox, sizeof(h_bbox), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    occ_bbox_kernel<<<(2 * m->num_buckets + 255) / 256, 256, 0, st>>>(m->buckets, m->num_buckets, d_bbox);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)pool_free(d_bbox);
+  if (e != hipSuccess) {
+    set_hip_error(e, "ensure_occupancy: bounding box");
+    return GLIM_AMD_ERR_HIP;
+  }
+  if (h_bbox[0] > h_bbox[3]) {  // no voxel at all: nothing to cull against (the kernel finds no correspondence anyway)
+    m->occ_state = -1;
+    return GLIM_AMD_OK;
+  }
+  int shift = 0;
+  long long dim[3], words = 0;
+  for (; shift <= 21; shift++) {
+    for (int a = 0; a < 3; a++) dim[a] = (((long long)h_bbox[3 + a] - h_bbox[a]) >> shift) + 1;
+    words = ((dim[0] + 31) / 32) * dim[1] * dim[2];
+    if (words <= OCC_MAX_WORDS) break;
+  }
+  if (words > OCC_MAX_WORDS) {
+    m->occ_state = -1;
+    return GLIM_AMD_OK;
+  }
+  unsigned int* occ = nullptr;
+  GA_HIP(pool_malloc(&occ, (size_t)words * sizeof(unsigned int)));
+  const int row_words = (int)((dim[0] + 31) / 32);
+  e = hipMemsetAsync(occ, 0, (size_t)words * sizeof(unsigned int), st);
+  if (e == hipSuccess) {
+    occ_fill_kernel<<<(2 * m->num_buckets + 255) / 256, 256, 0, st>>>(m->buckets, m->num_buckets, h_bbox[0], h_bbox[1], h_bbox[2], shift, (int)dim[1], row_words, occ);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // complete before anybody sees the pointer
+  if (e != hipSuccess) {
+    (void)pool_free(occ);
+    set_hip_error(e, "ensure_occupancy: fill");
+    return GLIM_AMD_ERR_HIP;
+  }
+  for (int a = 0; a < 3; a++) {
+    m->occ_org[a] = h_bbox[a];
+    m->occ_dim[a] = (int)dim[a];
+  }
+  m->occ_shift = shift;
+  m->occ_row_words = row_words;
+  m->occ = occ;
+  m->occ_state = 1;
+  return GLIM_AMD_OK;
+}
 }  // namespace glim_amd
 
 extern "C" {
@@ -767,6 +872,7 @@ int glim_amd_voxelmap_destroy(glim_amd_voxelmap* m) {
   if (m->pending_stats) (void)pool_free(m->pending_stats);
   if (m->ready_event) event_put(m->ctx ? m->ctx->device : -1, m->ready_event);  // (voxelmap_wait_ready above has seen it complete; no owner: destroyed)
   if (m->buckets_sm) (void)pool_free(m->buckets_sm);
+  if (m->occ) (void)pool_free(m->occ);
   if (m->buckets) {
     if (m->ctx && m->ctx->diag.bucket_factor == 0) recycle_table(m->ctx->device, m->buckets, m->num_buckets);
     else (void)pool_free(m->buckets);
@@ -983,6 +1089,9 @@ int glim_amd_voxelmap_insert(glim_amd_voxelmap* m, const glim_amd_cloud* cloud) 
     std::lock_guard<std::mutex> vlock(m->view_mu);
     if (m->buckets_sm) (void)pool_free(m->buckets_sm);
     m->buckets_sm = view2;
+    if (m->occ) (void)pool_free(m->occ);  // (the occupancy mask likewise: rebuilt on the next use by a large factor set)
+    m->occ = nullptr;
+    m->occ_state = 0;
   }
   if (old) (void)pool_free(old);
   else if (n > 0) remember_voxel_ratio(ctx, res_class, (double)num_voxels / (double)n);

@@ -26,6 +26,8 @@ extern "C" {
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
  * served by a resident kernel that leaves after <n> us without a request; auto, the default: only in a context created with priority 1 -- the
  * session costs whatever else runs on the device 1.3-1.4x while it is alive, so it is opt-in), pp_fast=0|1 (random-grid preprocessing without sorts),
+ * cull=0|1|2 (general-form sets of >= 16 384 plan rows -- 2: of any size --: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask and the
+ * factor kernel walks the live trips only; same bits either way),
  * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,
  * multi_host_gather=0|1, multi_virtual=0|1 (glim_amd_multi_create accepts one physical device several times, see
  * glim_amd_debug_multi_create_virtual below).  Unknown keys / bad values: GLIM_AMD_ERR_INVALID and nothing changes.  get_diag prints the current state in the
@@ -71,6 +73,11 @@ int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_a
  * and the algebra, summed over every evaluation of the set's current plan since the last reset, and the trips ONE evaluation of the plan makes
  * (blocks x 4 wavefronts x points per thread).  bench.py prices the kernel's instruction floor with the measured share instead of a constant. */
 int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_trips, uint64_t* total_trips_per_evaluation, int reset);
+/* Measurement aid: the pre-cull of a large general-form set: wavefront trips the pre-pass marked as unable to find a correspondence
+ * (their 64-point chunk box, moved by the evaluation's pose, touches no occupied cell of the target's occupancy mask) and the trips that hold
+ * points at all, summed over the evaluations of the set's current plan since the last reset.  GLIM_AMD_ERR_UNSUPPORTED (and zeros) when the plan has no
+ * pre-cull (small set, plane-form factors only, switch cull=0). */
+int glim_amd_factor_set_cull_stats(glim_amd_factor_set* set, uint64_t* culled_trips, uint64_t* trips_with_points, int reset);
 /* The same pattern with every iteration timed on its own (samples_us: `iters` entries) and `gap_us` of host busy-waiting between iterations -- the
  * optimiser's own work between two linearisations --, for latency percentiles while other threads load the device (bench.py
  * --workload odometry_under_load). */

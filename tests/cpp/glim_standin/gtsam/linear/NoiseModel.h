@@ -24,6 +24,30 @@ public:
   static shared_ptr Sigma(size_t dim, double sigma);
   static shared_ptr Precision(size_t dim, double precision);
 };
+namespace mEstimator {
+class Base {
+public:
+  typedef std::shared_ptr<Base> shared_ptr;
+  virtual ~Base() {}
+};
+class Huber : public Base {
+public:
+  static shared_ptr Create(double k);
+};
+class Cauchy : public Base {
+public:
+  static shared_ptr Create(double k);
+};
+class Tukey : public Base {
+public:
+  static shared_ptr Create(double k);
+};
+}  // namespace mEstimator
+class Robust : public Base {
+public:
+  typedef std::shared_ptr<Robust> shared_ptr;
+  static shared_ptr Create(const mEstimator::Base::shared_ptr&, const Base::shared_ptr&);
+};
 }  // namespace noiseModel
 typedef noiseModel::Base::shared_ptr SharedNoiseModel;
 }  // namespace gtsam

@@ -18,6 +18,7 @@ public:
   template <class F>
   void add(const std::shared_ptr<F>& f) { factors_.push_back(f); }
   void add(const NonlinearFactorGraph&);
+  void add(const std::vector<NonlinearFactor::shared_ptr>& fs) { for (const auto& f : fs) factors_.push_back(f); }
   void push_back(const NonlinearFactor::shared_ptr& f) { factors_.push_back(f); }
   template <class F, class... A>
   void emplace_shared(A&&... a) { factors_.push_back(std::make_shared<F>(std::forward<A>(a)...)); }

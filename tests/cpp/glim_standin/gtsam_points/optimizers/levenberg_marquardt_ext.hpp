@@ -13,6 +13,7 @@ public:
   void setlambdaInitial(double);
   std::function<void(const LevenbergMarquardtOptimizationStatus&, const gtsam::Values&)> callback;
   std::function<void(const gtsam::Values&)> status_msg_callback;
+  std::function<bool(const gtsam::Values&)> termination_criteria;  // odometry_estimation_cpu.cpp:121
 };
 class LevenbergMarquardtOptimizerExt {
 public:

@@ -33,6 +33,7 @@ struct PointCloudCPU : public PointCloud {
 };
 double median_distance(const PointCloud::ConstPtr& frame, size_t max_scan_count);
 PointCloudCPU::Ptr random_sampling(const PointCloud::ConstPtr& frame, double sampling_rate, std::mt19937& mt);
+PointCloudCPU::Ptr transform(const PointCloud::ConstPtr& frame, const Eigen::Isometry3d& T);  // odometry_estimation_cpu.cpp:184
 PointCloudCPU::Ptr merge_frames(const std::vector<Eigen::Isometry3d>& poses, const std::vector<PointCloud::ConstPtr>& frames, double downsample_resolution);
 PointCloudCPU::Ptr merge_frames(const std::vector<Eigen::Isometry3d>& poses, const std::vector<PointCloud::ConstPtr>& frames, double downsample_resolution,
                                 int target_num_points);

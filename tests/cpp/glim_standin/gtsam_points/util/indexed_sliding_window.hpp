@@ -8,6 +8,8 @@ public:
   const T& operator[](int i) const { return data_[(size_t)i]; }
   void clear() { data_.clear(); }
   int size() const { return (int)data_.size(); }
+  T& back() { return data_.back(); }
+  const T& back() const { return data_.back(); }
 
 private:
   std::deque<T> data_;

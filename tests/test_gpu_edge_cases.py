@@ -713,3 +713,73 @@ def test_a_stale_scratch_word_equal_to_the_next_build_number_does_not_end_the_wa
         cloud, maps = api.frame_create(p4, c16, n4, [0.5, 1.0], ctx=ctx)
         assert [m.voxelmap_info()["num_voxels"] for m in maps] == [want_t[0.5], want_t[1.0]]
     ctx.set_diag("")
+
+
+def test_pre_cull_of_the_general_kernel_changes_no_bit(api, orc):
+    """The pre-pass of large general-form sets (vgicp.hip cull_kernel) marks the wavefront trips whose 64-point chunk box, moved by the pose, touches no
+    occupied cell of the target's occupancy mask; the factor kernel then walks the live trips only.  A marked trip would have added exact zeros,
+    so linearise and error give the same bits with the pre-cull forced on (cull=2: sets of any size) and off -- for partly overlapping scans
+    (something IS culled), for a pose that moves the source clean off the map (everything is), for every ppt, and against the oracle."""
+    from glim_amd import synth
+
+    ctx = api.Context(0, 1)
+    scene = synth.Scene.default()
+    dirs = synth.lidar_directions(32, 256)
+    poses = synth.arc_trajectory(5)
+    rng = np.random.default_rng(5)
+    clouds, maps, refs = [], [], []
+    for i, T in enumerate(poses):
+        pts = synth.scan(scene, T, dirs, i)
+        a = rng.normal(size=(len(pts), 3, 3)) * 0.05
+        covs = np.zeros((len(pts), 4, 4))
+        covs[:, :3, :3] = a @ np.transpose(a, (0, 2, 1)) + 1e-3 * np.eye(3)  # general (non-plane) covariances: the 36 B/pt kernel
+        covs = covs.astype(np.float32).astype(np.float64)
+        g = api.PointCloudGPU.clone(pts.astype(np.float64), covs, ctx=ctx)
+        clouds.append((g, pts, covs))
+        maps.append(api.GaussianVoxelMapGPU(1.0, ctx=ctx).insert(g))
+        covs = covs[:, :3, :3]
+        clouds[-1] = (g, pts, covs)
+        refs.append(orc.VoxelMap(1.0).insert(pts, covs))
+    pairs = [(i, j) for i in range(5) for j in range(5) if i != j]
+    far = np.eye(4)
+    far[:3, 3] = (500.0, -300.0, 40.0)
+    for pose_of in (lambda i, j: synth.relative_pose(poses[i], poses[j]), lambda i, j: far if (i + j) % 2 else synth.relative_pose(poses[i], poses[j]) @ far):
+        deltas = np.stack([api.pose12(pose_of(i, j)) for i, j in pairs])
+        got = {}
+        for ppt in (1, 4, 64):
+            for cull in (0, 2):
+                ctx.set_diag("")
+                ctx.set_diag(f"cull={cull},ppt={ppt}")
+                fset = api.NonlinearFactorSetGPU(ctx)
+                for i, j in pairs:
+                    fset.add(api.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j][0]))
+                out = fset.linearize_poses(deltas)
+                values = {k: poses[k] for k in range(5)}
+                stats = fset.cull_stats()
+                assert (stats is None) == (cull == 0)
+                if cull:
+                    assert 0 < stats[1] and 0 <= stats[0] <= stats[1]
+                    got[("culled", ppt)] = stats[0] / stats[1]
+                got[(cull, ppt)] = out
+                fset.close()
+            for a, b in zip(got[(0, ppt)], got[(2, ppt)]):
+                assert a["num_inliers"] == b["num_inliers"] and a["error"] == b["error"]
+                for k in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
+                    np.testing.assert_array_equal(a[k], b[k])
+        assert got[("culled", 1)] > 0.02, got  # partly overlapping scans / a source moved off the map: the pre-pass finds empty chunks
+    ctx.set_diag("")
+    # ... and the culled evaluation is the oracle's (first pair of the overlapping case)
+    deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
+    ctx.set_diag("cull=2")
+    fset = api.NonlinearFactorSetGPU(ctx)
+    for i, j in pairs:
+        fset.add(api.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j][0]))
+    out = fset.linearize_poses(deltas)
+    for k in (0, 7, 19):
+        i, j = pairs[k]
+        D = np.eye(4)
+        D[:3, :4] = deltas[k].reshape(3, 4)
+        ref = orc.vgicp_linearize(refs[i], clouds[j][1], clouds[j][2], D)
+        assert out[k]["num_inliers"] == ref["num_inliers"]
+        assert np.abs(gn(out[k]) - gn(ref)).max() < 1e-4
+    ctx.set_diag("")
