@@ -167,6 +167,8 @@ SYMBOLS = {
     "glim_amd_multi_profile": (_i, [_vp, _dp, _i, _fp]),
     "glim_amd_shard_bounds": (_i, [_dp, _i64, _i32, _lp]),
     "glim_amd_debug_scratch_poke": (_i, [_vp, _i32, _u32]),
+    "glim_amd_debug_resident_timeline": (_i, [_i, _i, _dp, _i32]),
+    "glim_amd_cloud_profile_neighbors": (_i, [_vp, _i, _i, _fp, _fp]),
     "glim_amd_factor_set_cull_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _i]),
     "glim_amd_multi_set_gather_mode": (_i, [_vp, _i32]),
     "glim_amd_multi_wait_gather": (_i, [_vp]),

@@ -289,6 +289,12 @@ class PointCloudGPU:
         nb = np.ascontiguousarray(neighbors, dtype=np.int32)
         check(lib().glim_amd_cloud_set_neighbors(self._h, nb.shape[1], _ip(nb)), "glim_amd_cloud_set_neighbors")
 
+    def profile_neighbors(self, k=10, iters=20):
+        """(wall ms per find_neighbors call, HIP-event ms of the query-group kernel inside it): glim_amd_cloud_profile_neighbors."""
+        a, b = C.c_float(), C.c_float()
+        check(lib().glim_amd_cloud_profile_neighbors(self._h, int(k), int(iters), C.byref(a), C.byref(b)), "glim_amd_cloud_profile_neighbors")
+        return a.value, b.value
+
     def estimate_covariances(self, k_neighbors):
         """CloudCovarianceEstimation::estimate on the device (fills covs + normals)."""
         check(lib().glim_amd_cloud_estimate_covariances(self._h, int(k_neighbors)), "glim_amd_cloud_estimate_covariances")
@@ -785,6 +791,23 @@ def scratch_poke(ctx, word, value=0xFFFFFFFF):
     """Test hook (glim_amd_debug_scratch_poke): leave `value` in a word of the context's pinned scratch; the default stands for the sequence
     number the context's next polled voxel-map build waits for."""
     check(lib().glim_amd_debug_scratch_poke(ctx._h, int(word), int(value)), "glim_amd_debug_scratch_poke")
+
+
+RESIDENT_TIMELINE_FIELDS = ("host_round_trip", "leader_published", "worker_pose_seen_min", "worker_pose_seen_median", "worker_pose_seen_max",
+                            "worker_row_computed_min", "worker_row_computed_median", "worker_row_computed_max", "worker_row_published_min",
+                            "worker_row_published_median", "worker_row_published_max", "finaliser_pose_seen", "finaliser_rows_summed",
+                            "finaliser_record_stored", "workers_accounted", "device_span")
+
+
+def resident_timeline(device=0, enable=True, read=True):
+    """glim_amd_debug_resident_timeline: ends the device's resident session; read=True returns the last request's timeline (microseconds relative to
+    the leader seeing the request; None when no stamped session has run); the stamps stay on / off for the next sessions per `enable`."""
+    us = np.zeros(len(RESIDENT_TIMELINE_FIELDS), dtype=np.float64)
+    rc = lib().glim_amd_debug_resident_timeline(int(device), int(bool(enable)), _dp(us) if read else None, len(us) if read else 0)
+    if rc == -5 and read:
+        return None
+    check(rc, "glim_amd_debug_resident_timeline")
+    return dict(zip(RESIDENT_TIMELINE_FIELDS, us.tolist())) if read else None
 
 
 def resident_stop(ctx=None):

@@ -139,7 +139,7 @@ struct Diag {
   int frame_fused = 1;    // frame_fused=0|1                     glim_amd_frame_create: one launch pulls the cloud and builds every level, one writes every level's records
   int pull_gated = 1;     // pull_gated=0|1                      ... and that kernel is launched BEFORE the conversion: its blocks wait for their piece of the staging block
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
-  int cull = 1;           // cull=0|1|2                          large general-form sets: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask (2: sets of any size, tests)
+  int cull = 0;           // cull=0|1|2 (default 0: measured on configs[3] the pre-pass costs more than the walk saves, profiles/r06/probe/precull_*.json)                          large general-form sets: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask (2: sets of any size, tests)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)
   int multi_virtual = 0;  // multi_virtual=0|1                   glim_amd_multi_create accepts one physical device several times ("virtual devices": the N > 1
@@ -443,8 +443,9 @@ struct FactorPlan {
   // find a correspondence (its chunk box, moved by this evaluation's pose, touches no occupied cell of the target's mask) or holds no point
   void* d_cull_descs = nullptr;                 // CullDesc per factor
   unsigned long long* d_cull_words = nullptr;   // (total_rows - plane_rows) x 4
-  unsigned long long* d_cull_stats = nullptr;   // [0] trips culled by the box test, [1] trips that hold points, summed over the evaluations since the last reset
+  unsigned long long* d_cull_stats = nullptr;   // 64 x {trips culled by the box test, trips that hold points}, summed over the counted evaluations since the last reset
   bool cull = false;
+  bool cull_count = false;                      // the pre-pass also counts (glim_amd_factor_set_cull_stats arms it: atomics, measurement only)
   int cull_log2p = 0;                           // log2 of the pre-pass's lanes per (row, wavefront) pair (the next power of two >= points per thread)
   char* d_rows16 = nullptr;       // tagged partial rows of the single-dispatch synchronous form (vgicp.hip TAG_ROW_BYTES per row), or null
   int* d_finmap = nullptr;        // factor ids the trailing blocks of each segment's single-dispatch launch finalise (plane-form segment first)

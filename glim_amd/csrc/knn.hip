@@ -14,6 +14,7 @@
 //     retry levels: 0.85 / 1.11 ms at the two sizes above, up to 5 ms on small clouds of uneven density; the cross-check of the chunk path.
 //   * exhaustive: LDS-tiled scan of every point (tiny clouds, and the grid path's last resort).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -22,6 +23,10 @@
 #include "scan.hpp"
 
 using namespace glim_amd;
+
+// measurement hook (glim_amd_cloud_profile_neighbors): when set, the calling thread's next kNN records these events around its query-group kernel
+static thread_local hipEvent_t g_knn_probe_events[2] = {nullptr, nullptr};
+
 
 namespace {
 
@@ -526,7 +531,9 @@ int knn_curve(glim_amd_ctx* ctx, hipStream_t st, int n, const float4* pts, int k
   const bool select = diag.knn_select != 0;  // per-lane threshold selection of the chunk kernels (k <= 10); knn_select=0: the plain mask pass
   const int* guard = stats.as<int>() + 2;
   if (qgroup) {
+    if (g_knn_probe_events[0]) (void)hipEventRecord(g_knn_probe_events[0], st);  // (glim_amd_cloud_profile_neighbors: HIP events around the dominant kernel)
     knn_launch_qgroup(st, n, C, sorted.as<float4>(), box.as<float>(), k, out, guard, n < 49152 ? 1 : 2, dbg.as<int>());
+    if (g_knn_probe_events[1]) (void)hipEventRecord(g_knn_probe_events[1], st);
   } else if (pair_lanes) {
     knn_launch_pairs(st, n, 2 * C, sorted.as<float4>(), box32.as<float>(), k, out, select, guard);
     GA_HIP(hipGetLastError());
@@ -578,6 +585,39 @@ int cloud_curve_rank(glim_amd_cloud* c, glim_amd_ctx* held, hipStream_t st) {
 }  // namespace glim_amd
 
 extern "C" {
+
+// Timing aid (bench.py rooflines of the kNN-led workloads): `iters` find_neighbors calls; wall milliseconds per call and the HIP-event duration of
+// the query-group kernel inside it (0 when another kernel answered: clouds <= 2 048 points, forced paths).
+int glim_amd_cloud_profile_neighbors(glim_amd_cloud* c, int k, int iters, float* ms_per_call, float* ms_qgroup_kernel) {
+  if (!c || iters <= 0) return GLIM_AMD_ERR_INVALID;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  GA_HIP(hipSetDevice(c->ctx->device));
+  GA_HIP(hipEventCreate(&e0));
+  GA_HIP(hipEventCreate(&e1));
+  int rc = glim_amd_cloud_find_neighbors(c, k, nullptr);  // warm-up (allocations, first-use paths)
+  double kernel_ms = 0.0;
+  int timed = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters && rc == GLIM_AMD_OK; i++) {
+    g_knn_probe_events[0] = e0;
+    g_knn_probe_events[1] = e1;
+    rc = glim_amd_cloud_find_neighbors(c, k, nullptr);
+    g_knn_probe_events[0] = g_knn_probe_events[1] = nullptr;
+    float ms = 0.f;
+    if (rc == GLIM_AMD_OK && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+      kernel_ms += ms;
+      timed++;
+    }
+    (void)hipGetLastError();
+  }
+  const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != GLIM_AMD_OK) return rc;
+  if (ms_per_call) *ms_per_call = (float)(wall_ms / iters);
+  if (ms_qgroup_kernel) *ms_qgroup_kernel = timed ? (float)(kernel_ms / timed) : 0.f;
+  return GLIM_AMD_OK;
+}
 
 int glim_amd_cloud_find_neighbors(glim_amd_cloud* c, int k, int32_t* neighbors_out) {
   if (!c || k <= 0) return GLIM_AMD_ERR_INVALID;

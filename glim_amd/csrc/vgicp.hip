@@ -297,7 +297,7 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
 // never arrives (cannot happen: the writing blocks wait for nothing) ends in a NaN record instead of a hung device.
 template <int INFLIGHT = 16>
 __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum,
-                                               const double* __restrict__ T) {
+                                               const double* __restrict__ T, unsigned long long* rows_seen_stamp = nullptr) {
   const int first = d.first_block, nb = d.num_blocks;
   double Tl[12];
   if (threadIdx.x < 4) {
@@ -341,6 +341,7 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
     s_part[g][3 * p + 2] = s2;
   }
   if (threadIdx.x < FIN_GROUPS) s_part[threadIdx.x][30] = s_part[threadIdx.x][31] = 0.0;
+  if (rows_seen_stamp && threadIdx.x == BLOCK - 1) *rows_seen_stamp = __builtin_amdgcn_s_memrealtime();  // (thread 255 handles no second-round pair: a lower bound; the barrier of finalize_tail follows)
   finalize_tail(f, fa, mode, s_part, s_sum, Tl);
 }
 
@@ -358,6 +359,10 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
 // carried).  0: the cofactor form on the plain table (A/B builds: tools/ab_variant.sh sm0 -DGLIM_AMD_PLANE_SM=0).
 #ifndef GLIM_AMD_PLANE_SM
 #define GLIM_AMD_PLANE_SM 1
+#endif
+// key compares of the probe resolution: 1 = every predicate formed once (four 64-bit compares per trip), 0 = round 5's form (six)
+#ifndef GLIM_AMD_KEYCMP4
+#define GLIM_AMD_KEYCMP4 0
 #endif
 
 struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: lives in SGPRs)
@@ -571,6 +576,25 @@ __device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLA
   unsigned long long k0 = (unsigned long long)__float_as_uint(cur.head.x) | ((unsigned long long)__float_as_uint(cur.head.y) << 32);
   unsigned long long k1 = (unsigned long long)__float_as_uint(cur.head.z) | ((unsigned long long)__float_as_uint(cur.head.w) << 32);
   unsigned int b = cur.bkt;
+#if GLIM_AMD_KEYCMP4
+  // four 64-bit compares per trip instead of six: each predicate is formed ONCE and reused as a lane mask -- the form below
+  // this #if re-evaluates `k0 == key` / `k1 == key` after the (rare) spill walk because the walk may have changed them
+  const bool valid = cur.key != EMPTY_KEY;
+  bool eq0 = k0 == cur.key, eq1 = k1 == cur.key;
+  if (valid && !eq0 && !eq1 && k1 != EMPTY_KEY) {
+    // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
+    do {
+      b = (b + 1 == d.num_buckets) ? 0u : b + 1;
+      const float4 h = gld4(reinterpret_cast<const char*>(d.buckets) + b * 128u);
+      k0 = (unsigned long long)__float_as_uint(h.x) | ((unsigned long long)__float_as_uint(h.y) << 32);
+      k1 = (unsigned long long)__float_as_uint(h.z) | ((unsigned long long)__float_as_uint(h.w) << 32);
+      eq0 = k0 == cur.key;
+      eq1 = k1 == cur.key;
+    } while (!eq0 && !eq1 && k1 != EMPTY_KEY);
+  }
+  const bool in1 = eq1;
+  const bool hit = valid && (eq0 || eq1);
+#else
   if (cur.key != EMPTY_KEY) {
     // rare spill: both ways of the home bucket hold other keys -> walk to the next bucket (exact compare, table never full)
     while (k0 != cur.key && k1 != cur.key && k1 != EMPTY_KEY) {
@@ -582,6 +606,7 @@ __device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLA
   }
   const bool in1 = (k1 == cur.key);
   const bool hit = (cur.key != EMPTY_KEY) && (k0 == cur.key || in1);
+#endif
   // A wavefront trip in which no lane has a correspondence skips the record gather and the algebra (its lanes would add exact zeros, so the
   // sums are bit-identical).  In Hilbert order misses come in runs: 17 % of the trips of the 256-submap all-pairs cost (inlier fraction
   // 0.69) have no hit at all; 13.9 -> 12.2 ms for that evaluation (BENCH_r02 `staged`).  General (36 B/pt) kernel only: under the
@@ -873,9 +898,18 @@ __global__ __launch_bounds__(256) void cull_kernel(const FactorDesc* __restrict_
     const unsigned long long field = log2p == 6 ? ~0ull : ((1ull << (1 << log2p)) - 1ull);
     words[pair] = (culled_lanes >> ((lane >> log2p) << log2p)) & field;
   }
-  if (lane == 0 && point_lanes) {  // counters (measurement: glim_amd_factor_set_cull_stats)
-    atomicAdd(&stats[0], (unsigned long long)__popcll(culled_lanes & point_lanes));
-    atomicAdd(&stats[1], (unsigned long long)__popcll(point_lanes));
+  // counters (measurement only, armed by glim_amd_factor_set_cull_stats: `stats` is null otherwise -- one atomic pair per WAVEFRONT on two words
+  // was 1.1 M same-address atomics per evaluation of configs[3], i.e. longer than the factor kernel itself).  One pair per block, spread over 64 slots.
+  if (stats) {
+    __shared__ unsigned int s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    if (lane == 0 && point_lanes) {
+      atomicAdd(&s_cnt[0], (unsigned int)__popcll(culled_lanes & point_lanes));
+      atomicAdd(&s_cnt[1], (unsigned int)__popcll(point_lanes));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&stats[2 * (blockIdx.x & 63) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
   }
 }
 
@@ -909,7 +943,16 @@ struct ResidentArgs {
   unsigned int* mail;              // host-mapped: [16] alive (1 while the kernel serves, 0 once it has left)
   unsigned int first_tag;          // the last tag served before this launch
   unsigned int idle_polls;         // leader: empty polls before it leaves
+  // Device timeline of the LAST request served (glim_amd_debug_resident_timeline; null = off): s_memrealtime stamps (100 MHz), device memory.
+  //   [0] leader: request seen in host memory        [1] leader: poses re-published on the device
+  //   [2] finaliser of factor 0: pose seen           [3] ... every row of its factor summed (all tags arrived)      [4] ... record stored towards the host
+  //   [8 + 4 b + {0, 1, 2}] worker block b: pose seen, first row computed (block-reduced), row granules published
+  unsigned long long* timeline;
 };
+constexpr int TL_WORKER0 = 8;
+__device__ __forceinline__ void tl_stamp(unsigned long long* tl, int slot) {
+  if (tl && threadIdx.x == 0) tl[slot] = __builtin_amdgcn_s_memrealtime();
+}
 constexpr unsigned int RES_EXIT = 0xffffffffu;
 
 // wave 0, lanes 0..11: wait for the 12 pose granules of factor f.  exact != 0: until their tag is `exact`; otherwise until it is a session tag
@@ -997,6 +1040,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
         }
         __builtin_amdgcn_s_sleep(2);
       }
+      tl_stamp(ra.timeline, 0);
       const int nd = ra.num_factors * 12;
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.replicas * nd * 16, 0x00020000);
       for (int base_w = 0; base_w < words; base_w += LEAD_WORDS) {
@@ -1025,6 +1069,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
           for (int c = 0; c < ra.replicas; c++) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (c * nd + i) * 16, 0, AUX_SC1);
         }
       }
+      tl_stamp(ra.timeline, 1);
       if (threadIdx.x == 0) s_tag = req;
       if (req == RES_EXIT) {
         if (threadIdx.x == 0) __hip_atomic_store(ra.mail + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1037,6 +1082,8 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
       wait_pose(ra, f, last, leader ? s_tag : 0u, s_pose, &s_tag);
       const unsigned int tag = s_tag;
       if (tag == RES_EXIT) return;
+      unsigned long long* const tlf = (b == ra.workers) ? ra.timeline : nullptr;  // (the finaliser of the plan's first factor keeps the account)
+      tl_stamp(tlf, 2);
       FinalizeArgs fa;
       fa.out = nullptr;
       fa.out_mirror = nullptr;
@@ -1051,7 +1098,8 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
       fa.finmap = ra.finmap;
       fa.cull_words = nullptr;
       const FactorDesc d = ra.descs[f];
-      fused_finalize<8>(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose);
+      fused_finalize<8>(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose, tlf ? tlf + 3 : nullptr);
+      tl_stamp(tlf, 4);
       __syncthreads();
       last = tag;
       continue;
@@ -1092,9 +1140,13 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
           Tl[i] = __longlong_as_double(((long long)hi << 32) | (long long)lo);
         }
       }
+      unsigned long long* const tlw = (ra.timeline && r == first_row) ? ra.timeline + TL_WORKER0 + 4 * b : nullptr;
+      tl_stamp(tlw, 0);
       if (PLANE_ONLY || d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
       else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
+      tl_stamp(tlw, 1);
       publish_row_tagged<MODE_LINEARIZE>(s_red, ra.rows16, (size_t)(d.first_block + bm.y), tag);
+      tl_stamp(tlw, 2);
       __syncthreads();  // s_red and s_pose are reused by the next row
     }
     last = tag;
@@ -1296,6 +1348,7 @@ void plan_release_cull(FactorPlan* p) {
   p->d_cull_words = nullptr;
   p->d_cull_stats = nullptr;
   p->cull = false;
+  p->cull_count = false;
 }
 void plan_release_buffers(FactorPlan* p) {
   plan_release_cull(p);
@@ -1659,7 +1712,7 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   // row: a set whose general segment runs for less than ~150 us would pay more than it gets back), every general factor at <= 64 points per thread
   plan_release_cull(plan);
   constexpr int CULL_MIN_ROWS = 16384;
-  bool want_cull = diag.cull && !fused_form && seg_rows[1] > 0 && (seg_rows[1] >= CULL_MIN_ROWS || diag.cull == 2);  // (cull=2: any size, for the tests)
+  bool want_cull = diag.cull && seg_rows[1] > 0 && (seg_rows[1] >= CULL_MIN_ROWS || diag.cull == 2);  // (cull=2: any size, for the tests; single-dispatch launches never use it)
   int cull_ppt = 1;
   for (int f = 0; f < nf && want_cull; f++)
     if (!plan->h_descs[f].plane) {
@@ -1691,9 +1744,9 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
     }
     hipError_t e = pool_malloc(&plan->d_cull_descs, cds.size() * sizeof(CullDesc));
     if (e == hipSuccess) e = pool_malloc(&plan->d_cull_words, (size_t)seg_rows[1] * 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = pool_malloc(&plan->d_cull_stats, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = pool_malloc(&plan->d_cull_stats, 128 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemcpyAsync(plan->d_cull_descs, cds.data(), cds.size() * sizeof(CullDesc), hipMemcpyHostToDevice, set->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(plan->d_cull_stats, 0, 2 * sizeof(unsigned long long), set->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(plan->d_cull_stats, 0, 128 * sizeof(unsigned long long), set->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(set->stream);  // (`cds` is pageable and goes out of scope)
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -1804,7 +1857,7 @@ void launch_segments(glim_amd_factor_set* set, const FinalizeArgs& fa, float* pa
   if (rows1 > 0 && plan->cull && !INLINE && !FUSED) {
     const long long cull_waves = ((4ll * rows1) + (64 >> plan->cull_log2p) - 1) / (64 >> plan->cull_log2p);
     cull_kernel<<<(unsigned int)((cull_waves + 3) / 4), 256, 0, set->stream>>>(plan->d_descs, static_cast<const CullDesc*>(plan->d_cull_descs), lin, plan->d_blockmap, rows0,
-                                                                              rows1, plan->cull_log2p, plan->d_cull_words, plan->d_cull_stats);
+                                                                              rows1, plan->cull_log2p, plan->d_cull_words, plan->cull_count ? plan->d_cull_stats : nullptr);
     vgicp_kernel<MODE, FROZEN, false, false, false, true><<<rows1, BLOCK, 0, set->stream>>>(plan->d_descs, lin, ev, plan->d_blockmap, partials, set->inline_args, fa, rows0,
                                                                                            per_round, rows1, fin0);
   } else if (rows1 > 0)
@@ -1985,8 +2038,14 @@ struct ResidentSession {
   std::atomic<bool> busy{false};
   std::chrono::steady_clock::time_point last_use;
   unsigned long long launches = 0, requests = 0;
+  // device timeline (glim_amd_debug_resident_timeline): on from the next launch when `timeline_on`; the buffer outlives the sessions
+  bool timeline_on = false;
+  unsigned long long* d_timeline = nullptr;
+  int timeline_workers = 0;
+  double last_request_host_us = 0.0;  // host: from posting the last request to its last record granule
 };
 ResidentSession g_resident[16];
+constexpr size_t TIMELINE_WORDS = TL_WORKER0 + 4 * 1024;
 
 unsigned int next_session_tag(ResidentSession& S) {
   S.counter = (S.counter >= 0x7ffffff0u) ? 1u : S.counter + 1u;
@@ -2082,6 +2141,18 @@ int resident_launch(ResidentSession& S, glim_amd_factor_set* set, FactorPlan* pl
   ra.first_tag = S.last_tag;
   // one empty poll of the request word is one PCIe read (~1.2 us) plus a short sleep
   ra.idle_polls = (unsigned int)std::max(100, ctx->diag.resident_idle_us * 2 / 3);
+  ra.timeline = nullptr;
+  if (S.timeline_on && ra.workers <= 1024) {
+    if (!S.d_timeline && hipMalloc(reinterpret_cast<void**>(&S.d_timeline), TIMELINE_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+      (void)hipGetLastError();
+      S.d_timeline = nullptr;
+    }
+    if (S.d_timeline) {
+      GA_HIP(hipMemsetAsync(S.d_timeline, 0, TIMELINE_WORDS * sizeof(unsigned long long), S.stream));
+      ra.timeline = S.d_timeline;
+      S.timeline_workers = ra.workers;
+    }
+  }
   if (plan->plane_rows == plan->total_rows) resident_kernel<true><<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
   else resident_kernel<false><<<ra.workers + nf, BLOCK, 0, S.stream>>>(ra);
   GA_HIP(hipGetLastError());
@@ -2101,6 +2172,7 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
   const size_t nf = set->entries.size();
   FactorPlan* plan = nullptr;
   unsigned int tag = 0;
+  std::chrono::steady_clock::time_point t_post;
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     GA_HIP(hipSetDevice(ctx->device));
@@ -2128,12 +2200,14 @@ int run_resident(glim_amd_factor_set* set, const double* T_lin) {
       if (resident_launch(S, set, plan) != GLIM_AMD_OK) return GLIM_AMD_ERR_UNSUPPORTED;
     }
     tag = next_session_tag(S);
+    t_post = std::chrono::steady_clock::now();
     resident_post(S, T_lin, nf * 12, tag);
     S.busy.store(true);
     S.last_use = now;
     S.requests++;
   }
   bool ok = collect_tagged_records(plan, nf, tag, reinterpret_cast<volatile unsigned int*>(S.h_mail) + 16);
+  S.last_request_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_post).count();
   if (!ok) {
     // the kernel left (idle time-out racing with this request) or is stuck: make sure it is gone, start a fresh one, which finds the pending
     // request in the mailbox
@@ -2171,6 +2245,70 @@ extern "C" int glim_amd_debug_resident_stats(int device, uint64_t* launches, uin
   if (requests) *requests = S.requests;
   if (alive) *alive = (S.launched && S.h_mail && reinterpret_cast<volatile unsigned int*>(S.h_mail)[16] != 0u) ? 1 : 0;
   return GLIM_AMD_OK;
+}
+
+// Device timeline of the resident session.  enable: the next session launch carries s_memrealtime stamps (a running session is
+// ended so that the next request starts one that does).  read: ends the session (its stamps are then in memory) and reports the LAST request,
+// microseconds relative to the moment the leader saw the request in host memory:
+//   [0] host: posting the request -> last record granule seen (the whole round trip, host clock)
+//   [1] leader: poses re-published on the device
+//   [2] [3] [4]    workers: pose seen                   min / median / max over the worker blocks
+//   [5] [6] [7]    workers: first row computed           min / median / max
+//   [8] [9] [10]   workers: row granules published        min / median / max
+//   [11] finaliser of factor 0: pose seen   [12] every row of the factor summed   [13] record stored towards the host   [14] worker blocks
+//   [15] device span: request seen -> record stored (= [13]);  [0] - [15] = host -> device -> host transit + host polling
+extern "C" int glim_amd_debug_resident_timeline(int device, int enable, double* us, int32_t num_fields) {
+  if (device < 0 || device >= 16) return GLIM_AMD_ERR_INVALID;
+  ResidentSession& S = g_resident[device];
+  std::lock_guard<std::mutex> slock(S.mu);
+  if (S.busy.load()) return GLIM_AMD_ERR_STATE;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  GA_HIP(hipSetDevice(device));
+  resident_stop(S);  // (ends the kernel: everything it stored is in memory now)
+  int rc = GLIM_AMD_OK;
+  if (us && num_fields > 0) {
+    for (int i = 0; i < num_fields; i++) us[i] = 0.0;
+    if (!S.d_timeline || S.timeline_workers <= 0) {
+      rc = GLIM_AMD_ERR_STATE;
+    } else {
+      std::vector<unsigned long long> h(TIMELINE_WORDS, 0ull);
+      GA_HIP(hipMemcpy(h.data(), S.d_timeline, TIMELINE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      const unsigned long long t0 = h[0];
+      auto rel = [&](unsigned long long t) { return t >= t0 && t0 ? (double)(t - t0) * 0.01 : -1.0; };  // 100 MHz ticks -> us
+      std::vector<double> a, b, c;
+      for (int w = 0; w < S.timeline_workers; w++) {
+        const unsigned long long* p = &h[(size_t)TL_WORKER0 + 4 * (size_t)w];
+        if (!p[0] || !p[1] || !p[2]) continue;
+        a.push_back(rel(p[0]));
+        b.push_back(rel(p[1]));
+        c.push_back(rel(p[2]));
+      }
+      auto put = [&](int i, double v) {
+        if (i < num_fields) us[i] = v;
+      };
+      auto mmm = [&](std::vector<double>& v, int i) {
+        if (v.empty()) return;
+        std::sort(v.begin(), v.end());
+        put(i, v.front());
+        put(i + 1, v[v.size() / 2]);
+        put(i + 2, v.back());
+      };
+      put(0, S.last_request_host_us);
+      put(1, rel(h[1]));
+      mmm(a, 2);
+      mmm(b, 5);
+      mmm(c, 8);
+      put(11, rel(h[2]));
+      put(12, rel(h[3]));
+      put(13, rel(h[4]));
+      put(14, (double)a.size());
+      put(15, rel(h[4]));
+    }
+  }
+  S.timeline_on = enable != 0;
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return rc;
 }
 
 extern "C" int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached) {
@@ -2766,14 +2904,16 @@ int glim_amd_factor_set_cull_stats(glim_amd_factor_set* set, uint64_t* culled_tr
   GA_HIP(hipSetDevice(set->ctx->device));
   GA_TRY(factor_set_prepare(set));
   FactorPlan* plan = set->plan;
-  unsigned long long h[2] = {0ull, 0ull};
+  unsigned long long h[128], sum[2] = {0ull, 0ull};
   if (plan->cull) {
     GA_HIP(hipStreamSynchronize(set->stream));
     GA_HIP(hipMemcpy(h, plan->d_cull_stats, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 128; i++) sum[i & 1] += h[i];
     if (reset) GA_HIP(hipMemset(plan->d_cull_stats, 0, sizeof(h)));
+    plan->cull_count = reset != 0;  // reset != 0: zero the counters and COUNT from now on; reset == 0: read and stop counting (the default state)
   }
-  if (culled_trips) *culled_trips = h[0];
-  if (trips_with_points) *trips_with_points = h[1];
+  if (culled_trips) *culled_trips = sum[0];
+  if (trips_with_points) *trips_with_points = sum[1];
   return plan->cull ? GLIM_AMD_OK : GLIM_AMD_ERR_UNSUPPORTED;
 }
 

@@ -75,7 +75,8 @@ int glim_amd_factor_set_profile_fresh(glim_amd_ctx* ctx, int32_t n, const glim_a
 int glim_amd_factor_set_trip_stats(glim_amd_factor_set* set, uint64_t* skipped_trips, uint64_t* total_trips_per_evaluation, int reset);
 /* Measurement aid: the pre-cull of a large general-form set: wavefront trips the pre-pass marked as unable to find a correspondence
  * (their 64-point chunk box, moved by the evaluation's pose, touches no occupied cell of the target's occupancy mask) and the trips that hold
- * points at all, summed over the evaluations of the set's current plan since the last reset.  GLIM_AMD_ERR_UNSUPPORTED (and zeros) when the plan has no
+ * points at all.  The pre-pass counts only while armed: reset != 0 zeroes the counters and arms it (the evaluations that follow are counted, at the price
+ * of a few thousand atomics each); reset == 0 reads the sums and disarms it.  GLIM_AMD_ERR_UNSUPPORTED (and zeros) when the plan has no
  * pre-cull (small set, plane-form factors only, switch cull=0). */
 int glim_amd_factor_set_cull_stats(glim_amd_factor_set* set, uint64_t* culled_trips, uint64_t* trips_with_points, int reset);
 /* The same pattern with every iteration timed on its own (samples_us: `iters` entries) and `gap_us` of host busy-waiting between iterations -- the
@@ -86,6 +87,10 @@ int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, cons
 /* One Levenberg-Marquardt iteration as the optimisers drive it (sub_mapping.cpp:435-443, odometry_estimation_cpu.cpp:116-149): a synchronous
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
 int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
+/* timing aid: `iters` glim_amd_cloud_find_neighbors(cloud, k) calls; wall milliseconds per call, and the HIP-event duration (events on the call's own
+ * stream) of the query-group kernel inside it -- the dominant kernel of the kNN-led workloads, whose roofline bench.py quotes (0 when another kernel
+ * answered: clouds <= 2 048 points, forced knn_path / knn_kernel). */
+int glim_amd_cloud_profile_neighbors(glim_amd_cloud* cloud, int k, int iters, float* ms_per_call, float* ms_qgroup_kernel);
 /* timing aid: `iters` back-to-back glim_amd_overlap_batch calls with these arguments; microseconds per call, measured inside the library. */
 int glim_amd_overlap_profile(glim_amd_ctx* ctx, int32_t num_queries, const int32_t* num_targets, const glim_amd_voxelmap* const* targets,
                              const double* T_target_source, const glim_amd_cloud* const* sources, int iters, float* us_per_call);
@@ -95,6 +100,16 @@ int glim_amd_overlap_profile(glim_amd_ctx* ctx, int32_t num_queries, const int32
  * on the device and takes its requests through host-mapped memory; it leaves by itself after `resident_idle_us` without a request): kernel
  * launches and requests served so far, whether one is alive right now. */
 int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requests, int32_t* alive);
+/* Device timeline of the resident session's LAST request: ends the session, reports (us / num_fields may be NULL / 0: switch only)
+ * and leaves the stamps on (enable != 0) or off for the sessions that start afterwards.  Microseconds, device stamps (s_memrealtime, 10 ns) relative
+ * to the moment the session's leader saw the request in host memory:
+ *   [0] host clock: posting the request -> last record granule seen      [1] leader: poses re-published on the device
+ *   [2..4] worker blocks: pose seen, min / median / max   [5..7] first row computed   [8..10] row granules published
+ *   [11] finaliser of factor 0: pose seen   [12] every row of its factor summed   [13] record stored towards the host
+ *   [14] worker blocks with a complete account   [15] = [13]: the device's share of [0]
+ * GLIM_AMD_ERR_STATE: a request is in flight, or no session has run with the stamps on. */
+#define GLIM_AMD_RESIDENT_TIMELINE_FIELDS 16
+int glim_amd_debug_resident_timeline(int device, int enable, double* microseconds, int32_t num_fields);
 /* ends the device's resident session now instead of letting it idle out (GLIM_AMD_ERR_STATE while a request is in flight). */
 int glim_amd_debug_resident_stop(int device);
 /* parity / debug only: factor plans this context has built for new factor lists, how many of them took over the buffers of the plan its full

@@ -743,18 +743,18 @@ def test_pre_cull_of_the_general_kernel_changes_no_bit(api, orc):
     pairs = [(i, j) for i in range(5) for j in range(5) if i != j]
     far = np.eye(4)
     far[:3, 3] = (500.0, -300.0, 40.0)
-    for pose_of in (lambda i, j: synth.relative_pose(poses[i], poses[j]), lambda i, j: far if (i + j) % 2 else synth.relative_pose(poses[i], poses[j]) @ far):
+    for case, pose_of in enumerate((lambda i, j: synth.relative_pose(poses[i], poses[j]), lambda i, j: far if (i + j) % 2 else synth.relative_pose(poses[i], poses[j]) @ far)):
         deltas = np.stack([api.pose12(pose_of(i, j)) for i, j in pairs])
         got = {}
         for ppt in (1, 4, 64):
             for cull in (0, 2):
                 ctx.set_diag("")
-                ctx.set_diag(f"cull={cull},ppt={ppt}")
+                ctx.set_diag(f"cull={cull},ppt={ppt},fuse=0")  # (fuse=0: a small synchronous set takes the two-dispatch form, whose factor launch is the culled one)
                 fset = api.NonlinearFactorSetGPU(ctx)
                 for i, j in pairs:
                     fset.add(api.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j][0]))
+                fset.cull_stats(reset=True)  # (arm the counters)
                 out = fset.linearize_poses(deltas)
-                values = {k: poses[k] for k in range(5)}
                 stats = fset.cull_stats()
                 assert (stats is None) == (cull == 0)
                 if cull:
@@ -766,11 +766,12 @@ def test_pre_cull_of_the_general_kernel_changes_no_bit(api, orc):
                 assert a["num_inliers"] == b["num_inliers"] and a["error"] == b["error"]
                 for k in ("H_ss", "b_s", "H_tt", "H_ts", "b_t"):
                     np.testing.assert_array_equal(a[k], b[k])
-        assert got[("culled", 1)] > 0.02, got  # partly overlapping scans / a source moved off the map: the pre-pass finds empty chunks
+        if case == 1:
+            assert got[("culled", 1)] > 0.9, got[("culled", 1)]  # a source moved 500 m off the map: the pre-pass proves (nearly) every chunk empty
     ctx.set_diag("")
     # ... and the culled evaluation is the oracle's (first pair of the overlapping case)
     deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j])) for i, j in pairs])
-    ctx.set_diag("cull=2")
+    ctx.set_diag("cull=2,fuse=0")
     fset = api.NonlinearFactorSetGPU(ctx)
     for i, j in pairs:
         fset.add(api.IntegratedVGICPFactorGPU(i, j, maps[i], clouds[j][0]))
