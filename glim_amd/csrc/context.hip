@@ -63,6 +63,7 @@ const DiagKey kDiagKeys[] = {
   {"resident", &Diag::resident, kResidentWords, 0, 2},
   {"resident_idle_us", &Diag::resident_idle_us, nullptr, 100, 1000000},
   {"cull", &Diag::cull, nullptr, 0, 2},
+  {"small_rows", &Diag::small_rows, nullptr, 0, 4096},
   {"pool", &Diag::pool, nullptr, 0, 1},
   {"multi_rccl", &Diag::multi_rccl, nullptr, 0, 1},
   {"multi_host_gather", &Diag::multi_host_gather, nullptr, 0, 1},

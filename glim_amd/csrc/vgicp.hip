@@ -195,7 +195,7 @@ __host__ __device__ inline void rotate_part(int part, const double* sum, const d
 // same-address atomic) for longer than the second dispatch costs.  So did summing the rows on the host as they arrive (35.9 us: the host
 // ping-pongs cache lines with the device's writes).
 constexpr int FIN_GROUPS = 32;
-__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double (&Tl)[12]);
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl);
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
                                                 double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
   const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
@@ -233,7 +233,8 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 
 // Second half of a factor's finalisation, shared by the finalise kernel and by the finalising blocks of the single-dispatch kernel (same
 // bits): the 32 group sums of s_part added in group order, the four R^T B R rotations, the record, the completion word.
-__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double (&Tl)[12]) {
+// Tl: the factor's pose, registers of threads 0..3 (finalize_factor) or 12 doubles in LDS written before this call (fused_finalize)
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl) {
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
     double t = 0.0;
@@ -295,54 +296,106 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
 // rows as they arrive.  (group, piece) pair k = 10 g + p is handled by thread k, pairs 256..319 by threads 0..63 in a second round.  A
 // thread re-reads the <= 16 granules of a round until every tag is this call's; then it adds them.  The spin is bounded (~1 s): a row that
 // never arrives (cannot happen: the writing blocks wait for nothing) ends in a NaN record instead of a hung device.
-template <int INFLIGHT = 16>
+// (Round 6: the 320 (group, piece) pairs are 256 + 64, so threads 0..63 own TWO pairs.  They used to poll them one after the other -- each pair in
+//  nb / (32 INFLIGHT) all-or-nothing batches -- which put up to four dependent polling round trips (~1.2 us each: write-through granules read past the
+//  L2) behind the last row of a 512-row factor: the device timeline of the resident call showed 5 us between the last row and the record.  Both
+//  pairs now advance in LOCKSTEP, 2 x INFLIGHT loads in flight per batch; the order in which a pair's rows are added is unchanged: same bits.)
+template <int INFLIGHT = 8>
 __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum,
                                                const double* __restrict__ T, unsigned long long* rows_seen_stamp = nullptr) {
   const int first = d.first_block, nb = d.num_blocks;
-  double Tl[12];
-  if (threadIdx.x < 4) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) Tl[i] = T[i];
-  }
+  // the pose is needed at the very end (rotate_part): fetched now so that its latency hides behind the row polls, and parked in LDS -- 24 registers
+  // of every thread for the whole poll otherwise, which is what made the two-pair form spill under the resident kernel's 128-register cap
+  __shared__ double s_T[12];
+  if (threadIdx.x < 12) s_T[threadIdx.x] = T[threadIdx.x];
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rows16 + (size_t)first * TAG_ROW_BYTES, 0, nb * TAG_ROW_BYTES, 0x00020000);
   const int seq = (int)fa.seq;
+  static_assert(FIN_GROUPS * TAG_PIECES <= 2 * BLOCK, "a thread owns at most two (group, piece) pairs");
+  const int kA = (int)threadIdx.x, kB = (int)threadIdx.x + BLOCK;
+  const bool hasB = kB < FIN_GROUPS * TAG_PIECES;
+  const int gA = kA / TAG_PIECES, pA = kA - gA * TAG_PIECES;
+  const int gB = hasB ? kB / TAG_PIECES : gA, pB = hasB ? kB - gB * TAG_PIECES : pA;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
   bool lost = false;
-  for (int k = threadIdx.x; k < FIN_GROUPS * TAG_PIECES; k += BLOCK) {
-    const int g = k / TAG_PIECES, p = k - g * TAG_PIECES;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int c = g; c < nb; c += FIN_GROUPS * INFLIGHT) {
-      v4i_t v[INFLIGHT];
-      for (unsigned int spins = 0;; spins++) {
+  for (int base = 0;; base += FIN_GROUPS * INFLIGHT) {
+    const int cA = gA + base, cB = gB + base;
+    const bool moreA = cA < nb, moreB = hasB && cB < nb;
+    if (!moreA && !moreB) break;
+    v4i_t va[INFLIGHT], vb[INFLIGHT];
+    bool okA = !moreA, okB = !moreB;
+    for (unsigned int spins = 0;; spins++) {
+      if (!okA) {
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < INFLIGHT; u++) {
-          const int row = min(c + FIN_GROUPS * u, nb - 1);  // past the end: a valid row, value unused
-          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * TAG_ROW_BYTES + p * 16, 0, AUX_SC1_VOLATILE);
-          ok = ok && v[u].w == seq;
+          const int row = min(cA + FIN_GROUPS * u, nb - 1);  // past the end: a valid row, value unused
+          va[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * TAG_ROW_BYTES + pA * 16, 0, AUX_SC1_VOLATILE);
         }
-        if (ok) break;
-        if (spins > (1u << 20)) {
-          lost = true;
-          break;
+        if (!okB) {  // (both pairs' loads are in flight before either is looked at)
+#pragma unroll
+          for (int u = 0; u < INFLIGHT; u++) {
+            const int row = min(cB + FIN_GROUPS * u, nb - 1);
+            vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * TAG_ROW_BYTES + pB * 16, 0, AUX_SC1_VOLATILE);
+          }
         }
-        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; u++) ok = ok && va[u].w == seq;
+        okA = ok;
+        if (!okB) {
+          bool okb = true;
+#pragma unroll
+          for (int u = 0; u < INFLIGHT; u++) okb = okb && vb[u].w == seq;
+          okB = okb;
+        }
+      } else if (!okB) {
+        bool okb = true;
+#pragma unroll
+        for (int u = 0; u < INFLIGHT; u++) {
+          const int row = min(cB + FIN_GROUPS * u, nb - 1);
+          vb[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * TAG_ROW_BYTES + pB * 16, 0, AUX_SC1_VOLATILE);
+          okb = okb && vb[u].w == seq;
+        }
+        okB = okb;
       }
+      if (okA && okB) break;
+      if (spins > (1u << 20)) {
+        lost = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (moreA) {
 #pragma unroll
       for (int u = 0; u < INFLIGHT; u++)
-        if (c + FIN_GROUPS * u < nb) {
-          s0 += (double)__int_as_float(v[u].x);
-          s1 += (double)__int_as_float(v[u].y);
-          s2 += (double)__int_as_float(v[u].z);
+        if (cA + FIN_GROUPS * u < nb) {
+          a0 += (double)__int_as_float(va[u].x);
+          a1 += (double)__int_as_float(va[u].y);
+          a2 += (double)__int_as_float(va[u].z);
         }
     }
-    if (lost) s0 = s1 = s2 = __builtin_nan("");
-    s_part[g][3 * p + 0] = s0;
-    s_part[g][3 * p + 1] = s1;
-    s_part[g][3 * p + 2] = s2;
+    if (moreB) {
+#pragma unroll
+      for (int u = 0; u < INFLIGHT; u++)
+        if (cB + FIN_GROUPS * u < nb) {
+          b0 += (double)__int_as_float(vb[u].x);
+          b1 += (double)__int_as_float(vb[u].y);
+          b2 += (double)__int_as_float(vb[u].z);
+        }
+    }
+    if (lost) break;
+  }
+  if (lost) a0 = a1 = a2 = b0 = b1 = b2 = __builtin_nan("");
+  s_part[gA][3 * pA + 0] = a0;
+  s_part[gA][3 * pA + 1] = a1;
+  s_part[gA][3 * pA + 2] = a2;
+  if (hasB) {
+    s_part[gB][3 * pB + 0] = b0;
+    s_part[gB][3 * pB + 1] = b1;
+    s_part[gB][3 * pB + 2] = b2;
   }
   if (threadIdx.x < FIN_GROUPS) s_part[threadIdx.x][30] = s_part[threadIdx.x][31] = 0.0;
-  if (rows_seen_stamp && threadIdx.x == BLOCK - 1) *rows_seen_stamp = __builtin_amdgcn_s_memrealtime();  // (thread 255 handles no second-round pair: a lower bound; the barrier of finalize_tail follows)
-  finalize_tail(f, fa, mode, s_part, s_sum, Tl);
+  if (rows_seen_stamp && threadIdx.x == 0) *rows_seen_stamp = __builtin_amdgcn_s_memrealtime();  // (thread 0 owns two pairs: the longer path; the barrier of finalize_tail follows)
+  finalize_tail(f, fa, mode, s_part, s_sum, s_T);  // (its first barrier orders the s_T stores before the rotation reads them)
 }
 
 // resident waves per SIMD the register allocation aims for: the plane-form kernel fits 96 VGPRs (5 waves), the general one needs 99 (4 waves)
@@ -360,9 +413,10 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
 #ifndef GLIM_AMD_PLANE_SM
 #define GLIM_AMD_PLANE_SM 1
 #endif
-// key compares of the probe resolution: 1 = every predicate formed once (four 64-bit compares per trip), 0 = round 5's form (six)
+// key compares of the probe resolution: 1 = every predicate formed once (four 64-bit compares per trip; adopted in round 6: configs[3] kernel
+// 11.11 -> 10.96 ms same box, alternating, -1.4 %; plane-form kernel and synchronous call unchanged: profiles/r06/probe/keycmp4_ab.json), 0 = round 5's form (six)
 #ifndef GLIM_AMD_KEYCMP4
-#define GLIM_AMD_KEYCMP4 0
+#define GLIM_AMD_KEYCMP4 1
 #endif
 
 struct Rot32 {  // rotation of the linearisation pose in FP32 (wave-uniform: lives in SGPRs)
@@ -991,8 +1045,11 @@ __device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigne
 // registers -- what a session HOLDS while it idles is what everything else on the device cannot use: at 168 registers (both stream forms in one
 // kernel) two resident blocks per CU left room for ONE wave per SIMD of any other kernel, and an 8-factor launch beside an idle session took
 // 29 instead of 12 us (tools/res_probe.py).
+#ifndef GLIM_AMD_RES_MINW
+#define GLIM_AMD_RES_MINW 4
+#endif
 template <bool PLANE_ONLY>
-__global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(const ResidentArgs ra) {
+__global__ __launch_bounds__(BLOCK, PLANE_ONLY ? GLIM_AMD_RES_MINW : 3) void resident_kernel(const ResidentArgs ra) {
   __shared__ double s_lds[(FIN_GROUPS + 1) * PARTIAL_STRIDE];
   __shared__ double s_pose[12];
   __shared__ unsigned int s_tag;
@@ -1040,7 +1097,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      tl_stamp(ra.timeline, 0);
+      if (req != RES_EXIT) tl_stamp(ra.timeline, 0);  // (the exit request must not overwrite the account of the last served one)
       const int nd = ra.num_factors * 12;
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ra.pose16, 0, ra.replicas * nd * 16, 0x00020000);
       for (int base_w = 0; base_w < words; base_w += LEAD_WORDS) {
@@ -1069,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? 4 : 3) void resident_kernel(con
           for (int c = 0; c < ra.replicas; c++) __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, (c * nd + i) * 16, 0, AUX_SC1);
         }
       }
-      tl_stamp(ra.timeline, 1);
+      if (req != RES_EXIT) tl_stamp(ra.timeline, 1);
       if (threadIdx.x == 0) s_tag = req;
       if (req == RES_EXIT) {
         if (threadIdx.x == 0) __hip_atomic_store(ra.mail + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1199,19 +1256,35 @@ __global__ __launch_bounds__(BLOCK) void finalize_short_kernel(const FactorDesc*
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   double* o = fa.out + ((size_t)fa.out_row_offset + f) * COMPACT;
+  // (the record once more for an asynchronous caller's host array, glim_amd_multi: round 5 added the second store to finalize_tail only, so a
+  //  piece of > 2048 short factors -- every piece of configs[3] -- left the host array untouched; found by round 6's virtual-device run)
+  double* om = fa.out_mirror ? fa.out_mirror + ((size_t)fa.out_row_offset + f) * COMPACT : nullptr;
   if (t == 29 && fa.trip_stats && s_sum[wave][29] > 0.0) atomicAdd(&fa.trip_stats[f & 63], (unsigned long long)s_sum[wave][29]);
-  if (t == 0) o[0] = s_sum[wave][28];
-  if (t == 1) o[1] = s_sum[wave][27];
+  double value = 0.0;
+  bool mine = false;
+  if (t == 0) {
+    value = s_sum[wave][28];
+    mine = true;
+  }
+  if (t == 1) {
+    value = s_sum[wave][27];
+    mine = true;
+  }
   if (mode == MODE_LINEARIZE) {
     if (t < 4) rotate_part(t, s_sum[wave], Tl, s_rot[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (t < 21) o[2 + t] = s_rot[wave][c_acc_of_upper[t]];
-    if (t >= 21 && t < 24) o[2 + t] = s_rot[wave][t];
-    if (t >= 24 && t < 27) o[2 + t] = -s_rot[wave][t];
-  } else if (t >= 2 && t < COMPACT) {
-    o[t] = 0.0;
+  }
+  if (mine) {
+    o[t] = value;
+    if (om) om[t] = value;
+  }
+  if (t < 27) {  // slots 2 .. 28 of the record, by lanes 0 .. 26
+    double v = 0.0;
+    if (mode == MODE_LINEARIZE) v = t < 21 ? s_rot[wave][c_acc_of_upper[t]] : (t < 24 ? s_rot[wave][t] : -s_rot[wave][t]);
+    o[2 + t] = v;
+    if (om) om[2 + t] = v;
   }
 }
 
@@ -1487,6 +1560,7 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   plan->built_plane = diag.plane;
   plan->built_ppt = diag.ppt;
   plan->built_cull = diag.cull;
+  plan->built_small_rows = diag.small_rows;
   plan->h_descs.assign(nf, FactorDesc());
   plan->h_finmap.clear();
   std::vector<int> nblocks(nf);
@@ -1541,7 +1615,12 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   // factor keeps its 512 one-point rows.  Larger sets keep the throughput rule below.
   int small_set_ppt = 0;
   if (!forced_ppt && nf >= 1 && nf <= RESIDENT_MAX_FACTORS) {
-    const long long cap = 2ll * std::max(1, ctx->num_cus);
+    // (round 6: ONE row per compute unit instead of two.  The device timeline of the resident call -- glim_amd_debug_resident_timeline -- showed the
+    //  rows of a 131 072-pt factor computed by 4.6 us after the request whether a thread takes one point or two (the second rides in the software
+    //  pipeline), while the finalising block pays for every row it has to collect: 512 -> 256 rows took the synchronous call 13.7 -> 11.4 us on
+    //  the same box, the single-dispatch form 14.9 -> 14.0, and a session of 257 blocks holds ONE wave slot per SIMD instead of two -- what it costs
+    //  a 128-factor launch beside it fell from 1.39x to 1.04x.  profiles/r06/probe/sync_rows_ab.json; diag small_rows=<n> overrides the cap.)
+    const long long cap = diag.small_rows > 0 ? (long long)diag.small_rows : 1ll * std::max(1, ctx->num_cus);
     for (int p = 1; p <= 8 && !small_set_ppt; p++) {
       long long rows = 0;
       for (int seg = 0; seg < 2; seg++) {
@@ -1772,10 +1851,10 @@ int factor_set_prepare(glim_amd_factor_set* set) {
   glim_amd_ctx* ctx = set->ctx;
   const uint64_t epoch = global_mutation_epoch().load();
   const Diag& diag = ctx->diag;
-  if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt && set->plan->built_cull == diag.cull) return GLIM_AMD_OK;
+  if (!set->dirty && set->plan && set->seen_epoch == epoch && set->plan->built_plane == diag.plane && set->plan->built_ppt == diag.ppt && set->plan->built_cull == diag.cull && set->plan->built_small_rows == diag.small_rows) return GLIM_AMD_OK;
   std::vector<PlanKey> key;
   make_key(set, key);
-  auto usable = [&](const FactorPlan* p) { return p->key == key && p->built_plane == diag.plane && p->built_ppt == diag.ppt && p->built_cull == diag.cull; };
+  auto usable = [&](const FactorPlan* p) { return p->key == key && p->built_plane == diag.plane && p->built_ppt == diag.ppt && p->built_cull == diag.cull && p->built_small_rows == diag.small_rows; };
   if (set->plan && !usable(set->plan)) factor_set_park_plan(set);
   if (!set->plan && diag.plan_cache) {
     for (size_t i = 0; i < ctx->plan_cache.size(); i++) {

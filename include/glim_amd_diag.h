@@ -26,6 +26,7 @@ extern "C" {
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
  * served by a resident kernel that leaves after <n> us without a request; auto, the default: only in a context created with priority 1 -- the
  * session costs whatever else runs on the device 1.3-1.4x while it is alive, so it is opt-in), pp_fast=0|1 (random-grid preprocessing without sorts),
+ * small_rows=<n> (partial rows a small synchronous set is planned into at most; 0, the default: one per compute unit -- round 5 planned two),
  * cull=0|1|2 (general-form sets of >= 16 384 plan rows -- 2: of any size --: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask and the
  * factor kernel walks the live trips only; same bits either way),
  * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,

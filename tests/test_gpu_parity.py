@@ -414,12 +414,16 @@ def test_knn_and_covariances_on_device_match_oracle(api, ctx, orc, small_pair):
     np.testing.assert_array_equal(tiny.find_neighbors(5), orc.knn(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), 5))
 
 
-def test_gauss_newton_iterations_track_oracle(api, ctx, orc):
-    """config 1 (plumbing): 16k-pt pair, 1.0 m voxels, unary factor, <= 8 iterations; per-iteration pose delta within 1e-4."""
+@pytest.mark.parametrize("rings,azimuths", [(128, 128), (64, 256)])
+def test_gauss_newton_iterations_track_oracle(api, ctx, orc, rings, azimuths):
+    """config 1 (plumbing): 16k-pt pair, 1.0 m voxels, unary factor, <= 8 iterations; per-iteration pose delta within 1e-4.  128 rings x 128
+    azimuths is the geometry SURVEY 8d / BASELINE.md name for configs[0] (2.8 deg between azimuths: the kNN neighbourhoods of far walls straddle
+    rings, the covariances are what the reference's estimator would give on such a scan -- both sides consume the same ones); 64 x 256 is the
+    denser-azimuth variant rounds 1-5 ran."""
     from glim_amd import synth
 
     scene = synth.Scene.default()
-    dirs = synth.lidar_directions(64, 256)  # 16 384 rays; denser azimuth keeps the kNN neighbourhoods planar
+    dirs = synth.lidar_directions(rings, azimuths)  # 16 384 rays
     Tw = synth.pose(-8.0, -5.0, 1.8, 0.2)
     xi = np.array([0.01, -0.02, 0.015, 0.10, -0.05, 0.02])
     tgt = synth.scan(scene, Tw, dirs, 0)

@@ -294,3 +294,30 @@ def test_multi_c_program_over_virtual_devices(tmp_path, ndev):
     # without the switch one ordinal twice is refused, as before
     bad = subprocess.run([exe, "virtual", "2"], capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k != "GLIM_AMD_DIAG"})
     assert bad.returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_shards_of_thousands_of_short_factors_reach_the_host_array(many_small_scans):
+    """More than 2 048 factors of a few rows each in ONE piece -- every piece of configs[3] -- are finalised by the wave-per-factor kernel, which in
+    round 5 never made the second store into the host array (the records of glim_amd_multi_records / `out` stayed zero; only the device-summed
+    cost was read by the bench, so nobody saw it).  5 520 factors over 1 (one piece of 4 x 1 380... the default split) and 2 virtual devices: host
+    records == every device's gathered array == the unsharded set, bit for bit."""
+    from glim_amd import api, synth
+
+    poses, scans = many_small_scans
+    base = [(i, j) for i in range(len(scans)) for j in range(len(scans)) if i != j]
+    pairs = base * 10
+    flags = [api.FACTOR_BINARY] * len(pairs)
+    deltas = np.stack([api.pose12(synth.relative_pose(poses[i], poses[j]) @ synth.pose(0.001 * (k % 7), 0.0, 0.0)) for k, (i, j) in enumerate(pairs)])
+    want, keep = _unsharded(api, scans, poses, pairs, flags, deltas)
+    for ndev, split in ((1, 1), (2, 1), (2, -1)):
+        md = _virtual_cost(api, ndev, scans, pairs, flags, split)
+        got, total = md.linearize(deltas)
+        _assert_same_bits(got, want)
+        rec = md.records()
+        assert np.all(rec[:, 0] == [w["num_inliers"] for w in want]) and np.abs(rec[:, 2:]).max() > 0
+        for d in range(ndev):
+            np.testing.assert_array_equal(md.gathered_records(d), rec)
+        md.close()
+    del keep

@@ -188,10 +188,31 @@ int main(int argc, char** argv) {
          "\"stage_p50_us\": {\"clone_and_two_voxelmaps\": %.2f, \"first_linearisation_new_factor_list\": %.2f, \"each_further_linearisation\": %.2f, "
          "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"factor_plans_built\": %llu, \"of_them_in_the_buffers_of_an_evicted_plan\": %llu, "
          "\"inside_frame_create_p50_us_since_entry\": {\"cloud_allocated\": %.2f, \"staging_and_stream_allocations\": %.2f, \"pull_kernel_launched\": %.2f, "
-         "\"host_conversion_done\": %.2f, \"map_kernels_enqueued\": %.2f, \"completion_word_seen\": %.2f, \"return\": %.2f}, \"checksum\": %.6g}\n",
+         "\"host_conversion_done\": %.2f, \"map_kernels_enqueued\": %.2f, \"completion_word_seen\": %.2f, \"return\": %.2f}, \"checksum\": %.6g, ",
          (int)total.size(), n, NF, iters, fused, pct(total, 0.5), pct(total, 0.99), mean, pct(total, 0.0), pct(stage[S_CLONE_MAPS], 0.5), pct(stage[S_LIN_FIRST], 0.5),
          pct(stage[S_LIN_REST], 0.5), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5), (unsigned long long)plans_built, (unsigned long long)plans_recycled, pct(inside[0], 0.5), pct(inside[1], 0.5), pct(inside[2], 0.5), pct(inside[3], 0.5),
          pct(inside[4], 0.5), pct(inside[5], 0.5), pct(inside[6], 0.5), checksum);
+  // the tail, named: every stage's p99, and the five slowest frames with the stage that carried their excess over the median
+  printf("\"stage_p99_us\": {\"clone_and_two_voxelmaps\": %.2f, \"first_linearisation_new_factor_list\": %.2f, \"each_further_linearisation\": %.2f, "
+         "\"overlap_15_targets\": %.2f, \"retire_oldest_window_frame\": %.2f}, \"slowest_frames\": [",
+         pct(stage[S_CLONE_MAPS], 0.99), pct(stage[S_LIN_FIRST], 0.99), pct(stage[S_LIN_REST], 0.99), pct(stage[S_OVERLAP], 0.99), pct(stage[S_RETIRE], 0.99));
+  {
+    std::vector<size_t> order(total.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return total[a] > total[b]; });
+    const double med[S_COUNT] = {pct(stage[S_CLONE_MAPS], 0.5), pct(stage[S_LIN_FIRST], 0.5), pct(stage[S_LIN_REST], 0.5) * (iters - 1), pct(stage[S_OVERLAP], 0.5), pct(stage[S_RETIRE], 0.5)};
+    const char* names[S_COUNT] = {"clone_and_two_voxelmaps", "first_linearisation", "further_linearisations", "overlap", "retire"};
+    for (size_t r = 0; r < 5 && r < order.size(); r++) {
+      const size_t i = order[r];
+      const double v[S_COUNT] = {stage[S_CLONE_MAPS][i], stage[S_LIN_FIRST][i], stage[S_LIN_REST][i] * (iters - 1), stage[S_OVERLAP][i], stage[S_RETIRE][i]};
+      int worst = 0;
+      for (int k = 1; k < S_COUNT; k++)
+        if (v[k] - med[k] > v[worst] - med[worst]) worst = k;
+      printf("%s{\"frame\": %zu, \"frame_us\": %.1f, \"excess_in\": \"%s\", \"excess_us\": %.1f, \"stages_us\": [%.1f, %.1f, %.1f, %.1f, %.1f]}", r ? ", " : "", i, total[i],
+             names[worst], v[worst] - med[worst], v[0], v[1], v[2], v[3], v[4]);
+    }
+  }
+  printf("]}\n");
   for (auto& d : keyframes) drop_frame(&d);
   for (auto& d : window) drop_frame(&d);
   CHECK(glim_amd_ctx_destroy(ctx));
