@@ -139,7 +139,7 @@ struct Diag {
   int frame_fused = 1;    // frame_fused=0|1                     glim_amd_frame_create: one launch pulls the cloud and builds every level, one writes every level's records
   int pull_gated = 1;     // pull_gated=0|1                      ... and that kernel is launched BEFORE the conversion: its blocks wait for their piece of the staging block
   int pool = 1;           // pool=0|1                            device / pinned memory caches (process-wide: GLIM_AMD_DIAG only)
-  int small_rows = 0;     // small_rows=<n>                      partial rows a small synchronous set is planned into at most (0: one per compute unit)
+  int small_rows = 0;     // small_rows=<n>                      partial rows ONE factor of a small synchronous set is planned into at most (0: one per compute unit)
   int cull = 0;           // cull=0|1|2 (default 0: measured on configs[3] the pre-pass costs more than the walk saves, profiles/r06/probe/precull_*.json)                          large general-form sets: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask (2: sets of any size, tests)
   int multi_rccl = 1;     // multi_rccl=0|1                      glim_amd_multi: skip the collective on a single device
   int multi_host_gather = 0;  // multi_host_gather=0|1           glim_amd_multi: allow a host gather when librccl cannot be loaded (tests)

@@ -1615,18 +1615,24 @@ int plan_build(glim_amd_factor_set* set, FactorPlan* plan) {
   // factor keeps its 512 one-point rows.  Larger sets keep the throughput rule below.
   int small_set_ppt = 0;
   if (!forced_ppt && nf >= 1 && nf <= RESIDENT_MAX_FACTORS) {
-    // (round 6: ONE row per compute unit instead of two.  The device timeline of the resident call -- glim_amd_debug_resident_timeline -- showed the
-    //  rows of a 131 072-pt factor computed by 4.6 us after the request whether a thread takes one point or two (the second rides in the software
-    //  pipeline), while the finalising block pays for every row it has to collect: 512 -> 256 rows took the synchronous call 13.7 -> 11.4 us on
-    //  the same box, the single-dispatch form 14.9 -> 14.0, and a session of 257 blocks holds ONE wave slot per SIMD instead of two -- what it costs
-    //  a 128-factor launch beside it fell from 1.39x to 1.04x.  profiles/r06/probe/sync_rows_ab.json; diag small_rows=<n> overrides the cap.)
-    const long long cap = diag.small_rows > 0 ? (long long)diag.small_rows : 1ll * std::max(1, ctx->num_cus);
+    // Round 6: ... and no FACTOR gets more rows than one per compute unit.  The device timeline of the resident call
+    // (glim_amd_debug_resident_timeline) showed the rows of a 131 072-pt factor computed by 4.6 us after the request whether a thread takes one
+    // point or two (the second rides in the software pipeline), while the factor's finalising block pays for every row it has to collect:
+    // 512 -> 256 rows took the synchronous call 13.7 -> 11.4 us on the same box, the single-dispatch form 14.9 -> 14.0, and a session of 257
+    // blocks holds ONE wave slot per SIMD instead of two -- a 128-factor launch beside it pays 1.04x instead of 1.39x
+    // (profiles/r06/probe/sync_rows_ab.json).  The odometry's 34-factor sets keep their 4 points per thread: planned into 256 rows in TOTAL they
+    // were 6 % slower (8 points per thread; their factors own 10 rows each, nothing for a finaliser to wait for: sync_rows_34_factor_ab.json).
+    // diag small_rows=<n> overrides the per-factor cap.
+    const long long cap = 2ll * std::max(1, ctx->num_cus);
+    const long long factor_cap = diag.small_rows > 0 ? (long long)diag.small_rows : 1ll * std::max(1, ctx->num_cus);
     for (int p = 1; p <= 8 && !small_set_ppt; p++) {
       long long rows = 0;
       for (int seg = 0; seg < 2; seg++) {
         std::vector<long long> nb;
         for (int f = 0; f < nf; f++)
           if ((plan->h_descs[f].plane != 0) == (seg == 0)) nb.push_back(std::max(1, (plan->h_descs[f].n + BLOCK * p - 1) / (BLOCK * p)));
+        for (long long b : nb)
+          if (b > factor_cap) rows = cap + 1;  // (a factor with too many rows at this p: try the next)
         if (nb.size() < 16) {
           for (long long b : nb) rows += b;
         } else {  // the XCD-aware map pads every XCD's list to the longest one

@@ -26,7 +26,7 @@ extern "C" {
  * fuse=0|1 (small synchronous sets in ONE dispatch), resident=0|1|auto + resident_idle_us=<n> (repeated synchronous linearisations of a small set
  * served by a resident kernel that leaves after <n> us without a request; auto, the default: only in a context created with priority 1 -- the
  * session costs whatever else runs on the device 1.3-1.4x while it is alive, so it is opt-in), pp_fast=0|1 (random-grid preprocessing without sorts),
- * small_rows=<n> (partial rows a small synchronous set is planned into at most; 0, the default: one per compute unit -- round 5 planned two),
+ * small_rows=<n> (partial rows ONE factor of a small synchronous set is planned into at most; 0, the default: one per compute unit -- round 5: two),
  * cull=0|1|2 (general-form sets of >= 16 384 plan rows -- 2: of any size --: a pre-pass marks the wavefront trips whose chunk box misses the target's occupancy mask and the
  * factor kernel walks the live trips only; same bits either way),
  * knn_debug=<file>; and, in GLIM_AMD_DIAG ONLY (they are process-wide: set_diag refuses them), pool=0|1, multi_rccl=0|1,
@@ -88,7 +88,7 @@ int glim_amd_factor_set_profile_fresh_samples(glim_amd_ctx* ctx, int32_t n, cons
 /* One Levenberg-Marquardt iteration as the optimisers drive it (sub_mapping.cpp:435-443, odometry_estimation_cpu.cpp:116-149): a synchronous
  * linearize() of the whole set (records expanded on the host) and a synchronous error() at the trial values, each timed over `iters` calls. */
 int glim_amd_factor_set_profile_lm(glim_amd_factor_set* set, const double* T_target_source, int iters, float* ms_linearize, float* ms_error);
-/* timing aid: `iters` glim_amd_cloud_find_neighbors(cloud, k) calls; wall milliseconds per call, and the HIP-event duration (events on the call's own
+/* timing aid: `iters` calls of glim_amd_cloud_find_neighbors with this k; wall milliseconds per call, and the HIP-event duration (events on the call's own
  * stream) of the query-group kernel inside it -- the dominant kernel of the kNN-led workloads, whose roofline bench.py quotes (0 when another kernel
  * answered: clouds <= 2 048 points, forced knn_path / knn_kernel). */
 int glim_amd_cloud_profile_neighbors(glim_amd_cloud* cloud, int k, int iters, float* ms_per_call, float* ms_qgroup_kernel);

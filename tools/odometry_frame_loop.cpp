@@ -118,7 +118,8 @@ int main(int argc, char** argv) {
   std::vector<glim_amd_linearized6> lin((size_t)NF);
   std::vector<const glim_amd_voxelmap*> ov_maps((size_t)K);
   enum { S_CLONE_MAPS = 0, S_LIN_FIRST, S_LIN_REST, S_OVERLAP, S_RETIRE, S_COUNT };
-  std::vector<double> total, stage[S_COUNT], inside[7];
+  std::vector<double> total, stage[S_COUNT], inside[7], when_ms;  // when_ms: start of the frame, milliseconds since the first timed frame
+  double t_first_timed = 0.0;
   double checksum = 0.0;
   const int warm = 20;
   for (int it = 0; it < warm + timed; it++) {
@@ -170,6 +171,8 @@ int main(int argc, char** argv) {
     window[(size_t)WIN - 1] = cur;
     const double t4 = now_us();
     if (it >= warm) {
+      if (total.empty()) t_first_timed = t0;
+      when_ms.push_back((t0 - t_first_timed) * 1e-3);
       total.push_back(t4 - t0);
       stage[S_CLONE_MAPS].push_back(t1 - t0);
       stage[S_LIN_FIRST].push_back(t_first - t1);
@@ -208,11 +211,29 @@ int main(int argc, char** argv) {
       int worst = 0;
       for (int k = 1; k < S_COUNT; k++)
         if (v[k] - med[k] > v[worst] - med[worst]) worst = k;
-      printf("%s{\"frame\": %zu, \"frame_us\": %.1f, \"excess_in\": \"%s\", \"excess_us\": %.1f, \"stages_us\": [%.1f, %.1f, %.1f, %.1f, %.1f]}", r ? ", " : "", i, total[i],
-             names[worst], v[worst] - med[worst], v[0], v[1], v[2], v[3], v[4]);
+      printf("%s{\"frame\": %zu, \"at_ms\": %.2f, \"frame_us\": %.1f, \"excess_in\": \"%s\", \"excess_us\": %.1f, \"stages_us\": [%.1f, %.1f, %.1f, %.1f, %.1f]}", r ? ", " : "", i,
+             when_ms[i], total[i], names[worst], v[worst] - med[worst], v[0], v[1], v[2], v[3], v[4]);
     }
+    // slow frames (> 1.4 x the median) come in BURSTS of consecutive frames or alone?  [first frame, last frame, start ms] of every run of them
+    const double slow = 1.4 * pct(total, 0.5);
+    int n_slow = 0;
+    printf("], \"frames_above_1p4x_median\": {\"runs\": [");
+    bool first_run = true;
+    for (size_t i = 0; i < total.size();) {
+      if (total[i] <= slow) {
+        i++;
+        continue;
+      }
+      size_t j = i;
+      while (j + 1 < total.size() && (total[j + 1] > slow || (j + 2 < total.size() && total[j + 2] > slow))) j++;  // (one fast frame inside a run does not end it)
+      for (size_t k = i; k <= j; k++) n_slow += total[k] > slow ? 1 : 0;
+      printf("%s[%zu, %zu, %.2f]", first_run ? "" : ", ", i, j, when_ms[i]);
+      first_run = false;
+      i = j + 1;
+    }
+    printf("], \"count\": %d, \"of\": %zu}", n_slow, total.size());
   }
-  printf("]}\n");
+  printf("}\n");
   for (auto& d : keyframes) drop_frame(&d);
   for (auto& d : window) drop_frame(&d);
   CHECK(glim_amd_ctx_destroy(ctx));
