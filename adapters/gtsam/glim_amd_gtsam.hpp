@@ -37,6 +37,14 @@
 
 #include <glim_amd/gtsam_points_compat.hpp>
 
+// One of the three semantic choices that could not be checked against gtsam_points in the image this repository is developed in:
+// whether IntegratedVGICPFactor{,GPU}::error() returns E = sum r^T M r or E / 2.  H, b -- and with them every Gauss-Newton / LM step -- do not depend
+// on it; an LM accept / reject test compares error() of the SAME factor type at two points, so it does not either.  A maintainer who finds upstream
+// returns E / 2 builds with -DGLIM_AMD_VGICP_ERROR_SCALE=0.5 (the oracle's twin is ORC_ERROR_SCALE in oracle/vgicp_oracle.h).
+#ifndef GLIM_AMD_VGICP_ERROR_SCALE
+#define GLIM_AMD_VGICP_ERROR_SCALE 1.0
+#endif
+
 namespace glim_amd {
 
 // ---- type conversions ------------------------------------------------------------------------------------------------
@@ -70,8 +78,9 @@ inline gtsam::GaussianFactor::shared_ptr make_hessian_factor(const gtsam::KeyVec
     return v;
   };
   if (binary)
-    return gtsam::GaussianFactor::shared_ptr(new gtsam::HessianFactor(keys[0], keys[1], mat(l.H_tt), mat(l.H_ts), neg(l.b_t), mat(l.H_ss), neg(l.b_s), l.error));
-  return gtsam::GaussianFactor::shared_ptr(new gtsam::HessianFactor(keys[0], mat(l.H_ss), neg(l.b_s), l.error));
+    return gtsam::GaussianFactor::shared_ptr(
+      new gtsam::HessianFactor(keys[0], keys[1], mat(l.H_tt), mat(l.H_ts), neg(l.b_t), mat(l.H_ss), neg(l.b_s), GLIM_AMD_VGICP_ERROR_SCALE * l.error));
+  return gtsam::GaussianFactor::shared_ptr(new gtsam::HessianFactor(keys[0], mat(l.H_ss), neg(l.b_s), GLIM_AMD_VGICP_ERROR_SCALE * l.error));
 }
 
 inline bool same_pose(const Isometry3d& a, const Isometry3d& b) { return a.m == b.m; }
@@ -131,7 +140,7 @@ public:
     if (err_valid_ && same_pose(delta, err_delta_)) return err_;
     // after a linearisation the GPU factor evaluates with the correspondences frozen at the linearisation point; the
     // CPU-named factor (gtsam_points/factors/integrated_vgicp_factor.hpp of the shim tree) finds them at `values` (row a6)
-    err_ = impl_->error(to_values(values), (frozen_error_ && lin_valid_) ? &lin_values_ : nullptr);
+    err_ = GLIM_AMD_VGICP_ERROR_SCALE * impl_->error(to_values(values), (frozen_error_ && lin_valid_) ? &lin_values_ : nullptr);
     err_delta_ = delta;
     err_valid_ = true;
     return err_;
@@ -254,7 +263,7 @@ public:
       }
     }
     const std::vector<double> e = set_.error(gather(values), frozen ? &lin : nullptr);
-    for (std::size_t i = 0; i < factors_.size(); i++) factors_[i]->store_error(values, e[i]);
+    for (std::size_t i = 0; i < factors_.size(); i++) factors_[i]->store_error(values, GLIM_AMD_VGICP_ERROR_SCALE * e[i]);
   }
   std::vector<gtsam::GaussianFactor::shared_ptr> calc_linear_factors(const gtsam::Values& linearization_point) override {
     linearize(linearization_point);

@@ -142,7 +142,8 @@ def isa_stats_of(which):
     one JSON line per kernel instantiation, stamped with the kernel source id).  which: "plane" | "general" (launch-per-call LINEARIZE kernels)."""
     import glob
 
-    want = {"plane": "vgicp_kernelILi0ELb0ELb1ELb0ELb0E", "general": "vgicp_kernelILi0ELb0ELb0ELb0ELb0E"}[which]
+    # <MODE = linearise, FROZEN = 0, PLANE, INLINE = 0, FUSED = 0, CULL = 0> (round 6 added the CULL parameter; the pre-cull variant is off by default)
+    want = {"plane": "vgicp_kernelILi0ELb0ELb1ELb0ELb0ELb0EEE", "general": "vgicp_kernelILi0ELb0ELb0ELb0ELb0ELb0EEE"}[which]
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "isa_stats.json"))):
         try:

@@ -414,12 +414,16 @@ def test_knn_and_covariances_on_device_match_oracle(api, ctx, orc, small_pair):
     np.testing.assert_array_equal(tiny.find_neighbors(5), orc.knn(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], dtype=np.float32), 5))
 
 
-@pytest.mark.parametrize("rings,azimuths", [(128, 128), (64, 256)])
-def test_gauss_newton_iterations_track_oracle(api, ctx, orc, rings, azimuths):
+@pytest.mark.parametrize("rings,azimuths,truth_tol", [(128, 128, None), (64, 256, 0.02)])
+def test_gauss_newton_iterations_track_oracle(api, ctx, orc, rings, azimuths, truth_tol):
     """config 1 (plumbing): 16k-pt pair, 1.0 m voxels, unary factor, <= 8 iterations; per-iteration pose delta within 1e-4.  128 rings x 128
     azimuths is the geometry SURVEY 8d / BASELINE.md name for configs[0] (2.8 deg between azimuths: the kNN neighbourhoods of far walls straddle
     rings, the covariances are what the reference's estimator would give on such a scan -- both sides consume the same ones); 64 x 256 is the
-    denser-azimuth variant rounds 1-5 ran."""
+    denser-azimuth variant rounds 1-5 ran.  What is asserted at both: the same inlier count and the same step every iteration, and that the pose
+    iterated with the HIP path's own steps ends where the oracle's does.  Distance to the simulated truth is only asserted on the dense geometry:
+    at 128 x 128 the undamped Gauss-Newton iteration of the ORACLE itself settles 0.114 m from the truth (cost 68.6e3 after the first step, 79.8e3
+    at the fixed point -- the vertical-line neighbourhoods give the cost a biased minimum; measured on the CPU, round 6), so a truth bound there
+    would test the scan pattern, not the kernels."""
     from glim_amd import synth
 
     scene = synth.Scene.default()
@@ -448,11 +452,14 @@ def test_gauss_newton_iterations_track_oracle(api, ctx, orc, rings, azimuths):
         lam = 1e-6 * np.trace(ref["H_ss"]) / 6
         d_got, d_ref = gn_step(got, lam), gn_step(ref, lam)
         assert np.abs(d_got - d_ref).max() < POSE_TOL, (it, d_got, d_ref)
+        T_hip = T @ orc.se3_exp(d_got)
         T = T @ orc.se3_exp(d_ref)
         if np.linalg.norm(d_ref[3:]) < 1e-3 and np.linalg.norm(d_ref[:3]) < 1e-3 * np.pi / 180:
             break
-    err = np.linalg.inv(orc.se3_exp(xi)) @ T
-    assert np.linalg.norm(err[:3, 3]) < 0.02
+    assert np.abs(np.linalg.inv(T) @ T_hip - np.eye(4)).max() < 2 * POSE_TOL
+    if truth_tol is not None:
+        err = np.linalg.inv(orc.se3_exp(xi)) @ T
+        assert np.linalg.norm(err[:3, 3]) < truth_tol
 
 
 def test_full_size_scan_properties(api, ctx, orc):

@@ -74,7 +74,9 @@ def main():
         if os.environ.get("ISA_STATS_JSON"):
             import json
             with open(os.environ["ISA_STATS_JSON"], "a") as jf:
-                jf.write(json.dumps({"kernel": name, "vgpr": meta[".amdhsa_next_free_vgpr"], "sgpr": meta[".amdhsa_next_free_sgpr"], "loop_instructions": sum(ops.values()),
+                sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                from bench import kernel_source_id  # (stamps the factor kernel's source id: bench.py says whether a count belongs to the kernel it times)
+                jf.write(json.dumps({"kernel": name, "kernel_source_id": kernel_source_id(), "vgpr": meta[".amdhsa_next_free_vgpr"], "sgpr": meta[".amdhsa_next_free_sgpr"], "loop_instructions": sum(ops.values()),
                                      "mix": dict(cat), "fp32_flops_per_point": fl32, "fp64_flops_per_point": fl64, "ops": dict(ops)}) + "\n")
         print(name[:90])
         print("  fp32 flops per trip:", fl32, "| fp64 flops per trip:", fl64)
