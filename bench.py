@@ -737,6 +737,7 @@ def run_odometry_frame(args, D, api, ctx):
 def live_odometry_loop(api, host, poses, c32_of, frames, K, WIN, res0, iters, timed):
     """Writes the scene (every frame with the covariances / normals the device estimated, in the reference's Vector4d / Matrix4d layout), builds
     tools/odometry_frame_loop.cpp against the library this process uses and runs it twice: create_frame as three calls and as one submission."""
+    import contextlib
     import subprocess
     import tempfile
 
@@ -744,7 +745,10 @@ def live_odometry_loop(api, host, poses, c32_of, frames, K, WIN, res0, iters, ti
 
     n = len(host[0])
     out = {}
-    with tempfile.TemporaryDirectory() as tmp:
+    keep_dir = os.environ.get("BENCH_KEEP_FRAME_LOOP")  # diagnostic: leave scene.bin and the built tool in this directory (tools/frame_tail_trace.sh runs it under rocprofv3)
+    if keep_dir:
+        os.makedirs(keep_dir, exist_ok=True)
+    with (contextlib.nullcontext(keep_dir) if keep_dir else tempfile.TemporaryDirectory()) as tmp:
         scene = os.path.join(tmp, "scene.bin")
         with open(scene, "wb") as f:
             np.array([len(host), n, K, WIN], dtype=np.int32).tofile(f)

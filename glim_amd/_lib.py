@@ -101,6 +101,8 @@ SYMBOLS = {
     "glim_amd_multi_last_timing": (_i, [_vp, _fp, _fp]),
     "glim_amd_multi_last_breakdown": (_i, [_vp, _i32, _dp, _i32]),
     "glim_amd_debug_plan_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
+    "glim_amd_debug_ctx_query_streams": (_i, [_vp, _ip]),
+    "glim_amd_debug_pool_stats": (_i, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "glim_amd_debug_frame_stages": (_i, [_dp, _i32]),
     "glim_amd_multi_set_one_rank_collective": (_i, [_vp, _i32]),
     "glim_amd_multi_set_host_records": (_i, [_vp, _i32]),

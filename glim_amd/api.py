@@ -796,7 +796,8 @@ def scratch_poke(ctx, word, value=0xFFFFFFFF):
 RESIDENT_TIMELINE_FIELDS = ("host_round_trip", "leader_published", "worker_pose_seen_min", "worker_pose_seen_median", "worker_pose_seen_max",
                             "worker_row_computed_min", "worker_row_computed_median", "worker_row_computed_max", "worker_row_published_min",
                             "worker_row_published_median", "worker_row_published_max", "finaliser_pose_seen", "finaliser_rows_summed",
-                            "finaliser_record_stored", "workers_accounted", "device_span")
+                            "finaliser_record_stored", "workers_accounted", "device_span", "worker_loop_left_min", "worker_loop_left_median",
+                            "worker_loop_left_max", "finaliser_group_sums_added", "finaliser_blocks_rotated", "shader_clock_mhz")
 
 
 def resident_timeline(device=0, enable=True, read=True):

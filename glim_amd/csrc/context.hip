@@ -311,6 +311,38 @@ int glim_amd_ctx_synchronize(glim_amd_ctx* ctx) {
   return GLIM_AMD_OK;
 }
 
+}  // extern "C"
+namespace glim_amd {
+void pool_stats(unsigned long long* device_mallocs, unsigned long long* device_frees, unsigned long long* pinned_mallocs, unsigned long long* cached_bytes);  // below
+}
+extern "C" {
+int glim_amd_debug_pool_stats(uint64_t* device_mallocs, uint64_t* device_frees, uint64_t* pinned_mallocs, uint64_t* cached_bytes) {
+  unsigned long long a = 0, b = 0, c = 0, d = 0;
+  glim_amd::pool_stats(&a, &b, &c, cached_bytes ? &d : nullptr);
+  if (device_mallocs) *device_mallocs = a;
+  if (device_frees) *device_frees = b;
+  if (pinned_mallocs) *pinned_mallocs = c;
+  if (cached_bytes) *cached_bytes = d;
+  return GLIM_AMD_OK;
+}
+
+int glim_amd_debug_ctx_query_streams(glim_amd_ctx* ctx, int32_t* busy) {
+  if (!ctx) return GLIM_AMD_ERR_INVALID;
+  GA_HIP(hipSetDevice(ctx->device));
+  int n = 0;
+  for (auto s : ctx->streams) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipErrorNotReady) n++;
+    else if (e != hipSuccess) {
+      set_hip_error(e, "hipStreamQuery");
+      return GLIM_AMD_ERR_HIP;
+    }
+  }
+  (void)hipGetLastError();
+  if (busy) *busy = n;
+  return GLIM_AMD_OK;
+}
+
 int glim_amd_device_info(glim_amd_ctx* ctx, char* name, size_t name_len, size_t* free_bytes, size_t* total_bytes, int* num_cus) {
   if (!ctx) return GLIM_AMD_ERR_INVALID;
   GA_HIP(hipSetDevice(ctx->device));
@@ -353,6 +385,9 @@ DevicePool& pool_of(int device) {
   return pools[(device >= 0 && device < 64) ? device : 0];
 }
 constexpr size_t kMaxCachedBytes = 32ull << 30;
+// calls that went past the caches to the runtime (glim_amd_debug_pool_stats): a real hipMalloc / hipHostMalloc in a steady-state loop is a latency
+// event for everything on the device, not only for the caller
+std::atomic<unsigned long long> g_device_mallocs{0}, g_device_frees{0}, g_pinned_mallocs{0};
 bool pool_disabled() {
   static const bool off = process_diag().pool == 0;
   return off;
@@ -376,6 +411,7 @@ hipError_t pool_malloc_impl(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
+  g_device_mallocs++;
   hipError_t e = hipMalloc(p, want);
   if (e != hipSuccess && !pool_disabled()) {  // out of memory: drop the cache and retry once
     (void)hipGetLastError();
@@ -408,7 +444,21 @@ hipError_t pool_free(void* p) {
       return hipSuccess;
     }
   }
+  g_device_frees++;
   return hipFree(p);
+}
+
+void pool_stats(unsigned long long* device_mallocs, unsigned long long* device_frees, unsigned long long* pinned_mallocs, unsigned long long* cached_bytes) {
+  if (device_mallocs) *device_mallocs = g_device_mallocs.load();
+  if (device_frees) *device_frees = g_device_frees.load();
+  if (pinned_mallocs) *pinned_mallocs = g_pinned_mallocs.load();
+  if (cached_bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevicePool& P = pool_of(dev);
+    std::lock_guard<std::mutex> lock(P.mu);
+    *cached_bytes = P.cached_bytes;
+  }
 }
 
 // Pinned, device-mapped host memory (completion flags, pose / result staging of a factor set): hipHostMalloc / hipHostFree cost
@@ -442,6 +492,7 @@ hipError_t pinned_malloc_impl(void** p, size_t bytes) {
       return hipSuccess;
     }
   }
+  g_pinned_mallocs++;
   hipError_t e = hipHostMalloc(p, want, hipHostMallocMapped | hipHostMallocPortable);  // cached blocks may be handed to a context on another device
   if (e == hipSuccess && !pool_disabled()) {
     std::lock_guard<std::mutex> lock(P.mu);

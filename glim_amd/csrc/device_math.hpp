@@ -109,6 +109,29 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
 
+// N wavefront sums at once, STEP-major: step k of all N values before step k + 1 of any.  Called value by value (wave_sum_to_lane63 in a loop) the
+// compiler emits N dependent chains one after the other, every DPP read two wait states behind the write it depends on (s_nop) -- 28 values: ~400
+// instructions of which 170 are s_nop / register copies, ~3 400 cycles of ONE wavefront, 1.35 us on the device timeline of the synchronous call
+// (round 6: the point loop is left 2.7 us after the request, the row is block-reduced at 4.05).  Step-major the N values of a step are independent:
+// no wait states, 6 N additions.  Every value goes through the same six additions in the same order as in wave_sum_to_lane63: the same bits.
+template <int N>
+__device__ __forceinline__ void wave_sums_to_lane63(float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0xB1, 0xF>(v[j]);   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x4E, 0xF>(v[j]);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x141, 0xF>(v[j]);  // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x140, 0xF>(v[j]);  // row_mirror
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x142, 0xA>(v[j]);  // row_bcast:15 -> rows 1,3
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x143, 0xC>(v[j]);  // row_bcast:31 -> rows 2,3
+  // (the row_bcast steps stay three instructions per value -- zero, masked move, add: giving the masked-out rows -0.0, the addition's identity,
+  //  does not make the compiler fold them into one v_add_f32_dpp either)
+}
+
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]

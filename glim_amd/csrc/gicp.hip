@@ -302,10 +302,10 @@ __global__ __launch_bounds__(BLOCK) void gicp_kernel(const GicpArgs a, float* __
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sums_to_lane63<NACC>(acc);  // (step-major: device_math.hpp; the same six additions per value)
+  if (lane == 63) {
 #pragma unroll
-  for (int j = 0; j < NACC; j++) {
-    const float v = wave_sum_to_lane63(acc[j]);
-    if (lane == 63) s_red[wave][j] = v;
+    for (int j = 0; j < NACC; j++) s_red[wave][j] = acc[j];
   }
   {
     const float v = wave_sum_to_lane63((float)inliers);

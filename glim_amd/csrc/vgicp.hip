@@ -51,7 +51,25 @@ constexpr int NACC = 28;  // FP32 accumulators per thread (see layout below); sl
 // accumulator layout:  0..5  Hww (00 01 02 11 12 22)   6..14 G = hat(p) A (row-major 3x3 = H_wv)   15..20 A (00 01 02 11 12 22)
 //                      21..23 u x p (= b_w)            24..26 u (b_v = -u)                          27 e
 // compact record:      [count, error, 21 upper-triangular H_ss entries row-major, 6 b_s]
-__constant__ int c_acc_of_upper[21] = {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20};
+// A/B knobs of round 6's work on the synchronous call (tools/ab_variant.sh <name> -DGLIM_AMD_ROT27=0 ...): one thread per rotated value in the
+// finalisers (rotate_element) / the four-thread form; the resident workers skip the probe of a point no lane has (TAILSKIP) / run it
+#ifndef GLIM_AMD_ROT27
+#define GLIM_AMD_ROT27 1
+#endif
+// the 28 wavefront sums of a row step-major (device_math.hpp wave_sums_to_lane63) / value by value (rounds 1-5)
+#ifndef GLIM_AMD_STEP_MAJOR_SUMS
+#define GLIM_AMD_STEP_MAJOR_SUMS 1
+#endif
+#ifndef GLIM_AMD_RES_TAILSKIP
+#define GLIM_AMD_RES_TAILSKIP 1
+#endif
+// accumulator slot of entry i of the upper triangle of H_ss -- {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20} -- as two
+// immediates (5 bits per entry, entries 0..11 and 12..20): the finalisers' last step looks its slot up with two shifts instead of a load from
+// constant memory behind the last barrier of a call the host is waiting for
+__device__ __forceinline__ int acc_of_upper(int i) {
+  const unsigned long long lo = 0x2ad4920d0730820ull, hi = 0x149ca307b9acull;
+  return (int)(((i < 12 ? lo >> (5 * i) : hi >> (5 * (i - 12)))) & 31ull);
+}
 
 __device__ __forceinline__ float4 ld16(const void* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -184,6 +202,36 @@ __host__ __device__ inline void rotate_part(int part, const double* sum, const d
   }
 }
 
+// One element of rotate_part's result, for a thread of its own (the device finalisers: 27 threads instead of 4, a chain of 20 dependent FP64
+// operations instead of 72): slot j of the accumulator layout -- 0..5 Hww (upper triangle), 6..14 Hwv, 15..20 Hvv (upper triangle), 21..23 and 24..26
+// the two vectors.  The SAME expressions in the same order as rotate_block / rotate_part, no contraction: the same bits (the host-finalised call and
+// finalize_short_kernel keep rotate_part; tests/test_gpu_edge_cases.py compares the forms bit for bit).
+__device__ __forceinline__ double rotate_element(int j, const double* sum, const double* T) {
+#pragma clang fp contract(off)
+  // (sum and T are LDS arrays: every run-time index below is an address, not a register number; R[3 a + b] of rotate_part is T[4 a + b])
+  if (j >= 21) {
+    const int c = (j - 21) % 3, o = j < 24 ? 21 : 24;
+    return T[c] * sum[o] + T[4 + c] * sum[o + 1] + T[8 + c] * sum[o + 2];
+  }
+  double B0, B1, B2, B3, B4, B5, B6, B7, B8;
+  int r, c;
+  if (j >= 6 && j < 15) {
+    B0 = sum[6]; B1 = sum[7]; B2 = sum[8]; B3 = sum[9]; B4 = sum[10]; B5 = sum[11]; B6 = sum[12]; B7 = sum[13]; B8 = sum[14];
+    r = (j - 6) / 3;
+    c = (j - 6) % 3;
+  } else {
+    const int o = j < 6 ? 0 : 15, u = j - o;  // upper-triangle index 0..5 -> (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    B0 = sum[o]; B1 = sum[o + 1]; B2 = sum[o + 2]; B3 = B1; B4 = sum[o + 3]; B5 = sum[o + 4]; B6 = B2; B7 = B5; B8 = sum[o + 5];
+    r = u < 3 ? 0 : (u < 5 ? 1 : 2);
+    c = u < 3 ? u : (u < 5 ? u - 2 : 2);
+  }
+  const double Rc0 = T[c], Rc1 = T[4 + c], Rc2 = T[8 + c];
+  const double br0 = B0 * Rc0 + B1 * Rc1 + B2 * Rc2;
+  const double br1 = B3 * Rc0 + B4 * Rc1 + B5 * Rc2;
+  const double br2 = B6 * Rc0 + B7 * Rc1 + B8 * Rc2;
+  return T[r] * br0 + T[4 + r] * br1 + T[8 + r] * br2;
+}
+
 // Fixed-order FP64 sum of factor f's partial rows -> compact record; executed by the 256 threads of ONE block of the finalise kernel.  A
 // factor's rows are consecutive (row first_block + c belongs to its chunk c).  Thread t sums rows g, g + 32, g + 64, ... (g = t / 8) of the
 // four values 4 q .. 4 q + 3 (q = t % 8), as ONE batch of up to 16 independent 16-byte loads per thread and per 512 rows; the 32 group sums
@@ -195,17 +243,15 @@ __host__ __device__ inline void rotate_part(int part, const double* sum, const d
 // same-address atomic) for longer than the second dispatch costs.  So did summing the rows on the host as they arrive (35.9 us: the host
 // ping-pongs cache lines with the device's writes).
 constexpr int FIN_GROUPS = 32;
-__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl);
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl,
+                                              unsigned long long* tail_stamps = nullptr);
 __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, const float* __restrict__ partials, const FinalizeArgs& fa, int mode,
                                                 double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* __restrict__ T) {
   const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
   const int first = d.first_block, nb = d.num_blocks;
   // the pose is needed at the very end (rotate_part): fetched now, so that its latency hides behind the row loads
-  double Tl[12];
-  if (threadIdx.x < 4) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) Tl[i] = T[i];
-  }
+  __shared__ double Tl[12];
+  if (threadIdx.x < 12) Tl[threadIdx.x] = T[threadIdx.x];  // (finalize_tail's first barrier orders the stores before the rotation reads them)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   constexpr int INFLIGHT = 16;
   for (int c = g; c < nb; c += FIN_GROUPS * INFLIGHT) {
@@ -233,8 +279,11 @@ __device__ __forceinline__ void finalize_factor(const FactorDesc& d, int f, cons
 
 // Second half of a factor's finalisation, shared by the finalise kernel and by the finalising blocks of the single-dispatch kernel (same
 // bits): the 32 group sums of s_part added in group order, the four R^T B R rotations, the record, the completion word.
-// Tl: the factor's pose, registers of threads 0..3 (finalize_factor) or 12 doubles in LDS written before this call (fused_finalize)
-__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl) {
+// Tl: the factor's pose, 12 doubles in LDS written before this call
+// tail_stamps (device timeline of a resident session, else null): [0] the group sums are added, [1] the blocks are rotated -- s_memrealtime, kept in
+// registers and stored behind the record so that the stamps do not sit in front of a barrier
+__device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int mode, double (*s_part)[PARTIAL_STRIDE], double* s_sum, const double* Tl,
+                                              unsigned long long* tail_stamps) {
   __syncthreads();
   if (threadIdx.x < PARTIAL_STRIDE) {
     double t = 0.0;
@@ -243,18 +292,25 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
     s_sum[threadIdx.x] = t;
   }
   __syncthreads();
+  unsigned long long st0 = 0ull, st1 = 0ull;
+  if (tail_stamps) st0 = __builtin_amdgcn_s_memrealtime();
   const int t = threadIdx.x;
   if (t == 29 && fa.trip_stats && s_sum[29] > 0.0) atomicAdd(&fa.trip_stats[f & 63], (unsigned long long)s_sum[29]);
   __shared__ double s_rot[32];
   if (mode == MODE_LINEARIZE) {
+#if GLIM_AMD_ROT27
+    if (t < 27) s_rot[t] = rotate_element(t, s_sum, Tl);  // one thread per rotated value (rotate_part's bits)
+#else
     if (t < 4) rotate_part(t, s_sum, Tl, s_rot);  // thread k < 3 rotates block k (Hww, Hwv, Hvv), thread 3 the two vectors
+#endif
     __syncthreads();
   }
+  if (tail_stamps) st1 = __builtin_amdgcn_s_memrealtime();
   // slot t of the compact record: [count, error, 21 upper-triangular H_ss entries, b_w = R^T sum u x q', b_v = -R^T sum u]
   double value = 0.0;
   if (t == 0) value = s_sum[28];
   else if (t == 1) value = s_sum[27];
-  else if (mode == MODE_LINEARIZE && t < COMPACT) value = t < 23 ? s_rot[c_acc_of_upper[t - 2]] : (t < 26 ? s_rot[t - 2] : -s_rot[t - 2]);
+  else if (mode == MODE_LINEARIZE && t < COMPACT) value = t < 23 ? s_rot[acc_of_upper(t - 2)] : (t < 26 ? s_rot[t - 2] : -s_rot[t - 2]);
   if (fa.rec16) {
     // Single-dispatch form: the record goes to host-mapped memory as 29 self-validating 16-byte granules {value, sequence number}, one
     // store each -- a PCIe write lands as a unit, so a granule whose tag is this call's carries this call's value.  The host polls the
@@ -266,6 +322,10 @@ __device__ __forceinline__ void finalize_tail(int f, const FinalizeArgs& fa, int
       // resident kernel does not do (measured: every request then took exactly one idle time-out).
       const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.rec16 + (size_t)f * COMPACT * 16, 0, COMPACT * 16, 0x00020000);
       __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, t * 16, 0, AUX_SYSTEM);
+    }
+    if (tail_stamps && t == 0) {
+      tail_stamps[0] = st0;
+      tail_stamps[1] = st1;
     }
     return;
   }
@@ -395,7 +455,7 @@ __device__ __forceinline__ void fused_finalize(const FactorDesc& d, int f, const
   }
   if (threadIdx.x < FIN_GROUPS) s_part[threadIdx.x][30] = s_part[threadIdx.x][31] = 0.0;
   if (rows_seen_stamp && threadIdx.x == 0) *rows_seen_stamp = __builtin_amdgcn_s_memrealtime();  // (thread 0 owns two pairs: the longer path; the barrier of finalize_tail follows)
-  finalize_tail(f, fa, mode, s_part, s_sum, s_T);  // (its first barrier orders the s_T stores before the rotation reads them)
+  finalize_tail(f, fa, mode, s_part, s_sum, s_T, rows_seen_stamp ? rows_seen_stamp + 2 : nullptr);  // (its first barrier orders the s_T stores before the rotation reads them)
 }
 
 // resident waves per SIMD the register allocation aims for: the plane-form kernel fits 96 VGPRs (5 waves), the general one needs 99 (4 waves)
@@ -621,7 +681,10 @@ struct PipeCtx {  // wave-uniform context of the pipelined loop
 // dependent memory round trips (one of them HBM) exposed per trip per wave, which 5 waves per SIMD could not cover (waves parked on
 // memory 71 % of their cycles; 50 % with this form -- tools/pmc_kexp.sh, profiles/r02/probe/).
 // i1 / ok1: the point this trip probes (stream data in `nxt`) and whether it exists; i2: the point whose stream loads this trip issues.
-template <int MODE, bool FROZEN, bool PLANE>
+// TAILSKIP (the resident kernels: a wavefront there walks one or two trips and the caller waits for it): the probe and the stream loads of a point that
+// no lane has -- the last trip's steps (2) and (3), ~80 instructions in front of the last algebra -- are skipped behind a scalar branch.  Nothing
+// that is added depends on them: same bits.  (The launch-per-call kernels walk 30-60 trips and stay as they are: their loop sits at its register cap.)
+template <int MODE, bool FROZEN, bool PLANE, bool TAILSKIP = false>
 __device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int i1, bool ok1, int i2, float (&acc)[NACC], int& wave_inliers,
                                              int& wave_skips) {
   const FactorDesc& d = pc.d;
@@ -680,10 +743,12 @@ __device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLA
     r1 = gld4(rp + 16);   // c01 c02 c11 c12
     r2 = gld1(rp + 32);   // c22
   }
-  // (2) probe of point it+AHEAD (a lane past its last point probes with EMPTY_KEY at a clamped, valid address)
-  pr = probe_point<FROZEN, PLANE>(d, nxt, i1, ok1, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
-  // (3) stream loads of point it+AHEAD+1
-  nxt = load_point<PLANE>(d, (unsigned int)min(i2, pc.last));
+  if (!TAILSKIP || ok1) {
+    // (2) probe of point it+AHEAD (a lane past its last point probes with EMPTY_KEY at a clamped, valid address)
+    pr = probe_point<FROZEN, PLANE>(d, nxt, i1, ok1, pc.Tl, pc.Te, pc.R, pc.validate, pc.last);
+    // (3) stream loads of point it+AHEAD+1
+    nxt = load_point<PLANE>(d, (unsigned int)min(i2, pc.last));
+  }
   // (4) algebra of point `it`
   if (any_hit) accumulate_point<MODE, PLANE>(acc, hit, r0, r1, r2, cur, pc.R);
   // The key gather the NEXT trip resolves is consumed HERE, at the very end of this trip, and nowhere earlier: without this pin the
@@ -694,10 +759,10 @@ __device__ __forceinline__ void pipe_trip_at(const PipeCtx<PLANE>& pc, Probe<PLA
   // conversions into the next trip and carries the six FP64 values (12 VGPRs instead of 6) around the loop.
   asm volatile("" : "+v"(pr.qr0), "+v"(pr.qr1), "+v"(pr.qr2), "+v"(pr.qp0), "+v"(pr.qp1), "+v"(pr.qp2));
 }
-template <int MODE, bool FROZEN, bool PLANE>
+template <int MODE, bool FROZEN, bool PLANE, bool TAILSKIP = false>
 __device__ __forceinline__ void pipe_trip(const PipeCtx<PLANE>& pc, Probe<PLANE>& pr, PointIn& nxt, int it, float (&acc)[NACC], int& wave_inliers, int& wave_skips) {
   constexpr int AHEAD = 1;
-  pipe_trip_at<MODE, FROZEN, PLANE>(pc, pr, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.base + (it + AHEAD + 1) * pc.stride, acc, wave_inliers,
+  pipe_trip_at<MODE, FROZEN, PLANE, TAILSKIP>(pc, pr, nxt, pc.base + (it + AHEAD) * pc.stride, it + AHEAD < pc.ppt, pc.base + (it + AHEAD + 1) * pc.stride, acc, wave_inliers,
                                     wave_skips);
 }
 
@@ -725,9 +790,10 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // find a correspondence.  The wavefront then walks its LIVE trips only, through the same two-trip pipeline: a culled trip costs nothing at all --
 // no stream load, no FP64 transform, no hash, no key gather (the in-loop skip of an all-miss trip still pays those: 40 % of a trip) -- and since
 // a culled trip would have added exact zeros in every lane, the sums are the same bits.
-template <int MODE, bool FROZEN, bool PLANE, bool CULL = false>
+template <int MODE, bool FROZEN, bool PLANE, bool CULL = false, bool TAILSKIP = false>
 __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* __restrict__ Tl, const double* __restrict__ Te, int chunk, int prio_phase,
-                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr, const unsigned long long* cull = nullptr) {
+                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr, const unsigned long long* cull = nullptr,
+                                            unsigned long long* loop_done_stamp = nullptr) {
   // rotation of the linearisation pose in FP32 (R[r][c])
   // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
   const float R00 = (float)Tl[0], R01 = (float)Tl[1], R02 = (float)Tl[2];
@@ -781,19 +847,28 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
     nxt = load_point<PLANE>(d, (unsigned int)min(base + stride, last));
     for (int it = 0; it < ppt; it++) {
       rotate_priority(it + prio_phase);
-      pipe_trip<MODE, FROZEN, PLANE>(pc, pr, nxt, it, acc, wave_inliers, wave_skips);
+      pipe_trip<MODE, FROZEN, PLANE, TAILSKIP>(pc, pr, nxt, it, acc, wave_inliers, wave_skips);
     }
     }
   }
 
+  if (loop_done_stamp && threadIdx.x == 0) *loop_done_stamp = __builtin_amdgcn_s_memrealtime();  // (device timeline of a resident session: the algebra of the last point is issued)
   // ---- block reduction: DPP wave sums -> LDS ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE == MODE_LINEARIZE) {
+#if GLIM_AMD_STEP_MAJOR_SUMS
+    wave_sums_to_lane63<NACC>(acc);  // (step-major: device_math.hpp)
+    if (lane == 63) {
+#pragma unroll
+      for (int j = 0; j < NACC; j++) s_red[wave][j] = acc[j];
+    }
+#else
 #pragma unroll
     for (int j = 0; j < NACC; j++) {
       const float v = wave_sum_to_lane63(acc[j]);
       if (lane == 63) s_red[wave][j] = v;
     }
+#endif
   } else {
     const float v = wave_sum_to_lane63(acc[27]);
     if (lane == 63) s_red[wave][27] = v;
@@ -1000,7 +1075,8 @@ struct ResidentArgs {
   // Device timeline of the LAST request served (glim_amd_debug_resident_timeline; null = off): s_memrealtime stamps (100 MHz), device memory.
   //   [0] leader: request seen in host memory        [1] leader: poses re-published on the device
   //   [2] finaliser of factor 0: pose seen           [3] ... every row of its factor summed (all tags arrived)      [4] ... record stored towards the host
-  //   [8 + 4 b + {0, 1, 2}] worker block b: pose seen, first row computed (block-reduced), row granules published
+  //   [5] ... its 32 group sums added   [6] ... its blocks rotated (finalize_tail)   [7] shader-clock ticks (s_memtime) between [2] and [4]
+  //   [8 + 4 b + {0, 1, 2, 3}] worker block b: pose seen, first row computed (block-reduced), row granules published, point loop left (before the reduction)
   unsigned long long* timeline;
 };
 constexpr int TL_WORKER0 = 8;
@@ -1011,6 +1087,9 @@ constexpr unsigned int RES_EXIT = 0xffffffffu;
 
 // wave 0, lanes 0..11: wait for the 12 pose granules of factor f.  exact != 0: until their tag is `exact`; otherwise until it is a session tag
 // different from `last`.  Returns the tag through s_tag (RES_EXIT when the session ends or the wait gives up) and the pose through s_pose.
+// (Round 6 also had every block read the HOST's request lines of its own factor when a request was due, to save the leader's re-publication hop
+//  -- 1.15 us median, 1.43 us for the last worker: 257 blocks reading host memory turned a 12 us call into a 385 us one and slowed a kernel launched
+//  beside the session 32x; one reader is what the link serves well.  profiles/r06/probe/resident_direct_host_poll_refuted.json)
 __device__ __forceinline__ void wait_pose(const ResidentArgs& ra, int f, unsigned int last, unsigned int exact, double* s_pose, unsigned int* s_tag) {
   if (threadIdx.x < 64) {
     const int lane = (int)threadIdx.x < 12 ? (int)threadIdx.x : 0;
@@ -1141,6 +1220,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? GLIM_AMD_RES_MINW : 3) void res
       if (tag == RES_EXIT) return;
       unsigned long long* const tlf = (b == ra.workers) ? ra.timeline : nullptr;  // (the finaliser of the plan's first factor keeps the account)
       tl_stamp(tlf, 2);
+      const unsigned long long shader_ticks0 = tlf ? __builtin_amdgcn_s_memtime() : 0ull;  // (shader clock counter: with the 100 MHz stamps it gives the clock the session runs at)
       FinalizeArgs fa;
       fa.out = nullptr;
       fa.out_mirror = nullptr;
@@ -1157,6 +1237,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? GLIM_AMD_RES_MINW : 3) void res
       const FactorDesc d = ra.descs[f];
       fused_finalize<8>(d, f, fa, MODE_LINEARIZE, reinterpret_cast<double (*)[PARTIAL_STRIDE]>(s_lds), s_lds + FIN_GROUPS * PARTIAL_STRIDE, s_pose, tlf ? tlf + 3 : nullptr);
       tl_stamp(tlf, 4);
+      if (tlf && threadIdx.x == 0) tlf[7] = __builtin_amdgcn_s_memtime() - shader_ticks0;
       __syncthreads();
       last = tag;
       continue;
@@ -1199,8 +1280,8 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? GLIM_AMD_RES_MINW : 3) void res
       }
       unsigned long long* const tlw = (ra.timeline && r == first_row) ? ra.timeline + TL_WORKER0 + 4 * b : nullptr;
       tl_stamp(tlw, 0);
-      if (PLANE_ONLY || d.plane) compute_row<MODE_LINEARIZE, false, true>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
-      else compute_row<MODE_LINEARIZE, false, false>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0);
+      if (PLANE_ONLY || d.plane) compute_row<MODE_LINEARIZE, false, true, false, GLIM_AMD_RES_TAILSKIP != 0>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0, nullptr, tlw ? tlw + 3 : nullptr);
+      else compute_row<MODE_LINEARIZE, false, false, false, GLIM_AMD_RES_TAILSKIP != 0>(d, Tl, Tl, bm.y, r / ra.blocks_per_round, s_red, &p0, nullptr, tlw ? tlw + 3 : nullptr);
       tl_stamp(tlw, 1);
       publish_row_tagged<MODE_LINEARIZE>(s_red, ra.rows16, (size_t)(d.first_block + bm.y), tag);
       tl_stamp(tlw, 2);
@@ -1282,7 +1363,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_short_kernel(const FactorDesc*
   }
   if (t < 27) {  // slots 2 .. 28 of the record, by lanes 0 .. 26
     double v = 0.0;
-    if (mode == MODE_LINEARIZE) v = t < 21 ? s_rot[wave][c_acc_of_upper[t]] : (t < 24 ? s_rot[wave][t] : -s_rot[wave][t]);
+    if (mode == MODE_LINEARIZE) v = t < 21 ? s_rot[wave][acc_of_upper(t)] : (t < 24 ? s_rot[wave][t] : -s_rot[wave][t]);
     o[2 + t] = v;
     if (om) om[2 + t] = v;
   }
@@ -2361,13 +2442,14 @@ extern "C" int glim_amd_debug_resident_timeline(int device, int enable, double* 
       GA_HIP(hipMemcpy(h.data(), S.d_timeline, TIMELINE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       const unsigned long long t0 = h[0];
       auto rel = [&](unsigned long long t) { return t >= t0 && t0 ? (double)(t - t0) * 0.01 : -1.0; };  // 100 MHz ticks -> us
-      std::vector<double> a, b, c;
+      std::vector<double> a, b, c, l;
       for (int w = 0; w < S.timeline_workers; w++) {
         const unsigned long long* p = &h[(size_t)TL_WORKER0 + 4 * (size_t)w];
         if (!p[0] || !p[1] || !p[2]) continue;
         a.push_back(rel(p[0]));
         b.push_back(rel(p[1]));
         c.push_back(rel(p[2]));
+        if (p[3]) l.push_back(rel(p[3]));
       }
       auto put = [&](int i, double v) {
         if (i < num_fields) us[i] = v;
@@ -2389,6 +2471,10 @@ extern "C" int glim_amd_debug_resident_timeline(int device, int enable, double* 
       put(13, rel(h[4]));
       put(14, (double)a.size());
       put(15, rel(h[4]));
+      mmm(l, 16);
+      put(19, rel(h[5]));
+      put(20, rel(h[6]));
+      put(21, (h[4] > h[2] && h[2]) ? (double)h[7] / ((double)(h[4] - h[2]) * 0.01) : 0.0);  // shader ticks per microsecond = MHz
     }
   }
   S.timeline_on = enable != 0;

@@ -108,14 +108,24 @@ int glim_amd_debug_resident_stats(int device, uint64_t* launches, uint64_t* requ
  *   [2..4] worker blocks: pose seen, min / median / max   [5..7] first row computed   [8..10] row granules published
  *   [11] finaliser of factor 0: pose seen   [12] every row of its factor summed   [13] record stored towards the host
  *   [14] worker blocks with a complete account   [15] = [13]: the device's share of [0]
+ *   [16..18] worker blocks: point loop left (before the wave / block reduction), min / median / max
+ *   [19] finaliser: its 32 group sums added   [20] its 3x3 blocks rotated (the record store follows)
+ *   [21] NOT a time: the shader clock the session ran at between [11] and [13], MHz (s_memtime ticks per s_memrealtime microsecond)
  * GLIM_AMD_ERR_STATE: a request is in flight, or no session has run with the stamps on. */
-#define GLIM_AMD_RESIDENT_TIMELINE_FIELDS 16
+#define GLIM_AMD_RESIDENT_TIMELINE_FIELDS 22
 int glim_amd_debug_resident_timeline(int device, int enable, double* microseconds, int32_t num_fields);
 /* ends the device's resident session now instead of letting it idle out (GLIM_AMD_ERR_STATE while a request is in flight). */
 int glim_amd_debug_resident_stop(int device);
 /* parity / debug only: factor plans this context has built for new factor lists, how many of them took over the buffers of the plan its full
  * cache was about to evict (a new list of the same shape: GLIM's odometry brings one per frame), idle plans cached right now. */
 int glim_amd_debug_plan_stats(glim_amd_ctx* ctx, uint64_t* built, uint64_t* recycled, int32_t* cached);
+/* parity / debug only: calls of this process that went PAST the library's block caches to the runtime so far -- hipMalloc, hipFree, hipHostMalloc --
+ * and the bytes the calling thread's current device holds in its cache of freed blocks.  A steady-state loop should add none (a real allocation
+ * stalls everything on the device, not only its caller: tools/odometry_frame_loop.cpp reports the count per slow frame).  Any pointer may be NULL. */
+int glim_amd_debug_pool_stats(uint64_t* device_mallocs, uint64_t* device_frees, uint64_t* pinned_mallocs, uint64_t* cached_bytes);
+/* measurement only: hipStreamQuery on every stream of the context (how many still have work: *busy).  tools/odometry_frame_loop.cpp uses it to
+ * ask whether the runtime retires its finished commands when a loop that only ever POLLS completion words looks at its streams now and then. */
+int glim_amd_debug_ctx_query_streams(glim_amd_ctx* ctx, int32_t* busy);
 /* parity / debug only: host-side account of the calling thread's LAST one-submission glim_amd_frame_create, microseconds since its entry:
  * [0] cloud allocated, [1] staging block + stream allocations, [2] pull kernel launched, [3] host conversion done, [4] voxel-map kernels
  * enqueued, [5] completion word seen, [6] return (tools/odometry_frame_loop.cpp prints the medians). */

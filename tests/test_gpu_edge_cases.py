@@ -676,6 +676,58 @@ def test_resident_session_lifecycle(api, ctx, orc, small_pair):
         c2.close()
 
 
+def test_resident_requests_that_race_the_idle_out(api, ctx, orc, small_pair):
+    """A request may arrive in the very moment the session's leader decides to idle out.  Calls spaced around a SHORT idle time-out (100 us; pauses
+    of 0..400 us on top of the binding's own time per call) hit that moment many times in a few thousand calls: every call must return the
+    launch-per-call bits and none may hang (the call whose request the leaving kernel did not take is answered by a restarted session, which finds
+    the request in the lines), for one chip-wide factor and for a 34-factor set.  (Written for round 6's direct look of every block into the host's
+    request lines -- refuted by measurement and removed, profiles/r06/probe/resident_direct_host_poll_refuted.json; the race it guards is older.)"""
+    import time
+
+    rng = np.random.default_rng(11)
+    for rings, azimuths, copies, calls in ((64, 512, 1, 1500), (16, 256, 34, 600)):  # (the 34-factor set at the odometry's size: a plan of <= 2 x CUs rows)
+        tgt, src, tg, sg, delta = _full_size_pair(api, ctx, rings, azimuths)
+        vms = [api.GaussianVoxelMapGPU(r, ctx=ctx).insert(tg) for r in (0.5, 1.0)]
+        factors = [api.IntegratedVGICPFactorGPU(0 if k < 4 else np.eye(4), 1 + k, vms[k % 2], sg) for k in range(copies)]
+        poses = []
+        for which in range(3):
+            values = {0: np.eye(4)}
+            for k in range(copies):
+                values[1 + k] = delta @ orc.se3_exp(np.array([0.002, -0.001, 0.003, 0.02, 0.01, -0.02]) * (1 + 0.1 * k + which))
+            poses.append(values)
+        with ctx.diag("resident=0,fuse=0"):
+            ref = api.NonlinearFactorSetGPU(ctx)
+            for f in factors:
+                ref.add(f)
+            want = [ref.linearize(v) for v in poses]
+            ref.close()
+        for mode in ("resident=1,resident_idle_us=100",):
+            with ctx.diag(mode):
+                before = api.resident_stats(ctx)
+                fset = api.NonlinearFactorSetGPU(ctx)
+                for f in factors:
+                    fset.add(f)
+                t0 = time.perf_counter()
+                for rep in range(calls):
+                    got = fset.linearize(poses[rep % 3])
+                    for k, (L, B) in enumerate(zip(got, want[rep % 3])):
+                        assert L["num_inliers"] == B["num_inliers"], (mode, rep, k)
+                        assert L["error"] == B["error"], (mode, rep, k)
+                        np.testing.assert_array_equal(L["H_ss"], B["H_ss"], err_msg=f"{mode} rep {rep} factor {k}")
+                        np.testing.assert_array_equal(L["b_s"], B["b_s"], err_msg=f"{mode} rep {rep} factor {k}")
+                    pause = rng.uniform(0.0, 400e-6)
+                    t1 = time.perf_counter()
+                    while time.perf_counter() - t1 < pause:
+                        pass
+                elapsed = time.perf_counter() - t0
+                after = api.resident_stats(ctx)
+                fset.close()
+                api.resident_stop(ctx)
+                # the session was restarted many times (the race was exercised) and no call waited out a lost row (~1 s each)
+                assert after["launches"] >= before["launches"] + 10, (mode, before, after)
+                assert elapsed < 60.0, (mode, elapsed)
+
+
 def test_a_stale_scratch_word_equal_to_the_next_build_number_does_not_end_the_wait(api, orc, small_pair):
     """the polled completion word of voxelmap_insert (word 2) and of glim_amd_frame_create (word 4 * (levels - 1) + 2) lives in the context's
     shared pinned scratch, where read_back_sync() leaves small integers (kNN counters, kept points).  A leftover equal to the NEXT build's sequence

@@ -73,6 +73,15 @@ bursts=one.get('frames_above_1p4x_median',{}); slowest=one.get('slowest_frames',
 burst_txt=(f"{bursts.get('count',0)} of {bursts.get('of',0)} frames above 1.4 × the median, in {len(bursts.get('runs',[]))} run(s) "+', '.join(f"[frames {r[0]}–{r[1]} at {r[2]:.0f} ms]" for r in bursts.get('runs',[])[:6])+"; the slowest frames' excess sits in "+', '.join(sorted(set(x['excess_in'] for x in slowest)))) if bursts else 'n/a'
 p99s=one.get('stage_p99_us',{})
 transit=tl['host_round_trip']-tl['device_span']
+def counters_txt(c):
+    a=c['counters_avg_per_dispatch']; dvv=c.get('derived',{}); cyc=a['SQ_BUSY_CYCLES']/32.0; per_simd=a['SQ_INSTS_VALU']/1024.0
+    return (f"{a['SQ_INSTS_VALU']/max(1,a['SQ_WAVES']):.0f} vector instructions per wavefront, {cyc/1e3:.0f} k cycles per launch at {cyc/c['kernel_avg_us_rocprof']/1e3:.2f} GHz, "
+            f"one vector instruction issued per {cyc/per_simd:.2f} cycles of a SIMD, wavefronts waiting on a counter {100*(dvv.get('share_of_wave_cycles_waiting_on_any_counter') or 0):.0f} % of their resident "
+            f"cycles, L2 hit rate {100*(dvv.get('l2_hit_rate') or 0):.0f} % of {a.get('TCC_REQ_sum',0)/1e6:.0f} M requests"), cyc/per_simd
+m2c=json.load(open(d+'m2_counters.json')); m2c_txt,m2_cpv=counters_txt(m2c); m1c_txt,m1_cpv=counters_txt(m1c)
+loc=json.load(open(d+'probe/m2_locality_probe.json'))
+loc_rep=sum(v['ns_per_1000_visits'] for k,v in loc.items() if k.startswith('sample64_x'))/max(1,sum(1 for k in loc if k.startswith('sample64_x')))
+loc_shuf=sum(v['ns_per_1000_visits'] for k,v in loc.items() if k.startswith('sample64_shuffled'))/max(1,sum(1 for k in loc if k.startswith('sample64_shuffled')))
 vals.update({
  'CPU_THREADS': str(cb['cores']), 'M2_PTS': sp(m2['config']['mean_points_per_submap']),
  'SYNC_RES': f(byv['resident_session'],1), 'SYNC_SINGLE': f(byv['default_context_no_session'],1), 'SYNC_TWO': f(byv['two_dispatches'],1),
@@ -87,9 +96,10 @@ vals.update({
  'KNN_RGBD_US': f(kr['kernel_ms']*1e3,1), 'KNN_RGBD_ROC': pct_or(kr.get('kernel_avg_us_rocprof'),1), 'KNN_RGBD_TRAFFIC': pct_or(kr['traffic']/1e6 if kr.get('traffic') else None,1), 'KNN_RGBD_ALGO': f(kr['algorithmic_bytes_per_launch']/1e6,1), 'KNN_RGBD_FRAC': f(kr['frac'],3),
  'KNN_FE_N': sp(kf['points']), 'KNN_FE_US': f(kf['kernel_ms']*1e3,1), 'KNN_FE_TRAFFIC': pct_or(kf['traffic']/1e6 if kf.get('traffic') else None,2), 'KNN_FE_FRAC': f(kf['frac'],4),
  'FRONT_RETIRE': f(fe['config']['stage_ms']['retire_the_frame_before_last'],3), 'FRONT_LIN': f(fe['config']['stage_ms']['linearize'],3),
- 'M1_COUNTERS': (f"{ca.get('SQ_INSTS_VALU',0)/max(1,ca.get('SQ_WAVES',1)):.0f} vector-ALU instructions per wavefront; the vector ALU busy {100*(dv.get('valu_busy_share_of_wave_cycles') or 0):.0f} % of the wavefronts' resident cycles, "
-                 f"{100*(dv.get('share_of_wave_cycles_waiting_on_any_counter') or 0):.0f} % of them spent waiting on a counter (`SQ_WAIT_INST_ANY` / `SQ_WAVE_CYCLES`), {100*(dv.get('share_of_wave_cycles_issuing_vmem') or 0):.1f} % issuing vector-memory instructions; "
-                 f"L2 hit rate {100*(dv.get('l2_hit_rate') or 0):.0f} % ({ca.get('TCC_REQ_sum',0)/1e6:.1f} M requests per launch, {ca.get('TCP_TCC_READ_REQ_sum',0)/1e6:.1f} M of them reads from the L1s)"),
+ 'M1_COUNTERS': m1c_txt,
+ 'M2_COUNTERS': m2c_txt, 'M1_CPV': f(m1_cpv,2), 'M2_CPV': f(m2_cpv,2), 'M1_ISSUE_PCT': f(100*2.85/m1_cpv,0), 'M2_ISSUE_PCT': f(100*2.74/m2_cpv,0),
+ 'LOC_ALL': f(loc['all_pairs']['ns_per_1000_visits'],2), 'LOC_REP': f(loc_rep,2), 'LOC_SHUF': f(loc_shuf,2), 'LOC_ONE': f(loc['one_pair_x32640']['ns_per_1000_visits'],2),
+ 'LOC_GAIN': f(100*(1-loc_rep/loc['all_pairs']['ns_per_1000_visits']),1),
  'FRAME_BURSTS': burst_txt, 'FRAME_P99_STAGES': ', '.join(f"{k.replace('_',' ')} {v:.0f}" for k,v in p99s.items()) if p99s else 'n/a',
  'UL_TABLE': ul_table,
  'UL_MAPPING': (f"{mt.get('loops_per_s_alone',0):.0f} loops/s alone, {mt.get('loops_per_s_beside_the_odometry',0):.0f} beside the odometry's resident session ({mt.get('slowdown',0):.2f}×), {mtl.get('loops_per_s_beside_the_odometry',0):.0f} beside its launch-per-call form ({mtl.get('slowdown',0):.2f}×)") if mt else 'n/a',

@@ -57,10 +57,13 @@ double pct(std::vector<double> v, double p) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1] [diag switches]\n", argv[0]);
+    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1] [diag switches] [tidy=0|1|2|3]\n", argv[0]);
     return 2;
   }
   const int timed = argc > 2 ? atoi(argv[2]) : 300, iters = argc > 3 ? atoi(argv[3]) : 3, fused = argc > 4 ? atoi(argv[4]) : 0;
+  // tidy (measurement): what the loop does about the runtime's bookkeeping at the END of a frame, inside the timed unit -- 0 nothing (GLIM's loop), 1 glim_amd_ctx_synchronize
+  // every frame, 2 every 16th frame, 3 a stream query on every stream of the context every frame
+  const int tidy = argc > 6 ? atoi(argv[6]) : 0;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 2;
   int32_t hdr[4];
@@ -119,12 +122,15 @@ int main(int argc, char** argv) {
   std::vector<const glim_amd_voxelmap*> ov_maps((size_t)K);
   enum { S_CLONE_MAPS = 0, S_LIN_FIRST, S_LIN_REST, S_OVERLAP, S_RETIRE, S_COUNT };
   std::vector<double> total, stage[S_COUNT], inside[7], when_ms;  // when_ms: start of the frame, milliseconds since the first timed frame
+  std::vector<int> real_allocs;  // hipMalloc + hipHostMalloc calls the library made during the frame (glim_amd_debug_pool_stats): a steady loop should make none
   double t_first_timed = 0.0;
   double checksum = 0.0;
   const int warm = 20;
   for (int it = 0; it < warm + timed; it++) {
     // forwards then backwards along the arriving part of the trajectory
     const int period = 2 * (arrivals - 1), ph = it % period, h = first + (ph < arrivals ? ph : period - ph);
+    uint64_t dm0 = 0, pm0 = 0, dm1 = 0, pm1 = 0;
+    (void)glim_amd_debug_pool_stats(&dm0, nullptr, &pm0, nullptr);
     const double t0 = now_us();
     DeviceFrame cur;
     if (make_frame(h, &cur)) return 1;
@@ -169,8 +175,12 @@ int main(int argc, char** argv) {
     drop_frame(&window[0]);  // the oldest window frame is marginalised
     for (int w = 0; w + 1 < WIN; w++) window[(size_t)w] = window[(size_t)w + 1];
     window[(size_t)WIN - 1] = cur;
+    if (tidy == 1 || (tidy == 2 && it % 16 == 15)) (void)glim_amd_ctx_synchronize(ctx);
+    if (tidy == 3) (void)glim_amd_debug_ctx_query_streams(ctx, nullptr);
     const double t4 = now_us();
+    (void)glim_amd_debug_pool_stats(&dm1, nullptr, &pm1, nullptr);
     if (it >= warm) {
+      real_allocs.push_back((int)((dm1 - dm0) + (pm1 - pm0)));
       if (total.empty()) t_first_timed = t0;
       when_ms.push_back((t0 - t_first_timed) * 1e-3);
       total.push_back(t4 - t0);
@@ -211,8 +221,8 @@ int main(int argc, char** argv) {
       int worst = 0;
       for (int k = 1; k < S_COUNT; k++)
         if (v[k] - med[k] > v[worst] - med[worst]) worst = k;
-      printf("%s{\"frame\": %zu, \"at_ms\": %.2f, \"frame_us\": %.1f, \"excess_in\": \"%s\", \"excess_us\": %.1f, \"stages_us\": [%.1f, %.1f, %.1f, %.1f, %.1f]}", r ? ", " : "", i,
-             when_ms[i], total[i], names[worst], v[worst] - med[worst], v[0], v[1], v[2], v[3], v[4]);
+      printf("%s{\"frame\": %zu, \"at_ms\": %.2f, \"frame_us\": %.1f, \"excess_in\": \"%s\", \"excess_us\": %.1f, \"stages_us\": [%.1f, %.1f, %.1f, %.1f, %.1f], \"runtime_allocations\": %d}",
+             r ? ", " : "", i, when_ms[i], total[i], names[worst], v[worst] - med[worst], v[0], v[1], v[2], v[3], v[4], real_allocs[i]);
     }
     // slow frames (> 1.4 x the median) come in BURSTS of consecutive frames or alone?  [first frame, last frame, start ms] of every run of them
     const double slow = 1.4 * pct(total, 0.5);
@@ -226,12 +236,15 @@ int main(int argc, char** argv) {
       }
       size_t j = i;
       while (j + 1 < total.size() && (total[j + 1] > slow || (j + 2 < total.size() && total[j + 2] > slow))) j++;  // (one fast frame inside a run does not end it)
-      for (size_t k = i; k <= j; k++) n_slow += total[k] > slow ? 1 : 0;
-      printf("%s[%zu, %zu, %.2f]", first_run ? "" : ", ", i, j, when_ms[i]);
+      int run_allocs = 0;
+      for (size_t k = i; k <= j; k++) n_slow += total[k] > slow ? 1 : 0, run_allocs += real_allocs[k] + (k > 0 && k == i ? real_allocs[k - 1] : 0);  // (the frame before a run counts: its allocation may be what the run pays for)
+      printf("%s[%zu, %zu, %.2f, %d]", first_run ? "" : ", ", i, j, when_ms[i], run_allocs);
       first_run = false;
       i = j + 1;
     }
-    printf("], \"count\": %d, \"of\": %zu}", n_slow, total.size());
+    int all_allocs = 0;
+    for (int a : real_allocs) all_allocs += a;
+    printf("], \"runs_are\": \"[first frame, last frame, start ms, runtime allocations in the run and the frame before it]\", \"count\": %d, \"of\": %zu, \"runtime_allocations_in_all_timed_frames\": %d}", n_slow, total.size(), all_allocs);
   }
   printf("}\n");
   for (auto& d : keyframes) drop_frame(&d);
