@@ -85,8 +85,10 @@ loc_shuf=sum(v['ns_per_1000_visits'] for k,v in loc.items() if k.startswith('sam
 vals.update({
  'CPU_THREADS': str(cb['cores']), 'M2_PTS': sp(m2['config']['mean_points_per_submap']),
  'SYNC_RES': f(byv['resident_session'],1), 'SYNC_SINGLE': f(byv['default_context_no_session'],1), 'SYNC_TWO': f(byv['two_dispatches'],1),
- 'SYNC_VERDICT': ('met on this box' if byv['resident_session']<=10.5 else f"not met on this box ({byv['resident_session']:.1f} µs; the same library ran the call at 11.1–11.5 µs on the box of the row A/B, whose round-5 form took 13.7)"),
+ 'SYNC_VERDICT': ('met on this box' if byv['resident_session']<=10.5 else f"not met on this box ({byv['resident_session']:.1f} µs; 10.76–10.84 on the box of the step-major A/B, whose round-5 form would have taken ≈ 13.7)"),
  'TL_PUB': f(tl['leader_published'],2), 'TL_POSE': f(tl['worker_pose_seen_median'],2), 'TL_ROWS': f(tl['worker_row_computed_max'],2), 'TL_PUBROW': f(tl['worker_row_published_max'],2),
+ 'TL_LOOP': f(tl.get('worker_loop_left_median',0),2), 'TL_LOOPMAX': f(tl.get('worker_loop_left_max',0),2), 'TL_GSUM': f(tl.get('finaliser_group_sums_added',0),2), 'TL_ROT': f(tl.get('finaliser_blocks_rotated',0),2),
+ 'TL_CLOCK': f(tl.get('shader_clock_mhz',0),0), 'SPEEDUP': f(b['speedup_vs_cpu_baseline'],1),
  'TL_SUM': f(tl['finaliser_rows_summed'],2), 'TL_REC': f(tl['finaliser_record_stored'],2), 'TL_HOST': f(tl['host_round_trip'],2), 'TL_TRANSIT': f(transit,1),
  'COST128': f(rc['batched_128_factor_kernel_ms']['slowdown'],2), 'COST8': f(rc['8_factor_kernel_ms']['slowdown'],2),
  'VIRT_MS': f(vb['ms_per_evaluation'],2), 'VIRT_WAIT_BEHIND': f(vb['host_wait_for_the_exchange_after_the_call_us'],0), 'VIRT_WAIT_SYNC': f(vs['host_wait_for_the_exchange_after_the_call_us'],0),
