@@ -132,6 +132,21 @@ __device__ __forceinline__ void wave_sums_to_lane63(float (&v)[N]) {
   //  does not make the compiler fold them into one v_add_f32_dpp either)
 }
 
+// The first four steps only: every lane of a 16-lane row ends up with its ROW's sum (lanes 15 / 31 / 47 / 63 are where the two row_bcast steps of
+// wave_sums_to_lane63 would read them).  A caller that hands the four row sums r0..r3 to somebody who adds them as (r3 + r2) + (r1 + r0) -- what lane 63
+// holds after row_bcast:15 and row_bcast:31 -- gets the same bits for 4 N instead of 10 N instructions per wavefront.
+template <int N>
+__device__ __forceinline__ void wave_row_sums(float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0xB1, 0xF>(v[j]);   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x4E, 0xF>(v[j]);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x141, 0xF>(v[j]);  // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] += dpp_f<0x140, 0xF>(v[j]);  // row_mirror
+}
+
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_f<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v += dpp_f<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]

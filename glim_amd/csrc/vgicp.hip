@@ -63,6 +63,17 @@ constexpr int NACC = 28;  // FP32 accumulators per thread (see layout below); sl
 #ifndef GLIM_AMD_RES_TAILSKIP
 #define GLIM_AMD_RES_TAILSKIP 1
 #endif
+// the four 16-lane ROW sums of every wavefront go to LDS and whoever forms the row's values adds them as (r3 + r2) + (r1 + r0), what the two
+// row_bcast steps left in lane 63 (same bits; 4 instead of 10 instructions per value and wavefront) / 0: the wavefront sums as before
+#ifndef GLIM_AMD_ROW_SUMS_LDS
+#define GLIM_AMD_ROW_SUMS_LDS 1
+#endif
+#if GLIM_AMD_ROW_SUMS_LDS
+constexpr int RED_ROWS = 4;  // s_red[wavefront][16-lane row][value]
+#else
+constexpr int RED_ROWS = 1;  // s_red[wavefront][0][value]
+#endif
+typedef float RedRow[RED_ROWS][glim_amd::PARTIAL_STRIDE];
 // accumulator slot of entry i of the upper triangle of H_ss -- {0, 1, 2, 6, 7, 8, 3, 4, 9, 10, 11, 5, 12, 13, 14, 15, 16, 17, 18, 19, 20} -- as two
 // immediates (5 bits per entry, entries 0..11 and 12..20): the finalisers' last step looks its slot up with two shifts instead of a load from
 // constant memory behind the last barrier of a call the host is waiting for
@@ -784,7 +795,8 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // One (factor, chunk) row of a plan, computed by the 256 threads of a block: its lanes walk the factor's points in 256-point hands dealt
 // round robin to the factor's blocks, through the two-trip software pipeline of pipe_trip, with the wave priority rotated every trip; every lane
 // runs the algebra (a lane without a match contributes exact zeros) and the only branch on the hot path is the rare bucket spill.  On return
-// (after a block barrier) s_red[w][j] holds wavefront w's sum of accumulator j, s_red[w][28] its inlier count.
+// (after a block barrier) s_red[w] holds wavefront w's sums -- as its four 16-lane row sums (GLIM_AMD_ROW_SUMS_LDS; wave_value adds them) -- of
+// accumulator j, [28] its inlier count.
 // first: the stream data of this lane's first point when the caller has loaded it already (a resident worker does, while it waits for its pose).
 // cull (CULL only): this block's four pre-cull words (cull_kernel), one per wavefront: bit t set = trip t of that wavefront has no point or cannot
 // find a correspondence.  The wavefront then walks its LIVE trips only, through the same two-trip pipeline: a culled trip costs nothing at all --
@@ -792,7 +804,7 @@ __device__ __forceinline__ void rotate_priority(int step) {
 // a culled trip would have added exact zeros in every lane, the sums are the same bits.
 template <int MODE, bool FROZEN, bool PLANE, bool CULL = false, bool TAILSKIP = false>
 __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* __restrict__ Tl, const double* __restrict__ Te, int chunk, int prio_phase,
-                                            float (*s_red)[PARTIAL_STRIDE], const PointIn* first = nullptr, const unsigned long long* cull = nullptr,
+                                            RedRow* s_red, const PointIn* first = nullptr, const unsigned long long* cull = nullptr,
                                             unsigned long long* loop_done_stamp = nullptr) {
   // rotation of the linearisation pose in FP32 (R[r][c])
   // (wave-uniform: the compiler keeps these in SGPRs; forcing readfirstlane changed nothing -- 93 VGPRs either way)
@@ -855,41 +867,69 @@ __device__ __forceinline__ void compute_row(const FactorDesc& d, const double* _
   if (loop_done_stamp && threadIdx.x == 0) *loop_done_stamp = __builtin_amdgcn_s_memrealtime();  // (device timeline of a resident session: the algebra of the last point is issued)
   // ---- block reduction: DPP wave sums -> LDS ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if GLIM_AMD_ROW_SUMS_LDS
+  // every 16-lane row of the wavefront leaves ITS sum (lanes 15 / 31 / 47 / 63); row_value adds the four as the row_bcast steps did.  Values that
+  // exist once per wavefront (error-only sum, inlier count, skipped trips) go to row 3, zeros to the others: (v + 0) + (0 + 0) is v.
+  const bool row_end = (lane & 15) == 15;
+  const int rrow = lane >> 4;
+  if (MODE == MODE_LINEARIZE) {
+    wave_row_sums<NACC>(acc);
+    if (row_end) {
+#pragma unroll
+      for (int j = 0; j < NACC; j++) s_red[wave][rrow][j] = acc[j];
+    }
+  } else {
+    const float v = wave_sum_to_lane63(acc[27]);
+    if (row_end) s_red[wave][rrow][27] = rrow == 3 ? v : 0.f;
+  }
+  if (row_end) {
+    s_red[wave][rrow][28] = rrow == 3 ? (float)wave_inliers : 0.f;  // <= 64 * ppt: exact in FP32
+    s_red[wave][rrow][29] = rrow == 3 ? (float)wave_skips : 0.f;    // <= ppt
+  }
+#else
   if (MODE == MODE_LINEARIZE) {
 #if GLIM_AMD_STEP_MAJOR_SUMS
     wave_sums_to_lane63<NACC>(acc);  // (step-major: device_math.hpp)
     if (lane == 63) {
 #pragma unroll
-      for (int j = 0; j < NACC; j++) s_red[wave][j] = acc[j];
+      for (int j = 0; j < NACC; j++) s_red[wave][0][j] = acc[j];
     }
 #else
 #pragma unroll
     for (int j = 0; j < NACC; j++) {
       const float v = wave_sum_to_lane63(acc[j]);
-      if (lane == 63) s_red[wave][j] = v;
+      if (lane == 63) s_red[wave][0][j] = v;
     }
 #endif
   } else {
     const float v = wave_sum_to_lane63(acc[27]);
-    if (lane == 63) s_red[wave][27] = v;
+    if (lane == 63) s_red[wave][0][27] = v;
   }
   {
-    if (lane == 63) s_red[wave][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
-    if (lane == 63) s_red[wave][29] = (float)wave_skips;    // <= ppt
+    if (lane == 63) s_red[wave][0][28] = (float)wave_inliers;  // <= 64 * ppt: exact in FP32
+    if (lane == 63) s_red[wave][0][29] = (float)wave_skips;    // <= ppt
   }
+#endif
   __syncthreads();
 }
 
 // value j of the block's partial row from the four wavefront sums (the same expression wherever a row is published: same bits)
+__device__ __forceinline__ float wave_value(const RedRow* s_red, int w, int j) {
+#if GLIM_AMD_ROW_SUMS_LDS
+  return (s_red[w][3][j] + s_red[w][2][j]) + (s_red[w][1][j] + s_red[w][0][j]);  // lane 63 after row_bcast:15 and row_bcast:31
+#else
+  return s_red[w][0][j];
+#endif
+}
 template <int MODE>
-__device__ __forceinline__ float row_value(const float (*s_red)[PARTIAL_STRIDE], int j) {
+__device__ __forceinline__ float row_value(const RedRow* s_red, int j) {
   const bool live = (MODE == MODE_LINEARIZE) ? (j <= 29) : (j >= 27 && j <= 29);  // 0..26 sums, 27 error, 28 inliers, 29 skipped trips
-  return live ? (s_red[0][j] + s_red[1][j]) + (s_red[2][j] + s_red[3][j]) : 0.f;
+  return live ? (wave_value(s_red, 0, j) + wave_value(s_red, 1, j)) + (wave_value(s_red, 2, j) + wave_value(s_red, 3, j)) : 0.f;
 }
 
 // tagged granules (see TAG_PIECES): thread p < 10 publishes values 3p .. 3p + 2 and the call's tag with ONE write-through 16-byte store
 template <int MODE>
-__device__ __forceinline__ void publish_row_tagged(const float (*s_red)[PARTIAL_STRIDE], char* rows16, size_t row, unsigned int tag) {
+__device__ __forceinline__ void publish_row_tagged(const RedRow* s_red, char* rows16, size_t row, unsigned int tag) {
   if (threadIdx.x < TAG_PIECES) {
     const int j = 3 * (int)threadIdx.x;
     const v4i_t piece = {__float_as_int(row_value<MODE>(s_red, j)), __float_as_int(row_value<MODE>(s_red, j + 1)), __float_as_int(row_value<MODE>(s_red, j + 2)),
@@ -915,9 +955,10 @@ __global__ __launch_bounds__(BLOCK, (PLANE && !FUSED) ? GLIM_AMD_MINW_PLANE : GL
                                                           const double* __restrict__ poses_eval, const int2* __restrict__ blockmap,
                                                           float* __restrict__ partials, const InlineArgs ip, const FinalizeArgs fa, int block_offset,
                                                           int blocks_per_round, int seg_rows, int fin_offset) {
-  // one LDS object: the row blocks use the first 512 bytes (s_red), a finalising block all of it (s_part, s_sum)
-  __shared__ double s_lds[FUSED ? (FIN_GROUPS + 1) * PARTIAL_STRIDE : (4 * PARTIAL_STRIDE * (int)sizeof(float)) / (int)sizeof(double)];
-  float (*s_red)[PARTIAL_STRIDE] = reinterpret_cast<float (*)[PARTIAL_STRIDE]>(s_lds);
+  // one LDS object: the row blocks use its first 4 x sizeof(RedRow) bytes (s_red), a finalising block all of it (s_part, s_sum)
+  __shared__ double s_lds[FUSED ? (FIN_GROUPS + 1) * PARTIAL_STRIDE : (4 * (int)sizeof(RedRow)) / (int)sizeof(double)];
+  static_assert(4 * sizeof(RedRow) <= (FIN_GROUPS + 1) * PARTIAL_STRIDE * sizeof(double), "s_red fits the finalisers' LDS object");
+  RedRow* s_red = reinterpret_cast<RedRow*>(s_lds);
   if (FUSED && (int)blockIdx.x >= seg_rows) {
     const int ff = INLINE ? 0 : fa.finmap[fin_offset + ((int)blockIdx.x - seg_rows)];
     const FactorDesc fd = INLINE ? ip.d : descs[ff];
@@ -1132,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK, PLANE_ONLY ? GLIM_AMD_RES_MINW : 3) void res
   __shared__ double s_lds[(FIN_GROUPS + 1) * PARTIAL_STRIDE];
   __shared__ double s_pose[12];
   __shared__ unsigned int s_tag;
-  float (*s_red)[PARTIAL_STRIDE] = reinterpret_cast<float (*)[PARTIAL_STRIDE]>(s_lds);
+  RedRow* s_red = reinterpret_cast<RedRow*>(s_lds);
   const int b = (int)blockIdx.x;
   const bool finaliser = b >= ra.workers, leader = b == ra.workers;
   unsigned int last = ra.first_tag;

@@ -62,6 +62,8 @@ for w in odometry_frame odometry_under_load submap20 rgbd300k frontend128k; do
 done
 # configs[3] through the native multi-device C-ABI path (world 1 here) + the N > 1 path over 8 virtual devices
 timeout -k 5 500 python bench.py --gpus 1 --native > $OUT/bench_global256_native.json 2> $OUT/bench_global256_native.err < /dev/null
+# the driver's N > 1 launch form with ONE rank (the only world this box has): must print one JSON line, rc 0
+timeout -k 5 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_torchrun_world1.json 2> $OUT/bench_torchrun_world1.err < /dev/null; echo "torchrun world 1 rc $?" >> $OUT/summarize.log
 BENCH_FRONTEND_FINE=1 timeout -k 5 200 python bench.py --workload frontend128k --no-cpu-baseline > /dev/null 2> $OUT/frontend_linearize_stage_fine.txt < /dev/null
 timeout -k 5 100 python tools/voxelmap_time.py 2>&1 | grep -v '^[WE]20' > $OUT/voxelmap_time.txt
 du -sh $REPO/gpurun_out
