@@ -58,6 +58,36 @@ __global__ __launch_bounds__(256) void init_tables_kernel(VoxelBucket* __restric
   if (i < acc_words) acc16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// The same clearing for a RECYCLED table on the side stream (recycle_table), with a completion word instead of an event: the block that arrives
+// last publishes `done_seq` in host-mapped memory, and the host hands the table to a new map only after it has seen that word -- a load where the
+// event cost a hipEventRecord per retired map and a hipEventQuery per look (a frame of the odometry made four records and four queries, ~10 us of
+// runtime calls, and fed the runtime's bulk retirement of marker commands).  A FEW FAT blocks (grid-stride), ONE release per block: a release at
+// agent scope writes the XCD's L2 back, and the first form of this kernel -- init_tables_kernel's one thread per 16 bytes, every thread fencing before
+// the arrival -- put 2 048 such write-backs behind one another: 125 us per table, and the frame build beside it went from 62 to 187 us.  Here
+// every wavefront waits for its own stores (vmcnt), the barrier collects the block, thread 0 releases once.  arrivals: device counter, left at zero.
+constexpr int CLEAR_BLOCKS = 64;
+__global__ __launch_bounds__(256) void clear_recycled_kernel(VoxelBucket* __restrict__ buckets, unsigned int n, uint4* __restrict__ acc16, size_t acc_words,
+                                                             int* __restrict__ stats, int* __restrict__ arrivals, unsigned int* __restrict__ done_word,
+                                                             unsigned int done_seq) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (first == 0) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  for (size_t i = first; i < (size_t)n * 8; i += stride) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((i & 7) == 0) v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // key[0] = key[1] = EMPTY_KEY
+    reinterpret_cast<uint4*>(buckets)[i] = v;
+  }
+  for (size_t i = first; i < acc_words; i += stride) acc16[i] = make_uint4(0u, 0u, 0u, 0u);
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // (release: the block's lines leave this XCD's L2)
+    if (ticket == (int)gridDim.x - 1) {
+      __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done_word, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // Wavefront-level grouping of equal keys: consecutive points of a scan usually fall into the same voxel, and 64 lanes hammering
 // one table word with atomics serialise in the L2.  Every distinct key of the wavefront elects ONE leader lane; `group` is the
 // ballot of the lanes sharing this lane's key.  The loop is wave-uniform (one trip per distinct key, ~10 on LiDAR scans).
@@ -298,8 +328,12 @@ __global__ __launch_bounds__(256) void frame_build_kernel(const PullArgs pa, con
   // added its share, and the host need not wait for a dependent launch to start (2 us of a 10 000-pt frame).  (Every block's counter updates, and its report of a
   // point off the plane form, are ordered before its arrival by the fence; the arrival counter is left at zero for the table's next life.)
   if (poll_seq) {  // EVERY wavefront's stores (cloud arrays, factor streams, accumulator atomics) are performed before the block arrives: the
-    __threadfence();  // barrier alone orders the waves, it does not wait for their outstanding stores, and the host frees one stream
-    __syncthreads();  // family and lets readers of other streams in the moment it sees the completion word
+    // barrier alone orders the waves, it does not wait for their outstanding stores, and the host frees one stream family and lets
+    // readers of other streams in the moment it sees the completion word.  Each wavefront waits for ITS stores to be acknowledged (vmcnt: they are
+    // in this XCD's L2 then); the ONE system-scope fence of thread 0 below writes that L2 back.  (Round 5 had every thread execute __threadfence():
+    // an L2 write-back per wavefront, which is what made the first completion-word form of the table-clearing kernel take 125 us.)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
   }
   if (poll_seq && threadIdx.x == 0) {
     __threadfence_system();
@@ -610,13 +644,20 @@ struct ClearedTable {
   long long* acc = nullptr;
   int* stats = nullptr;
   unsigned int nb = 0;
-  hipEvent_t done = nullptr;
+  int slot = -1;              // completion word of its clearing kernel (ClearedCache::h_done[slot]) ...
+  unsigned int done_seq = 0;  // ... and the value that word takes when the kernel is complete
 };
+constexpr int CLEARED_SLOTS = 32;
 struct ClearedCache {
   std::mutex mu;
   std::vector<ClearedTable> tables;
   hipStream_t stream = nullptr;
   size_t bytes = 0;
+  // completion words of the clearing kernels (host-mapped, one per table in flight or cached) and the kernels' arrival counter (device)
+  unsigned int *h_done = nullptr, *h_done_dev = nullptr;
+  int* d_arrivals = nullptr;
+  bool slot_used[CLEARED_SLOTS] = {};
+  unsigned int seq = 0;
 };
 constexpr size_t CLEARED_MAX_TABLES = 8, CLEARED_MAX_BYTES = 256ull << 20, CLEARED_MAX_TABLE_BYTES = 48ull << 20;
 ClearedCache& cleared_cache(int device) {
@@ -624,6 +665,13 @@ ClearedCache& cleared_cache(int device) {
   return caches[(device >= 0 && device < 64) ? device : 0];
 }
 size_t cleared_bytes(unsigned int nb) { return (size_t)nb * (sizeof(VoxelBucket) + 2 * ACC_STRIDE * sizeof(long long)); }
+
+// true when the clearing kernel of `t` has published its completion word (acquire)
+bool cleared_done(const ClearedCache& C, const ClearedTable& t) {
+  if (t.slot < 0 || *reinterpret_cast<const volatile unsigned int*>(C.h_done + t.slot) != t.done_seq) return false;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return true;
+}
 
 // the table of a map that is going away (nobody reads it any more: the caller has quiesced the device): cleared for re-use, or back to the pool
 void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
@@ -643,27 +691,75 @@ void recycle_table(int device, VoxelBucket* buckets, unsigned int nb) {
       }
       if (!C.stream && hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking) != hipSuccess) keep = false;
     }
-    for (ClearedTable& old : evicted) {
-      (void)hipEventSynchronize(old.done);  // (its clearing kernel was enqueued at least a cache's worth of maps ago)
-      event_put(device, old.done);
-      (void)pool_free(old.buckets);
-      (void)pool_free(old.acc);
-      (void)pool_free(old.stats);
+    // once per device: the completion words (host-mapped) and the clearing kernels' arrival counter.  Allocated OUTSIDE the cache's lock (a pool
+    // that runs out of memory trims this very cache), installed under it.
+    if (keep && !C.h_done) {
+      unsigned int *h = nullptr, *hd = nullptr;
+      int* d = nullptr;
+      bool ok = pinned_malloc(&h, CLEARED_SLOTS * sizeof(unsigned int)) == hipSuccess && pool_malloc(&d, sizeof(int)) == hipSuccess &&
+                hipMemsetAsync(d, 0, sizeof(int), C.stream) == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0) == hipSuccess;
+      if (ok) {
+        memset(h, 0, CLEARED_SLOTS * sizeof(unsigned int));
+        std::lock_guard<std::mutex> lock(C.mu);
+        if (!C.h_done) {
+          C.h_done_dev = hd;
+          C.d_arrivals = d;
+          C.h_done = h;
+          h = nullptr;
+          d = nullptr;
+        }
+      } else {
+        (void)hipGetLastError();
+        keep = false;
+      }
+      if (h) (void)pinned_free(h);  // (not installed: another thread was first, or a step failed)
+      if (d) {
+        (void)hipStreamSynchronize(C.stream);  // (its memset may still be on the way)
+        (void)pool_free(d);
+      }
+    }
+    if (!evicted.empty()) {
+      // (their clearing kernels were enqueued at least a cache's worth of maps ago; one synchronise of the side stream covers the rare one that is not done)
+      bool all_done = true;
+      for (const ClearedTable& old : evicted) all_done = all_done && cleared_done(C, old);
+      if (!all_done && C.stream) (void)hipStreamSynchronize(C.stream);
+      std::lock_guard<std::mutex> lock(C.mu);
+      for (ClearedTable& old : evicted) {
+        if (old.slot >= 0) C.slot_used[old.slot] = false;
+        (void)pool_free(old.buckets);
+        (void)pool_free(old.acc);
+        (void)pool_free(old.stats);
+      }
     }
   }
-  if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 4 * sizeof(int)) == hipSuccess &&
-                   event_get(device, &t.done) == hipSuccess;
+  if (keep) keep = pool_malloc(&t.acc, (size_t)nb * 2 * ACC_STRIDE * sizeof(long long)) == hipSuccess && pool_malloc(&t.stats, 4 * sizeof(int)) == hipSuccess;
+  if (keep) {
+    std::lock_guard<std::mutex> lock(C.mu);
+    for (int k = 0; k < CLEARED_SLOTS && t.slot < 0; k++)
+      if (!C.slot_used[k]) t.slot = k;
+    if (t.slot >= 0) {
+      C.slot_used[t.slot] = true;
+      t.done_seq = ++C.seq ? C.seq : ++C.seq;  // (never 0: a fresh word reads 0)
+      *reinterpret_cast<volatile unsigned int*>(C.h_done + t.slot) = 0u;  // (a word cannot carry this sequence number from an earlier life: the counter only grows)
+    } else {
+      keep = false;
+    }
+  }
   if (keep) {
     const size_t acc_words = (size_t)nb * (2 * ACC_STRIDE * sizeof(long long) / sizeof(uint4));
-    init_tables_kernel<<<(unsigned int)((std::max<size_t>((size_t)nb * 8, acc_words) + 255) / 256), 256, 0, C.stream>>>(buckets, nb, (uint4*)t.acc, acc_words, t.stats);
-    keep = hipGetLastError() == hipSuccess && hipEventRecord(t.done, C.stream) == hipSuccess;
+    // (clearing kernels of one device run one after the other on the side stream: ONE arrival counter, left at zero by every launch)
+    clear_recycled_kernel<<<CLEAR_BLOCKS, 256, 0, C.stream>>>(buckets, nb, (uint4*)t.acc, acc_words, t.stats, C.d_arrivals, C.h_done_dev + t.slot, t.done_seq);
+    keep = hipGetLastError() == hipSuccess;
     if (!keep) (void)hipStreamSynchronize(C.stream);
   }
   if (!keep) {
     (void)hipGetLastError();
     if (t.acc) (void)pool_free(t.acc);
     if (t.stats) (void)pool_free(t.stats);
-    if (t.done) event_put(device, t.done);
+    if (t.slot >= 0) {
+      std::lock_guard<std::mutex> lock(C.mu);
+      C.slot_used[t.slot] = false;
+    }
     (void)pool_free(buckets);
     return;
   }
@@ -679,15 +775,14 @@ bool take_cleared_table(int device, unsigned int nb, ClearedTable* out) {
   ClearedCache& C = cleared_cache(device);
   std::lock_guard<std::mutex> lock(C.mu);
   for (size_t i = 0; i < C.tables.size(); i++) {
-    if (C.tables[i].nb != nb || hipEventQuery(C.tables[i].done) != hipSuccess) continue;
+    if (C.tables[i].nb != nb || !cleared_done(C, C.tables[i])) continue;
     *out = C.tables[i];
     C.tables.erase(C.tables.begin() + (long)i);
     C.bytes -= cleared_bytes(nb);
-    event_put(device, out->done);
-    out->done = nullptr;
+    C.slot_used[out->slot] = false;
+    out->slot = -1;
     return true;
   }
-  (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error)
   return false;
 }
 
@@ -708,8 +803,10 @@ void voxelmap_drop_cleared_tables(int device) {
     (void)pool_free(t.buckets);
     (void)pool_free(t.acc);
     (void)pool_free(t.stats);
-    (void)hipEventDestroy(t.done);
   }
+  std::lock_guard<std::mutex> lock(C.mu);
+  for (ClearedTable& t : all)
+    if (t.slot >= 0) C.slot_used[t.slot] = false;
 }
 }  // namespace glim_amd
 
