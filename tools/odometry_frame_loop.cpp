@@ -57,12 +57,12 @@ double pct(std::vector<double> v, double p) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1] [diag switches] [tidy=0|1|2|3]\n", argv[0]);
+    fprintf(stderr, "usage: %s scene.bin [frames=300] [iters=3] [one_submission=0|1] [diag switches] [tidy=0|1|2|3|4]\n", argv[0]);
     return 2;
   }
   const int timed = argc > 2 ? atoi(argv[2]) : 300, iters = argc > 3 ? atoi(argv[3]) : 3, fused = argc > 4 ? atoi(argv[4]) : 0;
   // tidy (measurement): what the loop does about the runtime's bookkeeping at the END of a frame, inside the timed unit -- 0 nothing (GLIM's loop), 1 glim_amd_ctx_synchronize
-  // every frame, 2 every 16th frame, 3 a stream query on every stream of the context every frame
+  // every frame, 2 every 16th frame, 3 a stream query on every stream of the context every frame, 4 glim_amd_ctx_synchronize right BEHIND create_frame
   const int tidy = argc > 6 ? atoi(argv[6]) : 0;
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 2;
@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
     const double t0 = now_us();
     DeviceFrame cur;
     if (make_frame(h, &cur)) return 1;
+    if (tidy == 4) (void)glim_amd_ctx_synchronize(ctx);  // (right behind create_frame: only the maps' records kernel is still on its way)
     const double t1 = now_us();
     double fs[7] = {0, 0, 0, 0, 0, 0, 0};
     if (fused) (void)glim_amd_debug_frame_stages(fs, 7);
