@@ -39,13 +39,39 @@ __global__ void poll_kernel(const unsigned int* request, unsigned int* completio
   }
 }
 
+// The same responder with the poll spread over the four wavefronts of a 256-thread block: every wavefront keeps ONE read of the request word in
+// flight, started a quarter of a round trip after its neighbour's, and the first to see a new value answers (LDS compare-and-swap).  The expected
+// wait of a request for the next poll to START drops from half a read round trip to an eighth.
+__global__ void poll_kernel_staggered(const unsigned int* request, unsigned int* completion, unsigned int idle_limit, int stagger_sleep) {
+  __shared__ unsigned int s_last;
+  if (threadIdx.x == 0) s_last = 0u;
+  __syncthreads();
+  if ((threadIdx.x & 63) != 0) return;
+  const int wave = (int)threadIdx.x >> 6;
+  for (int k = 0; k < wave * stagger_sleep; k++) __builtin_amdgcn_s_sleep(1);  // (64 cycles each: the s_sleep argument has to be a constant)
+  for (unsigned int idle = 0; idle < idle_limit; idle++) {
+    const unsigned int r = __hip_atomic_load(request, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (r == 0xffffffffu) return;
+    const unsigned int last = __hip_atomic_load(&s_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (r != last) {
+      unsigned int expected = last;
+      if (__hip_atomic_compare_exchange_strong(&s_last, &expected, r, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        idle = 0;
+        __hip_atomic_store(completion, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 static sigjmp_buf g_jmp;
 static void on_segv(int) { siglongjmp(g_jmp, 1); }
 
-static double run(volatile unsigned int* request_host_view, const unsigned int* request_dev, volatile unsigned int* h_done, unsigned int* d_done, hipStream_t st) {
+static double run(volatile unsigned int* request_host_view, const unsigned int* request_dev, volatile unsigned int* h_done, unsigned int* d_done, hipStream_t st, int stagger = -1) {
   *request_host_view = 0;
   *h_done = 0;
-  poll_kernel<<<1, 64, 0, st>>>(request_dev, d_done, 1u << 22);
+  if (stagger < 0) poll_kernel<<<1, 64, 0, st>>>(request_dev, d_done, 1u << 22);
+  else poll_kernel_staggered<<<1, 256, 0, st>>>(request_dev, d_done, 1u << 22, stagger);
   std::vector<double> us;
   unsigned int s = 0;
   for (int i = 0; i < 2200; i++) {
@@ -71,6 +97,8 @@ int main() {
   CK(hipHostMalloc(&h, 256, hipHostMallocMapped));
   CK(hipHostGetDevicePointer((void**)&d, h, 0));
   printf("host_word   (request polled over PCIe):      %.2f us per request\n", run(h, d, h + 16, d + 16, st));
+  for (int stagger : {0, 4, 8, 12}) printf("host_word, four staggered wavefronts (s_sleep %2d between their first polls): %.2f us per request\n", stagger, run(h, d, h + 16, d + 16, st, stagger));
+  printf("host_word   (again):                         %.2f us per request\n", run(h, d, h + 16, d + 16, st));
   unsigned int* fine = nullptr;
   hipError_t e = hipExtMallocWithFlags((void**)&fine, 256, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
